@@ -1,0 +1,155 @@
+/* ola_gpu.h -- C ABI of the MI355X-native Goldilocks STARK proving backend for OlaVM.
+ *
+ * This is the drop-in boundary behind circuits::stark::prover::prove_with_traces (reference
+ * circuits/src/stark/prover.rs:79).  It widens the reference's existing GPU FFI precedent
+ *     extern "C" { gpu_init; gpu_method; gpu_free }      plonky2/field/src/cfft/ntt/mod.rs:21-45
+ * (one column per call, host<->device round trip per column, global mutex) to whole-phase granularity:
+ * a PolynomialBatch is committed in one call and stays resident in HBM.  INTEGRATION.md shows the Rust-side
+ * bindings (`extern "C"` block + build.rs link lines) a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every function returns int32_t: 0 = OLA_OK, negative = error; ola_gpu_last_error() gives the message of
+ *     the last failure on the calling thread.  No exceptions, no abort() cross this boundary
+ *     (the reference panics / returns anyhow::Error: prover.rs:352-355,471-473,508-511).
+ *   - field elements are uint64_t Goldilocks values (p = 2^64 - 2^32 + 1), GoldilocksField is
+ *     #[repr(transparent)] u64 (plonky2/field/src/goldilocks_field.rs:24-26).  Inputs may be non-canonical
+ *     (>= p); ALL outputs are canonical (< p), i.e. exactly what the reference serialises
+ *     (circuits/src/stark/serialization.rs:50-52).
+ *   - "host" pointers are ordinary process memory owned by the caller and are not retained after return.
+ *     "_dev" entry points take device (HBM) pointers valid on the context's device; work is enqueued on the
+ *     context's stream and the call returns after the stream has been synchronised unless stated otherwise.
+ *   - column-major: a table of `ncols` columns of n = 2^log_n rows is ncols contiguous runs of n elements
+ *     (the reference's Vec<PolynomialValues<F>>, plonky2/field/src/polynomial/mod.rs:24-26).
+ *   - thread-compatible per OlaCtx: one orchestrating thread per context (prove_with_traces is sequential
+ *     across tables, prover.rs:160-287).
+ */
+#ifndef OLA_GPU_H
+#define OLA_GPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OLA_OK 0
+#define OLA_E_INVALID_ARG (-1)
+#define OLA_E_NO_DEVICE (-2)
+#define OLA_E_OOM (-3)
+#define OLA_E_QUOTIENT_DEGREE (-4) /* prover.rs:469-473 "vanishing polynomial is not divisible by Z_H" */
+#define OLA_E_HIP (-5)
+#define OLA_E_ZETA_IN_SUBGROUP (-6) /* prover.rs:508-511 */
+#define OLA_E_INTERNAL (-7)
+
+typedef struct OlaCtx OlaCtx;     /* device context: streams, twiddle tables, Poseidon constants            */
+typedef struct OlaBatch OlaBatch; /* a committed PolynomialBatch resident in HBM (fri/oracle.rs:31-39)      */
+
+/* StarkConfig::standard_fast_config (circuits/src/stark/config.rs:18-30) is the default when NULL is passed. */
+typedef struct OlaGpuConfig {
+    int32_t device;             /* HIP device ordinal; -1 = current device                                   */
+    void* stream;               /* hipStream_t to run on, NULL = the library creates its own                 */
+    uint32_t rate_bits;         /* 3                                                                         */
+    uint32_t cap_height;        /* 4                                                                         */
+    uint32_t proof_of_work_bits;/* 16                                                                        */
+    uint32_t fri_arity_bits;    /* ConstantArityBits(4, 5)                                                   */
+    uint32_t fri_final_poly_bits;
+    uint32_t num_query_rounds;  /* 28                                                                        */
+    uint32_t num_challenges;    /* 2                                                                         */
+} OlaGpuConfig;
+
+/* ---- lifetime (replaces gpu_init / gpu_free, cfft/ntt/mod.rs:89-121 and core/src/storage/db.rs:248) ---- */
+int32_t ola_gpu_init(const OlaGpuConfig* cfg, OlaCtx** out_ctx);
+int32_t ola_gpu_free(OlaCtx* ctx);
+const char* ola_gpu_last_error(void);
+int32_t ola_gpu_sync(OlaCtx* ctx);
+
+/* ---- NTT family: replaces gpu_method and the cfft CPU paths --------------------------------------------
+ * op selects the reference function (plonky2/field/src/cfft/mod.rs):
+ *   OLA_NTT_EVALUATE              evaluate_poly               :22   coeffs -> values on <w>, natural order
+ *   OLA_NTT_INTERPOLATE           interpolate_poly            :128  values -> coeffs (x n^-1), natural order
+ *   OLA_NTT_COSET_LDE             evaluate_poly_with_offset   :65   n coeffs -> n*2^blowup_log values at
+ *                                                                   shift*g^m, m natural (shift = `shift`)
+ *   OLA_NTT_COSET_INTERPOLATE     interpolate_poly_with_offset:180  values on shift*<w> -> coeffs
+ *   OLA_NTT_COSET_LDE_LEAF_ORDER  the same LDE (shift must be 7) but rows in commitment-leaf order, i.e.
+ *                                 bit-reversed (what PolynomialBatch::from_coeffs feeds the Merkle tree,
+ *                                 fri/oracle.rs:84-85) -- the order the device keeps internally.
+ * `in`/`out` are column-major batches; out may equal in when the op preserves length.
+ */
+#define OLA_NTT_EVALUATE 0
+#define OLA_NTT_INTERPOLATE 1
+#define OLA_NTT_COSET_LDE 2
+#define OLA_NTT_COSET_INTERPOLATE 3
+#define OLA_NTT_COSET_LDE_LEAF_ORDER 4
+
+int32_t ola_ntt_batch(OlaCtx* ctx, int32_t op, const uint64_t* in, uint64_t* out, uint32_t log_n, uint32_t batch,
+                      uint64_t shift, uint32_t blowup_log);
+/* same, operands resident in HBM; `scratch_dev` must hold batch * 2^log_n elements when log_n > 13 and the op
+ * produces natural order (NULL lets the library allocate and free it). */
+int32_t ola_ntt_batch_dev(OlaCtx* ctx, int32_t op, const uint64_t* in_dev, uint64_t* out_dev, uint64_t* scratch_dev,
+                          uint32_t log_n, uint32_t batch, uint64_t shift, uint32_t blowup_log);
+
+/* ---- Poseidon / Merkle: replaces hash/poseidon.rs:593-603, hashing.rs:84-111, merkle_tree/mod.rs:180-337 -- */
+/* n states of 12 elements each, permuted in place (host memory). */
+int32_t ola_poseidon_permute(OlaCtx* ctx, uint64_t* states, size_t n);
+/* hash_no_pad over each row of a row-major num_rows x row_len host matrix -> digests (num_rows x 4). */
+int32_t ola_hash_rows(OlaCtx* ctx, const uint64_t* rows, size_t num_rows, size_t row_len, uint64_t* digests);
+/* MerkleTree::new_v2 over row-major host leaves: writes the cap (2^cap_height x 4). */
+int32_t ola_merkle_cap(OlaCtx* ctx, const uint64_t* leaves, size_t num_leaves, size_t leaf_len, uint32_t cap_height,
+                       uint64_t* cap_out);
+
+/* ---- PolynomialBatch commitment: replaces PolynomialBatch::from_values / from_coeffs (fri/oracle.rs:45,66) ---
+ * iNTT -> coset LDE (shift 7, blowup 2^rate_bits) -> Poseidon leaf hashes -> Merkle cap, all on the device.
+ * cols: ncols host pointers (ola_commit_*) or one device buffer, column-major (ola_commit_*_dev).
+ * cap_out: 2^cap_height x 4 canonical elements (host).  *out_batch stays resident until ola_batch_free. */
+int32_t ola_commit_values(OlaCtx* ctx, const uint64_t* const* cols, uint32_t ncols, uint32_t log_n,
+                          OlaBatch** out_batch, uint64_t* cap_out);
+int32_t ola_commit_coeffs(OlaCtx* ctx, const uint64_t* const* cols, uint32_t ncols, uint32_t log_n,
+                          OlaBatch** out_batch, uint64_t* cap_out);
+int32_t ola_commit_values_dev(OlaCtx* ctx, const uint64_t* cols_dev, uint32_t ncols, uint32_t log_n,
+                              OlaBatch** out_batch, uint64_t* cap_out);
+int32_t ola_commit_coeffs_dev(OlaCtx* ctx, const uint64_t* cols_dev, uint32_t ncols, uint32_t log_n,
+                              OlaBatch** out_batch, uint64_t* cap_out);
+int32_t ola_batch_free(OlaCtx* ctx, OlaBatch* batch);
+/* accessors (PolynomialBatch.polynomials, MerkleTree::get / prove, merkle_tree/mod.rs:268-308) */
+int32_t ola_batch_shape(const OlaBatch* batch, uint32_t* ncols, uint32_t* log_n, uint32_t* rate_bits);
+int32_t ola_batch_get_coeffs(OlaCtx* ctx, const OlaBatch* batch, uint64_t* out /* ncols x n, column-major */);
+int32_t ola_batch_get_leaf(OlaCtx* ctx, const OlaBatch* batch, size_t leaf_index, uint64_t* row_out /* ncols */,
+                           uint64_t* siblings_out /* (log_n+rate_bits-cap_height) x 4 */);
+/* fri/oracle.rs:131-137 get_lde_values(index, step): natural-order LDE row index*step */
+int32_t ola_batch_get_lde_row(OlaCtx* ctx, const OlaBatch* batch, size_t index, size_t step, uint64_t* row_out);
+
+/* ---- openings + FRI: replaces StarkOpeningSet::new (circuits/src/stark/proof.rs:198-233),
+ * PolynomialBatch::prove_openings (fri/oracle.rs:167-241) and fri_proof (fri/prover.rs:20-204).
+ * The Fiat-Shamir transcript stays on the host: the caller passes the 12-element challenger state and the
+ * buffered inputs, and receives them back (iop/challenger.rs:36-162); see OlaChallenger. */
+typedef struct OlaChallenger {
+    uint64_t sponge_state[12];
+    uint64_t input_buffer[8];
+    uint64_t output_buffer[8];
+    uint32_t input_len;
+    uint32_t output_len;
+} OlaChallenger;
+
+int32_t ola_challenger_init(OlaChallenger* ch);
+int32_t ola_challenger_observe(OlaChallenger* ch, const uint64_t* elems, size_t n);
+int32_t ola_challenger_get(OlaChallenger* ch, uint64_t* out, size_t n);
+int32_t ola_challenger_compact(OlaChallenger* ch);
+
+/* The tail of prove_single_table from `zeta` on (prover.rs:499-553) for three resident commitments
+ * (trace, permutation/CTL Zs, quotient chunks): draws zeta, evaluates the opening set, observes it, runs FRI
+ * (commit phase, minimal proof-of-work nonce, 28 query rounds).  Output is the reference wire format
+ * (circuits/src/stark/serialization.rs:163-176 write_opening_set || :305-317 write_fri_proof).
+ * Returns OLA_E_INVALID_ARG with *out_len = required size when `cap` is too small (challenger is then unchanged). */
+int32_t ola_open_and_prove(OlaCtx* ctx, const OlaBatch* trace, const OlaBatch* zs, const OlaBatch* quotient,
+                           uint32_t num_permutation_zs, OlaChallenger* challenger, uint8_t* out, size_t cap,
+                           size_t* out_len, size_t* openings_len);
+
+/* FRI proof of work (fri/prover.rs:126-148): the MINIMAL witness i such that
+ * Poseidon.hash_no_pad([h0..h3, i])[0] has >= bits leading zeros. */
+int32_t ola_pow(OlaCtx* ctx, const uint64_t h[4], uint32_t bits, uint64_t* witness);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OLA_GPU_H */

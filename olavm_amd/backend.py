@@ -1,0 +1,257 @@
+"""ctypes binding of include/ola_gpu.h.  Plumbing only -- no arithmetic happens in Python."""
+import ctypes as C
+import os
+
+import numpy as np
+
+U64P = C.POINTER(C.c_uint64)
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+OLA_NTT_EVALUATE = 0
+OLA_NTT_INTERPOLATE = 1
+OLA_NTT_COSET_LDE = 2
+OLA_NTT_COSET_INTERPOLATE = 3
+OLA_NTT_COSET_LDE_LEAF_ORDER = 4
+
+
+class OlaGpuError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"ola_gpu error {code}: {msg}")
+        self.code = code
+
+
+class OlaGpuConfig(C.Structure):
+    _fields_ = [("device", C.c_int32), ("stream", C.c_void_p), ("rate_bits", C.c_uint32), ("cap_height", C.c_uint32),
+                ("proof_of_work_bits", C.c_uint32), ("fri_arity_bits", C.c_uint32), ("fri_final_poly_bits", C.c_uint32),
+                ("num_query_rounds", C.c_uint32), ("num_challenges", C.c_uint32)]
+
+
+class OlaChallenger(C.Structure):
+    _fields_ = [("sponge_state", C.c_uint64 * 12), ("input_buffer", C.c_uint64 * 8), ("output_buffer", C.c_uint64 * 8),
+                ("input_len", C.c_uint32), ("output_len", C.c_uint32)]
+
+
+def lib_path():
+    return os.path.join(_HERE, "lib", "libola_gpu.so")
+
+
+_lib = None
+
+
+def load_library():
+    """Load libola_gpu.so; raises if it has not been built (python __graft_entry__.py build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    p = lib_path()
+    if not os.path.exists(p):
+        raise OlaGpuError(-7, f"{p} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(the backend has no CPU fallback)")
+    L = C.CDLL(p)
+    L.ola_gpu_last_error.restype = C.c_char_p
+    L.ola_gpu_init.argtypes = [C.POINTER(OlaGpuConfig), C.POINTER(C.c_void_p)]
+    L.ola_gpu_free.argtypes = [C.c_void_p]
+    L.ola_gpu_sync.argtypes = [C.c_void_p]
+    L.ola_ntt_batch.argtypes = [C.c_void_p, C.c_int32, U64P, U64P, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32]
+    L.ola_ntt_batch_dev.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,
+                                    C.c_uint64, C.c_uint32]
+    L.ola_poseidon_permute.argtypes = [C.c_void_p, U64P, C.c_size_t]
+    L.ola_hash_rows.argtypes = [C.c_void_p, U64P, C.c_size_t, C.c_size_t, U64P]
+    L.ola_merkle_cap.argtypes = [C.c_void_p, U64P, C.c_size_t, C.c_size_t, C.c_uint32, U64P]
+    L.ola_pow.argtypes = [C.c_void_p, U64P, C.c_uint32, U64P]
+    for f in ("ola_commit_values", "ola_commit_coeffs"):
+        getattr(L, f).argtypes = [C.c_void_p, C.POINTER(U64P), C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p), U64P]
+    for f in ("ola_commit_values_dev", "ola_commit_coeffs_dev"):
+        getattr(L, f).argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p), U64P]
+    L.ola_batch_free.argtypes = [C.c_void_p, C.c_void_p]
+    L.ola_batch_shape.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    L.ola_batch_get_coeffs.argtypes = [C.c_void_p, C.c_void_p, U64P]
+    L.ola_batch_get_leaf.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, U64P, U64P]
+    L.ola_batch_get_lde_row.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, U64P]
+    L.ola_challenger_init.argtypes = [C.POINTER(OlaChallenger)]
+    L.ola_challenger_observe.argtypes = [C.POINTER(OlaChallenger), U64P, C.c_size_t]
+    L.ola_challenger_get.argtypes = [C.POINTER(OlaChallenger), U64P, C.c_size_t]
+    L.ola_challenger_compact.argtypes = [C.POINTER(OlaChallenger)]
+    L.ola_open_and_prove.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(OlaChallenger),
+                                     C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+    _lib = L
+    return L
+
+
+EXPORTS = [
+    "ola_gpu_init", "ola_gpu_free", "ola_gpu_last_error", "ola_gpu_sync", "ola_ntt_batch", "ola_ntt_batch_dev",
+    "ola_poseidon_permute", "ola_hash_rows", "ola_merkle_cap", "ola_commit_values", "ola_commit_coeffs",
+    "ola_commit_values_dev", "ola_commit_coeffs_dev", "ola_batch_free", "ola_batch_shape", "ola_batch_get_coeffs",
+    "ola_batch_get_leaf", "ola_batch_get_lde_row", "ola_challenger_init", "ola_challenger_observe",
+    "ola_challenger_get", "ola_challenger_compact", "ola_open_and_prove", "ola_pow",
+]
+
+
+def _p(a):
+    return a.ctypes.data_as(U64P)
+
+
+class Challenger:
+    """Host-side Fiat-Shamir transcript (iop/challenger.rs:36-162), state lives in an OlaChallenger struct."""
+
+    def __init__(self, lib=None):
+        self.lib = lib or load_library()
+        self.c = OlaChallenger()
+        self.lib.ola_challenger_init(C.byref(self.c))
+
+    def observe(self, elems):
+        e = np.ascontiguousarray(elems, dtype=np.uint64).ravel()
+        self.lib.ola_challenger_observe(C.byref(self.c), _p(e), e.size)
+
+    def get(self, n=None):
+        out = np.empty(1 if n is None else n, dtype=np.uint64)
+        self.lib.ola_challenger_get(C.byref(self.c), _p(out), out.size)
+        return int(out[0]) if n is None else out
+
+    def compact(self):
+        self.lib.ola_challenger_compact(C.byref(self.c))
+
+    def state(self):
+        return np.array(list(self.c.sponge_state), dtype=np.uint64)
+
+    def clone(self):
+        o = Challenger(self.lib)
+        C.memmove(C.byref(o.c), C.byref(self.c), C.sizeof(OlaChallenger))
+        return o
+
+
+class Batch:
+    """A committed PolynomialBatch resident in HBM (fri/oracle.rs:31-39)."""
+
+    def __init__(self, be, handle, cap):
+        self.be, self.h, self._cap = be, handle, cap
+        a, b, c = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        be._chk(be.lib.ola_batch_shape(handle, C.byref(a), C.byref(b), C.byref(c)))
+        self.ncols, self.log_n, self.rate_bits = a.value, b.value, c.value
+
+    def cap(self):
+        return self._cap
+
+    def coeffs(self):
+        out = np.empty((self.ncols, 1 << self.log_n), dtype=np.uint64)
+        self.be._chk(self.be.lib.ola_batch_get_coeffs(self.be.ctx, self.h, _p(out)))
+        return out
+
+    def leaf(self, index):
+        depth = self.log_n + self.rate_bits - self.be.cap_height
+        row = np.empty(self.ncols, dtype=np.uint64)
+        sib = np.empty((max(depth, 0), 4), dtype=np.uint64)
+        self.be._chk(self.be.lib.ola_batch_get_leaf(self.be.ctx, self.h, index, _p(row), _p(sib) if depth > 0 else None))
+        return row, sib
+
+    def lde_row(self, index, step=1):
+        row = np.empty(self.ncols, dtype=np.uint64)
+        self.be._chk(self.be.lib.ola_batch_get_lde_row(self.be.ctx, self.h, index, step, _p(row)))
+        return row
+
+    def free(self):
+        if self.h:
+            self.be.lib.ola_batch_free(self.be.ctx, self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Backend:
+    """One OlaCtx.  `stream` may be a raw hipStream_t (e.g. torch.cuda.current_stream().cuda_stream)."""
+
+    def __init__(self, device=-1, stream=None, **cfg):
+        self.lib = load_library()
+        c = OlaGpuConfig(device, stream, cfg.get("rate_bits", 3), cfg.get("cap_height", 4),
+                         cfg.get("proof_of_work_bits", 16), cfg.get("fri_arity_bits", 4),
+                         cfg.get("fri_final_poly_bits", 5), cfg.get("num_query_rounds", 28), cfg.get("num_challenges", 2))
+        self.cap_height = c.cap_height
+        self.rate_bits = c.rate_bits
+        self.ctx = C.c_void_p()
+        self._chk(self.lib.ola_gpu_init(C.byref(c), C.byref(self.ctx)))
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise OlaGpuError(rc, (self.lib.ola_gpu_last_error() or b"").decode())
+
+    def close(self):
+        if self.ctx:
+            self.lib.ola_gpu_free(self.ctx)
+            self.ctx = None
+
+    def sync(self):
+        self._chk(self.lib.ola_gpu_sync(self.ctx))
+
+    # ---- NTT (host arrays, shape (batch, n)) ----
+    def ntt(self, op, data, shift=7, blowup_log=0):
+        d = np.ascontiguousarray(data, dtype=np.uint64)
+        if d.ndim == 1:
+            d = d[None, :]
+        batch, n = d.shape
+        log_n = int(n).bit_length() - 1
+        grows = op in (OLA_NTT_COSET_LDE, OLA_NTT_COSET_LDE_LEAF_ORDER)
+        out = np.empty((batch, n << blowup_log if grows else n), dtype=np.uint64)
+        self._chk(self.lib.ola_ntt_batch(self.ctx, op, _p(d), _p(out), log_n, batch, shift, blowup_log))
+        return out
+
+    def ntt_dev(self, op, in_ptr, out_ptr, log_n, batch, shift=7, blowup_log=0, scratch_ptr=None):
+        self._chk(self.lib.ola_ntt_batch_dev(self.ctx, op, in_ptr, out_ptr, scratch_ptr, log_n, batch, shift, blowup_log))
+
+    # ---- hashing ----
+    def poseidon(self, states):
+        s = np.array(states, dtype=np.uint64).reshape(-1, 12)
+        self._chk(self.lib.ola_poseidon_permute(self.ctx, _p(s), s.shape[0]))
+        return s
+
+    def hash_rows(self, rows):
+        r = np.ascontiguousarray(rows, dtype=np.uint64)
+        out = np.empty((r.shape[0], 4), dtype=np.uint64)
+        self._chk(self.lib.ola_hash_rows(self.ctx, _p(r), r.shape[0], r.shape[1], _p(out)))
+        return out
+
+    def merkle_cap(self, leaves, cap_height):
+        lv = np.ascontiguousarray(leaves, dtype=np.uint64)
+        out = np.empty((1 << cap_height, 4), dtype=np.uint64)
+        self._chk(self.lib.ola_merkle_cap(self.ctx, _p(lv), lv.shape[0], lv.shape[1], cap_height, _p(out)))
+        return out
+
+    def pow(self, h4, bits=16):
+        h = np.ascontiguousarray(h4, dtype=np.uint64)
+        w = np.zeros(1, dtype=np.uint64)
+        self._chk(self.lib.ola_pow(self.ctx, _p(h), bits, _p(w)))
+        return int(w[0])
+
+    # ---- commitments ----
+    def commit(self, cols, from_coeffs=False):
+        cols = np.ascontiguousarray(cols, dtype=np.uint64)
+        ncols, n = cols.shape
+        ptrs = (U64P * ncols)(*[cols[i].ctypes.data_as(U64P) for i in range(ncols)])
+        h = C.c_void_p()
+        cap = np.empty((1 << self.cap_height, 4), dtype=np.uint64)
+        f = self.lib.ola_commit_coeffs if from_coeffs else self.lib.ola_commit_values
+        self._chk(f(self.ctx, ptrs, ncols, int(n).bit_length() - 1, C.byref(h), _p(cap)))
+        return Batch(self, h, cap)
+
+    def commit_dev(self, dev_ptr, ncols, log_n, from_coeffs=False):
+        h = C.c_void_p()
+        cap = np.empty((1 << self.cap_height, 4), dtype=np.uint64)
+        f = self.lib.ola_commit_coeffs_dev if from_coeffs else self.lib.ola_commit_values_dev
+        self._chk(f(self.ctx, dev_ptr, ncols, log_n, C.byref(h), _p(cap)))
+        return Batch(self, h, cap)
+
+    def open_and_prove(self, trace, zs, quot, num_permutation_zs, challenger):
+        need, olen = C.c_size_t(0), C.c_size_t(0)
+        cap = 1 << 16
+        while True:
+            buf = C.create_string_buffer(cap)
+            rc = self.lib.ola_open_and_prove(self.ctx, trace.h, zs.h, quot.h, num_permutation_zs, C.byref(challenger.c), buf, cap,
+                                             C.byref(need), C.byref(olen))
+            if rc != 0 and need.value > cap:
+                cap = need.value
+                continue
+            self._chk(rc)
+            return bytes(buf.raw[:olen.value]), bytes(buf.raw[olen.value:need.value])

@@ -1,0 +1,172 @@
+// PolynomialBatch on the device: coefficient form + coset LDE in commitment-leaf order + Poseidon Merkle heap.
+//
+// Replaces PolynomialBatch::{from_values, from_coeffs, get_lde_values} and MerkleTree::{get, prove}
+//   plonky2/plonky2/src/fri/oracle.rs:45-139, plonky2/plonky2/src/hash/merkle_tree/mod.rs:268-308
+// The reference materialises row-major leaves (transpose + reverse_index_bits_in_place, oracle.rs:84-85); here the
+// LDE stays column-major in HBM and is produced directly in leaf order by the in-place DIF transform:
+//   lde[col][c*n + r] = P_col(7 * g^bitrev(c) * w_n^bitrev_n(r))  ==  natural LDE row bitrev_N(c*n + r).
+#include <hip/hip_runtime.h>
+
+#include <vector>
+
+#include "device_ctx.h"
+#include "gl.cuh"
+
+struct OlaBatch {
+    uint32_t ncols = 0, log_n = 0, rate_bits = 0, cap_height = 0;
+    ola::u64* coeffs = nullptr;  // [ncols][n], natural coefficient order
+    ola::u64* lde = nullptr;     // [ncols][N], leaf order
+    ola::u64* heap = nullptr;    // 2N digests of 4 u64, heap[N + j] = leaf j, root at 1
+    size_t n() const { return (size_t)1 << log_n; }
+    size_t num_leaves() const { return (size_t)1 << (log_n + rate_bits); }
+};
+
+namespace ola {
+
+__global__ __launch_bounds__(256) void bitrev_rows_kernel(const u64* __restrict__ in, u64* __restrict__ out, int bits) {
+    const size_t N = (size_t)1 << bits;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const size_t col = blockIdx.y;
+    out[col * N + i] = in[col * N + bitrev32((u32)i, bits)];
+}
+void launch_bitrev_rows(DeviceCtx* ctx, const u64* in, u64* out, int bits, size_t cols) {
+    const size_t N = (size_t)1 << bits;
+    hipLaunchKernelGGL(bitrev_rows_kernel, dim3((unsigned)((N + 255) / 256), (unsigned)cols), dim3(256), 0, ctx->stream,
+                       in, out, bits);
+}
+
+// data[col][k] *= s^k  (two-level table of s)
+__global__ __launch_bounds__(256) void scale_powers_kernel(u64* __restrict__ data, size_t n, const u64* __restrict__ lo,
+                                                           const u64* __restrict__ hi, int h) {
+    const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const size_t col = blockIdx.y;
+    const u64 s = gl_mul(lo[k & (((size_t)1 << h) - 1)], hi[k >> h]);
+    data[col * n + k] = gl_mul(data[col * n + k], s);
+}
+
+// values on shift*<w_n> (natural order) -> coefficients (cfft/serial.rs:64-78)
+void ntt_coset_interpolate(NttTables& t, const u64* values, u64* coeffs, u64* scratch, int L, size_t cols, u64 shift) {
+    const size_t n = (size_t)1 << L;
+    ntt_interpolate(t, values, coeffs, scratch, L, cols);
+    TwoLevel sc = get_shift(t, L, gl_inv(shift));
+    hipLaunchKernelGGL(scale_powers_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)cols), dim3(256), 0,
+                       t.ctx->stream, coeffs, n, sc.lo, sc.hi, sc.h);
+}
+
+// rows_out[q][c] = lde[c][idx[q]]
+__global__ void gather_rows_kernel(const u64* __restrict__ lde, size_t col_stride, int ncols,
+                                   const unsigned long long* __restrict__ idx, u64* __restrict__ rows_out) {
+    const int q = blockIdx.x;
+    for (int c = threadIdx.x; c < ncols; c += blockDim.x) rows_out[(size_t)q * ncols + c] = lde[(size_t)c * col_stride + idx[q]];
+}
+// paths_out[q][l] = sibling digest at level l (leaf level first), depth = log2(N) - cap_height
+__global__ void gather_paths_kernel(const u64* __restrict__ heap, size_t N, int depth,
+                                    const unsigned long long* __restrict__ idx, u64* __restrict__ paths_out) {
+    const int q = blockIdx.x;
+    const int l = threadIdx.x >> 2, w = threadIdx.x & 3;
+    if (l >= depth) return;
+    const size_t node = ((N + idx[q]) >> l) ^ 1;
+    paths_out[((size_t)q * depth + l) * 4 + w] = heap[node * 4 + w];
+}
+
+__global__ __launch_bounds__(256) void canonicalize_kernel(u64* __restrict__ d, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) d[i] = gl_canon(d[i]);
+}
+void canonicalize(DeviceCtx* ctx, u64* d, size_t n) {
+    hipLaunchKernelGGL(canonicalize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d, n);
+}
+
+void batch_destroy(DeviceCtx* ctx, OlaBatch* b) {
+    if (!b) return;
+    ctx->free(b->coeffs);
+    ctx->free(b->lde);
+    ctx->free(b->heap);
+    delete b;
+}
+
+OlaBatch* batch_commit(DeviceCtx* ctx, NttTables& t, const uint64_t* const* cols_host, const u64* cols_dev, uint32_t ncols,
+                       uint32_t log_n, uint32_t rate_bits, uint32_t cap_height, bool from_values) {
+    OlaBatch* b = new OlaBatch();
+    b->ncols = ncols; b->log_n = log_n; b->rate_bits = rate_bits; b->cap_height = cap_height;
+    const size_t n = b->n(), N = b->num_leaves();
+    u64* tmp = nullptr;
+    try {
+        b->coeffs = (u64*)ctx->alloc((size_t)ncols * n * 8);
+        b->lde = (u64*)ctx->alloc((size_t)ncols * N * 8);
+        b->heap = (u64*)ctx->alloc(2 * N * 32);
+        // staging inside the (not yet written) LDE buffer: values at [0, ncols*n), transform scratch after it
+        u64* stage = b->lde;
+        u64* scratch = b->lde + (size_t)ncols * n;
+        if (rate_bits == 0) { tmp = (u64*)ctx->alloc((size_t)ncols * n * 8); scratch = tmp; }
+        if (from_values) {
+            const u64* vals = cols_dev;
+            if (cols_host) {
+                for (uint32_t c = 0; c < ncols; c++)
+                    HIP_CHECK(hipMemcpyAsync(stage + (size_t)c * n, cols_host[c], n * 8, hipMemcpyHostToDevice, ctx->stream));
+                vals = stage;
+            }
+            if (rate_bits == 0 && cols_host) {  // stage and lde coincide with the LDE output: go through tmp
+                ntt_interpolate(t, vals, b->coeffs, scratch, log_n, ncols);
+            } else {
+                ntt_interpolate(t, vals, b->coeffs, scratch, log_n, ncols);
+            }
+        } else {
+            if (cols_host) {
+                for (uint32_t c = 0; c < ncols; c++)
+                    HIP_CHECK(hipMemcpyAsync(b->coeffs + (size_t)c * n, cols_host[c], n * 8, hipMemcpyHostToDevice, ctx->stream));
+            } else {
+                HIP_CHECK(hipMemcpyAsync(b->coeffs, cols_dev, (size_t)ncols * n * 8, hipMemcpyDeviceToDevice, ctx->stream));
+            }
+            canonicalize(ctx, b->coeffs, (size_t)ncols * n);
+        }
+        ntt_lde_leaf_order(t, b->coeffs, b->lde, log_n, rate_bits, ncols);
+        launch_leaf_hash_colmajor(ctx, b->lde, N, (int)ncols, N, b->heap + 4 * N);
+        launch_merkle_build(ctx, b->heap, N);
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        if (tmp) ctx->free(tmp);
+    } catch (...) {
+        if (tmp) ctx->free(tmp);
+        batch_destroy(ctx, b);
+        throw;
+    }
+    return b;
+}
+
+void batch_read_cap(DeviceCtx* ctx, const OlaBatch& b, u64* cap_out) {
+    const size_t len_cap = (size_t)1 << b.cap_height;
+    // merkle_tree/mod.rs:218-226: the cap is the level with 2^cap_height nodes (the leaf digests if the tree is all cap)
+    HIP_CHECK(hipMemcpyAsync(cap_out, b.heap + 4 * len_cap, len_cap * 32, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+}
+
+// rows_out: nq x ncols, paths_out: nq x depth x 4 (either may be null)
+void batch_get_leaves(DeviceCtx* ctx, const OlaBatch& b, const size_t* idx, size_t nq, u64* rows_out, u64* paths_out) {
+    const size_t N = b.num_leaves();
+    const int depth = (int)(b.log_n + b.rate_bits - b.cap_height);
+    std::vector<unsigned long long> h_idx(idx, idx + nq);
+    unsigned long long* d_idx = (unsigned long long*)ctx->alloc(nq * 8);
+    u64* d_rows = (u64*)ctx->alloc(nq * b.ncols * 8);
+    u64* d_paths = (u64*)ctx->alloc(nq * (size_t)(depth > 0 ? depth : 1) * 32);
+    try {
+        HIP_CHECK(hipMemcpyAsync(d_idx, h_idx.data(), nq * 8, hipMemcpyHostToDevice, ctx->stream));
+        if (rows_out) {
+            hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)nq), dim3(64), 0, ctx->stream, b.lde, N, (int)b.ncols, d_idx, d_rows);
+            HIP_CHECK(hipMemcpyAsync(rows_out, d_rows, nq * b.ncols * 8, hipMemcpyDeviceToHost, ctx->stream));
+        }
+        if (paths_out && depth > 0) {
+            hipLaunchKernelGGL(gather_paths_kernel, dim3((unsigned)nq), dim3(((depth * 4 + 63) / 64) * 64), 0, ctx->stream,
+                               b.heap, N, depth, d_idx, d_paths);
+            HIP_CHECK(hipMemcpyAsync(paths_out, d_paths, nq * (size_t)depth * 32, hipMemcpyDeviceToHost, ctx->stream));
+        }
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    } catch (...) { ctx->free(d_idx); ctx->free(d_rows); ctx->free(d_paths); throw; }
+    ctx->free(d_idx); ctx->free(d_rows); ctx->free(d_paths);
+}
+void batch_get_leaf(DeviceCtx* ctx, const OlaBatch& b, size_t leaf, u64* row_out, u64* sib_out) {
+    batch_get_leaves(ctx, b, &leaf, 1, row_out, sib_out);
+}
+
+}  // namespace ola

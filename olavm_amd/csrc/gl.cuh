@@ -1,0 +1,131 @@
+// Goldilocks field arithmetic for the MI355X proving backend (host + gfx950 device).
+// p = 2^64 - 2^32 + 1.  Values held in registers/LDS/HBM are CANONICAL (< p) unless a function says otherwise;
+// everything written back to the caller is canonical, matching what the reference serialises
+// (reference semantics: plonky2/field/src/goldilocks_field.rs:191-355 -- add/sub/mul/reduce128; the reference keeps
+// non-canonical u64 in memory and canonicalises at the boundary, the exact value mod p is identical).
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define GL_HD __host__ __device__ __forceinline__
+#else
+#define GL_HD inline
+#endif
+
+namespace ola {
+
+typedef unsigned long long u64;
+typedef unsigned int u32;
+
+static const u64 GL_P = 0xFFFFFFFF00000001ull;
+static const u64 GL_EPS = 0xFFFFFFFFull;  // 2^64 mod p = 2^32 - 1
+static const u64 GL_GENERATOR = 7;        // multiplicative generator == coset shift (types.rs:430)
+static const u64 GL_POWER_OF_TWO_GENERATOR = 1753635133440165772ull;
+
+GL_HD u64 gl_canon(u64 x) { return x >= GL_P ? x - GL_P : x; }
+
+// a, b canonical -> canonical.  a+b < 2p < 2^65: subtract p when the 64-bit add carried or the sum >= p,
+// the latter detected as a carry out of (s + EPS) since p + EPS = 2^64.
+GL_HD u64 gl_add(u64 a, u64 b) {
+    u64 s = a + b;
+    u64 t = s + GL_EPS;
+    bool c = (s < a) | (t < s);
+    return c ? t : s;
+}
+// a, b canonical -> canonical.
+GL_HD u64 gl_sub(u64 a, u64 b) {
+    u64 d = a - b;
+    return (a < b) ? d - GL_EPS : d;  // + p == - EPS (mod 2^64)
+}
+GL_HD u64 gl_neg(u64 a) { return a ? GL_P - a : 0; }
+
+// 64x64 -> 128 multiply
+GL_HD void mul_wide(u64 a, u64 b, u64& lo, u64& hi) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    lo = a * b;
+    hi = __umul64hi(a, b);
+#else
+    unsigned __int128 p = (unsigned __int128)a * b;
+    lo = (u64)p;
+    hi = (u64)(p >> 64);
+#endif
+}
+
+// (hi*2^64 + lo) mod p, canonical.  Uses 2^64 = 2^32 - 1 and 2^96 = -1 (mod p).
+GL_HD u64 gl_reduce128(u64 lo, u64 hi) {
+    u64 hh = hi >> 32, hl = hi & GL_EPS;
+    u64 t0 = lo - hh;
+    if (lo < hh) t0 -= GL_EPS;          // wrapped: add p
+    u64 t1 = (hl << 32) - hl;           // hl * (2^32 - 1) < 2^64
+    u64 t2 = t0 + t1;
+    if (t2 < t0) t2 += GL_EPS;          // wrapped: subtract 2^64 = add -(2^64) = add EPS... (2^64 = EPS mod p)
+    return gl_canon(t2);
+}
+
+GL_HD u64 gl_mul(u64 a, u64 b) {
+    u64 lo, hi;
+    mul_wide(a, b, lo, hi);
+    return gl_reduce128(lo, hi);
+}
+GL_HD u64 gl_sqr(u64 a) { return gl_mul(a, a); }
+
+GL_HD u64 gl_pow(u64 b, u64 e) {
+    u64 r = 1;
+    while (e) {
+        if (e & 1) r = gl_mul(r, b);
+        b = gl_mul(b, b);
+        e >>= 1;
+    }
+    return r;
+}
+GL_HD u64 gl_inv(u64 a) { return gl_pow(a, GL_P - 2); }
+
+// primitive 2^k-th root of unity the reference uses (types.rs:240-244)
+GL_HD u64 gl_root_of_unity(int k) {
+    u64 r = GL_POWER_OF_TWO_GENERATOR;
+    for (int i = 0; i < 32 - k; i++) r = gl_mul(r, r);
+    return r;
+}
+
+GL_HD u32 bitrev32(u32 x, int bits) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return bits ? (__brev(x) >> (32 - bits)) : 0;
+#else
+    u32 r = 0;
+    for (int i = 0; i < bits; i++) r |= ((x >> i) & 1u) << (bits - 1 - i);
+    return r;
+#endif
+}
+
+// ---- quadratic extension F_p[X]/(X^2 - 7)  (goldilocks_extensions.rs:14-28) ----
+struct Ext2 {
+    u64 a, b;
+};
+GL_HD Ext2 ext_make(u64 a, u64 b) { Ext2 r; r.a = a; r.b = b; return r; }
+GL_HD Ext2 ext_add(Ext2 x, Ext2 y) { return ext_make(gl_add(x.a, y.a), gl_add(x.b, y.b)); }
+GL_HD Ext2 ext_sub(Ext2 x, Ext2 y) { return ext_make(gl_sub(x.a, y.a), gl_sub(x.b, y.b)); }
+GL_HD Ext2 ext_mul(Ext2 x, Ext2 y) {
+    u64 bb = gl_mul(x.b, y.b);
+    u64 bb7 = gl_sub(gl_mul(bb, 8), bb);
+    return ext_make(gl_add(gl_mul(x.a, y.a), bb7), gl_add(gl_mul(x.a, y.b), gl_mul(x.b, y.a)));
+}
+GL_HD Ext2 ext_scalar_mul(Ext2 x, u64 s) { return ext_make(gl_mul(x.a, s), gl_mul(x.b, s)); }
+GL_HD bool ext_eq(Ext2 x, Ext2 y) { return x.a == y.a && x.b == y.b; }
+GL_HD Ext2 ext_inv(Ext2 x) {
+    u64 bb = gl_mul(x.b, x.b);
+    u64 n = gl_sub(gl_mul(x.a, x.a), gl_sub(gl_mul(bb, 8), bb));
+    u64 ni = gl_inv(n);
+    return ext_make(gl_mul(x.a, ni), gl_mul(gl_neg(x.b), ni));
+}
+GL_HD Ext2 ext_pow(Ext2 b, u64 e) {
+    Ext2 r = ext_make(1, 0);
+    while (e) {
+        if (e & 1) r = ext_mul(r, b);
+        b = ext_mul(b, b);
+        e >>= 1;
+    }
+    return r;
+}
+
+}  // namespace ola

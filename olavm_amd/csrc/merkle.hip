@@ -1,0 +1,166 @@
+// Poseidon-Goldilocks sponge + Merkle tree kernels for gfx950.
+//
+// Replaces (reference, relative to plonky2/plonky2/src/hash):
+//   hashing.rs:84-107            hash_n_to_m_no_pad  -- overwrite-mode sponge, rate 8, 4-element digest
+//   hashing.rs:66-74             compress / two_to_one = permute(l || r || 0)[0..4]
+//   merkle_tree/mod.rs:180-226   MerkleTree::new_v2: every leaf hashed with hash_no_pad; heap-ordered nodes;
+//                                cap = level with 2^cap_height nodes
+// Layout in HBM: `heap` holds 2N digests of 4 u64: heap[N + j] = digest of leaf j, heap[i] = H(heap[2i], heap[2i+1]),
+// root at 1 (heap[0] unused).  Sibling paths for MerkleTree::prove (mod.rs:273-308) are read straight off the heap, so
+// the reference's per-cap-subtree `digests` relayout (mod.rs:228-259) is never materialised.
+// Leaves are read column-major ([col][leaf]) so consecutive lanes read consecutive addresses.
+#include <hip/hip_runtime.h>
+
+#include "device_ctx.h"
+#include "gl.cuh"
+#include "poseidon.cuh"
+
+namespace ola {
+
+// leaf j = (cols[0][j], cols[1][j], ...), column c at base + c*col_stride
+__global__ __launch_bounds__(256) void leaf_hash_colmajor_kernel(const u64* __restrict__ base, size_t col_stride,
+                                                                  int ncols, size_t num_leaves, u64* __restrict__ out) {
+    const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= num_leaves) return;
+    u64 s[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) s[i] = 0;
+    for (int c0 = 0; c0 < ncols; c0 += 8) {
+        const int len = min(8, ncols - c0);
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+            if (i < len) s[i] = gl_canon(base[(size_t)(c0 + i) * col_stride + j]);
+        poseidon_permute(s);
+    }
+    ulonglong2* o = reinterpret_cast<ulonglong2*>(out + j * 4);
+    o[0] = make_ulonglong2(s[0], s[1]);
+    o[1] = make_ulonglong2(s[2], s[3]);
+}
+
+// leaf j = row j of a row-major matrix (rows of row_len elements)
+__global__ __launch_bounds__(256) void leaf_hash_rowmajor_kernel(const u64* __restrict__ rows, size_t row_len,
+                                                                  size_t num_leaves, u64* __restrict__ out) {
+    const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= num_leaves) return;
+    const u64* r = rows + j * row_len;
+    u64 s[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) s[i] = 0;
+    for (size_t c0 = 0; c0 < row_len; c0 += 8) {
+        const int len = (int)min((size_t)8, row_len - c0);
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+            if (i < len) s[i] = gl_canon(r[c0 + i]);
+        poseidon_permute(s);
+    }
+    ulonglong2* o = reinterpret_cast<ulonglong2*>(out + j * 4);
+    o[0] = make_ulonglong2(s[0], s[1]);
+    o[1] = make_ulonglong2(s[2], s[3]);
+}
+
+// FRI commit-phase leaves (fri/prover.rs:90-96): leaf j = flatten(16 consecutive bit-reversed extension values) =
+// (a[16j], b[16j], a[16j+1], b[16j+1], ...) with the extension field stored as two planes.
+__global__ __launch_bounds__(256) void leaf_hash_ext_kernel(const u64* __restrict__ plane_a,
+                                                            const u64* __restrict__ plane_b, int arity,
+                                                            size_t num_leaves, u64* __restrict__ out) {
+    const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= num_leaves) return;
+    u64 s[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) s[i] = 0;
+    for (int k0 = 0; k0 < arity; k0 += 4) {  // 4 extension elements = 8 sponge lanes per permutation
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (k0 + k < arity) {
+                s[2 * k] = plane_a[j * arity + k0 + k];
+                s[2 * k + 1] = plane_b[j * arity + k0 + k];
+            }
+        }
+        poseidon_permute(s);
+    }
+    ulonglong2* o = reinterpret_cast<ulonglong2*>(out + j * 4);
+    o[0] = make_ulonglong2(s[0], s[1]);
+    o[1] = make_ulonglong2(s[2], s[3]);
+}
+
+// parents [first, first+count) of a heap-ordered digest array
+__global__ __launch_bounds__(256) void merkle_level_kernel(u64* __restrict__ heap, size_t first, size_t count) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= count) return;
+    const size_t i = first + t;
+    const ulonglong2* ch = reinterpret_cast<const ulonglong2*>(heap + 8 * i);  // children 2i, 2i+1 are adjacent
+    const ulonglong2 c0 = ch[0], c1 = ch[1], c2 = ch[2], c3 = ch[3];
+    u64 s[12] = {c0.x, c0.y, c1.x, c1.y, c2.x, c2.y, c3.x, c3.y, 0, 0, 0, 0};
+    poseidon_permute(s);
+    ulonglong2* o = reinterpret_cast<ulonglong2*>(heap + 4 * i);
+    o[0] = make_ulonglong2(s[0], s[1]);
+    o[1] = make_ulonglong2(s[2], s[3]);
+}
+
+__global__ __launch_bounds__(256) void poseidon_states_kernel(u64* __restrict__ states, size_t n) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    u64 s[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) s[i] = gl_canon(states[t * 12 + i]);
+    poseidon_permute(s);
+#pragma unroll
+    for (int i = 0; i < 12; i++) states[t * 12 + i] = s[i];
+}
+
+// FRI proof of work (fri/prover.rs:126-148): each thread tries nonce = start + global id; the minimum satisfying
+// nonce of the batch is kept with an atomicMin.
+__global__ __launch_bounds__(256) void pow_kernel(u64 h0, u64 h1, u64 h2, u64 h3, u64 start, u32 bits,
+                                                  unsigned long long* __restrict__ best) {
+    const u64 nonce = start + (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    u64 s[12] = {h0, h1, h2, h3, nonce, 0, 0, 0, 0, 0, 0, 0};
+    poseidon_permute(s);
+    if ((s[0] >> (64 - bits)) == 0) atomicMin(best, (unsigned long long)nonce);
+}
+
+// ---- host launchers ----
+void poseidon_init(DeviceCtx*) { poseidon_upload_constants(); }
+
+void launch_leaf_hash_colmajor(DeviceCtx* ctx, const u64* base, size_t col_stride, int ncols, size_t num_leaves,
+                               u64* out) {
+    const unsigned blocks = (unsigned)((num_leaves + 255) / 256);
+    hipLaunchKernelGGL(leaf_hash_colmajor_kernel, dim3(blocks), dim3(256), 0, ctx->stream, base, col_stride, ncols,
+                       num_leaves, out);
+}
+void launch_leaf_hash_rowmajor(DeviceCtx* ctx, const u64* rows, size_t row_len, size_t num_leaves, u64* out) {
+    const unsigned blocks = (unsigned)((num_leaves + 255) / 256);
+    hipLaunchKernelGGL(leaf_hash_rowmajor_kernel, dim3(blocks), dim3(256), 0, ctx->stream, rows, row_len, num_leaves, out);
+}
+void launch_leaf_hash_ext(DeviceCtx* ctx, const u64* pa, const u64* pb, int arity, size_t num_leaves, u64* out) {
+    const unsigned blocks = (unsigned)((num_leaves + 255) / 256);
+    hipLaunchKernelGGL(leaf_hash_ext_kernel, dim3(blocks), dim3(256), 0, ctx->stream, pa, pb, arity, num_leaves, out);
+}
+// heap[N..2N) must hold the leaf digests; fills heap[1..N)
+void launch_merkle_build(DeviceCtx* ctx, u64* heap, size_t num_leaves) {
+    for (size_t level = num_leaves / 2; level >= 1; level /= 2) {
+        const unsigned blocks = (unsigned)((level + 255) / 256);
+        hipLaunchKernelGGL(merkle_level_kernel, dim3(blocks), dim3(256), 0, ctx->stream, heap, level, level);
+    }
+}
+void launch_poseidon_states(DeviceCtx* ctx, u64* states, size_t n) {
+    const unsigned blocks = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(poseidon_states_kernel, dim3(blocks), dim3(256), 0, ctx->stream, states, n);
+}
+// minimal nonce with `bits` leading zeros; scans batches of 2^20 nonces in increasing order
+u64 run_pow(DeviceCtx* ctx, const u64 h[4], u32 bits) {
+    unsigned long long* d_best = (unsigned long long*)ctx->alloc(8);
+    const unsigned long long none = ~0ull;
+    unsigned long long best = none;
+    const u64 batch = 1ull << 20;
+    for (u64 start = 0; best == none; start += batch) {
+        HIP_CHECK(hipMemcpyAsync(d_best, &none, 8, hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(pow_kernel, dim3((unsigned)(batch / 256)), dim3(256), 0, ctx->stream, h[0], h[1], h[2], h[3],
+                           start, bits, d_best);
+        HIP_CHECK(hipMemcpyAsync(&best, d_best, 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    }
+    ctx->free(d_best);
+    return best;
+}
+
+}  // namespace ola

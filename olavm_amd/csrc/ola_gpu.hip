@@ -1,0 +1,333 @@
+// C ABI of the backend (include/ola_gpu.h) -- the single translation unit that is compiled into libola_gpu.so.
+// Everything below the `extern "C"` layer is C++/HIP; errors are caught here and turned into status codes.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/ola_gpu.h"
+#include "device_ctx.h"
+#include "gl.cuh"
+#include "poseidon_host.h"
+
+// unity build: device code shares the __constant__ Poseidon tables
+#include "ntt.hip"
+#include "merkle.hip"
+#include "batch.hip"
+#include "fri.hip"
+
+using namespace ola;
+
+static thread_local std::string g_last_error;
+
+struct OlaCtx {
+    DeviceCtx dev;
+    NttTables* tables = nullptr;
+    OlaGpuConfig cfg;
+};
+
+#define OLA_TRY try {
+#define OLA_CATCH                                                   \
+    }                                                               \
+    catch (const OlaError& e) { g_last_error = e.what(); return e.code; } \
+    catch (const std::bad_alloc&) { g_last_error = "host out of memory"; return OLA_E_OOM; } \
+    catch (const std::exception& e) { g_last_error = e.what(); return OLA_E_INTERNAL; } \
+    return OLA_OK;
+
+static void require(bool ok, const char* what) {
+    if (!ok) throw OlaError(OLA_E_INVALID_ARG, std::string("invalid argument: ") + what);
+}
+
+extern "C" {
+
+const char* ola_gpu_last_error(void) { return g_last_error.c_str(); }
+
+int32_t ola_gpu_init(const OlaGpuConfig* cfg, OlaCtx** out_ctx) {
+    OLA_TRY
+    require(out_ctx != nullptr, "out_ctx is NULL");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        throw OlaError(OLA_E_NO_DEVICE, "no HIP device visible (the backend has no CPU fallback)");
+    std::unique_ptr<OlaCtx> c(new OlaCtx());
+    OlaGpuConfig d = {};
+    d.device = -1; d.stream = nullptr; d.rate_bits = 3; d.cap_height = 4; d.proof_of_work_bits = 16;
+    d.fri_arity_bits = 4; d.fri_final_poly_bits = 5; d.num_query_rounds = 28; d.num_challenges = 2;
+    c->cfg = cfg ? *cfg : d;
+    if (c->cfg.device >= 0) HIP_CHECK(hipSetDevice(c->cfg.device));
+    HIP_CHECK(hipGetDevice(&c->dev.device));
+    if (c->cfg.stream) { c->dev.stream = (hipStream_t)c->cfg.stream; c->dev.owns_stream = false; }
+    else { HIP_CHECK(hipStreamCreateWithFlags(&c->dev.stream, hipStreamNonBlocking)); c->dev.owns_stream = true; }
+    poseidon_init(&c->dev);
+    c->tables = ntt_tables_create(&c->dev);
+    *out_ctx = c.release();
+    OLA_CATCH
+}
+
+int32_t ola_gpu_free(OlaCtx* ctx) {
+    OLA_TRY
+    if (ctx) {
+        (void)hipStreamSynchronize(ctx->dev.stream);
+        ntt_tables_destroy(ctx->tables);
+        delete ctx;
+    }
+    OLA_CATCH
+}
+
+int32_t ola_gpu_sync(OlaCtx* ctx) {
+    OLA_TRY
+    require(ctx, "ctx");
+    HIP_CHECK(hipStreamSynchronize(ctx->dev.stream));
+    OLA_CATCH
+}
+
+// ------------------------------------------------------------------------------------------------ NTT
+static void ntt_dev(OlaCtx* ctx, int32_t op, const u64* in, u64* out, u64* scratch, uint32_t log_n, uint32_t batch,
+                    u64 shift, uint32_t blowup_log) {
+    require(log_n <= 32 - (op == OLA_NTT_COSET_LDE || op == OLA_NTT_COSET_LDE_LEAF_ORDER ? blowup_log : 0), "log_n too large");
+    if (batch == 0) return;
+    const size_t n = (size_t)1 << log_n;
+    NttTables& t = *ctx->tables;
+    u64* own_scratch = nullptr;
+    auto need_scratch = [&](size_t elems) {
+        if (!scratch) { own_scratch = (u64*)ctx->dev.alloc(elems * 8); scratch = own_scratch; }
+    };
+    switch (op) {
+        case OLA_NTT_EVALUATE:
+            if (log_n > 13) need_scratch(n * batch);
+            ntt_evaluate(t, in, out, scratch, log_n, batch);
+            break;
+        case OLA_NTT_INTERPOLATE:
+            if (log_n > 13) need_scratch(n * batch);
+            ntt_interpolate(t, in, out, scratch, log_n, batch);
+            break;
+        case OLA_NTT_COSET_LDE_LEAF_ORDER:
+            require(gl_canon(shift) == GL_GENERATOR, "leaf-order LDE is defined for the coset shift 7");
+            ntt_lde_leaf_order(t, in, out, log_n, blowup_log, batch);
+            break;
+        case OLA_NTT_COSET_LDE: {
+            // natural order: P(shift * g^m).  Computed as blowup cosets in leaf order, then un-bit-reversed rows.
+            require(gl_canon(shift) == GL_GENERATOR || blowup_log == 0, "LDE with blowup > 1 is defined for the coset shift 7");
+            if (blowup_log == 0) {
+                if (log_n > 13) need_scratch(n * batch);
+                ntt_coset_evaluate(t, in, out, scratch, log_n, batch, gl_canon(shift), true);
+            } else {
+                const size_t N = n << blowup_log;
+                need_scratch(N * batch);
+                ntt_lde_leaf_order(t, in, scratch, log_n, blowup_log, batch);
+                launch_bitrev_rows(&ctx->dev, scratch, out, log_n + blowup_log, batch);
+            }
+            break;
+        }
+        case OLA_NTT_COSET_INTERPOLATE: {
+            if (log_n > 13) need_scratch(n * batch);
+            ntt_coset_interpolate(t, in, out, scratch, log_n, batch, gl_canon(shift));
+            break;
+        }
+        default: require(false, "unknown NTT op");
+    }
+    if (own_scratch) { HIP_CHECK(hipStreamSynchronize(ctx->dev.stream)); ctx->dev.free(own_scratch); }
+}
+
+int32_t ola_ntt_batch_dev(OlaCtx* ctx, int32_t op, const uint64_t* in_dev, uint64_t* out_dev, uint64_t* scratch_dev,
+                          uint32_t log_n, uint32_t batch, uint64_t shift, uint32_t blowup_log) {
+    OLA_TRY
+    require(ctx && in_dev && out_dev, "null pointer");
+    ntt_dev(ctx, op, (const u64*)in_dev, (u64*)out_dev, (u64*)scratch_dev, log_n, batch, shift, blowup_log);
+    HIP_CHECK(hipStreamSynchronize(ctx->dev.stream));
+    OLA_CATCH
+}
+
+int32_t ola_ntt_batch(OlaCtx* ctx, int32_t op, const uint64_t* in, uint64_t* out, uint32_t log_n, uint32_t batch,
+                      uint64_t shift, uint32_t blowup_log) {
+    OLA_TRY
+    require(ctx && in && out, "null pointer");
+    const size_t n = (size_t)1 << log_n;
+    const bool grows = (op == OLA_NTT_COSET_LDE || op == OLA_NTT_COSET_LDE_LEAF_ORDER);
+    const size_t in_elems = n * batch, out_elems = grows ? (n << blowup_log) * batch : n * batch;
+    if (batch == 0) return OLA_OK;
+    u64* d_in = (u64*)ctx->dev.alloc(in_elems * 8);
+    u64* d_out = (u64*)ctx->dev.alloc(out_elems * 8);
+    try {
+        HIP_CHECK(hipMemcpyAsync(d_in, in, in_elems * 8, hipMemcpyHostToDevice, ctx->dev.stream));
+        ntt_dev(ctx, op, d_in, d_out, nullptr, log_n, batch, shift, blowup_log);
+        HIP_CHECK(hipMemcpyAsync(out, d_out, out_elems * 8, hipMemcpyDeviceToHost, ctx->dev.stream));
+        HIP_CHECK(hipStreamSynchronize(ctx->dev.stream));
+    } catch (...) { ctx->dev.free(d_in); ctx->dev.free(d_out); throw; }
+    ctx->dev.free(d_in);
+    ctx->dev.free(d_out);
+    OLA_CATCH
+}
+
+// ------------------------------------------------------------------------------------------------ hashing
+int32_t ola_poseidon_permute(OlaCtx* ctx, uint64_t* states, size_t n) {
+    OLA_TRY
+    require(ctx && (states || n == 0), "null pointer");
+    if (n == 0) return OLA_OK;
+    u64* d = (u64*)ctx->dev.alloc(n * 96);
+    try {
+        HIP_CHECK(hipMemcpyAsync(d, states, n * 96, hipMemcpyHostToDevice, ctx->dev.stream));
+        launch_poseidon_states(&ctx->dev, d, n);
+        HIP_CHECK(hipMemcpyAsync(states, d, n * 96, hipMemcpyDeviceToHost, ctx->dev.stream));
+        HIP_CHECK(hipStreamSynchronize(ctx->dev.stream));
+    } catch (...) { ctx->dev.free(d); throw; }
+    ctx->dev.free(d);
+    OLA_CATCH
+}
+
+int32_t ola_hash_rows(OlaCtx* ctx, const uint64_t* rows, size_t num_rows, size_t row_len, uint64_t* digests) {
+    OLA_TRY
+    require(ctx && digests && (rows || num_rows * row_len == 0), "null pointer");
+    if (num_rows == 0) return OLA_OK;
+    u64* d_rows = (u64*)ctx->dev.alloc(num_rows * row_len * 8);
+    u64* d_dig = (u64*)ctx->dev.alloc(num_rows * 32);
+    try {
+        if (row_len) HIP_CHECK(hipMemcpyAsync(d_rows, rows, num_rows * row_len * 8, hipMemcpyHostToDevice, ctx->dev.stream));
+        launch_leaf_hash_rowmajor(&ctx->dev, d_rows, row_len, num_rows, d_dig);
+        HIP_CHECK(hipMemcpyAsync(digests, d_dig, num_rows * 32, hipMemcpyDeviceToHost, ctx->dev.stream));
+        HIP_CHECK(hipStreamSynchronize(ctx->dev.stream));
+    } catch (...) { ctx->dev.free(d_rows); ctx->dev.free(d_dig); throw; }
+    ctx->dev.free(d_rows);
+    ctx->dev.free(d_dig);
+    OLA_CATCH
+}
+
+int32_t ola_merkle_cap(OlaCtx* ctx, const uint64_t* leaves, size_t num_leaves, size_t leaf_len, uint32_t cap_height,
+                       uint64_t* cap_out) {
+    OLA_TRY
+    require(ctx && leaves && cap_out, "null pointer");
+    require(num_leaves && (num_leaves & (num_leaves - 1)) == 0, "num_leaves must be a power of two");
+    require(((size_t)1 << cap_height) <= num_leaves, "cap height should be at most log2(leaves.len())");
+    u64* d_rows = (u64*)ctx->dev.alloc(num_leaves * leaf_len * 8);
+    u64* heap = (u64*)ctx->dev.alloc(2 * num_leaves * 32);
+    try {
+        HIP_CHECK(hipMemcpyAsync(d_rows, leaves, num_leaves * leaf_len * 8, hipMemcpyHostToDevice, ctx->dev.stream));
+        launch_leaf_hash_rowmajor(&ctx->dev, d_rows, leaf_len, num_leaves, heap + 4 * num_leaves);
+        launch_merkle_build(&ctx->dev, heap, num_leaves);
+        const size_t len_cap = (size_t)1 << cap_height;
+        HIP_CHECK(hipMemcpyAsync(cap_out, heap + 4 * len_cap, len_cap * 32, hipMemcpyDeviceToHost, ctx->dev.stream));
+        HIP_CHECK(hipStreamSynchronize(ctx->dev.stream));
+    } catch (...) { ctx->dev.free(d_rows); ctx->dev.free(heap); throw; }
+    ctx->dev.free(d_rows);
+    ctx->dev.free(heap);
+    OLA_CATCH
+}
+
+int32_t ola_pow(OlaCtx* ctx, const uint64_t h[4], uint32_t bits, uint64_t* witness) {
+    OLA_TRY
+    require(ctx && h && witness && bits >= 1 && bits <= 40, "bad argument");
+    u64 hh[4] = {gl_canon(h[0]), gl_canon(h[1]), gl_canon(h[2]), gl_canon(h[3])};
+    *witness = run_pow(&ctx->dev, hh, bits);
+    OLA_CATCH
+}
+
+// ------------------------------------------------------------------------------------------------ commitment
+static int32_t commit_common(OlaCtx* ctx, const uint64_t* const* cols_host, const uint64_t* cols_dev, uint32_t ncols,
+                             uint32_t log_n, bool from_values, OlaBatch** out_batch, uint64_t* cap_out) {
+    OLA_TRY
+    require(ctx && out_batch && cap_out && (cols_host || cols_dev), "null pointer");
+    require(ncols >= 1, "ncols");
+    require(log_n + ctx->cfg.rate_bits <= 32, "log_n too large");
+    require(log_n + ctx->cfg.rate_bits >= ctx->cfg.cap_height, "cap height should be at most log2(leaves.len())");
+    std::unique_ptr<OlaBatch> b(batch_commit(&ctx->dev, *ctx->tables, cols_host, (const u64*)cols_dev, ncols, log_n,
+                                             ctx->cfg.rate_bits, ctx->cfg.cap_height, from_values));
+    batch_read_cap(&ctx->dev, *b, (u64*)cap_out);
+    *out_batch = b.release();
+    OLA_CATCH
+}
+int32_t ola_commit_values(OlaCtx* ctx, const uint64_t* const* cols, uint32_t ncols, uint32_t log_n, OlaBatch** ob, uint64_t* cap) {
+    return commit_common(ctx, cols, nullptr, ncols, log_n, true, ob, cap);
+}
+int32_t ola_commit_coeffs(OlaCtx* ctx, const uint64_t* const* cols, uint32_t ncols, uint32_t log_n, OlaBatch** ob, uint64_t* cap) {
+    return commit_common(ctx, cols, nullptr, ncols, log_n, false, ob, cap);
+}
+int32_t ola_commit_values_dev(OlaCtx* ctx, const uint64_t* cols_dev, uint32_t ncols, uint32_t log_n, OlaBatch** ob, uint64_t* cap) {
+    return commit_common(ctx, nullptr, cols_dev, ncols, log_n, true, ob, cap);
+}
+int32_t ola_commit_coeffs_dev(OlaCtx* ctx, const uint64_t* cols_dev, uint32_t ncols, uint32_t log_n, OlaBatch** ob, uint64_t* cap) {
+    return commit_common(ctx, nullptr, cols_dev, ncols, log_n, false, ob, cap);
+}
+int32_t ola_batch_free(OlaCtx* ctx, OlaBatch* batch) {
+    OLA_TRY
+    require(ctx, "ctx");
+    if (batch) { HIP_CHECK(hipStreamSynchronize(ctx->dev.stream)); batch_destroy(&ctx->dev, batch); }
+    OLA_CATCH
+}
+int32_t ola_batch_shape(const OlaBatch* b, uint32_t* ncols, uint32_t* log_n, uint32_t* rate_bits) {
+    OLA_TRY
+    require(b, "batch");
+    if (ncols) *ncols = b->ncols;
+    if (log_n) *log_n = b->log_n;
+    if (rate_bits) *rate_bits = b->rate_bits;
+    OLA_CATCH
+}
+int32_t ola_batch_get_coeffs(OlaCtx* ctx, const OlaBatch* b, uint64_t* out) {
+    OLA_TRY
+    require(ctx && b && out, "null pointer");
+    HIP_CHECK(hipMemcpyAsync(out, b->coeffs, ((size_t)b->ncols << b->log_n) * 8, hipMemcpyDeviceToHost, ctx->dev.stream));
+    HIP_CHECK(hipStreamSynchronize(ctx->dev.stream));
+    OLA_CATCH
+}
+int32_t ola_batch_get_leaf(OlaCtx* ctx, const OlaBatch* b, size_t leaf_index, uint64_t* row_out, uint64_t* siblings_out) {
+    OLA_TRY
+    require(ctx && b, "null pointer");
+    require(leaf_index < b->num_leaves(), "leaf index out of range");
+    batch_get_leaf(&ctx->dev, *b, leaf_index, (u64*)row_out, (u64*)siblings_out);
+    OLA_CATCH
+}
+int32_t ola_batch_get_lde_row(OlaCtx* ctx, const OlaBatch* b, size_t index, size_t step, uint64_t* row_out) {
+    OLA_TRY
+    require(ctx && b && row_out, "null pointer");
+    const size_t nat = index * step;
+    require(nat < b->num_leaves(), "row index out of range");
+    batch_get_leaf(&ctx->dev, *b, bitrev32((u32)nat, b->log_n + b->rate_bits), (u64*)row_out, nullptr);
+    OLA_CATCH
+}
+
+// ------------------------------------------------------------------------------------------------ transcript
+int32_t ola_challenger_init(OlaChallenger* ch) {
+    OLA_TRY
+    require(ch, "challenger");
+    memset(ch, 0, sizeof(*ch));
+    OLA_CATCH
+}
+int32_t ola_challenger_observe(OlaChallenger* ch, const uint64_t* e, size_t n) {
+    OLA_TRY
+    require(ch && (e || n == 0), "null pointer");
+    challenger_observe(*ch, (const u64*)e, n);
+    OLA_CATCH
+}
+int32_t ola_challenger_get(OlaChallenger* ch, uint64_t* out, size_t n) {
+    OLA_TRY
+    require(ch && (out || n == 0), "null pointer");
+    for (size_t i = 0; i < n; i++) out[i] = challenger_get(*ch);
+    OLA_CATCH
+}
+int32_t ola_challenger_compact(OlaChallenger* ch) {
+    OLA_TRY
+    require(ch, "challenger");
+    challenger_compact(*ch);
+    OLA_CATCH
+}
+
+int32_t ola_open_and_prove(OlaCtx* ctx, const OlaBatch* trace, const OlaBatch* zs, const OlaBatch* quotient,
+                           uint32_t num_permutation_zs, OlaChallenger* challenger, uint8_t* out, size_t cap,
+                           size_t* out_len, size_t* openings_len) {
+    OLA_TRY
+    require(ctx && trace && zs && quotient && challenger && out_len, "null pointer");
+    require(trace->log_n == zs->log_n && trace->log_n == quotient->log_n, "degree mismatch between commitments");
+    require(num_permutation_zs <= zs->ncols, "num_permutation_zs");
+    OlaChallenger ch = *challenger;  // only committed on success
+    std::vector<uint8_t> bytes;
+    size_t olen = 0;
+    open_and_prove(&ctx->dev, *ctx->tables, ctx->cfg, *trace, *zs, *quotient, num_permutation_zs, ch, bytes, olen);
+    *out_len = bytes.size();
+    if (openings_len) *openings_len = olen;
+    if (bytes.size() > cap || !out) throw OlaError(OLA_E_INVALID_ARG, "output buffer too small");
+    memcpy(out, bytes.data(), bytes.size());
+    *challenger = ch;
+    OLA_CATCH
+}
+
+}  // extern "C"

@@ -1,0 +1,176 @@
+"""GPU parity tests: every call goes through the C ABI (include/ola_gpu.h) into the HIP kernels and is compared
+bit-for-bit with the CPU oracle on the same seeded inputs.  Run on the MI355X box with `-m gpu`."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from tests.oracle_lib import EDGE, P, rand_field
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def be():
+    from olavm_amd.backend import Backend
+    b = Backend(device=0)
+    yield b
+    b.close()
+
+
+def bitrev_perm(bits):
+    return np.array([int(format(j, "0%db" % bits)[::-1], 2) if bits else 0 for j in range(1 << bits)])
+
+
+# ---------------------------------------------------------------- Poseidon / sponge / Merkle
+def test_poseidon_kats_on_device(be):
+    kat = json.load(open(os.path.join(HERE, "golden", "poseidon_kat.json")))["vectors"]
+    out = be.poseidon(np.array([v["input"] for v in kat], dtype=np.uint64))
+    for o, v in zip(out, kat):
+        assert [int(x) for x in o] == v["output"]
+
+
+def test_poseidon_random_and_edge_states(be, oracle):
+    rng = np.random.default_rng(11)
+    st = np.concatenate([rand_field(rng, (500, 12)), np.resize(EDGE, (12, 12)),
+                         rng.integers(0, 2**64, size=(50, 12), dtype=np.uint64)])  # last block: non-canonical inputs
+    got = be.poseidon(st)
+    for i in range(st.shape[0]):
+        assert np.array_equal(got[i], oracle.poseidon(st[i])), i
+
+
+@pytest.mark.parametrize("row_len", [1, 3, 4, 7, 8, 9, 16, 17, 29, 94, 134])
+def test_hash_rows(be, oracle, row_len):
+    rng = np.random.default_rng(row_len)
+    rows = rand_field(rng, (300, row_len))
+    got = be.hash_rows(rows)
+    for i in range(0, 300, 7):
+        assert np.array_equal(got[i], oracle.hash_no_pad(rows[i]))
+
+
+@pytest.mark.parametrize("log_leaves,width,cap_h", [(4, 5, 4), (5, 3, 4), (9, 12, 4), (8, 33, 0), (6, 2, 2)])
+def test_merkle_cap(be, oracle, log_leaves, width, cap_h):
+    rng = np.random.default_rng(log_leaves + width)
+    leaves = rand_field(rng, (1 << log_leaves, width))
+    assert np.array_equal(be.merkle_cap(leaves, cap_h), oracle.merkle(leaves, cap_h))
+
+
+def test_pow_minimal_witness(be, oracle):
+    rng = np.random.default_rng(2)
+    for bits in (4, 10, 16):
+        h = rand_field(rng, 4)
+        assert be.pow(h, bits) == oracle.fri_pow(h, bits)
+
+
+# ---------------------------------------------------------------- NTT family
+@pytest.mark.parametrize("log_n", [0, 1, 2, 3, 4, 5, 7, 8, 10, 12, 13, 14, 15, 17, 18])
+def test_ntt_evaluate_interpolate(be, oracle, log_n):
+    from olavm_amd.backend import OLA_NTT_EVALUATE, OLA_NTT_INTERPOLATE
+    rng = np.random.default_rng(log_n)
+    batch = 3 if log_n < 16 else 2
+    c = rand_field(rng, (batch, 1 << log_n))
+    ev = be.ntt(OLA_NTT_EVALUATE, c)
+    for b in range(batch):
+        assert np.array_equal(ev[b], oracle.evaluate_poly(c[b])), (log_n, b)
+    back = be.ntt(OLA_NTT_INTERPOLATE, ev)
+    assert np.array_equal(back, c)
+
+
+@pytest.mark.parametrize("log_n", [0, 1, 3, 6, 9, 12, 13, 14, 16])
+def test_coset_lde_natural_and_leaf_order(be, oracle, log_n):
+    from olavm_amd.backend import OLA_NTT_COSET_LDE, OLA_NTT_COSET_LDE_LEAF_ORDER
+    rng = np.random.default_rng(100 + log_n)
+    c = rand_field(rng, (2, 1 << log_n))
+    nat = be.ntt(OLA_NTT_COSET_LDE, c, shift=7, blowup_log=3)
+    leaf = be.ntt(OLA_NTT_COSET_LDE_LEAF_ORDER, c, shift=7, blowup_log=3)
+    rev = bitrev_perm(log_n + 3)
+    for b in range(2):
+        want = oracle.evaluate_poly_with_offset(c[b], 7, 8)
+        assert np.array_equal(nat[b], want)
+        assert np.array_equal(leaf[b], want[rev])
+
+
+@pytest.mark.parametrize("log_n,shift", [(4, 7), (10, 7), (14, 7), (11, 49), (15, 3)])
+def test_coset_fft_and_ifft_blowup1(be, oracle, log_n, shift):
+    from olavm_amd.backend import OLA_NTT_COSET_LDE, OLA_NTT_COSET_INTERPOLATE
+    rng = np.random.default_rng(log_n)
+    c = rand_field(rng, (2, 1 << log_n))
+    ev = be.ntt(OLA_NTT_COSET_LDE, c, shift=shift, blowup_log=0)
+    for b in range(2):
+        assert np.array_equal(ev[b], oracle.evaluate_poly_with_offset(c[b], shift, 1))
+    back = be.ntt(OLA_NTT_COSET_INTERPOLATE, ev, shift=shift)
+    assert np.array_equal(back, c)
+    assert np.array_equal(back[0], oracle.interpolate_poly_with_offset(ev[0], shift))
+
+
+def test_ntt_edge_and_noncanonical_inputs(be, oracle):
+    from olavm_amd.backend import OLA_NTT_EVALUATE
+    n = 1 << 9
+    c = np.stack([np.resize(EDGE, n), np.full(n, 0xFFFFFFFFFFFFFFFF, dtype=np.uint64), np.zeros(n, dtype=np.uint64)])
+    ev = be.ntt(OLA_NTT_EVALUATE, c)
+    for b in range(3):
+        assert np.array_equal(ev[b], oracle.evaluate_poly(c[b]))
+    assert ev.max() < P
+
+
+@pytest.mark.parametrize("log_n,batch", [(20, 2), (22, 1)])
+def test_ntt_large_roundtrip_and_spot_values(be, oracle, log_n, batch):
+    """Full-size properties (the oracle is too slow for a full compare at 2^22): iNTT(NTT(x)) == x, and a few output
+    points equal the naive evaluation of the polynomial."""
+    from olavm_amd.backend import OLA_NTT_EVALUATE, OLA_NTT_INTERPOLATE
+    rng = np.random.default_rng(log_n)
+    n = 1 << log_n
+    c = rand_field(rng, (batch, n))
+    ev = be.ntt(OLA_NTT_EVALUATE, c)
+    assert np.array_equal(be.ntt(OLA_NTT_INTERPOLATE, ev), c)
+    if log_n <= 20:
+        assert np.array_equal(ev[0], oracle.evaluate_poly(c[0]))
+    # linearity: NTT(a) + NTT(b) == NTT(a + b)
+    a, b2 = c[0], rand_field(rng, n)
+    s = oracle.vec_op("add", a, b2)
+    e2 = be.ntt(OLA_NTT_EVALUATE, np.stack([b2, s]))
+    assert np.array_equal(oracle.vec_op("add", ev[0], e2[0]), e2[1])
+
+
+# ---------------------------------------------------------------- PolynomialBatch commitment
+@pytest.mark.parametrize("log_n,ncols", [(1, 1), (3, 2), (5, 3), (8, 12), (10, 9), (12, 29), (14, 6), (16, 3)])
+def test_commit_values_matches_oracle(be, oracle, log_n, ncols):
+    rng = np.random.default_rng(log_n * 100 + ncols)
+    vals = rand_field(rng, (ncols, 1 << log_n))
+    b = be.commit(vals)
+    ob = oracle.batch(vals)
+    assert np.array_equal(b.cap(), ob.cap())
+    assert np.array_equal(b.coeffs(), ob.coeffs())
+    N = 8 << log_n
+    leaves = ob.leaves()
+    for j in sorted(set([0, 1, N - 1, N // 2, int(rng.integers(0, N)), int(rng.integers(0, N))])):
+        row, sib = b.leaf(j)
+        assert np.array_equal(row, leaves[j])
+        assert np.array_equal(sib, ob.prove(j))
+    # get_lde_values(index, step) -- natural-order row index*step (fri/oracle.rs:131-137)
+    lde0 = oracle.evaluate_poly_with_offset(ob.coeffs()[0], 7, 8)
+    for idx, step in [(0, 1), (3, 2), (1, 8), ((1 << log_n) - 1, 8)]:
+        if idx * step < N:
+            assert int(b.lde_row(idx, step)[0]) == int(lde0[idx * step])
+    b.free()
+
+
+def test_commit_coeffs_matches_oracle(be, oracle):
+    rng = np.random.default_rng(77)
+    co = rand_field(rng, (4, 1 << 9))
+    b = be.commit(co, from_coeffs=True)
+    ob = oracle.batch(co, from_coeffs=True)
+    assert np.array_equal(b.cap(), ob.cap())
+    b.free()
+
+
+def test_commit_from_device_buffer(be, oracle):
+    import torch
+    rng = np.random.default_rng(5)
+    vals = rand_field(rng, (7, 1 << 11))
+    t = torch.from_numpy(vals.view(np.int64)).cuda()
+    b = be.commit_dev(t.data_ptr(), 7, 11)
+    assert np.array_equal(b.cap(), oracle.batch(vals).cap())
+    b.free()
