@@ -1,0 +1,145 @@
+#!/usr/bin/env python3
+"""bench.py -- headline measurement for the MI355X Goldilocks proving backend.
+
+Step = one pass of the hot path over one batch of synthetic input already resident in HBM:
+a batched forward NTT (the reference's cfft::evaluate_poly, natural order in and out) over the columns of a
+2^22-row trace (94 columns = the width of OlaVM's CPU table), BASELINE.json configs[1].
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One rank per GPU; columns are independent, so ranks shard them with no data-path collective (weak scaling: every
+rank transforms its own `--cols` columns).  Rank 0 prints one JSON line.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def cpu_baseline(log_n, seconds_budget=20.0):
+    """The CPU oracle's evaluate_poly (a port of the reference's cfft, NOT the reference itself: no Rust toolchain here)
+    timed on the host cores over a bounded sample of the same workload."""
+    from tests import oracle_lib
+    o = oracle_lib.load()
+    lib = o.lib
+    lib.oracle_num_threads.restype = C.c_int
+    lib.oracle_evaluate_poly_batch.argtypes = [oracle_lib.U64P, C.c_size_t, C.c_size_t]
+    cores = int(lib.oracle_num_threads())
+    n = 1 << log_n
+    rng = np.random.default_rng(1)
+    # calibrate on one column per core, then size the sample to the budget
+    d = oracle_lib.rand_field(rng, (cores, n))
+    t0 = time.perf_counter()
+    lib.oracle_evaluate_poly_batch(oracle_lib.ptr(d), n, cores)
+    t1 = time.perf_counter() - t0
+    rounds = max(1, min(8, int(seconds_budget / max(t1, 1e-3)) - 1))
+    cols = cores * rounds
+    d = oracle_lib.rand_field(rng, (cols, n))
+    t0 = time.perf_counter()
+    lib.oracle_evaluate_poly_batch(oracle_lib.ptr(d), n, cols)
+    dt = time.perf_counter() - t0
+    gbps = 16.0 * n * cols / dt / 1e9
+    return {"value": round(gbps, 4), "unit": "GB/s", "cores": cores, "kind": "port",
+            "sample": f"{cols} columns x 2^{log_n} forward NTT (oracle evaluate_poly, OpenMP over columns) in {dt:.2f}s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--log-n", type=int, default=22)
+    ap.add_argument("--cols", type=int, default=94)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the backend has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from olavm_amd.backend import Backend, OLA_NTT_EVALUATE
+    stream = torch.cuda.current_stream()
+    be = Backend(device=local_rank, stream=stream.cuda_stream)
+
+    n = 1 << args.log_n
+    cols = args.cols
+    # synthetic trace columns: uniform 64-bit words reduced mod p on the fly by the kernels (inputs may be non-canonical)
+    g = torch.Generator(device="cuda").manual_seed(0x01A5EED + rank)
+    data = torch.randint(-2**63, 2**63 - 1, (cols, n), dtype=torch.int64, device="cuda", generator=g)
+    out = torch.empty_like(data)
+    scratch = torch.empty_like(data)
+
+    def step():
+        be.ntt_dev(OLA_NTT_EVALUATE, data.data_ptr(), out.data_ptr(), args.log_n, cols, scratch_ptr=scratch.data_ptr())
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record(stream)
+    for _ in range(args.steps):
+        step()
+    ev1.record(stream)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    dev_ms = ev0.elapsed_time(ev1)
+    if world > 1:
+        t = torch.tensor([elapsed, dev_ms], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed, dev_ms = float(t[0]), float(t[1])
+
+    if rank == 0:
+        bytes_per_step = 16.0 * n * cols            # algorithmic: one read + one write of every element
+        total_bytes = bytes_per_step * world * args.steps
+        value = total_bytes / elapsed / 1e9
+        # dominant kernel = ntt_pass_kernel; a 2^22 natural-order transform launches it `passes` times over the batch
+        passes = 1 if args.log_n <= 13 else (2 if args.log_n <= 18 else 3)
+        launch_ms = dev_ms / args.steps / passes
+        achieved = bytes_per_step / passes / (launch_ms * 1e-3) / 1e9
+        res = {
+            "metric": "goldilocks_ntt_throughput", "value": round(value, 2), "unit": "GB/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "config": {"workload": f"standalone batched Goldilocks NTT (cfft::evaluate_poly, natural in/out), "
+                                   f"{cols} columns x 2^{args.log_n} rows per GPU, inputs resident in HBM",
+                       "log_n": args.log_n, "columns_per_gpu": cols, "parallelism": f"columns sharded over {world} GPU(s), no collective"},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                         "kernel": "ntt_pass_kernel", "launches_per_step": passes,
+                         "avg_launch_ms": round(launch_ms, 4)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(args.log_n)
+        print(json.dumps(res), flush=True)
+    be.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -47,6 +47,12 @@ def load_library():
     if not os.path.exists(p):
         raise OlaGpuError(-7, f"{p} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                               "(the backend has no CPU fallback)")
+    # torch bundles its own libamdhip64.so.7 + HSA runtime; two HIP runtimes in one process fight over the device, so
+    # let torch's load first (same SONAME -> the dynamic loader then binds our library to the already-loaded one).
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
     L = C.CDLL(p)
     L.ola_gpu_last_error.restype = C.c_char_p
     L.ola_gpu_init.argtypes = [C.POINTER(OlaGpuConfig), C.POINTER(C.c_void_p)]

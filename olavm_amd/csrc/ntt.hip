@@ -330,7 +330,7 @@ static void dispatch_pass(int R, const NttPassParams& p, size_t tiles, size_t co
 static void dispatch_contig(int R, const NttPassParams& p, size_t tiles, size_t cols, size_t cosets, hipStream_t s) {
     switch (R) {
 #define OLA_CASE(r) case r: launch_pass<r, 0, MODE_CONTIG>(p, tiles, cols, cosets, s); break;
-        OLA_CASE(1) OLA_CASE(2) OLA_CASE(3) OLA_CASE(4) OLA_CASE(5) OLA_CASE(6) OLA_CASE(7) OLA_CASE(8) OLA_CASE(9)
+        OLA_CASE(0) OLA_CASE(1) OLA_CASE(2) OLA_CASE(3) OLA_CASE(4) OLA_CASE(5) OLA_CASE(6) OLA_CASE(7) OLA_CASE(8) OLA_CASE(9)
         OLA_CASE(10) OLA_CASE(11) OLA_CASE(12) OLA_CASE(13)
 #undef OLA_CASE
         default: break;

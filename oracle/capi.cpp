@@ -197,3 +197,13 @@ int oracle_verify_opening(const u64* caps, const int* num_polys, int degree_bits
 }
 
 }  // extern "C"
+
+// ---- batch helpers for bench.py's cpu_baseline leg (OpenMP over independent columns) ----
+#include <omp.h>
+extern "C" {
+int oracle_num_threads() { return omp_get_max_threads(); }
+void oracle_evaluate_poly_batch(u64* data, size_t n, size_t batch) {
+#pragma omp parallel for schedule(dynamic, 1)
+    for (long c = 0; c < (long)batch; c++) evaluate_poly(data + (size_t)c * n, n);
+}
+}
