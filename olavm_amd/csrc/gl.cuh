@@ -70,6 +70,43 @@ GL_HD u64 gl_mul(u64 a, u64 b) {
 }
 GL_HD u64 gl_sqr(u64 a) { return gl_mul(a, a); }
 
+// x * 2^S mod p for a compile-time S in [0, 96), x canonical -> canonical.  Shifts instead of a 64x64 multiply:
+// 2 is a 192nd root of unity in this field (2^96 = -1), so every 2^k-th root of unity with k <= 6 is +-2^s and the
+// butterflies of a radix-16 transform need no general multiplication at all.
+template <int S>
+GL_HD u64 gl_mul_pow2(u64 x) {
+    static_assert(S >= 0 && S < 96, "shift out of range");
+    if constexpr (S == 0) {
+        return x;
+    } else if constexpr (S < 64) {
+        const u64 lo = x << S;
+        const u64 hi = x >> (64 - S);
+        return gl_reduce128(lo, hi);
+    } else if constexpr (S == 64) {
+        return gl_reduce128(0, x);
+    } else {
+        // x*2^S = (x*2^(S-64)) * 2^64 ; with y = ylo + yhi*2^64:  y*2^64 = ylo*2^64 + yhi*2^128 = ylo*2^64 - yhi*2^32
+        constexpr int K = S - 64;
+        const u64 ylo = x << K;
+        const u64 yhi = x >> (64 - K);  // < 2^K <= 2^31
+        const u64 r0 = gl_reduce128(0, ylo);
+        return gl_sub(r0, yhi << 32);
+    }
+}
+// run-time dispatch on a small set of shifts (multiples of 12); folds away when `s` is a compile-time constant
+GL_HD u64 gl_mul_pow2_sw(u64 x, int s) {
+    switch (s) {
+        case 0: return x;
+        case 12: return gl_mul_pow2<12>(x);
+        case 24: return gl_mul_pow2<24>(x);
+        case 36: return gl_mul_pow2<36>(x);
+        case 48: return gl_mul_pow2<48>(x);
+        case 60: return gl_mul_pow2<60>(x);
+        case 72: return gl_mul_pow2<72>(x);
+        default: return gl_mul_pow2<84>(x);
+    }
+}
+
 GL_HD u64 gl_pow(u64 b, u64 e) {
     u64 r = 1;
     while (e) {

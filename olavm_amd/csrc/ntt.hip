@@ -444,20 +444,32 @@ void ntt_run(NttTables& t, const u64* in, size_t in_col_stride, u64* out, size_t
 }
 
 // ---- public (library-internal) entry points -----------------------------------------------------
+// Transforms of 2^14 points and more run on the second-generation passes (ntt2.hip); smaller ones fit one tile here.
+void ntt2_run(NttTables& t, const u64* in, size_t in_col_stride, u64* out, size_t out_col_stride, u64* scratch,
+              size_t scratch_col_stride, int L, size_t cols, bool inverse, bool natural_out, int sc_rate_bits, u64 sc_shift,
+              size_t cosets, size_t out_coset_stride);
+static const int NTT2_MIN_LOG = 14;
+
 // values (natural) -> coefficients (natural), per column.  scratch must hold cols * 2^L elements when L > 13.
 void ntt_interpolate(NttTables& t, const u64* values, u64* coeffs, u64* scratch, int L, size_t cols) {
     const size_t n = (size_t)1 << L;
+    if (L >= NTT2_MIN_LOG) { ntt2_run(t, values, n, coeffs, n, scratch, n, L, cols, true, true, -2, 0, 1, 0); return; }
     ntt_run(t, values, n, coeffs, n, scratch, n, L, cols, true, true, nullptr, 0, 1, 0, 1);
 }
 // coefficients (natural) -> values at w^i (natural)
 void ntt_evaluate(NttTables& t, const u64* coeffs, u64* values, u64* scratch, int L, size_t cols) {
     const size_t n = (size_t)1 << L;
+    if (L >= NTT2_MIN_LOG) { ntt2_run(t, coeffs, n, values, n, scratch, n, L, cols, false, true, -2, 0, 1, 0); return; }
     ntt_run(t, coeffs, n, values, n, scratch, n, L, cols, false, true, nullptr, 0, 1, 0, 1);
 }
 // coefficients (natural, n per column) -> LDE on 7*<g>, in commitment leaf order: out[col][c*n + r] =
 // P(7 * g^bitrev(c) * w_n^bitrev_n(r)); equals natural LDE row bitrev_N(c*n + r).
 void ntt_lde_leaf_order(NttTables& t, const u64* coeffs, u64* lde, int L, int rate_bits, size_t cols) {
     const size_t n = (size_t)1 << L;
+    if (L >= NTT2_MIN_LOG) {
+        ntt2_run(t, coeffs, n, lde, n << rate_bits, nullptr, 0, L, cols, false, false, rate_bits, 0, (size_t)1 << rate_bits, n);
+        return;
+    }
     size_t stride = 0;
     TwoLevel sc = get_coset(t, L, rate_bits, &stride);
     ntt_run(t, coeffs, n, lde, n << rate_bits, nullptr, 0, L, cols, false, false, &sc, stride, (size_t)1 << rate_bits, n, 1);
@@ -466,6 +478,7 @@ void ntt_lde_leaf_order(NttTables& t, const u64* coeffs, u64* lde, int L, int ra
 void ntt_coset_evaluate(NttTables& t, const u64* coeffs, u64* values, u64* scratch, int L, size_t cols, u64 shift,
                         bool natural_out) {
     const size_t n = (size_t)1 << L;
+    if (L >= NTT2_MIN_LOG) { ntt2_run(t, coeffs, n, values, n, scratch, n, L, cols, false, natural_out, -1, shift, 1, 0); return; }
     TwoLevel sc = get_shift(t, L, shift);
     ntt_run(t, coeffs, n, values, n, scratch, n, L, cols, false, natural_out, &sc, 0, 1, 0, 1);
 }

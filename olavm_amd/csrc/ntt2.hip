@@ -1,0 +1,343 @@
+// Second-generation NTT passes for large transforms (2^14 .. 2^32), gfx950.
+//
+// Same contract as ntt.hip (reference: plonky2/field/src/cfft/mod.rs:22-231, serial.rs:9-78) with a leaner kernel:
+//   * every pass carries 4..8 bits; a 256-thread workgroup owns 4096 elements (2^(8-R) tiles of 2^R x 16), each thread
+//     holds 16 values in registers;
+//   * a pass is two register rounds: a radix-16 transform straight from the global loads, one LDS exchange, then a
+//     radix-2^(R-4) transform whose results go straight to the global stores (the closing bit-reversed pass makes one
+//     more LDS trip so that its stores are contiguous);
+//   * the butterflies use NO general multiplication: w_16 = 2^156 = -2^60 in this field, so all twiddles inside a
+//     radix-16 block are +-2^(12k) and are applied with shifts (gl_mul_pow2);
+//   * the only 64x64 multiplications are one "round twiddle" per element between the two rounds (table of 2^R entries in
+//     LDS) and one "pass twiddle" per element between passes, generated per thread as base * step^k from two lookups;
+//   * every global access is a 128-byte segment (16 consecutive elements).
+#include <hip/hip_runtime.h>
+
+#include "device_ctx.h"
+#include "gl.cuh"
+
+namespace ola {
+
+enum { N2_STRIDED = 0, N2_BITREV_LAST = 1, N2_NATURAL_LAST = 2 };
+
+struct Ntt2Params {
+    const u64* in;
+    u64* out;
+    size_t in_col_stride, out_col_stride, in_coset_stride, out_coset_stride;
+    int log_n;  // L
+    int lo;     // pass handles index bits [lo, lo+R)
+    const u64* tw_r;   // w_{2^R}^e, e < 2^R
+    const u64* tw_lo;  // two-level powers of w_{2^(lo+R)}
+    const u64* tw_hi;
+    int tw_h;
+    u64 post_scale;    // folded into the pass twiddle (STRIDED only)
+    const u64* sc_lo;  // optional pre-scale s^k (coset transforms), two-level per coset
+    const u64* sc_hi;
+    int sc_h;
+    size_t sc_coset_stride;
+    const u64* sc_step;  // per coset: s^(2^(lo+R-4)) = ratio between consecutive register elements
+};
+
+__device__ __forceinline__ constexpr int rev_bits_c(int x, int bits) {
+    int r = 0;
+    for (int i = 0; i < bits; i++) r |= ((x >> i) & 1) << (bits - 1 - i);
+    return r;
+}
+
+// In-register decimation-in-frequency transform of 2^K values; output x[j] = X[bitrev_K(j)].
+// Twiddle of stage i for pair (j, j + 2^i): w_{2^(i+1)}^(j mod 2^i) = w_16^((j mod 2^i) << (3 - i)) = +-2^s.
+template <int K, bool INV>
+__device__ __forceinline__ void dft_pow2(u64* x) {
+#pragma unroll
+    for (int i = K - 1; i >= 0; --i) {
+#pragma unroll
+        for (int j = 0; j < (1 << K); ++j) {
+            if (j & (1 << i)) continue;
+            const int e16 = (j & ((1 << i) - 1)) << (3 - i);
+            const int t = ((INV ? 36 : 156) * e16) % 192;  // w_16 = 2^156, w_16^-1 = 2^36 ; 2^96 = -1
+            const u64 a = x[j], c = x[j + (1 << i)];
+            x[j] = gl_add(a, c);
+            const u64 d = (t >= 96) ? gl_sub(c, a) : gl_sub(a, c);
+            x[j + (1 << i)] = gl_mul_pow2_sw(d, t % 96);
+        }
+    }
+}
+
+__device__ __forceinline__ u64 two_level(const u64* __restrict__ lo, const u64* __restrict__ hi, int h, u64 e) {
+    return gl_mul(lo[e & (((u64)1 << h) - 1)], hi[e >> h]);
+}
+
+template <int R, int MODE>
+constexpr int ntt2_lds_elems() {
+    constexpr int K2 = R - 4;
+    if (MODE == N2_STRIDED) return 4096 + (K2 >= 1 ? 16 * (4096 >> (K2 + 4)) : 0);
+    return (1 << (8 - R)) * 16 * ((1 << R) + 1);
+}
+
+template <int R, int MODE, bool INV>
+__global__ __launch_bounds__(256) void ntt2_pass_kernel(Ntt2Params p) {
+    static_assert(R >= 4 && R <= 8, "pass width");
+    constexpr int K2 = R - 4;     // bits of the second round
+    constexpr int D = 8 - R;      // log2(tiles per workgroup)
+    constexpr int G2 = 1 << K2;   // values per second-round group
+    constexpr int ROW = (1 << R) + 1;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    u64* lds = reinterpret_cast<u64*>(smem_raw);
+    u64* tw1 = lds + ntt2_lds_elems<R, MODE>();
+
+    const int tid = threadIdx.x;
+    const u32 blk = blockIdx.x;
+    const size_t col = blockIdx.y, coset = blockIdx.z;
+    const u64* __restrict__ in = p.in + col * p.in_col_stride + coset * p.in_coset_stride;
+    u64* __restrict__ out = p.out + col * p.out_col_stride + coset * p.out_coset_stride;
+    const int L = p.log_n, lo = p.lo;
+
+    if (R > 4) {
+        if (tid < (1 << R)) tw1[tid] = p.tw_r[tid];
+    }
+
+    auto pad1 = [](int e) -> int { return K2 >= 1 ? e + ((e >> (K2 + 4)) << 4) : e; };
+
+    // ---------------------------------------------------------------- phase A: load + radix-16 round
+    {
+        int u, m_low, t;
+        if (MODE == N2_STRIDED) {
+            u = tid & 15;
+            const int rest = tid >> 4;
+            m_low = rest & ((1 << K2) - 1);
+            t = rest >> K2;
+        } else {
+            m_low = tid & ((1 << K2) - 1);
+            u = (tid >> K2) & 15;
+            t = tid >> R;
+        }
+        const u32 ntile = (blk << D) + t;
+        size_t a0;       // address of register element j = 0
+        size_t jstride;  // address distance between consecutive register elements
+        if (MODE == N2_STRIDED) {
+            const u32 lowblks = 1u << (lo - 4);
+            const u32 lb = ntile & (lowblks - 1), hi = ntile >> (lo - 4);
+            a0 = ((size_t)hi << (lo + R)) + ((size_t)lb << 4) + ((size_t)m_low << lo) + u;
+            jstride = (size_t)1 << (lo + K2);
+        } else if (MODE == N2_BITREV_LAST) {
+            a0 = ((((size_t)ntile << 4) + u) << R) + m_low;
+            jstride = (size_t)1 << K2;
+        } else {
+            const int ub = L - R - 4;
+            const size_t row = ((size_t)rev_bits_c(u, 4) << ub) + (ub ? bitrev32(ntile, ub) : 0);
+            a0 = (row << R) + m_low;
+            jstride = (size_t)1 << K2;
+        }
+        u64 x[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) x[j] = gl_canon(in[a0 + j * jstride]);
+        if (MODE == N2_STRIDED && p.sc_lo) {
+            const u64 sb = two_level(p.sc_lo + coset * p.sc_coset_stride, p.sc_hi + coset * p.sc_coset_stride, p.sc_h, a0);
+            const u64 st = p.sc_step[coset];
+            u64 w = sb;
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                x[j] = gl_mul(x[j], w);
+                if (j < 15) w = gl_mul(w, st);
+            }
+        }
+        dft_pow2<4, INV>(x);
+        if (R > 4) __syncthreads();  // tw1 visible
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const int q1 = rev_bits_c(j, 4);
+            u64 v = x[j];
+            if (R > 4 && q1 != 0) {
+                const int idx = m_low * q1;  // < 2^R
+                if (idx) v = gl_mul(v, tw1[idx]);
+            }
+            const int m = (j << K2) + m_low;
+            if (MODE == N2_STRIDED) lds[pad1((((t << R) + m) << 4) + u)] = v;
+            else lds[((t << 4) + u) * ROW + m] = v;
+        }
+    }
+    __syncthreads();
+
+    // ---------------------------------------------------------------- phase B: second round + store
+    {
+        const int u = tid & 15, m_hi = tid >> 4;
+        u64 y[16];
+#pragma unroll
+        for (int t = 0; t < (1 << D); t++) {
+#pragma unroll
+            for (int j2 = 0; j2 < G2; j2++) {
+                const int m = (m_hi << K2) + j2;
+                y[t * G2 + j2] = (MODE == N2_STRIDED) ? lds[pad1((((t << R) + m) << 4) + u)] : lds[((t << 4) + u) * ROW + m];
+            }
+        }
+        if (MODE == N2_STRIDED) {
+            // pass twiddle w_B^(low*q), q = rev_R(m) = rev_K2(j2)*16 + rev4(m_hi):  base * step^rev_K2(j2)
+            u64 base[1 << D], step[1 << D];
+            const u32 lowblks = 1u << (lo - 4);
+#pragma unroll
+            for (int t = 0; t < (1 << D); t++) {
+                const u32 ntile = (blk << D) + t;
+                const u64 low = ((u64)(ntile & (lowblks - 1)) << 4) + u;
+                base[t] = gl_mul(two_level(p.tw_lo, p.tw_hi, p.tw_h, low * (u64)rev_bits_c(m_hi & 15, 4)), p.post_scale);
+                step[t] = (K2 >= 1) ? two_level(p.tw_lo, p.tw_hi, p.tw_h, low << 4) : 1;
+            }
+#pragma unroll
+            for (int t = 0; t < (1 << D); t++) {
+                if (K2 >= 1) dft_pow2<(K2 >= 1 ? K2 : 1), INV>(y + t * G2);
+                const u32 ntile = (blk << D) + t;
+                const u32 lb = ntile & (lowblks - 1), hi = ntile >> (lo - 4);
+                const size_t b0 = ((size_t)hi << (lo + R)) + ((size_t)lb << 4) + u;
+                u64 w = base[t];
+#pragma unroll
+                for (int k = 0; k < G2; k++) {
+                    const int j2 = rev_bits_c(k, K2);
+                    const u64 v = gl_mul(y[t * G2 + j2], w);
+                    if (k + 1 < G2) w = gl_mul(w, step[t]);
+                    out[b0 + ((size_t)((m_hi << K2) + j2) << lo)] = v;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < (1 << D); t++)
+                if (K2 >= 1) dft_pow2<(K2 >= 1 ? K2 : 1), INV>(y + t * G2);
+            if (MODE == N2_NATURAL_LAST) {
+#pragma unroll
+                for (int t = 0; t < (1 << D); t++) {
+                    const u32 A = (blk << D) + t;
+#pragma unroll
+                    for (int j2 = 0; j2 < G2; j2++) {
+                        const u32 q = ((u32)rev_bits_c(j2, K2) << 4) + (u32)rev_bits_c(m_hi & 15, 4);
+                        out[((size_t)A << 4) + u + ((size_t)q << (L - R))] = y[t * G2 + j2];
+                    }
+                }
+            } else {
+                // bit-reversed (in-place) order: exchange through LDS once more so that the stores are contiguous
+#pragma unroll
+                for (int t = 0; t < (1 << D); t++)
+#pragma unroll
+                    for (int j2 = 0; j2 < G2; j2++) lds[((t << 4) + u) * ROW + (m_hi << K2) + j2] = y[t * G2 + j2];
+                __syncthreads();
+                const size_t b0 = (size_t)blk << 12;
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    const int c = (k << 8) + tid;  // element within the workgroup's 4096
+                    out[b0 + c] = lds[(c >> R) * ROW + (c & ((1 << R) - 1))];
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+template <int R, int MODE, bool INV>
+static void ntt2_launch(const Ntt2Params& p, size_t cols, size_t cosets, hipStream_t stream) {
+    const size_t lds_bytes = (size_t)(ntt2_lds_elems<R, MODE>() + (R > 4 ? (1 << R) : 0)) * 8;
+    dim3 grid((unsigned)(((size_t)1 << p.log_n) >> 12), (unsigned)cols, (unsigned)cosets);
+    hipLaunchKernelGGL((ntt2_pass_kernel<R, MODE, INV>), grid, dim3(256), lds_bytes, stream, p);
+}
+template <int MODE, bool INV>
+static void ntt2_dispatch_r(int R, const Ntt2Params& p, size_t cols, size_t cosets, hipStream_t s) {
+    switch (R) {
+        case 4: ntt2_launch<4, MODE, INV>(p, cols, cosets, s); break;
+        case 5: ntt2_launch<5, MODE, INV>(p, cols, cosets, s); break;
+        case 6: ntt2_launch<6, MODE, INV>(p, cols, cosets, s); break;
+        case 7: ntt2_launch<7, MODE, INV>(p, cols, cosets, s); break;
+        default: ntt2_launch<8, MODE, INV>(p, cols, cosets, s); break;
+    }
+}
+static void ntt2_dispatch(int R, int mode, bool inv, const Ntt2Params& p, size_t cols, size_t cosets, hipStream_t s) {
+    if (mode == N2_STRIDED) { if (inv) ntt2_dispatch_r<N2_STRIDED, true>(R, p, cols, cosets, s); else ntt2_dispatch_r<N2_STRIDED, false>(R, p, cols, cosets, s); }
+    else if (mode == N2_BITREV_LAST) { if (inv) ntt2_dispatch_r<N2_BITREV_LAST, true>(R, p, cols, cosets, s); else ntt2_dispatch_r<N2_BITREV_LAST, false>(R, p, cols, cosets, s); }
+    else { if (inv) ntt2_dispatch_r<N2_NATURAL_LAST, true>(R, p, cols, cosets, s); else ntt2_dispatch_r<N2_NATURAL_LAST, false>(R, p, cols, cosets, s); }
+}
+
+// full-circle table w_{2^R}^e, e < 2^R
+static const u64* get_full_small(NttTables& t, int R, int inverse) {
+    auto key = std::make_pair(100 + R, inverse);
+    auto it = t.small.find(key);
+    if (it != t.small.end()) return it->second;
+    std::vector<u64> v = powers(root_for(R, inverse), (size_t)1 << R);
+    return t.small[key] = upload(t.ctx, v);
+}
+
+// per-coset ratio s_c^(2^e) for the pre-scale recurrence
+static const u64* get_coset_steps(NttTables& t, int log_n, int rate_bits, int e, u64 single_shift) {
+    std::vector<u64> v;
+    if (rate_bits < 0) {
+        v.push_back(gl_pow(single_shift, (u64)1 << e));
+    } else {
+        const u64 g = gl_root_of_unity(log_n + rate_bits);
+        for (int c = 0; c < (1 << rate_bits); c++) {
+            const u64 s = gl_mul(gl_pow(g, bitrev32((u32)c, rate_bits)), GL_GENERATOR);
+            v.push_back(gl_pow(s, (u64)1 << e));
+        }
+    }
+    return upload(t.ctx, v);  // small; lives in the persistent pool
+}
+
+struct Ntt2StepCacheKey {
+    int log_n, rate_bits, e;
+    u64 shift;
+    bool operator<(const Ntt2StepCacheKey& o) const {
+        if (log_n != o.log_n) return log_n < o.log_n;
+        if (rate_bits != o.rate_bits) return rate_bits < o.rate_bits;
+        if (e != o.e) return e < o.e;
+        return shift < o.shift;
+    }
+};
+static std::map<std::pair<NttTables*, Ntt2StepCacheKey>, const u64*> g_step_cache;
+
+// Same contract as ntt_run (ntt.hip) for L >= 14.  prescale: rate_bits >= 0 selects the LDE coset family
+// (7*g^bitrev(c)), rate_bits = -1 with `shift` a single coset, -2 none.
+void ntt2_run(NttTables& t, const u64* in, size_t in_col_stride, u64* out, size_t out_col_stride, u64* scratch,
+              size_t scratch_col_stride, int L, size_t cols, bool inverse, bool natural_out, int sc_rate_bits, u64 sc_shift,
+              size_t cosets, size_t out_coset_stride) {
+    if (cols == 0) return;
+    hipStream_t stream = t.ctx->stream;
+    const int P = (L + 7) / 8;
+    std::vector<int> Rs = split_even(L, P);          // largest first ...
+    std::reverse(Rs.begin(), Rs.end());              // ... make the closing pass the widest (best coalescing)
+    const u64 final_scale = inverse ? gl_inv(((u64)1 << L) % GL_P) : 1;
+    u64* work = natural_out ? scratch : out;
+    const size_t work_col_stride = natural_out ? scratch_col_stride : out_col_stride;
+    const size_t work_coset_stride = natural_out ? 0 : out_coset_stride;
+
+    const u64* cur_in = in;
+    size_t cur_in_stride = in_col_stride, cur_in_coset = 0;
+    int lo = L;
+    for (int i = 0; i < P; i++) {
+        const int R = Rs[i];
+        lo -= R;
+        const bool last = (i == P - 1);
+        Ntt2Params p = {};
+        p.log_n = L; p.lo = lo;
+        p.tw_r = get_full_small(t, R, inverse);
+        p.post_scale = 1;
+        p.in = cur_in; p.in_col_stride = cur_in_stride; p.in_coset_stride = cur_in_coset;
+        if (!last) {
+            TwoLevel tw = get_two(t, lo + R, inverse);
+            p.tw_lo = tw.lo; p.tw_hi = tw.hi; p.tw_h = tw.h;
+            if (i == P - 2) p.post_scale = final_scale;
+            p.out = work; p.out_col_stride = work_col_stride; p.out_coset_stride = work_coset_stride;
+            if (i == 0 && sc_rate_bits != -2) {
+                TwoLevel sc;
+                size_t stride = 0;
+                if (sc_rate_bits >= 0) sc = get_coset(t, L, sc_rate_bits, &stride);
+                else sc = get_shift(t, L, sc_shift);
+                p.sc_lo = sc.lo; p.sc_hi = sc.hi; p.sc_h = sc.h; p.sc_coset_stride = stride;
+                Ntt2StepCacheKey key{L, sc_rate_bits, lo + R - 4, sc_rate_bits >= 0 ? 0 : sc_shift};
+                auto ck = std::make_pair(&t, key);
+                auto it = g_step_cache.find(ck);
+                if (it == g_step_cache.end()) it = g_step_cache.emplace(ck, get_coset_steps(t, L, sc_rate_bits, lo + R - 4, sc_shift)).first;
+                p.sc_step = it->second;
+            }
+            ntt2_dispatch(R, N2_STRIDED, inverse, p, cols, cosets, stream);
+            cur_in = work; cur_in_stride = work_col_stride; cur_in_coset = work_coset_stride;
+        } else {
+            p.out = out; p.out_col_stride = out_col_stride; p.out_coset_stride = out_coset_stride;
+            ntt2_dispatch(R, natural_out ? N2_NATURAL_LAST : N2_BITREV_LAST, inverse, p, cols, cosets, stream);
+        }
+    }
+}
+
+}  // namespace ola

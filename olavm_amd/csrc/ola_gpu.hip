@@ -14,6 +14,7 @@
 
 // unity build: device code shares the __constant__ Poseidon tables
 #include "ntt.hip"
+#include "ntt2.hip"
 #include "merkle.hip"
 #include "batch.hip"
 #include "fri.hip"
