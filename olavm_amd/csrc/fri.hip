@@ -1,8 +1,24 @@
 // Host-side Fiat-Shamir challenger + device-side opening / FRI pipeline.
 //
-// Challenger: plonky2/plonky2/src/iop/challenger.rs:36-162 (overwrite duplex, rate 8, pops from the back).
+// Replaces, for commitments resident in HBM (reference paths relative to /root/reference):
+//   plonky2/plonky2/src/iop/challenger.rs:36-162          Challenger (host; a few hundred permutations per proof)
+//   circuits/src/stark/proof.rs:198-233                    StarkOpeningSet::new      -> eval_points_kernel
+//   circuits/src/stark/stark.rs:87-146                     fri_instance (batches zeta, g*zeta, g^-1)
+//   plonky2/plonky2/src/fri/oracle.rs:167-241              prove_openings: composition, divide_by_linear, *X, LDE
+//   plonky2/field/src/polynomial/division.rs:74-87         divide_by_linear          -> weighted suffix scan
+//   plonky2/plonky2/src/fri/prover.rs:72-121               fri_committed_trees       -> leaf_hash_ext + fold + coset NTT
+//   plonky2/plonky2/src/fri/prover.rs:126-148              fri_proof_of_work         -> pow_kernel (minimal nonce)
+//   plonky2/plonky2/src/fri/prover.rs:150-204              query rounds              -> gathers
+//   circuits/src/stark/serialization.rs:163-176,305-317    wire format
+//
+// Data layout: extension-field arrays are two planes (a, b) of base elements so that an extension NTT is two base
+// NTTs (twiddles are base-field, plonky2/field/src/extension/quadratic.rs:61-65).  (p(X)-p(z))/(X-z) is not computed
+// by the reference's sequential Horner scan but as  q[k-1] = z^-k * sum_{j>=k} c_j z^j  (a parallel suffix sum);
+// multiplying by X afterwards (oracle.rs:218) cancels the index shift, so final[k] = sum_batches w_b * B_b[k], k >= 1.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <cstring>
 #include <vector>
 
 #include "../../include/ola_gpu.h"
@@ -12,6 +28,7 @@
 
 namespace ola {
 
+// ------------------------------------------------------------------------------------------------ challenger
 static void challenger_duplex(OlaChallenger& ch) {
     for (uint32_t i = 0; i < ch.input_len; i++) ch.sponge_state[i] = ch.input_buffer[i];
     ch.input_len = 0;
@@ -37,10 +54,497 @@ void challenger_compact(OlaChallenger& ch) {
     if (ch.input_len != 0) challenger_duplex(ch);
     ch.output_len = 0;
 }
+static Ext2 challenger_get_ext(OlaChallenger& ch) {
+    const u64 a = challenger_get(ch);
+    const u64 b = challenger_get(ch);
+    return ext_make(a, b);
+}
+static void challenger_observe_ext(OlaChallenger& ch, Ext2 e) {
+    u64 v[2] = {e.a, e.b};
+    challenger_observe(ch, v, 2);
+}
 
-void open_and_prove(DeviceCtx*, NttTables&, const OlaGpuConfig&, const OlaBatch&, const OlaBatch&, const OlaBatch&,
-                    uint32_t, OlaChallenger&, std::vector<uint8_t>&, size_t&) {
-    throw OlaError(OLA_E_INTERNAL, "ola_open_and_prove: not implemented yet");
+// ------------------------------------------------------------------------------------------------ kernels
+// two-level extension power table: z^k = lo[k & mask] * hi[k >> h]; stored as 4 planes [lo.a | lo.b | hi.a | hi.b]
+struct ExtPow {
+    const u64* lo_a; const u64* lo_b; const u64* hi_a; const u64* hi_b;
+    int h;
+};
+__device__ __forceinline__ Ext2 ext_pow_lookup(const ExtPow& t, size_t k) {
+    const size_t il = k & (((size_t)1 << t.h) - 1), ih = k >> t.h;
+    return ext_mul(ext_make(t.lo_a[il], t.lo_b[il]), ext_make(t.hi_a[ih], t.hi_b[ih]));
+}
+
+// Evaluate `ncols` base-field polynomials (column-major coefficients, n each) at up to two extension points.
+// Block (x = coefficient chunk, y = group of CG columns); partial sums out[pt][chunk][col] as (a, b).
+#define EVAL_CG 8
+__global__ __launch_bounds__(256) void eval_points_kernel(const u64* __restrict__ coeffs, size_t n, int ncols, ExtPow p0, ExtPow p1,
+                                                          int npoints, size_t chunk_len, u64* __restrict__ partial) {
+    __shared__ u64 red[256 * 2];
+    const int c0 = blockIdx.y * EVAL_CG;
+    const size_t k_begin = (size_t)blockIdx.x * chunk_len;
+    const size_t k_end = min(n, k_begin + chunk_len);
+    Ext2 acc[2][EVAL_CG];
+#pragma unroll
+    for (int p = 0; p < 2; p++)
+#pragma unroll
+        for (int c = 0; c < EVAL_CG; c++) acc[p][c] = ext_make(0, 0);
+    for (size_t k = k_begin + threadIdx.x; k < k_end; k += 256) {
+        const Ext2 w0 = ext_pow_lookup(p0, k);
+        Ext2 w1 = ext_make(0, 0);
+        if (npoints > 1) w1 = ext_pow_lookup(p1, k);
+#pragma unroll
+        for (int c = 0; c < EVAL_CG; c++) {
+            if (c0 + c < ncols) {
+                const u64 f = coeffs[(size_t)(c0 + c) * n + k];
+                acc[0][c] = ext_add(acc[0][c], ext_scalar_mul(w0, f));
+                if (npoints > 1) acc[1][c] = ext_add(acc[1][c], ext_scalar_mul(w1, f));
+            }
+        }
+    }
+    for (int p = 0; p < npoints; p++) {
+        for (int c = 0; c < EVAL_CG; c++) {
+            if (c0 + c >= ncols) break;
+            __syncthreads();
+            red[threadIdx.x] = acc[p][c].a;
+            red[256 + threadIdx.x] = acc[p][c].b;
+            __syncthreads();
+            for (int s = 128; s > 0; s >>= 1) {
+                if ((int)threadIdx.x < s) {
+                    red[threadIdx.x] = gl_add(red[threadIdx.x], red[threadIdx.x + s]);
+                    red[256 + threadIdx.x] = gl_add(red[256 + threadIdx.x], red[256 + threadIdx.x + s]);
+                }
+                __syncthreads();
+            }
+            if (threadIdx.x == 0) {
+                u64* o = partial + (((size_t)p * gridDim.x + blockIdx.x) * ncols + (c0 + c)) * 2;
+                o[0] = red[0];
+                o[1] = red[256];
+            }
+        }
+    }
+}
+
+// Composition polynomials of the three FRI batches (fri/oracle.rs:193-211, circuits stark.rs:117-141), thread per k:
+//   C1 = sum_{i<W+Z} alpha^i f_i     (batch g*zeta: trace, zs)
+//   C0 = C1 + sum_j alpha^(W+Z+j) q_j (batch zeta: trace, zs, quotient)
+//   C2 = sum_j alpha^j zs[nperm + j]  (batch g^-1: ctl zs)
+// out: 6 planes of n: C0.a C0.b C1.a C1.b C2.a C2.b ; alpha powers in apow (a-plane then b-plane, napow entries each)
+__global__ __launch_bounds__(256) void compose_kernel(const u64* __restrict__ trace, int W, const u64* __restrict__ zs, int Z,
+                                                      const u64* __restrict__ quot, int Q, int nperm, size_t n,
+                                                      const u64* __restrict__ apow, int napow, u64* __restrict__ out) {
+    const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    Ext2 c1 = ext_make(0, 0), cq = ext_make(0, 0), c2 = ext_make(0, 0);
+    for (int i = 0; i < W; i++) c1 = ext_add(c1, ext_scalar_mul(ext_make(apow[i], apow[napow + i]), trace[(size_t)i * n + k]));
+    for (int i = 0; i < Z; i++) {
+        const u64 f = zs[(size_t)i * n + k];
+        c1 = ext_add(c1, ext_scalar_mul(ext_make(apow[W + i], apow[napow + W + i]), f));
+        if (i >= nperm) c2 = ext_add(c2, ext_scalar_mul(ext_make(apow[i - nperm], apow[napow + i - nperm]), f));
+    }
+    for (int i = 0; i < Q; i++)
+        cq = ext_add(cq, ext_scalar_mul(ext_make(apow[W + Z + i], apow[napow + W + Z + i]), quot[(size_t)i * n + k]));
+    const Ext2 c0 = ext_add(c1, cq);
+    out[k] = c0.a; out[n + k] = c0.b;
+    out[2 * n + k] = c1.a; out[3 * n + k] = c1.b;
+    out[4 * n + k] = c2.a; out[5 * n + k] = c2.b;
+}
+
+// D[k] = C[k] * z^k, in place on a pair of planes
+__global__ __launch_bounds__(256) void weight_kernel(u64* __restrict__ pa, u64* __restrict__ pb, size_t n, ExtPow zp) {
+    const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const Ext2 d = ext_mul(ext_make(pa[k], pb[k]), ext_pow_lookup(zp, k));
+    pa[k] = d.a;
+    pb[k] = d.b;
+}
+
+// Additive suffix scan over one plane of base elements, 3 phases; blocks of SCAN_B elements.
+#define SCAN_B 2048
+__global__ __launch_bounds__(256) void scan_local_kernel(u64* __restrict__ d, size_t n, u64* __restrict__ block_tot) {
+    __shared__ u64 sh[256];
+    const size_t b0 = (size_t)blockIdx.x * SCAN_B;
+    const int t = threadIdx.x;
+    // thread t owns elements [b0 + 8t, b0 + 8t + 8); suffix order: later indices first
+    u64 v[8];
+    u64 run = 0;
+#pragma unroll
+    for (int i = 7; i >= 0; i--) {
+        const size_t k = b0 + (size_t)t * 8 + i;
+        run = gl_add(run, k < n ? d[k] : 0);
+        v[i] = run;
+    }
+    sh[t] = run;
+    __syncthreads();
+    // exclusive suffix scan of the thread totals (Hillis-Steele over 256 entries)
+    u64 incl = run;
+    for (int s = 1; s < 256; s <<= 1) {
+        const u64 other = (t + s < 256) ? sh[t + s] : 0;
+        __syncthreads();
+        incl = gl_add(incl, other);
+        sh[t] = incl;
+        __syncthreads();
+    }
+    const u64 excl = gl_sub(incl, run);
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const size_t k = b0 + (size_t)t * 8 + i;
+        if (k < n) d[k] = gl_add(v[i], excl);
+    }
+    if (t == 0) block_tot[blockIdx.x] = incl;
+}
+// single block: exclusive suffix scan of nblocks totals in place
+__global__ __launch_bounds__(256) void scan_totals_kernel(u64* __restrict__ tot, size_t nblocks) {
+    if (threadIdx.x != 0) return;
+    u64 run = 0;
+    for (size_t i = nblocks; i-- > 0;) {
+        const u64 v = tot[i];
+        tot[i] = run;
+        run = gl_add(run, v);
+    }
+}
+__global__ __launch_bounds__(256) void scan_add_kernel(u64* __restrict__ d, size_t n, const u64* __restrict__ tot) {
+    const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    d[k] = gl_add(d[k], tot[k / SCAN_B]);
+}
+
+// final[k] = sum_b w_b * S_b[k] * z_b^-k  (k >= 1), final[0] = 0.  S planes as produced by compose/weight/scan.
+// fa/fb have length N >= n and are zero beyond n.
+__global__ __launch_bounds__(256) void finalize_kernel(const u64* __restrict__ S, size_t n, ExtPow zi0, ExtPow zi1, ExtPow zi2,
+                                                       Ext2 w0, Ext2 w1, Ext2 w2, int use2, u64* __restrict__ fa,
+                                                       u64* __restrict__ fb, size_t N) {
+    const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= N) return;
+    Ext2 r = ext_make(0, 0);
+    if (k >= 1 && k < n) {
+        r = ext_mul(w0, ext_mul(ext_make(S[k], S[n + k]), ext_pow_lookup(zi0, k)));
+        r = ext_add(r, ext_mul(w1, ext_mul(ext_make(S[2 * n + k], S[3 * n + k]), ext_pow_lookup(zi1, k))));
+        if (use2) r = ext_add(r, ext_mul(w2, ext_mul(ext_make(S[4 * n + k], S[5 * n + k]), ext_pow_lookup(zi2, k))));
+    }
+    fa[k] = r.a;
+    fb[k] = r.b;
+}
+
+// FRI fold in the coefficient domain (fri/prover.rs:102-109): out[j] = sum_{k<arity} beta^k c[arity*j + k]
+__global__ __launch_bounds__(256) void fold_kernel(const u64* __restrict__ ca, const u64* __restrict__ cb, size_t out_len, int arity,
+                                                   Ext2 beta, u64* __restrict__ oa, u64* __restrict__ ob) {
+    const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= out_len) return;
+    Ext2 s = ext_make(0, 0);
+    for (int k = arity - 1; k >= 0; k--) s = ext_add(ext_mul(s, beta), ext_make(ca[j * arity + k], cb[j * arity + k]));
+    oa[j] = s.a;
+    ob[j] = s.b;
+}
+
+// out[q][2k], out[q][2k+1] = (a, b)[idx[q]*arity + k]
+__global__ void gather_ext_leaves_kernel(const u64* __restrict__ pa, const u64* __restrict__ pb, int arity,
+                                         const unsigned long long* __restrict__ idx, u64* __restrict__ out) {
+    const int q = blockIdx.x, k = threadIdx.x;
+    if (k >= arity) return;
+    out[((size_t)q * arity + k) * 2] = pa[idx[q] * arity + k];
+    out[((size_t)q * arity + k) * 2 + 1] = pb[idx[q] * arity + k];
+}
+
+// ------------------------------------------------------------------------------------------------ host helpers
+struct DevBuf {
+    DeviceCtx* ctx;
+    std::vector<void*> ptrs;
+    explicit DevBuf(DeviceCtx* c) : ctx(c) {}
+    u64* alloc(size_t elems) {
+        void* p = ctx->alloc(elems * 8);
+        ptrs.push_back(p);
+        return (u64*)p;
+    }
+    ~DevBuf() {
+        (void)hipStreamSynchronize(ctx->stream);
+        for (void* p : ptrs) ctx->free(p);
+    }
+};
+
+static ExtPow make_ext_pow(DevBuf& mem, Ext2 z, int log_n) {
+    const int h = (log_n + 1) / 2;
+    const size_t nlo = (size_t)1 << h, nhi = (size_t)1 << (log_n - h);
+    std::vector<u64> host(2 * (nlo + nhi));
+    Ext2 acc = ext_make(1, 0);
+    for (size_t i = 0; i < nlo; i++) { host[i] = acc.a; host[nlo + i] = acc.b; acc = ext_mul(acc, z); }
+    const Ext2 zh = acc;  // z^(2^h)
+    acc = ext_make(1, 0);
+    for (size_t i = 0; i < nhi; i++) { host[2 * nlo + i] = acc.a; host[2 * nlo + nhi + i] = acc.b; acc = ext_mul(acc, zh); }
+    u64* d = mem.alloc(host.size());
+    HIP_CHECK(hipMemcpyAsync(d, host.data(), host.size() * 8, hipMemcpyHostToDevice, mem.ctx->stream));
+    HIP_CHECK(hipStreamSynchronize(mem.ctx->stream));
+    ExtPow t;
+    t.lo_a = d; t.lo_b = d + nlo; t.hi_a = d + 2 * nlo; t.hi_b = d + 2 * nlo + nhi; t.h = h;
+    return t;
+}
+
+// all polynomials of a batch at one or two extension points -> host vectors
+static void eval_batch(DevBuf& mem, const OlaBatch& b, int npoints, ExtPow p0, ExtPow p1, std::vector<Ext2>* out0,
+                       std::vector<Ext2>* out1) {
+    DeviceCtx* ctx = mem.ctx;
+    const size_t n = b.n();
+    const size_t chunk_len = std::max<size_t>(4096, (n + 255) / 256);
+    const unsigned nchunks = (unsigned)((n + chunk_len - 1) / chunk_len);
+    const unsigned groups = (b.ncols + EVAL_CG - 1) / EVAL_CG;
+    const size_t pelems = (size_t)npoints * nchunks * b.ncols * 2;
+    u64* d_part = mem.alloc(pelems);
+    hipLaunchKernelGGL(eval_points_kernel, dim3(nchunks, groups), dim3(256), 0, ctx->stream, b.coeffs, n, (int)b.ncols, p0, p1,
+                       npoints, chunk_len, d_part);
+    std::vector<u64> part(pelems);
+    HIP_CHECK(hipMemcpyAsync(part.data(), d_part, pelems * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    for (int p = 0; p < npoints; p++) {
+        std::vector<Ext2>& o = p == 0 ? *out0 : *out1;
+        o.assign(b.ncols, ext_make(0, 0));
+        for (unsigned ch = 0; ch < nchunks; ch++)
+            for (uint32_t c = 0; c < b.ncols; c++) {
+                const u64* v = &part[(((size_t)p * nchunks + ch) * b.ncols + c) * 2];
+                o[c] = ext_add(o[c], ext_make(v[0], v[1]));
+            }
+    }
+}
+
+static void scan_plane(DevBuf& mem, u64* plane, size_t n, u64* tot) {
+    DeviceCtx* ctx = mem.ctx;
+    const size_t nblocks = (n + SCAN_B - 1) / SCAN_B;
+    hipLaunchKernelGGL(scan_local_kernel, dim3((unsigned)nblocks), dim3(256), 0, ctx->stream, plane, n, tot);
+    if (nblocks > 1) {
+        hipLaunchKernelGGL(scan_totals_kernel, dim3(1), dim3(256), 0, ctx->stream, tot, nblocks);
+        hipLaunchKernelGGL(scan_add_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, plane, n, tot);
+    }
+}
+
+struct ByteWriter {
+    std::vector<uint8_t>& b;
+    void u8(uint8_t x) { b.push_back(x); }
+    void u32(uint32_t x) { for (int i = 0; i < 4; i++) b.push_back((uint8_t)(x >> (8 * i))); }
+    void field(u64 x) { x = gl_canon(x); for (int i = 0; i < 8; i++) b.push_back((uint8_t)(x >> (8 * i))); }
+    void ext(Ext2 e) { field(e.a); field(e.b); }
+    void ext_vec(const std::vector<Ext2>& v) { u32((uint32_t)v.size()); for (auto& e : v) ext(e); }
+    void field_vec(const u64* v, size_t n) { u32((uint32_t)n); for (size_t i = 0; i < n; i++) field(v[i]); }
+    void hash(const u64* h) { for (int i = 0; i < 4; i++) field(h[i]); }
+    void cap(const u64* c, size_t len) { u32((uint32_t)len); for (size_t i = 0; i < len; i++) hash(c + 4 * i); }
+    void merkle_proof(const u64* sib, int depth) { u8((uint8_t)depth); for (int i = 0; i < depth; i++) hash(sib + 4 * i); }
+};
+
+static std::vector<int> fri_arities(const OlaGpuConfig& cfg, int degree_bits) {
+    // fri/reduction_strategies.rs:40-52  ConstantArityBits(arity_bits, final_poly_bits)
+    std::vector<int> v;
+    int d = degree_bits;
+    while (d > (int)cfg.fri_final_poly_bits && d + (int)cfg.rate_bits - (int)cfg.fri_arity_bits >= (int)cfg.cap_height) {
+        v.push_back((int)cfg.fri_arity_bits);
+        d -= (int)cfg.fri_arity_bits;
+    }
+    return v;
+}
+
+struct FriLayer {
+    u64* va; u64* vb;  // bit-reversed evaluations (planes), length len
+    u64* heap;         // 2 * (len/arity) digests
+    size_t len;
+    int arity_bits;
+    std::vector<u64> cap;
+};
+
+// ------------------------------------------------------------------------------------------------ the pipeline
+void open_and_prove(DeviceCtx* ctx, NttTables& tables, const OlaGpuConfig& cfg, const OlaBatch& trace, const OlaBatch& zs,
+                    const OlaBatch& quot, uint32_t nperm, OlaChallenger& ch, std::vector<uint8_t>& bytes, size_t& openings_len) {
+    DevBuf mem(ctx);
+    const int degree_bits = (int)trace.log_n;
+    const size_t n = trace.n();
+    const int rate_bits = (int)cfg.rate_bits;
+    const size_t N = n << rate_bits;
+    const int W = (int)trace.ncols, Z = (int)zs.ncols, Q = (int)quot.ncols;
+    const size_t len_cap = (size_t)1 << cfg.cap_height;
+    std::vector<int> arities = fri_arities(cfg, degree_bits);
+    {
+        int tot = 0;
+        for (int a : arities) tot += a;
+        if (tot > degree_bits + rate_bits - (int)cfg.cap_height) throw OlaError(OLA_E_INVALID_ARG, "FRI total reduction arity is too large.");
+    }
+
+    // ---- zeta and the opening set (prover.rs:499-524) ----
+    const Ext2 zeta = challenger_get_ext(ch);
+    if (ext_eq(ext_pow(zeta, (u64)1 << degree_bits), ext_make(1, 0))) throw OlaError(OLA_E_ZETA_IN_SUBGROUP, "Opening point is in the subgroup.");
+    const u64 g = gl_root_of_unity(degree_bits);
+    const Ext2 zeta_next = ext_scalar_mul(zeta, g);
+    const Ext2 g_inv = ext_make(gl_inv(g), 0);
+    ExtPow pz = make_ext_pow(mem, zeta, degree_bits), pzn = make_ext_pow(mem, zeta_next, degree_bits),
+           pgi = make_ext_pow(mem, g_inv, degree_bits);
+    std::vector<Ext2> local, next, zs_local, zs_next, q_local, zs_last_all, dummy;
+    eval_batch(mem, trace, 2, pz, pzn, &local, &next);
+    eval_batch(mem, zs, 2, pz, pzn, &zs_local, &zs_next);
+    eval_batch(mem, quot, 1, pz, pz, &q_local, &dummy);
+    eval_batch(mem, zs, 1, pgi, pgi, &zs_last_all, &dummy);
+    std::vector<u64> ctl_last;
+    for (int i = (int)nperm; i < Z; i++) ctl_last.push_back(zs_last_all[i].a);
+
+    ByteWriter w{bytes};
+    w.ext_vec(local); w.ext_vec(next); w.ext_vec(zs_local); w.ext_vec(zs_next);
+    w.field_vec(ctl_last.data(), ctl_last.size());
+    w.ext_vec(q_local);
+    openings_len = bytes.size();
+
+    // observe_openings (fri/challenges.rs:16-23) in to_fri_openings order (proof.rs:235-265)
+    for (auto& e : local) challenger_observe_ext(ch, e);
+    for (auto& e : zs_local) challenger_observe_ext(ch, e);
+    for (auto& e : q_local) challenger_observe_ext(ch, e);
+    for (auto& e : next) challenger_observe_ext(ch, e);
+    for (auto& e : zs_next) challenger_observe_ext(ch, e);
+    for (u64 x : ctl_last) challenger_observe_ext(ch, ext_make(x, 0));
+
+    // ---- prove_openings: final polynomial (fri/oracle.rs:178-219) ----
+    const Ext2 alpha = challenger_get_ext(ch);
+    const int napow = W + Z + Q;
+    std::vector<u64> h_apow(2 * (size_t)napow);
+    {
+        Ext2 acc = ext_make(1, 0);
+        for (int i = 0; i < napow; i++) { h_apow[i] = acc.a; h_apow[napow + i] = acc.b; acc = ext_mul(acc, alpha); }
+    }
+    u64* d_apow = mem.alloc(h_apow.size());
+    HIP_CHECK(hipMemcpyAsync(d_apow, h_apow.data(), h_apow.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    u64* S = mem.alloc(6 * n);
+    hipLaunchKernelGGL(compose_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, trace.coeffs, W, zs.coeffs, Z,
+                       quot.coeffs, Q, (int)nperm, n, d_apow, napow, S);
+    const int l0 = W + Z + Q, l1 = W + Z, l2 = Z - (int)nperm;
+    (void)l0;
+    const bool use2 = l2 > 0;
+    const Ext2 zpts[3] = {zeta, zeta_next, g_inv};
+    const ExtPow zpow[3] = {pz, pzn, pgi};
+    ExtPow zinv[3];
+    u64* tot = mem.alloc((n + SCAN_B - 1) / SCAN_B + 1);
+    for (int b = 0; b < 3; b++) {
+        zinv[b] = make_ext_pow(mem, ext_inv(zpts[b]), degree_bits);
+        if (b == 2 && !use2) continue;
+        hipLaunchKernelGGL(weight_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, S + 2 * b * n, S + (2 * b + 1) * n,
+                           n, zpow[b]);
+        scan_plane(mem, S + 2 * b * n, n, tot);
+        scan_plane(mem, S + (2 * b + 1) * n, n, tot);
+    }
+    // weights: ((q0 * alpha^l1) + q1) * alpha^l2 + q2   (oracle.rs:212-213)
+    const Ext2 w2 = ext_make(1, 0);
+    const Ext2 w1 = use2 ? ext_pow(alpha, (u64)l2) : ext_make(1, 0);
+    const Ext2 w0 = ext_mul(ext_pow(alpha, (u64)l1), w1);
+    // coefficient planes [fa | fb] of length N (zero padded: PolynomialCoeffs::lde, polynomial/mod.rs:215-217)
+    u64* coef = mem.alloc(2 * N);
+    hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, S, n, zinv[0], zinv[1], zinv[2], w0,
+                       w1, w2, use2 ? 1 : 0, coef, coef + N, N);
+
+    // ---- FRI commit phase (fri/prover.rs:72-121) ----
+    std::vector<FriLayer> layers;
+    u64 shift = GL_GENERATOR;
+    size_t len = N;
+    u64* cur_coef = coef;  // planes [a | b] each `len`
+    for (size_t li = 0; li < arities.size(); li++) {
+        const int ab = arities[li];
+        const int arity = 1 << ab;
+        int cur_bits = 0;
+        while (((size_t)1 << cur_bits) < len) cur_bits++;
+        // values = coset_fft(coeffs, shift), kept bit-reversed (reverse_index_bits_in_place, prover.rs:88)
+        FriLayer L;
+        L.len = len; L.arity_bits = ab;
+        L.va = mem.alloc(2 * len);
+        L.vb = L.va + len;
+        ntt_coset_evaluate(tables, cur_coef, L.va, nullptr, cur_bits, 2, shift, false);
+        const size_t nleaves = len >> ab;
+        L.heap = mem.alloc(2 * nleaves * 4);
+        launch_leaf_hash_ext(ctx, L.va, L.vb, arity, nleaves, L.heap + 4 * nleaves);
+        launch_merkle_build(ctx, L.heap, nleaves);
+        L.cap.resize(len_cap * 4);
+        HIP_CHECK(hipMemcpyAsync(L.cap.data(), L.heap + 4 * len_cap, len_cap * 32, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        challenger_observe(ch, L.cap.data(), L.cap.size());
+        const Ext2 beta = challenger_get_ext(ch);
+        const size_t out_len = len >> ab;
+        u64* folded = mem.alloc(2 * out_len);
+        hipLaunchKernelGGL(fold_kernel, dim3((unsigned)((out_len + 255) / 256)), dim3(256), 0, ctx->stream, cur_coef, cur_coef + len, out_len,
+                           arity, beta, folded, folded + out_len);
+        cur_coef = folded;
+        len = out_len;
+        shift = gl_pow(shift, (u64)arity);
+        layers.push_back(L);
+    }
+    // final polynomial: truncate to len / 2^rate_bits (prover.rs:114-119)
+    const size_t final_len = len >> rate_bits;
+    std::vector<u64> h_final(2 * len);
+    HIP_CHECK(hipMemcpyAsync(h_final.data(), cur_coef, 2 * len * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    std::vector<Ext2> final_poly(final_len);
+    for (size_t i = 0; i < final_len; i++) final_poly[i] = ext_make(h_final[i], h_final[len + i]);
+    for (auto& e : final_poly) challenger_observe_ext(ch, e);
+
+    // ---- proof of work (prover.rs:126-148), minimal witness ----
+    u64 hsh[4];
+    for (int i = 0; i < 4; i++) hsh[i] = challenger_get(ch);
+    const u64 pow_witness = run_pow(ctx, hsh, cfg.proof_of_work_bits);
+
+    // ---- query rounds (prover.rs:150-204) ----
+    const int nq = (int)cfg.num_query_rounds;
+    std::vector<size_t> xs(nq);
+    for (int r = 0; r < nq; r++) xs[r] = (size_t)(challenger_get(ch) % (u64)N);
+    const OlaBatch* oracles[3] = {&trace, &zs, &quot};
+    const int depth0 = degree_bits + rate_bits - (int)cfg.cap_height;
+    std::vector<std::vector<u64>> rows(3), paths(3);
+    for (int o = 0; o < 3; o++) {
+        rows[o].resize((size_t)nq * oracles[o]->ncols);
+        paths[o].resize((size_t)nq * (size_t)std::max(depth0, 1) * 4);
+        batch_get_leaves(ctx, *oracles[o], xs.data(), nq, rows[o].data(), paths[o].data());
+    }
+    // per layer: leaves (arity ext) and paths at x >> (sum of arity bits so far + this)
+    std::vector<std::vector<u64>> lrows(layers.size()), lpaths(layers.size());
+    std::vector<int> ldepth(layers.size());
+    {
+        std::vector<size_t> cur = xs;
+        unsigned long long* d_idx = (unsigned long long*)mem.alloc(nq);
+        for (size_t li = 0; li < layers.size(); li++) {
+            FriLayer& L = layers[li];
+            const int arity = 1 << L.arity_bits;
+            const size_t nleaves = L.len >> L.arity_bits;
+            int lb = 0;
+            while (((size_t)1 << lb) < nleaves) lb++;
+            ldepth[li] = lb - (int)cfg.cap_height;
+            std::vector<unsigned long long> h_idx(nq);
+            for (int r = 0; r < nq; r++) { cur[r] >>= L.arity_bits; h_idx[r] = cur[r]; }
+            HIP_CHECK(hipMemcpyAsync(d_idx, h_idx.data(), nq * 8, hipMemcpyHostToDevice, ctx->stream));
+            u64* d_rows = mem.alloc((size_t)nq * arity * 2);
+            hipLaunchKernelGGL(gather_ext_leaves_kernel, dim3((unsigned)nq), dim3(64), 0, ctx->stream, L.va, L.vb, arity, d_idx, d_rows);
+            lrows[li].resize((size_t)nq * arity * 2);
+            HIP_CHECK(hipMemcpyAsync(lrows[li].data(), d_rows, lrows[li].size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+            if (ldepth[li] > 0) {
+                u64* d_paths = mem.alloc((size_t)nq * ldepth[li] * 4);
+                hipLaunchKernelGGL(gather_paths_kernel, dim3((unsigned)nq), dim3(((ldepth[li] * 4 + 63) / 64) * 64), 0, ctx->stream, L.heap,
+                                   nleaves, ldepth[li], d_idx, d_paths);
+                lpaths[li].resize((size_t)nq * ldepth[li] * 4);
+                HIP_CHECK(hipMemcpyAsync(lpaths[li].data(), d_paths, lpaths[li].size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+            }
+            HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        }
+    }
+
+    // ---- serialise the FRI proof (serialization.rs:305-317) ----
+    w.u32((uint32_t)layers.size());
+    for (auto& L : layers) w.cap(L.cap.data(), len_cap);
+    w.u32((uint32_t)nq);
+    for (int r = 0; r < nq; r++) {
+        w.u32(3);
+        for (int o = 0; o < 3; o++) {
+            w.field_vec(rows[o].data() + (size_t)r * oracles[o]->ncols, oracles[o]->ncols);
+            w.merkle_proof(paths[o].data() + (size_t)r * (size_t)std::max(depth0, 0) * 4, std::max(depth0, 0));
+        }
+        w.u32((uint32_t)layers.size());
+        for (size_t li = 0; li < layers.size(); li++) {
+            const int arity = 1 << layers[li].arity_bits;
+            w.u32((uint32_t)arity);
+            for (int k = 0; k < arity; k++) {
+                w.field(lrows[li][((size_t)r * arity + k) * 2]);
+                w.field(lrows[li][((size_t)r * arity + k) * 2 + 1]);
+            }
+            w.merkle_proof(ldepth[li] > 0 ? lpaths[li].data() + (size_t)r * ldepth[li] * 4 : nullptr, ldepth[li] > 0 ? ldepth[li] : 0);
+        }
+    }
+    w.ext_vec(final_poly);
+    w.field(pow_witness);
 }
 
 }  // namespace ola

@@ -174,3 +174,57 @@ def test_commit_from_device_buffer(be, oracle):
     b = be.commit_dev(t.data_ptr(), 7, 11)
     assert np.array_equal(b.cap(), oracle.batch(vals).cap())
     b.free()
+
+
+# ---------------------------------------------------------------- openings + FRI (prover.rs:499-553 tail)
+@pytest.mark.parametrize("log_n,cols,nperm", [(5, (3, 2, 2), 0), (7, (5, 4, 4), 1), (9, (12, 6, 2), 2), (12, (9, 5, 4), 0),
+                                              (14, (6, 3, 2), 0)])
+def test_open_and_prove_bytes_match_oracle_and_verify(be, oracle, log_n, cols, nperm):
+    from olavm_amd.backend import Challenger
+    rng = np.random.default_rng(1000 + log_n)
+    n = 1 << log_n
+    tv, zv, qc = rand_field(rng, (cols[0], n)), rand_field(rng, (cols[1], n)), rand_field(rng, (cols[2], n))
+    # GPU path
+    gt, gz, gq = be.commit(tv), be.commit(zv), be.commit(qc, from_coeffs=True)
+    ch = Challenger()
+    for b in (gt, gz, gq):
+        ch.observe(b.cap())
+    g_open, g_fri = be.open_and_prove(gt, gz, gq, nperm, ch)
+    # oracle path
+    ot, oz, oq = oracle.batch(tv), oracle.batch(zv), oracle.batch(qc, from_coeffs=True)
+    och = oracle.challenger()
+    for b in (ot, oz, oq):
+        och.observe(b.cap())
+    vch = och.clone()
+    zeta, o_open, o_fri = oracle.open_and_prove(ot, oz, oq, nperm, och)
+    assert g_open == o_open, "opening set bytes differ"
+    assert g_fri == o_fri, "FRI proof bytes differ"
+    # the transcript ends in the same state
+    assert ch.get() == och.get()
+    # and the independently written verifier accepts the GPU proof
+    caps = np.stack([gt.cap(), gz.cap(), gq.cap()])
+    rc, why = oracle.verify_opening(caps, cols, log_n, nperm, g_open + g_fri, vch)
+    assert rc == 0, why
+    for b in (gt, gz, gq):
+        b.free()
+
+
+def test_open_and_prove_large_verifies(be, oracle):
+    """2^18 rows: too slow for the oracle prover, but the oracle VERIFIER checks the GPU proof end to end
+    (Merkle paths, FRI folding consistency, final polynomial, proof of work)."""
+    from olavm_amd.backend import Challenger
+    rng = np.random.default_rng(18)
+    log_n, cols, nperm = 18, (8, 4, 4), 0
+    n = 1 << log_n
+    gt = be.commit(rand_field(rng, (cols[0], n)))
+    gz = be.commit(rand_field(rng, (cols[1], n)))
+    gq = be.commit(rand_field(rng, (cols[2], n)), from_coeffs=True)
+    ch = Challenger()
+    och = oracle.challenger()
+    for b in (gt, gz, gq):
+        ch.observe(b.cap())
+        och.observe(b.cap())
+    g_open, g_fri = be.open_and_prove(gt, gz, gq, nperm, ch)
+    caps = np.stack([gt.cap(), gz.cap(), gq.cap()])
+    rc, why = oracle.verify_opening(caps, cols, log_n, nperm, g_open + g_fri, och)
+    assert rc == 0, why
