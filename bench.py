@@ -108,15 +108,12 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     dev_ms = ev0.elapsed_time(ev1)
-    if world > 1:
-        t = torch.tensor([elapsed, dev_ms], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, dev_ms = float(t[0]), float(t[1])
+    from olavm_amd import sharding
+    elapsed, dev_ms = sharding.max_over_ranks([elapsed, dev_ms], device="cuda")
 
     if rank == 0:
         bytes_per_step = 16.0 * n * cols            # algorithmic: one read + one write of every element
-        total_bytes = bytes_per_step * world * args.steps
-        value = total_bytes / elapsed / 1e9
+        value = sharding.aggregate_throughput(cols, 16.0 * n, world, args.steps, elapsed)
         # dominant kernel = ntt_pass_kernel; a 2^22 natural-order transform launches it `passes` times over the batch
         passes = 1 if args.log_n <= 13 else (2 if args.log_n <= 18 else 3)
         launch_ms = dev_ms / args.steps / passes
