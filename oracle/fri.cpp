@@ -40,7 +40,8 @@ PolynomialBatch batch_from_coeffs(std::vector<std::vector<u64>> coeffs, int rate
     b.rate_bits = rate_bits;
     int lde_bits = b.degree_log + rate_bits;
     std::vector<u64> leaves(N * ncols);
-    for (size_t c = 0; c < ncols; c++) {
+#pragma omp parallel for schedule(dynamic, 1)
+    for (long c = 0; c < (long)ncols; c++) {
         std::vector<u64> lde = evaluate_poly_with_offset(coeffs[c].data(), degree, GL_GENERATOR, (size_t)1 << rate_bits);
         // transpose + reverse_index_bits_in_place(leaves): leaf j is natural LDE row bitrev(j)
         for (size_t j = 0; j < N; j++) leaves[j * ncols + c] = lde[reverse_bits(j, lde_bits)];
@@ -52,7 +53,8 @@ PolynomialBatch batch_from_coeffs(std::vector<std::vector<u64>> coeffs, int rate
 
 PolynomialBatch batch_from_values(const std::vector<std::vector<u64>>& values, int rate_bits, int cap_height) {
     std::vector<std::vector<u64>> coeffs = values;
-    for (auto& c : coeffs) interpolate_poly(c.data(), c.size());
+#pragma omp parallel for schedule(dynamic, 1)
+    for (long c = 0; c < (long)coeffs.size(); c++) interpolate_poly(coeffs[c].data(), coeffs[c].size());
     return batch_from_coeffs(std::move(coeffs), rate_bits, cap_height);
 }
 

@@ -27,7 +27,18 @@ static inline u64 gl_canon(u64 x) { return x >= GL_P ? x - GL_P : x; }
 static inline u64 gl_add(u64 a, u64 b) { u128 s = (u128)a + b; return (u64)(s >= GL_P ? s - GL_P : s); }
 static inline u64 gl_sub(u64 a, u64 b) { return a >= b ? a - b : a + (GL_P - b); }
 static inline u64 gl_neg(u64 a) { return a ? GL_P - a : 0; }
-static inline u64 gl_mul(u64 a, u64 b) { return (u64)(((u128)a * b) % GL_P); }
+// goldilocks_field.rs:329-345 reduce128 (2^64 = 2^32 - 1, 2^96 = -1 mod p), followed by canonicalisation
+static inline u64 gl_reduce128(u128 x) {
+    u64 lo = (u64)x, hi = (u64)(x >> 64);
+    u64 hh = hi >> 32, hl = hi & 0xFFFFFFFFull;
+    u64 t0 = lo - hh;
+    if (lo < hh) t0 -= 0xFFFFFFFFull;
+    u64 t1 = hl * 0xFFFFFFFFull;
+    u64 t2 = t0 + t1;
+    if (t2 < t0) t2 += 0xFFFFFFFFull;
+    return gl_canon(t2);
+}
+static inline u64 gl_mul(u64 a, u64 b) { return gl_reduce128((u128)a * b); }
 static inline u64 gl_pow(u64 b, u64 e) {
     u64 r = 1;
     while (e) { if (e & 1) r = gl_mul(r, b); b = gl_mul(b, b); e >>= 1; }

@@ -18,10 +18,12 @@ MerkleTree merkle_new_v2(std::vector<u64> leaves, size_t num_leaves, size_t leaf
     t.cap_height = cap_height;
     t.leaves = std::move(leaves);
     t.leaf_hash.resize(num_leaves);
-    for (size_t i = 0; i < num_leaves; i++) t.leaf_hash[i] = hash_no_pad(t.get(i), leaf_len);
+#pragma omp parallel for schedule(static)
+    for (long i = 0; i < (long)num_leaves; i++) t.leaf_hash[i] = hash_no_pad(t.get(i), leaf_len);
     size_t n = num_leaves / 2;
     t.nodes.assign(2 * n > 0 ? 2 * n : 1, HashOut{0, 0, 0, 0});
-    for (size_t i = 0; i < n; i++) t.nodes[n + i] = two_to_one(t.leaf_hash[2 * i], t.leaf_hash[2 * i + 1]);
+#pragma omp parallel for schedule(static)
+    for (long i = 0; i < (long)n; i++) t.nodes[n + i] = two_to_one(t.leaf_hash[2 * i], t.leaf_hash[2 * i + 1]);
     for (size_t i = n; i-- > 1;) t.nodes[i] = two_to_one(t.nodes[2 * i], t.nodes[2 * i + 1]);
     size_t len_cap = (size_t)1 << cap_height;
     t.cap.resize(len_cap);

@@ -70,6 +70,14 @@ class Oracle:
         L.oracle_verify_opening.argtypes = [U64P, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_char_p, C.c_size_t,
                                             C.c_void_p, C.POINTER(C.c_int), C.c_char_p, C.c_size_t]
         L.oracle_verify_opening.restype = C.c_int
+        L.oracle_prove_with_traces.argtypes = [U64P, C.c_size_t, C.POINTER(U64P), C.POINTER(C.c_uint32), U64P, U64P,
+                                               C.POINTER(C.c_int), C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]
+        L.oracle_prove_with_traces.restype = C.c_size_t
+        L.oracle_verify_all_proof.argtypes = [U64P, C.c_size_t, U64P, C.POINTER(C.c_int), C.c_char_p, C.c_size_t, C.c_char_p,
+                                              C.c_size_t]
+        L.oracle_verify_all_proof.restype = C.c_int
+        L.oracle_check_constraints.argtypes = [U64P, C.c_size_t, C.c_int, U64P, C.c_uint32, U64P]
+        L.oracle_check_constraints.restype = C.c_long
         L.oracle_ext_mul.argtypes = [U64P, U64P, U64P]
         L.oracle_ext_inv.argtypes = [U64P, U64P]
 
@@ -186,6 +194,48 @@ class Oracle:
         rc = self.lib.oracle_verify_opening(ptr(caps), (C.c_int * 3)(*num_polys), degree_bits, num_perm_zs, proof_bytes,
                                             len(proof_bytes), challenger.h, c, msg, 256)
         return rc, msg.value.decode()
+
+
+    # ---- multi-table STARK (oracle/stark.cpp) ----
+    @staticmethod
+    def _stark_args(blob, traces, params, compress):
+        blob = np.ascontiguousarray(blob, dtype=np.uint64)
+        tr = [np.ascontiguousarray(t, dtype=np.uint64) for t in traces]
+        ptrs = (U64P * len(tr))(*[ptr(t) for t in tr])
+        logs = (C.c_uint32 * len(tr))(*[int(t.shape[1]).bit_length() - 1 for t in tr])
+        pr = np.ascontiguousarray(params if params is not None else [], dtype=np.uint64)
+        cc = np.ascontiguousarray(compress if compress is not None else np.zeros(len(tr)), dtype=np.uint64)
+        return blob, tr, ptrs, logs, pr, cc
+
+    def prove_with_traces(self, blob, traces, params=None, compress=None, cfg=None):
+        blob, tr, ptrs, logs, pr, cc = self._stark_args(blob, traces, params, compress)
+        c = None if cfg is None else (C.c_int * 6)(*cfg)
+        err = C.create_string_buffer(512)
+        cap = 1 << 22
+        while True:
+            buf = C.create_string_buffer(cap)
+            n = self.lib.oracle_prove_with_traces(ptr(blob), blob.size, ptrs, logs, ptr(pr) if pr.size else None, ptr(cc), c, buf,
+                                                  cap, err, 512)
+            if n == 0:
+                raise RuntimeError("oracle prover: " + err.value.decode())
+            if n <= cap:
+                return bytes(buf.raw[:n])
+            cap = n
+
+    def verify_all_proof(self, blob, proof_bytes, params=None, cfg=None):
+        blob = np.ascontiguousarray(blob, dtype=np.uint64)
+        pr = np.ascontiguousarray(params if params is not None else [], dtype=np.uint64)
+        c = None if cfg is None else (C.c_int * 6)(*cfg)
+        msg = C.create_string_buffer(512)
+        rc = self.lib.oracle_verify_all_proof(ptr(blob), blob.size, ptr(pr) if pr.size else None, c, proof_bytes, len(proof_bytes),
+                                              msg, 512)
+        return rc, msg.value.decode()
+
+    def check_constraints(self, blob, table, trace, params=None):
+        blob = np.ascontiguousarray(blob, dtype=np.uint64)
+        tr = np.ascontiguousarray(trace, dtype=np.uint64)
+        pr = np.ascontiguousarray(params if params is not None else [0], dtype=np.uint64)
+        return int(self.lib.oracle_check_constraints(ptr(blob), blob.size, table, ptr(tr), int(tr.shape[1]).bit_length() - 1, ptr(pr)))
 
 
 class Batch:
