@@ -149,6 +149,22 @@ int32_t ola_open_and_prove(OlaCtx* ctx, const OlaBatch* trace, const OlaBatch* z
  * Poseidon.hash_no_pad([h0..h3, i])[0] has >= bits leading zeros. */
 int32_t ola_pow(OlaCtx* ctx, const uint64_t h[4], uint32_t bits, uint64_t* witness);
 
+/* ---- the whole multi-table proof: replaces prove_with_traces (circuits/src/stark/prover.rs:79-327) -------------
+ * airset: the AIR-set description (tables, constraint programs, permutation pairs, cross-table lookups) as a u64
+ *   array -- the data form of the reference's OlaStark (stark/ola_stark.rs:29-64, 122-560); format and generator in
+ *   olavm_amd/air/dsl.py.
+ * traces[t]: host pointer to table t, column-major ncols x 2^log_n[t] (the [Vec<PolynomialValues<F>>; NUM_TABLES]
+ *   that generate_traces returns, generation/mod.rs:77-213).
+ * params: concatenated per-table constraint parameters (e.g. the bitwise/program compress challenge read inside
+ *   the AIR), may be NULL when no table has any; compress_challenges: one per table as carried in AllProof
+ *   (prover.rs:307-320), may be NULL (zeros).
+ * out: AllProof in the reference wire format (serialization.rs:377-393 write_all_proof).  Returns
+ * OLA_E_INVALID_ARG with *out_len = required size when `cap` is too small, OLA_E_QUOTIENT_DEGREE when the trace
+ * does not satisfy the constraints (prover.rs:469-473). */
+int32_t ola_prove_with_traces(OlaCtx* ctx, const uint64_t* airset, size_t airset_words, const uint64_t* const* traces,
+                              const uint32_t* log_n, const uint64_t* params, const uint64_t* compress_challenges,
+                              uint8_t* out, size_t cap, size_t* out_len);
+
 #ifdef __cplusplus
 }
 #endif

@@ -80,6 +80,8 @@ def load_library():
     L.ola_challenger_compact.argtypes = [C.POINTER(OlaChallenger)]
     L.ola_open_and_prove.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(OlaChallenger),
                                      C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+    L.ola_prove_with_traces.argtypes = [C.c_void_p, U64P, C.c_size_t, C.POINTER(U64P), C.POINTER(C.c_uint32), U64P, U64P,
+                                        C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]
     _lib = L
     return L
 
@@ -89,7 +91,7 @@ EXPORTS = [
     "ola_poseidon_permute", "ola_hash_rows", "ola_merkle_cap", "ola_commit_values", "ola_commit_coeffs",
     "ola_commit_values_dev", "ola_commit_coeffs_dev", "ola_batch_free", "ola_batch_shape", "ola_batch_get_coeffs",
     "ola_batch_get_leaf", "ola_batch_get_lde_row", "ola_challenger_init", "ola_challenger_observe",
-    "ola_challenger_get", "ola_challenger_compact", "ola_open_and_prove", "ola_pow",
+    "ola_challenger_get", "ola_challenger_compact", "ola_open_and_prove", "ola_pow", "ola_prove_with_traces",
 ]
 
 
@@ -248,6 +250,26 @@ class Backend:
         f = self.lib.ola_commit_coeffs_dev if from_coeffs else self.lib.ola_commit_values_dev
         self._chk(f(self.ctx, dev_ptr, ncols, log_n, C.byref(h), _p(cap)))
         return Batch(self, h, cap)
+
+    def prove_with_traces(self, airset_blob, traces, params=None, compress=None):
+        """AllProof bytes for the multi-table STARK described by `airset_blob` (olavm_amd.air.AirSet.blob())."""
+        blob = np.ascontiguousarray(airset_blob, dtype=np.uint64)
+        tr = [np.ascontiguousarray(t, dtype=np.uint64) for t in traces]
+        ptrs = (U64P * len(tr))(*[_p(t) for t in tr])
+        logs = (C.c_uint32 * len(tr))(*[int(t.shape[1]).bit_length() - 1 for t in tr])
+        pr = None if params is None else np.ascontiguousarray(params, dtype=np.uint64)
+        cc = None if compress is None else np.ascontiguousarray(compress, dtype=np.uint64)
+        need = C.c_size_t(0)
+        cap = 1 << 20
+        while True:
+            buf = C.create_string_buffer(cap)
+            rc = self.lib.ola_prove_with_traces(self.ctx, _p(blob), blob.size, ptrs, logs, None if pr is None else _p(pr),
+                                                None if cc is None else _p(cc), buf, cap, C.byref(need))
+            if rc != 0 and need.value > cap:
+                cap = need.value
+                continue
+            self._chk(rc)
+            return bytes(buf.raw[:need.value])
 
     def open_and_prove(self, trace, zs, quot, num_permutation_zs, challenger):
         need, olen = C.c_size_t(0), C.c_size_t(0)

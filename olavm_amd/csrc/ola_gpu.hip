@@ -18,6 +18,7 @@
 #include "merkle.hip"
 #include "batch.hip"
 #include "fri.hip"
+#include "stark.hip"
 
 using namespace ola;
 
@@ -328,6 +329,20 @@ int32_t ola_open_and_prove(OlaCtx* ctx, const OlaBatch* trace, const OlaBatch* z
     if (bytes.size() > cap || !out) throw OlaError(OLA_E_INVALID_ARG, "output buffer too small");
     memcpy(out, bytes.data(), bytes.size());
     *challenger = ch;
+    OLA_CATCH
+}
+
+int32_t ola_prove_with_traces(OlaCtx* ctx, const uint64_t* airset, size_t airset_words, const uint64_t* const* traces,
+                              const uint32_t* log_n, const uint64_t* params, const uint64_t* compress_challenges, uint8_t* out,
+                              size_t cap, size_t* out_len) {
+    OLA_TRY
+    require(ctx && airset && traces && log_n && out_len, "null pointer");
+    std::vector<uint8_t> bytes;
+    prove_with_traces(&ctx->dev, *ctx->tables, ctx->cfg, (const u64*)airset, airset_words, (const u64* const*)traces, log_n,
+                      (const u64*)params, (const u64*)compress_challenges, bytes);
+    *out_len = bytes.size();
+    if (bytes.size() > cap || !out) throw OlaError(OLA_E_INVALID_ARG, "output buffer too small");
+    memcpy(out, bytes.data(), bytes.size());
     OLA_CATCH
 }
 

@@ -1,0 +1,605 @@
+// Multi-table STARK prover on the device: CTL / permutation Z columns, constraint quotient, per-table proof assembly.
+//
+// Replaces (reference paths relative to /root/reference/circuits/src/stark):
+//   prover.rs:79-327        prove_with_traces         -> prove_with_traces() below (host orchestration, device data)
+//   prover.rs:330-567       prove_single_table
+//   prover.rs:571-705       compute_quotient_polys    -> quotient_kernel (one thread per LDE point, constraint program
+//                                                        interpreted out of an LDS register file) + coset iNTT
+//   cross_table_lookup.rs:224-311  cross_table_lookup_data / partial_products -> ctl_factor_kernel + product scan
+//   permutation.rs:103-155  compute_permutation_z_polys -> perm_factor_kernel + product scan
+//   constraint_consumer.rs:34-78, vanishing_poly.rs:20-45, permutation.rs:302-360, cross_table_lookup.rs:380-421
+//                           ConstraintConsumer / eval_vanishing_poly / permutation + CTL checks (inside quotient_kernel)
+//   serialization.rs:349-358,377-393   write_proof / write_all_proof
+// The table descriptions (constraint programs, permutation pairs, CTLs) are data: the AIR-set blob produced by
+// olavm_amd/air/dsl.py.  The sequential prefix products of the reference become three-phase parallel scans; the
+// quotient is evaluated directly on the resident LDE in leaf order (thread j <-> leaf j <-> natural LDE row bitrev(j)),
+// which for a table of quotient-degree 2^qdb are exactly the first n*2^qdb leaves (cosets 0..2^qdb-1).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/ola_gpu.h"
+#include "device_ctx.h"
+#include "gl.cuh"
+
+namespace ola {
+
+// ------------------------------------------------------------------------------------------------ AIR-set (host)
+enum { AOP_LOCAL = 0, AOP_NEXT, AOP_CONST, AOP_PARAM, AOP_ADD, AOP_SUB, AOP_MUL, AOP_EMIT };
+enum { AK_ALL = 0, AK_TRANSITION, AK_FIRST, AK_LAST };
+
+struct HLinCol { std::vector<std::pair<u64, u64>> terms; u64 constant = 0; };
+struct HTwc { int table = 0; std::vector<HLinCol> columns; bool has_filter = false; HLinCol filter; };
+struct HCtl { std::vector<HTwc> looking; HTwc looked; };
+struct HTable {
+    int ncols = 0, constraint_degree = 0, n_regs = 0, n_params = 0;
+    std::vector<std::vector<std::pair<u64, u64>>> perm_pairs;
+    std::vector<u64> ops;  // 2 words per op
+    int quotient_degree_factor() const { return std::max(1, constraint_degree - 1); }
+    int permutation_batch_size() const { return quotient_degree_factor(); }
+    int num_permutation_batches(int nch) const {
+        const int inst = (int)perm_pairs.size() * nch;
+        return inst ? (inst + permutation_batch_size() - 1) / permutation_batch_size() : 0;
+    }
+};
+struct HAirSet { std::vector<HTable> tables; std::vector<HCtl> ctls; };
+
+static HAirSet parse_airset(const u64* w, size_t n) {
+    size_t p = 0;
+    auto next = [&]() -> u64 {
+        if (p >= n) throw OlaError(OLA_E_INVALID_ARG, "AIR-set blob truncated");
+        return w[p++];
+    };
+    if (next() != 0x4F4C41414952ull || next() != 1) throw OlaError(OLA_E_INVALID_ARG, "AIR-set blob: bad magic/version");
+    const size_t nt = next(), nc = next();
+    HAirSet s;
+    for (size_t t = 0; t < nt; t++) {
+        HTable a;
+        a.ncols = (int)next(); a.constraint_degree = (int)next(); a.n_regs = (int)next(); a.n_params = (int)next();
+        const size_t np = next();
+        for (size_t i = 0; i < np; i++) {
+            const size_t len = next();
+            std::vector<std::pair<u64, u64>> pr;
+            for (size_t k = 0; k < len; k++) { const u64 l = next(); const u64 r = next(); pr.push_back({l, r}); }
+            a.perm_pairs.push_back(pr);
+        }
+        const size_t nops = next();
+        for (size_t i = 0; i < 2 * nops; i++) a.ops.push_back(next());
+        s.tables.push_back(a);
+    }
+    auto col = [&]() { HLinCol c; const size_t k = next(); for (size_t i = 0; i < k; i++) { const u64 cc = next(); const u64 f = next(); c.terms.push_back({cc, f}); } c.constant = next(); return c; };
+    auto twc = [&]() { HTwc t; t.table = (int)next(); const size_t k = next(); for (size_t i = 0; i < k; i++) t.columns.push_back(col()); t.has_filter = next() != 0; if (t.has_filter) t.filter = col(); return t; };
+    for (size_t c = 0; c < nc; c++) {
+        HCtl ctl;
+        const size_t nl = next();
+        for (size_t i = 0; i < nl; i++) ctl.looking.push_back(twc());
+        ctl.looked = twc();
+        for (auto& t : ctl.looking) if (t.table < 0 || t.table >= (int)nt) throw OlaError(OLA_E_INVALID_ARG, "CTL table index");
+        if (ctl.looked.table < 0 || ctl.looked.table >= (int)nt) throw OlaError(OLA_E_INVALID_ARG, "CTL table index");
+        s.ctls.push_back(ctl);
+    }
+    if (p != n) throw OlaError(OLA_E_INVALID_ARG, "AIR-set blob has trailing words");
+    return s;
+}
+
+static void push_lincol(std::vector<u64>& d, const HLinCol& c) {
+    d.push_back(c.terms.size());
+    for (auto& t : c.terms) { d.push_back(t.first); d.push_back(t.second); }
+    d.push_back(c.constant);
+}
+// [beta, gamma, ncols, lincol*, has_filter, lincol?]
+static void push_ctl_desc(std::vector<u64>& d, const HTwc& t, u64 beta, u64 gamma) {
+    d.push_back(beta); d.push_back(gamma); d.push_back(t.columns.size());
+    for (auto& c : t.columns) push_lincol(d, c);
+    d.push_back(t.has_filter ? 1 : 0);
+    if (t.has_filter) push_lincol(d, t.filter);
+}
+
+// ------------------------------------------------------------------------------------------------ device helpers
+// evaluate a linear combination of columns at row `row` of a column-major table (stride `cs`); advances the cursor
+__device__ __forceinline__ u64 dev_lincol(const u64* __restrict__ d, u32& p, const u64* __restrict__ tab, size_t cs, size_t row) {
+    const u32 nt = (u32)d[p++];
+    u64 s = 0;
+    for (u32 i = 0; i < nt; i++) {
+        const u64 c = d[p++], f = d[p++];
+        s = gl_add(s, gl_mul(gl_canon(tab[c * cs + row]), f));
+    }
+    return gl_add(s, d[p++]);
+}
+
+// CTL factor column: out[i] = filter(i) ? combine(i) : 1   (cross_table_lookup.rs:284-311)
+__global__ __launch_bounds__(256) void ctl_factor_kernel(const u64* __restrict__ trace, size_t n, const u64* __restrict__ desc,
+                                                         u64* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u32 p = 0;
+    const u64 beta = desc[p++], gamma = desc[p++];
+    const u32 ncol = (u32)desc[p++];
+    // combine = reduce_with_powers(evals, beta) + gamma = sum_k beta^k e_k + gamma
+    u64 acc = 0, bp = 1;
+    for (u32 k = 0; k < ncol; k++) {
+        acc = gl_add(acc, gl_mul(bp, dev_lincol(desc, p, trace, n, i)));
+        bp = gl_mul(bp, beta);
+    }
+    acc = gl_add(acc, gamma);
+    u64 f = 1;
+    if (desc[p++]) f = dev_lincol(desc, p, trace, n, i);
+    out[i] = (f == 1) ? acc : 1;  // a filter outside {0,1} is rejected on the host side of the reference (assert)
+}
+
+// permutation quotient column: out[i] = prod_inst (gamma + sum beta^k lhs_k) / prod_inst (gamma + sum beta^k rhs_k)
+// desc: [n_inst, (beta, gamma, npairs, (lhs, rhs)*)*]
+__global__ __launch_bounds__(256) void perm_factor_kernel(const u64* __restrict__ trace, size_t n, const u64* __restrict__ desc,
+                                                          u64* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u32 p = 0;
+    const u32 ninst = (u32)desc[p++];
+    u64 num = 1, den = 1;
+    for (u32 s = 0; s < ninst; s++) {
+        const u64 beta = desc[p++], gamma = desc[p++];
+        const u32 np = (u32)desc[p++];
+        u64 l = gamma, r = gamma, w = 1;
+        for (u32 k = 0; k < np; k++) {
+            const u64 cl = desc[p++], cr = desc[p++];
+            l = gl_add(l, gl_mul(gl_canon(trace[cl * n + i]), w));
+            r = gl_add(r, gl_mul(gl_canon(trace[cr * n + i]), w));
+            w = gl_mul(w, beta);
+        }
+        num = gl_mul(num, l);
+        den = gl_mul(den, r);
+    }
+    out[i] = gl_mul(num, gl_inv(den));
+}
+
+// multiplicative inclusive prefix scan, 3 phases, blocks of 2048
+#define PSCAN_B 2048
+__global__ __launch_bounds__(256) void pscan_local_kernel(u64* __restrict__ d, size_t n, u64* __restrict__ block_tot) {
+    __shared__ u64 sh[256];
+    const size_t b0 = (size_t)blockIdx.x * PSCAN_B;
+    const int t = threadIdx.x;
+    u64 v[8];
+    u64 run = 1;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const size_t k = b0 + (size_t)t * 8 + i;
+        run = gl_mul(run, k < n ? d[k] : 1);
+        v[i] = run;
+    }
+    sh[t] = run;
+    __syncthreads();
+    u64 incl = run;
+    for (int s = 1; s < 256; s <<= 1) {
+        const u64 other = (t >= s) ? sh[t - s] : 1;
+        __syncthreads();
+        incl = gl_mul(incl, other);
+        sh[t] = incl;
+        __syncthreads();
+    }
+    const u64 excl = (t > 0) ? sh[t - 1] : 1;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const size_t k = b0 + (size_t)t * 8 + i;
+        if (k < n) d[k] = gl_mul(v[i], excl);
+    }
+    if (t == 255) block_tot[blockIdx.x] = incl;
+}
+__global__ void pscan_totals_kernel(u64* __restrict__ tot, size_t nblocks) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    u64 run = 1;
+    for (size_t i = 0; i < nblocks; i++) {
+        const u64 v = tot[i];
+        tot[i] = run;
+        run = gl_mul(run, v);
+    }
+}
+__global__ __launch_bounds__(256) void pscan_apply_kernel(u64* __restrict__ d, size_t n, const u64* __restrict__ tot) {
+    const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    d[k] = gl_mul(d[k], tot[k / PSCAN_B]);
+}
+// exclusive form: out[0] = 1, out[i] = incl[i-1]
+__global__ __launch_bounds__(256) void shift_right_kernel(const u64* __restrict__ incl, u64* __restrict__ out, size_t n) {
+    const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    out[k] = k ? incl[k - 1] : 1;
+}
+
+static void product_scan_inclusive(DeviceCtx* ctx, u64* col, size_t n, u64* tot) {
+    const size_t nblocks = (n + PSCAN_B - 1) / PSCAN_B;
+    hipLaunchKernelGGL(pscan_local_kernel, dim3((unsigned)nblocks), dim3(256), 0, ctx->stream, col, n, tot);
+    if (nblocks > 1) {
+        hipLaunchKernelGGL(pscan_totals_kernel, dim3(1), dim3(64), 0, ctx->stream, tot, nblocks);
+        hipLaunchKernelGGL(pscan_apply_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, col, n, tot);
+    }
+}
+
+// Lagrange selector polynomials in coefficient form: L_0 = (1/n) sum X^k ; L_{n-1} = (1/n) sum g^k X^k
+__global__ __launch_bounds__(256) void lagrange_coeffs_kernel(u64* __restrict__ out, size_t n, u64 n_inv, const u64* __restrict__ g_lo,
+                                                              const u64* __restrict__ g_hi, int g_h) {
+    const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    out[k] = n_inv;
+    const u64 gk = gl_mul(g_lo[k & (((size_t)1 << g_h) - 1)], g_hi[k >> g_h]);
+    out[n + k] = gl_mul(n_inv, gk);
+}
+
+// any non-zero element in data[lo, hi)?
+__global__ __launch_bounds__(256) void any_nonzero_kernel(const u64* __restrict__ data, size_t lo, size_t hi, unsigned* __restrict__ flag) {
+    const size_t k = lo + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < hi && gl_canon(data[k]) != 0) atomicOr(flag, 1u);
+}
+
+// ------------------------------------------------------------------------------------------------ quotient kernel
+struct QuotParams {
+    const u64* trace_lde; const u64* zs_lde; const u64* lag_lde;  // leaf order, column stride N
+    size_t N, n;
+    int log_n, log_N, qdb;
+    const u64* gN_lo; const u64* gN_hi; int gN_h;   // two-level powers of the order-N root
+    const u64* desc;                                // per-proof descriptor (layout in build_quot_desc)
+    u64 g_inv;                                      // last = g^-1 (prover.rs:617)
+    u64* out;                                       // [num_challenges][size]
+    int n_regs;
+};
+
+#define QW 64  // one wavefront per workgroup; register file = n_regs x 64 lanes in LDS
+__global__ __launch_bounds__(QW) void quotient_kernel(QuotParams P) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    u64* regs = reinterpret_cast<u64*>(smem_raw);
+    const int lane = threadIdx.x;
+    const size_t size = P.n << P.qdb;
+    const size_t j = (size_t)blockIdx.x * QW + lane;
+    const bool active = j < size;
+    const size_t jj = active ? j : 0;
+    // leaf j = c*n + r  <->  natural row m = bitrev3(c) + 8*bitrev_n(r); next row m + 8 -> r' = bitrev_n(bitrev_n(r) + 1)
+    const size_t c = jj >> P.log_n, r = jj & (P.n - 1);
+    const u32 rr = bitrev32((u32)r, P.log_n);
+    const size_t rn = bitrev32((rr + 1) & (u32)(P.n - 1), P.log_n);
+    const size_t jn = (c << P.log_n) + rn;
+    const u64 m = ((u64)rr << (P.log_N - P.log_n)) + bitrev32((u32)c, P.log_N - P.log_n);
+    const u64 x = gl_mul(GL_GENERATOR, gl_mul(P.gN_lo[m & (((u64)1 << P.gN_h) - 1)], P.gN_hi[m >> P.gN_h]));
+    const u64 z_last = gl_sub(x, P.g_inv);
+    const u64 lag_first = P.lag_lde[jj], lag_last = P.lag_lde[P.N + jj];
+
+    const u64* __restrict__ D = P.desc;
+    const u32 n_ops = (u32)D[0], ops_off = (u32)D[1], nperm = (u32)D[2], perm_off = (u32)D[3], nctl = (u32)D[4], ctl_off = (u32)D[5];
+    const u32 params_off = (u32)D[7];
+    const u64 alpha0 = D[8], alpha1 = D[9];
+    const u64 zh_inv = D[10 + c];
+    u64 acc0 = 0, acc1 = 0;
+    auto emit = [&](int kind, u64 v) {
+        if (kind == AK_TRANSITION) v = gl_mul(v, z_last);
+        else if (kind == AK_FIRST) v = gl_mul(v, lag_first);
+        else if (kind == AK_LAST) v = gl_mul(v, lag_last);
+        acc0 = gl_add(gl_mul(acc0, alpha0), v);
+        acc1 = gl_add(gl_mul(acc1, alpha1), v);
+    };
+    const size_t N = P.N;
+
+    // ---- the table's constraint program ----
+    for (u32 i = 0; i < n_ops; i++) {
+        const u64 w0 = D[ops_off + 2 * i], w1 = D[ops_off + 2 * i + 1];
+        const int op = (int)(w0 & 0xff), kind = (int)((w0 >> 8) & 0xff);
+        const u32 dst = (u32)((w0 >> 16) & 0xffff), a = (u32)((w0 >> 32) & 0xffff), b = (u32)((w0 >> 48) & 0xffff);
+        u64 v;
+        switch (op) {
+            case AOP_LOCAL: v = gl_canon(P.trace_lde[(size_t)a * N + jj]); break;
+            case AOP_NEXT: v = gl_canon(P.trace_lde[(size_t)a * N + jn]); break;
+            case AOP_CONST: v = w1; break;
+            case AOP_PARAM: v = D[params_off + a]; break;
+            case AOP_ADD: v = gl_add(regs[a * QW + lane], regs[b * QW + lane]); break;
+            case AOP_SUB: v = gl_sub(regs[a * QW + lane], regs[b * QW + lane]); break;
+            case AOP_MUL: v = gl_mul(regs[a * QW + lane], regs[b * QW + lane]); break;
+            default: emit(kind, regs[a * QW + lane]); continue;
+        }
+        regs[dst * QW + lane] = v;
+    }
+    // ---- permutation checks (permutation.rs:302-360) ----
+    {
+        for (u32 i = 0; i < nperm; i++) emit(AK_FIRST, gl_sub(P.zs_lde[(size_t)i * N + jj], 1));
+        u32 p = perm_off;
+        for (u32 bI = 0; bI < nperm; bI++) {
+            const u32 ninst = (u32)D[p++];
+            u64 prod_l = 1, prod_r = 1;
+            for (u32 s = 0; s < ninst; s++) {
+                const u64 beta = D[p++], gamma = D[p++];
+                const u32 np = (u32)D[p++];
+                u64 l = 0, rr2 = 0, w = 1;
+                for (u32 k = 0; k < np; k++) {
+                    const u64 cl = D[p++], cr = D[p++];
+                    l = gl_add(l, gl_mul(gl_canon(P.trace_lde[cl * N + jj]), w));
+                    rr2 = gl_add(rr2, gl_mul(gl_canon(P.trace_lde[cr * N + jj]), w));
+                    w = gl_mul(w, beta);
+                }
+                prod_l = gl_mul(prod_l, gl_add(l, gamma));
+                prod_r = gl_mul(prod_r, gl_add(rr2, gamma));
+            }
+            const u64 zl = P.zs_lde[(size_t)bI * N + jj], zn = P.zs_lde[(size_t)bI * N + jn];
+            emit(AK_ALL, gl_sub(gl_mul(zn, prod_r), gl_mul(zl, prod_l)));
+        }
+    }
+    // ---- cross-table lookup checks (cross_table_lookup.rs:380-421) ----
+    {
+        u32 p = ctl_off;
+        for (u32 i = 0; i < nctl; i++) {
+            const u64 beta = D[p++], gamma = D[p++];
+            const u32 ncol = (u32)D[p++];
+            u64 cl = 0, cn = 0, bp = 1;
+            for (u32 k = 0; k < ncol; k++) {
+                u32 p2 = p;
+                const u64 el = dev_lincol(D, p, P.trace_lde, N, jj);
+                const u64 en = dev_lincol(D, p2, P.trace_lde, N, jn);
+                cl = gl_add(cl, gl_mul(bp, el));
+                cn = gl_add(cn, gl_mul(bp, en));
+                bp = gl_mul(bp, beta);
+            }
+            cl = gl_add(cl, gamma);
+            cn = gl_add(cn, gamma);
+            u64 fl = 1, fn = 1;
+            if (D[p++]) {
+                u32 p2 = p;
+                fl = dev_lincol(D, p, P.trace_lde, N, jj);
+                fn = dev_lincol(D, p2, P.trace_lde, N, jn);
+            }
+            // select(f, x) = f*x + 1 - f
+            const u64 sl = gl_sub(gl_add(gl_mul(fl, cl), 1), fl), sn = gl_sub(gl_add(gl_mul(fn, cn), 1), fn);
+            const u64 zl = P.zs_lde[(size_t)(nperm + i) * N + jj], zn = P.zs_lde[(size_t)(nperm + i) * N + jn];
+            emit(AK_FIRST, gl_sub(zl, sl));
+            emit(AK_TRANSITION, gl_sub(zn, gl_mul(zl, sn)));
+        }
+    }
+    if (active) {
+        P.out[j] = gl_mul(acc0, zh_inv);
+        P.out[size + j] = gl_mul(acc1, zh_inv);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ host orchestration
+struct GpChallenge { u64 beta, gamma; };
+
+static GpChallenge get_gp(OlaChallenger& ch) { const u64 b = challenger_get(ch); const u64 g = challenger_get(ch); return {b, g}; }
+
+struct CtlJob { const HTwc* twc; GpChallenge ch; };
+
+struct BatchHolder {
+    DeviceCtx* ctx;
+    OlaBatch* b = nullptr;
+    explicit BatchHolder(DeviceCtx* c) : ctx(c) {}
+    ~BatchHolder() { if (b) { (void)hipStreamSynchronize(ctx->stream); batch_destroy(ctx, b); } }
+};
+
+// values of one table resident on the device (column-major, n per column)
+struct DevTable { u64* vals = nullptr; uint32_t log_n = 0; size_t n() const { return (size_t)1 << log_n; } };
+
+static void write_cap(ByteWriter& w, const std::vector<u64>& cap) { w.cap(cap.data(), cap.size() / 4); }
+
+static void prove_single_table(DeviceCtx* ctx, NttTables& tables, const OlaGpuConfig& cfg, const HTable& air, const DevTable& tv,
+                               const OlaBatch& trace_c, const std::vector<u64>& trace_cap, const std::vector<CtlJob>& ctl,
+                               const u64* params, OlaChallenger& ch, std::vector<uint8_t>& bytes) {
+    DevBuf mem(ctx);
+    const int nch = (int)cfg.num_challenges;
+    if (nch != 2) throw OlaError(OLA_E_INVALID_ARG, "num_challenges must be 2");
+    const int degree_bits = (int)tv.log_n;
+    const size_t n = tv.n();
+    const int rate_bits = (int)cfg.rate_bits;
+    const size_t N = n << rate_bits;
+    const size_t len_cap = (size_t)1 << cfg.cap_height;
+
+    challenger_compact(ch);
+    // ---- permutation challenges + Z polys (prover.rs:360-377) ----
+    const int nperm = air.num_permutation_batches(nch);
+    const int bs = air.permutation_batch_size();
+    std::vector<std::vector<GpChallenge>> perm_sets;
+    if (!air.perm_pairs.empty())
+        for (int i = 0; i < bs; i++) { std::vector<GpChallenge> s; for (int c = 0; c < nch; c++) s.push_back(get_gp(ch)); perm_sets.push_back(s); }
+    const int nz = nperm + (int)ctl.size();
+    if (nz == 0) throw OlaError(OLA_E_INVALID_ARG, "No CTL?");
+    u64* zvals = mem.alloc((size_t)nz * n);
+    u64* tot = mem.alloc((n + PSCAN_B - 1) / PSCAN_B + 1);
+    u64* tmpcol = mem.alloc(n);
+    // perm descriptors (also reused by the quotient kernel)
+    std::vector<u64> perm_desc;
+    {
+        const int total = (int)air.perm_pairs.size() * nch;
+        int inst = 0;
+        for (int b = 0; b < nperm; b++) {
+            const size_t at = perm_desc.size();
+            perm_desc.push_back(0);
+            u64 cnt = 0;
+            for (int i = 0; i < bs && inst < total; i++, inst++, cnt++) {
+                const auto& pair = air.perm_pairs[inst / nch];
+                const GpChallenge c = perm_sets[i][inst % nch];
+                perm_desc.push_back(c.beta); perm_desc.push_back(c.gamma); perm_desc.push_back(pair.size());
+                for (auto& pr : pair) { perm_desc.push_back(pr.first); perm_desc.push_back(pr.second); }
+            }
+            perm_desc[at] = cnt;
+        }
+    }
+    if (nperm) {
+        u64* d_pd = mem.alloc(perm_desc.size());
+        HIP_CHECK(hipMemcpyAsync(d_pd, perm_desc.data(), perm_desc.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+        // offsets of each batch descriptor
+        size_t off = 0;
+        for (int b = 0; b < nperm; b++) {
+            hipLaunchKernelGGL(perm_factor_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, tv.vals, n, d_pd + off, tmpcol);
+            product_scan_inclusive(ctx, tmpcol, n, tot);
+            hipLaunchKernelGGL(shift_right_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, tmpcol, zvals + (size_t)b * n, n);
+            // advance to the next batch descriptor
+            const u64 cnt = perm_desc[off];
+            size_t p = off + 1;
+            for (u64 s = 0; s < cnt; s++) { const u64 np = perm_desc[p + 2]; p += 3 + 2 * np; }
+            off = p;
+        }
+    }
+    // ---- CTL Z polys (cross_table_lookup.rs:224-311) ----
+    std::vector<u64> ctl_desc;
+    std::vector<size_t> ctl_off;
+    for (auto& j : ctl) { ctl_off.push_back(ctl_desc.size()); push_ctl_desc(ctl_desc, *j.twc, j.ch.beta, j.ch.gamma); }
+    u64* d_cd = mem.alloc(ctl_desc.size() + 1);
+    if (!ctl_desc.empty()) HIP_CHECK(hipMemcpyAsync(d_cd, ctl_desc.data(), ctl_desc.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    for (size_t i = 0; i < ctl.size(); i++) {
+        u64* zc = zvals + (size_t)(nperm + i) * n;
+        hipLaunchKernelGGL(ctl_factor_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, tv.vals, n, d_cd + ctl_off[i], zc);
+        product_scan_inclusive(ctx, zc, n, tot);
+    }
+    // ---- Zs commitment ----
+    BatchHolder zs_c(ctx);
+    zs_c.b = batch_commit(ctx, tables, nullptr, zvals, (uint32_t)nz, (uint32_t)degree_bits, cfg.rate_bits, cfg.cap_height, true);
+    std::vector<u64> zs_cap(len_cap * 4);
+    batch_read_cap(ctx, *zs_c.b, zs_cap.data());
+    challenger_observe(ch, zs_cap.data(), zs_cap.size());
+    const u64 alpha0 = challenger_get(ch), alpha1 = challenger_get(ch);
+
+    // ---- quotient (prover.rs:571-705) ----
+    const int q = air.quotient_degree_factor();
+    int qdb = 0;
+    while ((1 << qdb) < q) qdb++;
+    if (qdb > rate_bits) throw OlaError(OLA_E_INVALID_ARG, "Having constraints of degree higher than the rate is not supported yet.");
+    const size_t size = n << qdb;
+    // Lagrange first/last on the LDE domain (leaf order)
+    u64* lag_coef = mem.alloc(2 * n);
+    u64* lag_lde = mem.alloc(2 * N);
+    {
+        TwoLevel gt = get_two(tables, degree_bits, 0);
+        const u64 n_inv = gl_inv(((u64)1 << degree_bits) % GL_P);
+        hipLaunchKernelGGL(lagrange_coeffs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, lag_coef, n, n_inv, gt.lo, gt.hi, gt.h);
+        ntt_lde_leaf_order(tables, lag_coef, lag_lde, degree_bits, rate_bits, 2);
+    }
+    // descriptor for the kernel
+    std::vector<u64> desc(18, 0);
+    {
+        // Z_H(x)^-1 per coset (zero_poly_coset.rs:18-33): x^n = 7^n * v^i, i = natural index mod 2^qdb; coset c <-> i = bitrev
+        u64 g_pow_n = GL_GENERATOR;
+        for (int i = 0; i < degree_bits; i++) g_pow_n = gl_mul(g_pow_n, g_pow_n);
+        const u64 v = gl_root_of_unity(qdb);
+        for (int c = 0; c < (1 << qdb); c++) {
+            const u32 i = bitrev32((u32)c, qdb);
+            desc[10 + c] = gl_inv(gl_sub(gl_mul(g_pow_n, gl_pow(v, i)), 1));
+        }
+        desc[0] = air.ops.size() / 2;
+        desc[1] = desc.size();
+        desc.insert(desc.end(), air.ops.begin(), air.ops.end());
+        desc[2] = (u64)nperm;
+        desc[3] = desc.size();
+        desc.insert(desc.end(), perm_desc.begin(), perm_desc.end());
+        desc[4] = ctl.size();
+        desc[5] = desc.size();
+        desc.insert(desc.end(), ctl_desc.begin(), ctl_desc.end());
+        desc[6] = (u64)air.n_params;
+        desc[7] = desc.size();
+        for (int i = 0; i < air.n_params; i++) desc.push_back(gl_canon(params[i]));
+        desc[8] = alpha0; desc[9] = alpha1;
+    }
+    u64* d_desc = mem.alloc(desc.size());
+    HIP_CHECK(hipMemcpyAsync(d_desc, desc.data(), desc.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    u64* qv = mem.alloc(2 * size);
+    {
+        QuotParams P = {};
+        P.trace_lde = trace_c.lde; P.zs_lde = zs_c.b->lde; P.lag_lde = lag_lde;
+        P.N = N; P.n = n; P.log_n = degree_bits; P.log_N = degree_bits + rate_bits; P.qdb = qdb;
+        TwoLevel gN = get_two(tables, degree_bits + rate_bits, 0);
+        P.gN_lo = gN.lo; P.gN_hi = gN.hi; P.gN_h = gN.h;
+        P.desc = d_desc;
+        P.g_inv = gl_inv(gl_root_of_unity(degree_bits));
+        P.out = qv;
+        P.n_regs = air.n_regs;
+        const size_t lds = (size_t)air.n_regs * QW * 8;
+        if (lds > 160 * 1024) throw OlaError(OLA_E_INVALID_ARG, "constraint program needs too many registers");
+        if (lds > 48 * 1024)
+            HIP_CHECK(hipFuncSetAttribute((const void*)quotient_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(quotient_kernel, dim3((unsigned)((size + QW - 1) / QW)), dim3(QW), lds, ctx->stream, P);
+    }
+    // qv is in bit-reversed order of the size-domain: un-reverse, coset iNTT (prover.rs:700-704)
+    const int size_bits = degree_bits + qdb;
+    u64* qnat = mem.alloc(2 * size);
+    u64* qcoef = mem.alloc(2 * size);
+    u64* qscratch = size_bits > 13 ? mem.alloc(2 * size) : nullptr;
+    launch_bitrev_rows(ctx, qv, qnat, size_bits, 2);
+    ntt_coset_interpolate(tables, qnat, qcoef, qscratch, size_bits, 2, GL_GENERATOR);
+    // trim_to_len(n*q) (prover.rs:469-473)
+    const size_t keep = n * (size_t)q;
+    if (keep < size) {
+        unsigned* d_flag = (unsigned*)mem.alloc(1);
+        HIP_CHECK(hipMemsetAsync(d_flag, 0, 8, ctx->stream));
+        for (int c = 0; c < 2; c++)
+            hipLaunchKernelGGL(any_nonzero_kernel, dim3((unsigned)((size - keep + 255) / 256)), dim3(256), 0, ctx->stream, qcoef + (size_t)c * size,
+                               keep, size, d_flag);
+        unsigned flag = 0;
+        HIP_CHECK(hipMemcpyAsync(&flag, d_flag, 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        if (flag) throw OlaError(OLA_E_QUOTIENT_DEGREE, "Quotient has failed, the vanishing polynomial is not divisible by Z_H");
+    }
+    // chunks of n coefficients: [challenge][k] -> column challenge*q + k
+    u64* chunks = mem.alloc((size_t)2 * q * n);
+    for (int c = 0; c < 2; c++)
+        HIP_CHECK(hipMemcpyAsync(chunks + (size_t)c * q * n, qcoef + (size_t)c * size, keep * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    BatchHolder q_c(ctx);
+    q_c.b = batch_commit(ctx, tables, nullptr, chunks, (uint32_t)(2 * q), (uint32_t)degree_bits, cfg.rate_bits, cfg.cap_height, false);
+    std::vector<u64> q_cap(len_cap * 4);
+    batch_read_cap(ctx, *q_c.b, q_cap.data());
+    challenger_observe(ch, q_cap.data(), q_cap.size());
+
+    // ---- write_proof (serialization.rs:349-358): caps, then opening set + FRI proof ----
+    ByteWriter w{bytes};
+    write_cap(w, trace_cap);
+    write_cap(w, zs_cap);
+    write_cap(w, q_cap);
+    size_t olen = 0;
+    open_and_prove(ctx, tables, cfg, trace_c, *zs_c.b, *q_c.b, (uint32_t)nperm, ch, bytes, olen);
+}
+
+// prove_with_traces (prover.rs:79-327).  traces[t]: host pointer to a column-major ncols x 2^log_n[t] table.
+void prove_with_traces(DeviceCtx* ctx, NttTables& tables, const OlaGpuConfig& cfg, const u64* airset, size_t airset_words,
+                       const u64* const* traces, const uint32_t* log_n, const u64* params, const u64* compress,
+                       std::vector<uint8_t>& bytes) {
+    HAirSet set = parse_airset(airset, airset_words);
+    const size_t nt = set.tables.size();
+    const int nch = (int)cfg.num_challenges;
+    const size_t len_cap = (size_t)1 << cfg.cap_height;
+    DevBuf mem(ctx);
+    std::vector<DevTable> dev(nt);
+    std::vector<std::unique_ptr<BatchHolder>> commits;
+    std::vector<std::vector<u64>> caps(nt, std::vector<u64>(len_cap * 4));
+    OlaChallenger ch;
+    memset(&ch, 0, sizeof(ch));
+    for (size_t t = 0; t < nt; t++) {
+        if (log_n[t] + cfg.rate_bits > 32 || log_n[t] + cfg.rate_bits < cfg.cap_height) throw OlaError(OLA_E_INVALID_ARG, "table size out of range");
+        dev[t].log_n = log_n[t];
+        const size_t elems = (size_t)set.tables[t].ncols << log_n[t];
+        dev[t].vals = mem.alloc(elems);
+        HIP_CHECK(hipMemcpyAsync(dev[t].vals, traces[t], elems * 8, hipMemcpyHostToDevice, ctx->stream));
+        canonicalize(ctx, dev[t].vals, elems);
+        commits.emplace_back(new BatchHolder(ctx));
+        commits[t]->b = batch_commit(ctx, tables, nullptr, dev[t].vals, (uint32_t)set.tables[t].ncols, log_n[t], cfg.rate_bits, cfg.cap_height, true);
+        batch_read_cap(ctx, *commits[t]->b, caps[t].data());
+    }
+    for (size_t t = 0; t < nt; t++) challenger_observe(ch, caps[t].data(), caps[t].size());
+    // CTL challenges and per-table job lists, in cross_table_lookup_data order
+    std::vector<GpChallenge> ctl_ch;
+    for (int c = 0; c < nch; c++) ctl_ch.push_back(get_gp(ch));
+    std::vector<std::vector<CtlJob>> jobs(nt);
+    for (const HCtl& ctl : set.ctls)
+        for (const GpChallenge& c : ctl_ch) {
+            for (const HTwc& twc : ctl.looking) jobs[twc.table].push_back({&twc, c});
+            jobs[ctl.looked.table].push_back({&ctl.looked, c});
+        }
+    ByteWriter w{bytes};
+    w.u32((uint32_t)nt);
+    size_t poff = 0;
+    std::vector<u64> zero_params(64, 0);
+    for (size_t t = 0; t < nt; t++) {
+        const u64* pr = params ? params + poff : zero_params.data();
+        if (!params && set.tables[t].n_params > 64) throw OlaError(OLA_E_INVALID_ARG, "params required");
+        poff += set.tables[t].n_params;
+        prove_single_table(ctx, tables, cfg, set.tables[t], dev[t], *commits[t]->b, caps[t], jobs[t], pr, ch, bytes);
+    }
+    // compress_challenges (prover.rs:307-320) -- produced by trace generation, carried through
+    w.u32((uint32_t)nt);
+    for (size_t t = 0; t < nt; t++) w.field(compress ? compress[t] : 0);
+}
+
+}  // namespace ola
