@@ -55,3 +55,21 @@ def test_two_table_proof_verifies_and_tampering_is_caught(oracle):
     p2 = oracle.prove_with_traces(blob, [cmp_t, rc_bad])
     rc, why = oracle.verify_all_proof(blob, p2)
     assert rc != 0 and "Cross-table" in why
+
+
+def test_poseidon_air_vanishes_on_reference_golden_rows(oracle):
+    """The reference ships the intermediate round states of two Poseidon permutations as constants
+    (core/src/util/poseidon_utils.rs:11-287; the ZERO row is the Poseidon table's padding row).  Our transcription of
+    PoseidonStark (with our own partial-round factorisation) must vanish on them."""
+    import json, os
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "poseidon_air_rows.json")))["rows"]
+    blob = AirSet([T.poseidon_table()], []).blob()
+    trace = np.array([g["ZERO"], g["1000"]], dtype=np.uint64).T.copy()     # 134 columns x 2 rows
+    assert oracle.check_constraints(blob, 0, trace) == -1
+    # outputs really are the permutation of the inputs
+    for tag in ("ZERO", "1000"):
+        row = g[tag]
+        assert [int(x) for x in oracle.poseidon(np.array(row[4:16], dtype=np.uint64))] == row[16:28]
+    bad = trace.copy()
+    bad[70, 1] ^= 1                                                         # one partial-round s-box input
+    assert oracle.check_constraints(blob, 0, bad) == 1
