@@ -10,6 +10,7 @@ lowers the DAG (with common-subexpression elimination and linear-scan register a
     LOCAL dst, col      dst = local_values[col]           NEXT dst, col    dst = next_values[col]
     CONST dst, imm      dst = imm (canonical)             PARAM dst, idx   dst = per-proof table parameter idx
     ADD/SUB/MUL dst,a,b                                   EMIT kind, a     consumer.<kind>(reg a)
+    ISZERO dst, a       dst = (a == 0) ? 1 : 0   (the data-dependent indicator of MemoryStark, memory_stark.rs:290-298)
         kind: 0 constraint, 1 constraint_transition, 2 constraint_first_row, 3 constraint_last_row
 
 and the whole configuration (tables, permutation pairs, cross-table lookups) to one u64 array:
@@ -25,7 +26,7 @@ P = 0xFFFFFFFF00000001
 MAGIC = 0x4F4C41414952  # "OLAAIR"
 VERSION = 1
 
-OP_LOCAL, OP_NEXT, OP_CONST, OP_PARAM, OP_ADD, OP_SUB, OP_MUL, OP_EMIT = range(8)
+OP_LOCAL, OP_NEXT, OP_CONST, OP_PARAM, OP_ADD, OP_SUB, OP_MUL, OP_EMIT, OP_ISZERO = range(9)
 KIND_ALL, KIND_TRANSITION, KIND_FIRST, KIND_LAST = range(4)
 
 
@@ -92,6 +93,9 @@ class AirTable:
         assert 0 <= i < self.n_params
         return self._node((OP_PARAM, i, 0))
 
+    def is_zero(self, e):
+        return self._node((OP_ISZERO, self.lift(e).id, 0))
+
     def lift(self, x):
         return x if isinstance(x, Expr) else self.const(x)
 
@@ -146,7 +150,7 @@ class AirTable:
                     stack.pop()
                     continue
                 op, a, b = nodes[j]
-                deps = [a, b] if op in (OP_ADD, OP_SUB, OP_MUL) else []
+                deps = [a, b] if op in (OP_ADD, OP_SUB, OP_MUL) else ([a] if op == OP_ISZERO else [])
                 pend = [d for d in deps if d not in done]
                 if pend:
                     stack.extend(pend)
@@ -164,6 +168,8 @@ class AirTable:
                 if op in (OP_ADD, OP_SUB, OP_MUL):
                     last_use[a] = pos
                     last_use[b] = pos
+                elif op == OP_ISZERO:
+                    last_use[a] = pos
             else:
                 last_use[it[2]] = pos
         free, reg, n_regs, ops = [], {}, 0, []
@@ -171,9 +177,9 @@ class AirTable:
             if it[0] == "node":
                 j = it[1]
                 op, a, b = nodes[j]
-                srcs = [a, b] if op in (OP_ADD, OP_SUB, OP_MUL) else []
+                srcs = [a, b] if op in (OP_ADD, OP_SUB, OP_MUL) else ([a] if op == OP_ISZERO else [])
                 ra = reg[a] if srcs else a
-                rb = reg[b] if srcs else 0
+                rb = reg[b] if len(srcs) == 2 else 0
                 # release sources whose last use is here (dst may reuse them)
                 for s in set(srcs):
                     if last_use.get(s) == pos:

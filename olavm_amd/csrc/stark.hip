@@ -29,7 +29,7 @@
 namespace ola {
 
 // ------------------------------------------------------------------------------------------------ AIR-set (host)
-enum { AOP_LOCAL = 0, AOP_NEXT, AOP_CONST, AOP_PARAM, AOP_ADD, AOP_SUB, AOP_MUL, AOP_EMIT };
+enum { AOP_LOCAL = 0, AOP_NEXT, AOP_CONST, AOP_PARAM, AOP_ADD, AOP_SUB, AOP_MUL, AOP_EMIT, AOP_ISZERO };
 enum { AK_ALL = 0, AK_TRANSITION, AK_FIRST, AK_LAST };
 
 struct HLinCol { std::vector<std::pair<u64, u64>> terms; u64 constant = 0; };
@@ -294,6 +294,7 @@ __global__ __launch_bounds__(QW) void quotient_kernel(QuotParams P) {
             case AOP_ADD: v = gl_add(regs[a * QW + lane], regs[b * QW + lane]); break;
             case AOP_SUB: v = gl_sub(regs[a * QW + lane], regs[b * QW + lane]); break;
             case AOP_MUL: v = gl_mul(regs[a * QW + lane], regs[b * QW + lane]); break;
+            case AOP_ISZERO: v = (regs[a * QW + lane] == 0) ? 1 : 0; break;
             default: emit(kind, regs[a * QW + lane]); continue;
         }
         regs[dst * QW + lane] = v;

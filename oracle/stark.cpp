@@ -22,7 +22,7 @@
 namespace ola_oracle {
 
 // ------------------------------------------------------------------------------------------------ AIR-set description
-enum { OP_LOCAL = 0, OP_NEXT, OP_CONST, OP_PARAM, OP_ADD, OP_SUB, OP_MUL, OP_EMIT };
+enum { OP_LOCAL = 0, OP_NEXT, OP_CONST, OP_PARAM, OP_ADD, OP_SUB, OP_MUL, OP_EMIT, OP_ISZERO };
 enum { KIND_ALL = 0, KIND_TRANSITION, KIND_FIRST, KIND_LAST };
 
 struct AirOp { int op, kind, dst, a, b; u64 imm; };
@@ -92,6 +92,7 @@ struct BaseF {
     static T add(T a, T b) { return gl_add(a, b); }
     static T sub(T a, T b) { return gl_sub(a, b); }
     static T mul(T a, T b) { return gl_mul(a, b); }
+    static bool is_zero(T a) { return a == 0; }
 };
 struct ExtF {
     typedef Ext2 T;
@@ -101,6 +102,7 @@ struct ExtF {
     static T add(T a, T b) { return ext_add(a, b); }
     static T sub(T a, T b) { return ext_sub(a, b); }
     static T mul(T a, T b) { return ext_mul(a, b); }
+    static bool is_zero(T a) { return a.a == 0 && a.b == 0; }
 };
 
 template <class F>
@@ -152,6 +154,7 @@ static void eval_vanishing_poly(const AirTable& air, int num_challenges, const t
             case OP_SUB: reg[o.dst] = F::sub(reg[o.a], reg[o.b]); break;
             case OP_MUL: reg[o.dst] = F::mul(reg[o.a], reg[o.b]); break;
             case OP_EMIT: consumer.emit(o.kind, reg[o.a]); break;
+            case OP_ISZERO: reg[o.dst] = F::is_zero(reg[o.a]) ? F::one() : F::zero(); break;
             default: throw std::runtime_error("bad AIR op");
         }
     }
