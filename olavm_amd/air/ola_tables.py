@@ -574,11 +574,12 @@ BW_FIX_COMPRESS_PERMUTED = range(55, 59)
 COL_NUM_BITWISE = 59
 
 
-def bitwise_table():
-    """builtins/bitwise/bitwise_stark.rs:40-362 (degree 3; parameter 0 = compress challenge beta, :77)."""
+def bitwise_table(limb_bits=8):
+    """builtins/bitwise/bitwise_stark.rs:40-362 (degree 3; parameter 0 = compress challenge beta, :77).  `limb_bits` is 8
+    in the reference (BASE = 1 << 8, :27); smaller values give the miniature table used by CPU-sized tests."""
     t = AirTable("bitwise", COL_NUM_BITWISE, 3, n_params=1)
     lv = t.local
-    base = t.const(1 << 8)
+    base = t.const(1 << limb_bits)
 
     def reduce_with_powers(cols, alpha):   # plonk_common.rs:116-128: Horner from the last term
         s = t.const(0)
@@ -1139,9 +1140,10 @@ def all_cross_table_lookups():
             ctl_prog_chunk_prog, ctl_prog_chunk_storage]
 
 
-def ola_stark():
-    """The 12-table OlaStark (stark/ola_stark.rs:29-64), tables in `enum Table` order."""
+def ola_stark(range_bits=16, limb_bits=8):
+    """The 12-table OlaStark (stark/ola_stark.rs:29-64), tables in `enum Table` order.  range_bits / limb_bits: see
+    rangecheck_table / bitwise_table (16 / 8 in the reference)."""
     from .dsl import AirSet
-    tables = [cpu_table(), memory_table(), bitwise_table(), cmp_table(), rangecheck_table(), poseidon_table(), poseidon_chunk_table(),
+    tables = [cpu_table(), memory_table(), bitwise_table(limb_bits), cmp_table(), rangecheck_table(range_bits), poseidon_table(), poseidon_chunk_table(),
               storage_access_table(), tape_table(), sccall_table(), program_table(), prog_chunk_table()]
     return AirSet(tables, all_cross_table_lookups())

@@ -58,3 +58,53 @@ def test_invalid_trace_yields_a_rejected_proof(be, oracle):
     assert proof == oracle.prove_with_traces(blob, [cmp_t, rc_t])
     rc, why = oracle.verify_all_proof(blob, proof)
     assert rc != 0 and "quotient" in why
+
+
+def test_twelve_table_all_proof_bytes_match_oracle(be, oracle):
+    """All 12 OlaStark tables and all 19 cross-table lookups (ola_stark.rs:29-64,122-560) on the empty-program instance
+    with miniature fixed tables: AllProof bytes identical to the oracle's and accepted by its verifier."""
+    s = T.ola_stark(range_bits=4, limb_bits=2)
+    blob = s.blob()
+    traces, params, compress = tracegen.empty_program_instance()
+    got = be.prove_with_traces(blob, traces, params, compress)
+    want = oracle.prove_with_traces(blob, traces, params, compress)
+    assert got == want
+    rc, why = oracle.verify_all_proof(blob, got, params)
+    assert rc == 0, why
+
+
+def test_twelve_table_larger_traces_verify(be, oracle):
+    """Same AIR set with 2^10-row padding traces and the u8 bitwise table of the reference (2^18 rows): the oracle
+    verifier accepts the GPU proof."""
+    s = T.ola_stark(range_bits=8, limb_bits=8)
+    blob = s.blob()
+    traces, params, compress = tracegen.empty_program_instance(log_n=10, range_bits=8, limb_bits=8)
+    assert traces[2].shape == (59, 1 << 18)
+    proof = be.prove_with_traces(blob, traces, params, compress)
+    rc, why = oracle.verify_all_proof(blob, proof, params)
+    assert rc == 0, why
+
+
+@pytest.mark.parametrize("table", ["cmp", "rangecheck", "tape", "cpu", "bitwise", "program", "sccall", "storage_access", "poseidon",
+                                   "poseidon_chunk", "prog_chunk", "memory"])
+def test_constraint_interpreter_on_random_rows(be, oracle, table):
+    """Random (invalid) traces drive every opcode of a table's constraint program with generic values.  When
+    quotient_degree_factor is a power of two the prover still emits bytes (trim_to_len is vacuous) and they
+    must equal the oracle's; otherwise both sides must refuse with the quotient-degree error (prover.rs:469-473)."""
+    full = T.ola_stark(range_bits=4, limb_bits=2)
+    i = [t.name for t in full.tables].index(table)
+    tab = full.tables[i]
+    s = AirSet([tab], [])
+    blob = s.blob()
+    rng = np.random.default_rng(i)
+    tr = rng.integers(0, tracegen.P, size=(tab.ncols, 16), dtype=np.uint64)
+    params = [int(x) for x in rng.integers(0, tracegen.P, size=tab.n_params, dtype=np.uint64)] or None
+    q = tab.quotient_degree_factor
+    if q & (q - 1) == 0:
+        assert be.prove_with_traces(blob, [tr], params) == oracle.prove_with_traces(blob, [tr], params)
+    else:
+        from olavm_amd.backend import OlaGpuError
+        with pytest.raises(OlaGpuError, match="quotient"):
+            be.prove_with_traces(blob, [tr], params)
+        with pytest.raises(RuntimeError, match="quotient"):
+            oracle.prove_with_traces(blob, [tr], params)

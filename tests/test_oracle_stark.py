@@ -73,3 +73,40 @@ def test_poseidon_air_vanishes_on_reference_golden_rows(oracle):
     bad = trace.copy()
     bad[70, 1] ^= 1                                                         # one partial-round s-box input
     assert oracle.check_constraints(blob, 0, bad) == 1
+
+
+def _per_table_params(airset, params):
+    out, k = [], 0
+    for t in airset.tables:
+        out.append(params[k:k + t.n_params] if t.n_params else None)
+        k += t.n_params
+    return out
+
+
+def test_all_twelve_tables_vanish_on_the_empty_program_instance(oracle):
+    """The reference's AIR test recipe (test_utils.rs:152-195) for every table, on padding rows as its trace generators
+    emit them (tests/tracegen.py); miniature fixed tables (range_bits 4, limb_bits 2) keep it CPU-sized."""
+    s = T.ola_stark(range_bits=4, limb_bits=2)
+    blob = s.blob()
+    traces, params, _ = tracegen.empty_program_instance()
+    assert [t.shape[0] for t in traces] == [94, 29, 59, 6, 12, 134, 53, 48, 6, 26, 18, 40]     # SURVEY 8: widths
+    for i, (tr, pr) in enumerate(zip(traces, _per_table_params(s, params))):
+        assert oracle.check_constraints(blob, i, tr, pr) == -1, s.tables[i].name
+    # and the programs do bite: one flipped cell per table is caught
+    flips = {0: (T.COL_S_END, 1), 1: (T.COL_MEM_IS_WRITE, 2), 2: (T.BW_OP0_LIMBS.start, 1), 5: (T.COL_POSEIDON_INPUT_RANGE.start, 1),
+             6: (T.COL_POSEIDON_CHUNK_IS_PADDING_LINE, 0), 8: (T.COL_TAPE_OPCODE, 1), 9: (T.COL_SCCALL_CLK_CALLER_RET, 0)}
+    for i, (c, r) in flips.items():
+        bad = traces[i].copy()
+        bad[c, r] = (int(bad[c, r]) + 1) % tracegen.P
+        assert oracle.check_constraints(blob, i, bad, _per_table_params(s, params)[i]) >= 0, s.tables[i].name
+
+
+def test_twelve_table_all_proof_verifies(oracle):
+    s = T.ola_stark(range_bits=4, limb_bits=2)
+    blob = s.blob()
+    traces, params, compress = tracegen.empty_program_instance()
+    proof = oracle.prove_with_traces(blob, traces, params, compress)
+    rc, why = oracle.verify_all_proof(blob, proof, params)
+    assert rc == 0, why
+    # the compress challenges travel in AllProof (prover.rs:307-320)
+    assert proof != oracle.prove_with_traces(blob, traces, params, [0] * 12)
