@@ -113,7 +113,7 @@ __device__ __forceinline__ u64 dev_lincol(const u64* __restrict__ d, u32& p, con
 
 // CTL factor column: out[i] = filter(i) ? combine(i) : 1   (cross_table_lookup.rs:284-311)
 __global__ __launch_bounds__(256) void ctl_factor_kernel(const u64* __restrict__ trace, size_t n, const u64* __restrict__ desc,
-                                                         u64* __restrict__ out) {
+                                                         u64* __restrict__ out, unsigned* __restrict__ bad_filter) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     u32 p = 0;
@@ -128,7 +128,8 @@ __global__ __launch_bounds__(256) void ctl_factor_kernel(const u64* __restrict__
     acc = gl_add(acc, gamma);
     u64 f = 1;
     if (desc[p++]) f = dev_lincol(desc, p, trace, n, i);
-    out[i] = (f == 1) ? acc : 1;  // a filter outside {0,1} is rejected on the host side of the reference (assert)
+    if (f > 1) atomicOr(bad_filter, 1u);  // cross_table_lookup.rs:303-305 panics "Non-binary filter?"
+    out[i] = (f == 1) ? acc : 1;
 }
 
 // permutation quotient column: out[i] = prod_inst (gamma + sum beta^k lhs_k) / prod_inst (gamma + sum beta^k rhs_k)
@@ -442,10 +443,19 @@ static void prove_single_table(DeviceCtx* ctx, NttTables& tables, const OlaGpuCo
     for (auto& j : ctl) { ctl_off.push_back(ctl_desc.size()); push_ctl_desc(ctl_desc, *j.twc, j.ch.beta, j.ch.gamma); }
     u64* d_cd = mem.alloc(ctl_desc.size() + 1);
     if (!ctl_desc.empty()) HIP_CHECK(hipMemcpyAsync(d_cd, ctl_desc.data(), ctl_desc.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    unsigned* d_bad_filter = (unsigned*)mem.alloc(1);
+    HIP_CHECK(hipMemsetAsync(d_bad_filter, 0, 8, ctx->stream));
     for (size_t i = 0; i < ctl.size(); i++) {
         u64* zc = zvals + (size_t)(nperm + i) * n;
-        hipLaunchKernelGGL(ctl_factor_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, tv.vals, n, d_cd + ctl_off[i], zc);
+        hipLaunchKernelGGL(ctl_factor_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, tv.vals, n, d_cd + ctl_off[i], zc,
+                           d_bad_filter);
         product_scan_inclusive(ctx, zc, n, tot);
+    }
+    if (!ctl.empty()) {
+        unsigned bad = 0;
+        HIP_CHECK(hipMemcpyAsync(&bad, d_bad_filter, 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        if (bad) throw OlaError(OLA_E_INVALID_ARG, "Non-binary filter?");
     }
     // ---- Zs commitment ----
     BatchHolder zs_c(ctx);

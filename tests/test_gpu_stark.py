@@ -94,17 +94,35 @@ def test_constraint_interpreter_on_random_rows(be, oracle, table):
     full = T.ola_stark(range_bits=4, limb_bits=2)
     i = [t.name for t in full.tables].index(table)
     tab = full.tables[i]
-    s = AirSet([tab], [])
+    # two copies of the table joined by one lookup, so that each has a CTL Z column (the prover refuses tables without
+    # any Z polynomial, prover.rs "No CTL?")
+    from olavm_amd.air.dsl import Col, CrossTableLookup, TableWithColumns
+    s = AirSet([tab, tab], [CrossTableLookup([TableWithColumns(0, [Col.single(0), Col.single(tab.ncols - 1)], Col.single(1))],
+                                             TableWithColumns(1, [Col.single(2), Col.single(3)]))])
     blob = s.blob()
     rng = np.random.default_rng(i)
-    tr = rng.integers(0, tracegen.P, size=(tab.ncols, 16), dtype=np.uint64)
-    params = [int(x) for x in rng.integers(0, tracegen.P, size=tab.n_params, dtype=np.uint64)] or None
+    tr = [rng.integers(0, tracegen.P, size=(tab.ncols, 16), dtype=np.uint64) for _ in range(2)]
+    tr[0][1] = rng.integers(0, 2, size=16, dtype=np.uint64)          # the lookup's filter column must be binary
+    params = [int(x) for x in rng.integers(0, tracegen.P, size=2 * tab.n_params, dtype=np.uint64)] or None
     q = tab.quotient_degree_factor
     if q & (q - 1) == 0:
-        assert be.prove_with_traces(blob, [tr], params) == oracle.prove_with_traces(blob, [tr], params)
+        assert be.prove_with_traces(blob, tr, params) == oracle.prove_with_traces(blob, tr, params)
     else:
         from olavm_amd.backend import OlaGpuError
-        with pytest.raises(OlaGpuError, match="quotient"):
-            be.prove_with_traces(blob, [tr], params)
-        with pytest.raises(RuntimeError, match="quotient"):
-            oracle.prove_with_traces(blob, [tr], params)
+        with pytest.raises(OlaGpuError, match="uotient"):
+            be.prove_with_traces(blob, tr, params)
+        with pytest.raises(RuntimeError, match="uotient"):
+            oracle.prove_with_traces(blob, tr, params)
+
+
+def test_non_binary_ctl_filter_is_refused(be, oracle):
+    """cross_table_lookup.rs:303-305: a filter value outside {0,1} aborts the prover."""
+    from olavm_amd.backend import OlaGpuError
+    rng = np.random.default_rng(5)
+    cmp_t, rc_t = tracegen.cmp_rangecheck_instance(rng, 6, 4)
+    rc_t[T.RC_CMP_FILTER, 3] = 2
+    blob = mini_set(4).blob()
+    with pytest.raises(OlaGpuError, match="Non-binary filter"):
+        be.prove_with_traces(blob, [cmp_t, rc_t])
+    with pytest.raises(RuntimeError, match="Non-binary filter"):
+        oracle.prove_with_traces(blob, [cmp_t, rc_t])
