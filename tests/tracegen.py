@@ -114,18 +114,20 @@ def memory_padding_trace(n):
     t = np.zeros((T.NUM_MEM_COLS, n), dtype=np.uint64)
     span = 2**32 - 1
     addr = (0 - span) % P
-    t[T.COL_MEM_S_PROPHET, 0] = 1                    # row 0: stack region, address 0, written once
-    t[T.COL_MEM_IS_WRITE, 0] = 1
-    for i in range(1, n):
-        t[T.COL_MEM_S_PROPHET, i] = 1
-        t[T.COL_MEM_ADDR, i] = addr
-        t[T.COL_MEM_IS_WRITE, i] = 1
-        t[T.COL_MEM_DIFF_ADDR, i] = 1 if i > 1 else addr
-        t[T.COL_MEM_DIFF_ADDR_INV, i] = pow(int(t[T.COL_MEM_DIFF_ADDR, i]), P - 2, P)
-        t[T.COL_MEM_DIFF_ADDR_COND, i] = (0 - addr) % P
-        t[T.COL_MEM_REGION_PROPHET, i] = 1
-        t[T.COL_MEM_RC_VALUE, i] = (0 - addr) % P
-        addr = (addr + 1) % P
+    t[T.COL_MEM_S_PROPHET] = 1
+    t[T.COL_MEM_IS_WRITE] = 1                        # row 0: stack region, address 0, written once
+    i = np.arange(1, n, dtype=np.uint64)
+    a = (np.uint64(addr) + (i - np.uint64(1))) % np.uint64(P)        # addr + i - 1 < 2^64 for every n used here
+    t[T.COL_MEM_ADDR, 1:] = a
+    t[T.COL_MEM_DIFF_ADDR, 1:] = 1
+    t[T.COL_MEM_DIFF_ADDR_INV, 1:] = 1
+    if n > 1:
+        t[T.COL_MEM_DIFF_ADDR, 1] = addr
+        t[T.COL_MEM_DIFF_ADDR_INV, 1] = pow(addr, P - 2, P)
+    neg = (np.uint64(P) - a) % np.uint64(P)
+    t[T.COL_MEM_DIFF_ADDR_COND, 1:] = neg
+    t[T.COL_MEM_RC_VALUE, 1:] = neg
+    t[T.COL_MEM_REGION_PROPHET, 1:] = 1
     return t
 
 
@@ -179,11 +181,13 @@ def program_padding_trace(n):
     return np.zeros((T.NUM_PROG_COLS, n), dtype=np.uint64)   # all-zero rows: compress = 0, lookups trivially hold
 
 
-def empty_program_instance(log_n=3, range_bits=4, limb_bits=2, bitwise_beta=12345, program_beta=67890):
-    """12 traces in `enum Table` order + per-table params + compress_challenges, for ola_stark(range_bits, limb_bits)."""
+def empty_program_instance(log_n=3, range_bits=4, limb_bits=2, bitwise_beta=12345, program_beta=67890, log_n_cpu=None, log_n_mem=None):
+    """12 traces in `enum Table` order + per-table params + compress_challenges, for ola_stark(range_bits, limb_bits).
+    log_n_cpu / log_n_mem override the height of the two tables that dominate a real execution."""
     n = 1 << log_n
     traces = [
-        cpu_padding_trace(n), memory_padding_trace(n), bitwise_padding_trace(bitwise_beta, limb_bits),
+        cpu_padding_trace(1 << (log_n_cpu or log_n)), memory_padding_trace(1 << (log_n_mem or log_n)),
+        bitwise_padding_trace(bitwise_beta, limb_bits),
         generate_cmp_trace([]), generate_rc_trace([], range_bits), poseidon_padding_trace(n),
         flag_padding_trace(T.NUM_POSEIDON_CHUNK_COLS, n, T.COL_POSEIDON_CHUNK_IS_PADDING_LINE),
         flag_padding_trace(T.NUM_COL_ST, n, T.COL_ST_IS_PADDING),
