@@ -1,0 +1,223 @@
+"""Ahead-of-time specialisation of the constraint-quotient kernel.
+
+The reference compiles every table's `eval_packed_generic` into the prover binary (e.g. cpu/cpu_stark.rs:325-1000).  The
+MI355X counterpart: for each table of an AirSet this module prints one straight-line HIP kernel (constraint program,
+permutation checks and cross-table-lookup checks unrolled, column indices and constants as immediates), which
+`olavm_amd/csrc/stark.hip` includes and selects at run time by the signature of the AIR-set blob it is handed
+(`AirSet.signature`).  A blob without a matching kernel runs on the generic interpreter kernel instead -- same results,
+fewer points per second.
+
+The random-linear-combination of constraints is accumulated lazily: sum_i alpha^(K-1-i) * c_i is the value the reference's
+Horner recurrence `acc = acc*alpha + c_i` (constraint_consumer.rs:57-64) produces, so each emitted constraint costs two
+64x64->128 multiply-accumulates into 160-bit sums (one per challenge) and the reductions mod p happen once per point.
+Transition constraints share their `z_last` factor the same way.
+
+Run as a script to (re)generate olavm_amd/csrc/gen/air_kernels.inc for the OlaStark table sets the tests and benches use.
+"""
+import os
+
+from .dsl import (OP_LOCAL, OP_NEXT, OP_CONST, OP_PARAM, OP_ADD, OP_SUB, OP_MUL, OP_ISZERO,
+                  KIND_ALL, KIND_TRANSITION, KIND_FIRST, KIND_LAST, P)
+
+D_ZH = 0          # D[0..8): 1/Z_H per coset
+D_W = 8           # D[8 .. 8+2K): alpha weights, challenge-major
+
+
+def _lit(v):
+    return "0x%Xull" % (int(v) % P)
+
+
+class _Emitter:
+    def __init__(self, K):
+        self.lines, self.K, self.idx = [], K, 0
+
+    def add(self, s):
+        self.lines.append("    " + s)
+
+    def emit(self, kind, expr):
+        i = self.idx
+        self.idx += 1
+        if kind == KIND_ALL:
+            self.add("AIRQ_EMIT_ALL(%d, %s);" % (i, expr))
+        elif kind == KIND_TRANSITION:
+            self.add("AIRQ_EMIT_TRANS(%d, %s);" % (i, expr))
+        elif kind == KIND_FIRST:
+            self.add("AIRQ_EMIT_ALL(%d, gl_mul(%s, lag_first));" % (i, expr))
+        else:
+            self.add("AIRQ_EMIT_ALL(%d, gl_mul(%s, lag_last));" % (i, expr))
+
+
+def _lincol(col, row):
+    """C expression of a Col (linear combination of trace columns) on the local ('L') or next ('N') row."""
+    acc = None
+    for c, f in col.terms:
+        v = "%sC(%d)" % (row, c)
+        if f == 1:
+            term, neg = v, False
+        elif f == P - 1:
+            term, neg = v, True
+        else:
+            term, neg = "gl_mul(%s, %s)" % (v, _lit(f)), False
+        if acc is None:
+            acc = ("gl_neg(%s)" % term) if neg else term
+        else:
+            acc = ("gl_sub(%s, %s)" if neg else "gl_add(%s, %s)") % (acc, term)
+    if acc is None:
+        return _lit(col.constant)
+    if col.constant:
+        acc = "gl_add(%s, %s)" % (acc, _lit(col.constant))
+    return acc
+
+
+def num_emits(airset, t, num_challenges=2):
+    tab = airset.tables[t]
+    return len(tab.emits) + 2 * tab.num_permutation_batches(num_challenges) + 2 * len(airset.ctl_jobs(t, num_challenges))
+
+
+def table_kernel(airset, t, name, num_challenges=2):
+    """-> (source text of the kernel, K)."""
+    tab = airset.tables[t]
+    jobs = airset.ctl_jobs(t, num_challenges)
+    nperm = tab.num_permutation_batches(num_challenges)
+    bs = tab.quotient_degree_factor
+    K = num_emits(airset, t, num_challenges)
+    d_params = D_W + 2 * K
+    d_perm = d_params + tab.n_params
+    d_ctl = d_perm + 2 * nperm * bs
+    e = _Emitter(K)
+    e.add("AIRQ_PROLOGUE(%d)" % K)
+    # ---- the table's constraint program ----
+    for it in tab.schedule():
+        if it[0] == "emit":
+            e.emit(it[1], "t%d" % it[2])
+            continue
+        j = it[1]
+        op, a, b = tab.nodes[j]
+        if op == OP_LOCAL:
+            rhs = "LC(%d)" % a
+        elif op == OP_NEXT:
+            rhs = "NC(%d)" % a
+        elif op == OP_CONST:
+            rhs = _lit(a)
+        elif op == OP_PARAM:
+            rhs = "D[%d]" % (d_params + a)
+        elif op == OP_ADD:
+            rhs = "gl_add(t%d, t%d)" % (a, b)
+        elif op == OP_SUB:
+            rhs = "gl_sub(t%d, t%d)" % (a, b)
+        elif op == OP_MUL:
+            rhs = "gl_mul(t%d, t%d)" % (a, b)
+        elif op == OP_ISZERO:
+            rhs = "(t%d == 0 ? 1ull : 0ull)" % a
+        else:
+            raise ValueError(op)
+        e.add("const u64 t%d = %s;" % (j, rhs))
+    # ---- permutation checks (permutation.rs:302-360) ----
+    for b in range(nperm):
+        e.emit(KIND_FIRST, "gl_sub(ZL(%d), 1)" % b)
+    total = len(tab.permutation_pairs) * num_challenges
+    inst = 0
+    for b in range(nperm):
+        e.add("{")
+        e.add("    u64 pl = 1, pr = 1;")
+        for i in range(bs):
+            if inst >= total:
+                break
+            pair = tab.permutation_pairs[inst // num_challenges]
+            slot = d_perm + 2 * (b * bs + i)
+            e.add("    { const u64 beta = D[%d], gamma = D[%d];" % (slot, slot + 1))
+            ls = ["LC(%d)" % l for l, _ in pair]
+            rs = ["LC(%d)" % r for _, r in pair]
+            e.add("      u64 l = %s, r = %s;" % (ls[-1], rs[-1]))
+            for k in range(len(pair) - 2, -1, -1):
+                e.add("      l = gl_add(gl_mul(l, beta), %s); r = gl_add(gl_mul(r, beta), %s);" % (ls[k], rs[k]))
+            e.add("      pl = gl_mul(pl, gl_add(l, gamma)); pr = gl_mul(pr, gl_add(r, gamma)); }")
+            inst += 1
+        e.emit(KIND_ALL, "gl_sub(gl_mul(ZN(%d), pr), gl_mul(ZL(%d), pl))" % (b, b))
+        e.add("}")
+    # ---- cross-table lookup checks (cross_table_lookup.rs:380-421) ----
+    evals = {}   # id(twc) -> per-column temporaries (shared by the jobs of the challenges of one lookup)
+    for i, twc in enumerate(jobs):
+        key = id(twc)
+        if key not in evals:
+            g = len(evals)
+            names = []
+            for k, col in enumerate(twc.columns):
+                e.add("const u64 c%d_%dl = %s, c%d_%dn = %s;" % (g, k, _lincol(col, "L"), g, k, _lincol(col, "N")))
+                names.append("c%d_%d" % (g, k))
+            fname = None
+            if twc.filter_column is not None:
+                fname = "f%d" % g
+                e.add("const u64 %sl = %s, %sn = %s;" % (fname, _lincol(twc.filter_column, "L"), fname, _lincol(twc.filter_column, "N")))
+            evals[key] = (names, fname)
+        names, fname = evals[key]
+        e.add("{ const u64 beta = D[%d], gamma = D[%d];" % (d_ctl + 2 * i, d_ctl + 2 * i + 1))
+        e.add("  u64 cl = %sl, cn = %sn;" % (names[-1], names[-1]))
+        for k in range(len(names) - 2, -1, -1):
+            e.add("  cl = gl_add(gl_mul(cl, beta), %sl); cn = gl_add(gl_mul(cn, beta), %sn);" % (names[k], names[k]))
+        e.add("  cl = gl_add(cl, gamma); cn = gl_add(cn, gamma);")
+        if fname is not None:   # select(f, x) = f*x + 1 - f
+            e.add("  cl = gl_sub(gl_add(gl_mul(%sl, cl), 1), %sl); cn = gl_sub(gl_add(gl_mul(%sn, cn), 1), %sn);" % (fname, fname, fname, fname))
+        e.add("  const u64 zl = ZL(%d), zn = ZN(%d);" % (nperm + i, nperm + i))
+        e.emit(KIND_FIRST, "gl_sub(zl, cl)")
+        e.emit(KIND_TRANSITION, "gl_sub(zn, gl_mul(zl, cn))")
+        e.add("}")
+    assert e.idx == K, (e.idx, K)
+    e.add("AIRQ_EPILOGUE")
+    head = "// table %d (%s): %d columns, %d constraints, %d permutation Zs, %d CTL Zs, K = %d\n" % (
+        t, tab.name, tab.ncols, len(tab.emits), nperm, len(jobs), K)
+    src = head + "__global__ __launch_bounds__(AIRQ_THREADS) void %s(QuotParams P) {\n%s\n}\n" % (name, "\n".join(e.lines))
+    return src, K
+
+
+def generate(airsets):
+    """-> {file name: source}: one translation unit per distinct table signature of the given AirSets (compiled in
+    parallel by build()) plus air_registry.inc, the list stark.hip searches."""
+    files, entries = {}, []
+    for s in airsets:
+        for t in range(len(s.tables)):
+            sig = s.signature(t)
+            name = "airq_%016x" % sig
+            if name + ".hip" in files:
+                continue
+            src, K = table_kernel(s, t, name)
+            tab = s.tables[t]
+            files[name + ".hip"] = (
+                "// GENERATED by olavm_amd/air/codegen.py -- do not edit; regenerated by __graft_entry__.build().\n"
+                "#define AIRQ_GENERATED_TU 1\n#include \"../airq.cuh\"\nnamespace ola {\n" + src +
+                "extern const AirKernelEntry %s_entry;\nconst AirKernelEntry %s_entry = {0x%016Xull, %s, %d, %d, %d, \"%s\"};\n}  // namespace ola\n"
+                % (name, name, sig, name, K, tab.n_params, tab.num_permutation_batches(), tab.name))
+            entries.append(name)
+    reg = "// GENERATED by olavm_amd/air/codegen.py -- do not edit.\n"
+    reg += "".join("extern const AirKernelEntry %s_entry;\n" % n for n in entries)
+    reg += "static const AirKernelEntry* const AIR_KERNELS[] = {\n%s\n};\n" % "\n".join("    &%s_entry," % n for n in entries)
+    files["air_registry.inc"] = reg
+    return files
+
+
+def default_airsets():
+    """The table sets with ahead-of-time kernels: the reference's OlaStark and the miniature variants the tests use."""
+    from . import ola_tables as T
+    return [T.ola_stark(), T.ola_stark(range_bits=8, limb_bits=8), T.ola_stark(range_bits=4, limb_bits=2)]
+
+
+def write_default(gen_dir):
+    """Writes the generated sources into gen_dir (only files whose content changed are touched, stale ones are removed);
+    returns the sorted list of .hip translation units."""
+    files = generate(default_airsets())
+    os.makedirs(gen_dir, exist_ok=True)
+    for f in os.listdir(gen_dir):
+        if f not in files and not f.endswith(".o"):
+            os.remove(os.path.join(gen_dir, f))
+    for f, src in files.items():
+        path = os.path.join(gen_dir, f)
+        if not os.path.exists(path) or open(path).read() != src:
+            with open(path, "w") as fh:
+                fh.write(src)
+    return sorted(os.path.join(gen_dir, f) for f in files if f.endswith(".hip"))
+
+
+if __name__ == "__main__":
+    here = os.path.dirname(os.path.abspath(__file__))
+    for f in write_default(os.path.join(here, "..", "csrc", "gen")):
+        print(f)

@@ -134,12 +134,11 @@ class AirTable:
         return -(-inst // self.quotient_degree_factor) if inst else 0
 
     # ---- lowering ----
-    def compile(self):
-        """-> (ops as list of (w0, w1), n_regs).  Emits are kept in program order; nodes are scheduled lazily right
-        before their first use, registers are recycled after their last use."""
+    def schedule(self):
+        """-> sequence of ('node', id) / ('emit', kind, id): emits in program order, every node right before its first
+        use."""
         nodes, emits = self.nodes, self.emits
-        last_use = {}
-        order = []     # sequence of ('node', id) / ('emit', kind, id)
+        order = []
         done = set()
 
         def visit(i):
@@ -162,6 +161,14 @@ class AirTable:
         for kind, i in emits:
             visit(i)
             order.append(("emit", kind, i))
+        return order
+
+    def compile(self):
+        """-> (ops as list of (w0, w1), n_regs): the schedule lowered to the register machine the interpreter kernel
+        runs; registers are recycled after their last use."""
+        nodes = self.nodes
+        order = self.schedule()
+        last_use = {}
         for pos, it in enumerate(order):
             if it[0] == "node":
                 op, a, b = nodes[it[1]]
@@ -293,6 +300,32 @@ class AirSet:
         for c in self.ctls:
             w += c.words()
         return np.array(w, dtype=np.uint64)
+
+    def ctl_jobs(self, table, num_challenges=2):
+        """The TableWithColumns behind each CTL Z column of `table`, in the order the prover creates them
+        (cross_table_lookup.rs:224-282: per lookup, per challenge, looking tables then the looked table)."""
+        jobs = []
+        for c in self.ctls:
+            for _ in range(num_challenges):
+                jobs += [t for t in c.looking_tables + [c.looked_table] if t.table == table]
+        return jobs
+
+    def signature_words(self, table):
+        """What a specialised quotient kernel depends on: the table's description and the static part of its CTL jobs.
+        Hashed (FNV-1a over the little-endian bytes) on both sides of the C ABI to pair a blob with a generated kernel."""
+        w = list(self.tables[table].words())
+        jobs = self.ctl_jobs(table)
+        w.append(len(jobs))
+        for j in jobs:
+            w += j.words()[1:]          # without the table index
+        return w
+
+    def signature(self, table):
+        h = 0xCBF29CE484222325
+        for x in self.signature_words(table):
+            for k in range(8):
+                h = ((h ^ ((int(x) >> (8 * k)) & 0xFF)) * 0x100000001B3) & 0xFFFFFFFFFFFFFFFF
+        return h
 
     def num_ctl_zs(self, table, num_challenges=2):
         n = 0

@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -25,6 +26,7 @@
 #include "../../include/ola_gpu.h"
 #include "device_ctx.h"
 #include "gl.cuh"
+#include "airq.cuh"
 
 namespace ola {
 
@@ -97,6 +99,31 @@ static void push_ctl_desc(std::vector<u64>& d, const HTwc& t, u64 beta, u64 gamm
     for (auto& c : t.columns) push_lincol(d, c);
     d.push_back(t.has_filter ? 1 : 0);
     if (t.has_filter) push_lincol(d, t.filter);
+}
+
+
+// FNV-1a over the little-endian bytes of the words a specialised kernel depends on (olavm_amd/air/dsl.py
+// AirSet.signature_words): the table description and the static part of each of its CTL Z columns.
+struct SigHasher {
+    u64 h = 0xCBF29CE484222325ull;
+    void word(u64 x) { for (int k = 0; k < 8; k++) { h ^= (x >> (8 * k)) & 0xFF; h *= 0x100000001B3ull; } }
+    void lincol(const HLinCol& c) { word(c.terms.size()); for (auto& t : c.terms) { word(t.first); word(t.second); } word(c.constant); }
+};
+static u64 air_signature(const HTable& a, const std::vector<const HTwc*>& jobs) {
+    SigHasher s;
+    s.word((u64)a.ncols); s.word((u64)a.constraint_degree); s.word((u64)a.n_regs); s.word((u64)a.n_params);
+    s.word(a.perm_pairs.size());
+    for (auto& pr : a.perm_pairs) { s.word(pr.size()); for (auto& lr : pr) { s.word(lr.first); s.word(lr.second); } }
+    s.word(a.ops.size() / 2);
+    for (u64 w : a.ops) s.word(w);
+    s.word(jobs.size());
+    for (const HTwc* t : jobs) {
+        s.word(t->columns.size());
+        for (auto& c : t->columns) s.lincol(c);
+        s.word(t->has_filter ? 1 : 0);
+        if (t->has_filter) s.lincol(t->filter);
+    }
+    return s.h;
 }
 
 // ------------------------------------------------------------------------------------------------ device helpers
@@ -236,16 +263,6 @@ __global__ __launch_bounds__(256) void any_nonzero_kernel(const u64* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------------ quotient kernel
-struct QuotParams {
-    const u64* trace_lde; const u64* zs_lde; const u64* lag_lde;  // leaf order, column stride N
-    size_t N, n;
-    int log_n, log_N, qdb;
-    const u64* gN_lo; const u64* gN_hi; int gN_h;   // two-level powers of the order-N root
-    const u64* desc;                                // per-proof descriptor (layout in build_quot_desc)
-    u64 g_inv;                                      // last = g^-1 (prover.rs:617)
-    u64* out;                                       // [num_challenges][size]
-    int n_regs;
-};
 
 #define QW 64  // one wavefront per workgroup; register file = n_regs x 64 lanes in LDS
 __global__ __launch_bounds__(QW) void quotient_kernel(QuotParams P) {
@@ -358,6 +375,22 @@ __global__ __launch_bounds__(QW) void quotient_kernel(QuotParams P) {
         P.out[j] = gl_mul(acc0, zh_inv);
         P.out[size + j] = gl_mul(acc1, zh_inv);
     }
+}
+
+// ------------------------------------------------------------------------------------------------ specialised quotient kernels
+// (airq.cuh; one translation unit per table signature under gen/, printed by olavm_amd/air/codegen.py)
+#include "gen/air_registry.inc"
+
+static const AirKernelEntry* find_air_kernel(u64 sig) {
+    for (const AirKernelEntry* e : AIR_KERNELS)
+        if (e->signature == sig) return e;
+    return nullptr;
+}
+
+// any element of a[0,len) != b[0,len)?
+__global__ __launch_bounds__(256) void any_diff_kernel(const u64* __restrict__ a, const u64* __restrict__ b, size_t len, unsigned* __restrict__ flag) {
+    const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < len && a[k] != b[k]) atomicOr(flag, 1u);
 }
 
 // ------------------------------------------------------------------------------------------------ host orchestration
@@ -518,11 +551,58 @@ static void prove_single_table(DeviceCtx* ctx, NttTables& tables, const OlaGpuCo
         P.g_inv = gl_inv(gl_root_of_unity(degree_bits));
         P.out = qv;
         P.n_regs = air.n_regs;
-        const size_t lds = (size_t)air.n_regs * QW * 8;
-        if (lds > 160 * 1024) throw OlaError(OLA_E_INVALID_ARG, "constraint program needs too many registers");
-        if (lds > 48 * 1024)
-            HIP_CHECK(hipFuncSetAttribute((const void*)quotient_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(quotient_kernel, dim3((unsigned)((size + QW - 1) / QW)), dim3(QW), lds, ctx->stream, P);
+        // OLA_AIR_KERNELS=interpreter forces the generic kernel, =crosscheck runs both and compares (tests)
+        const char* mode = getenv("OLA_AIR_KERNELS");
+        const bool force_interp = mode && !strcmp(mode, "interpreter"), crosscheck = mode && !strcmp(mode, "crosscheck");
+        std::vector<const HTwc*> twcs;
+        for (auto& jb : ctl) twcs.push_back(jb.twc);
+        const AirKernelEntry* spec = force_interp ? nullptr : find_air_kernel(air_signature(air, twcs));
+        auto run_interpreter = [&](u64* out) {
+            P.out = out;
+            const size_t lds = (size_t)air.n_regs * QW * 8;
+            if (lds > 160 * 1024) throw OlaError(OLA_E_INVALID_ARG, "constraint program needs too many registers");
+            if (lds > 48 * 1024)
+                HIP_CHECK(hipFuncSetAttribute((const void*)quotient_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(quotient_kernel, dim3((unsigned)((size + QW - 1) / QW)), dim3(QW), lds, ctx->stream, P);
+        };
+        if (!spec) {
+            run_interpreter(qv);
+        } else {
+            const int K = spec->n_emits;
+            std::vector<u64> sd(8 + 2 * (size_t)K, 0);
+            for (int c = 0; c < (1 << qdb); c++) sd[c] = desc[10 + c];
+            const u64 al[2] = {alpha0, alpha1};
+            for (int c = 0; c < 2; c++) {
+                u64 w = 1;
+                for (int i = K - 1; i >= 0; i--) { sd[8 + (size_t)c * K + i] = w; w = gl_mul(w, al[c]); }
+            }
+            for (int i = 0; i < air.n_params; i++) sd.push_back(gl_canon(params[i]));
+            for (int b = 0; b < nperm; b++)
+                for (int i = 0; i < bs; i++)
+                    for (int k = 0; k < 2; k++) {
+                        const int inst = b * bs + i;
+                        const bool live = inst < (int)air.perm_pairs.size() * nch;
+                        sd.push_back(live ? (k ? perm_sets[i][inst % nch].gamma : perm_sets[i][inst % nch].beta) : 0);
+                    }
+            for (auto& jb : ctl) { sd.push_back(jb.ch.beta); sd.push_back(jb.ch.gamma); }
+            u64* d_sd = mem.alloc(sd.size());
+            HIP_CHECK(hipMemcpyAsync(d_sd, sd.data(), sd.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+            HIP_CHECK(hipStreamSynchronize(ctx->stream));   // sd is a stack-lifetime staging buffer
+            QuotParams S = P;
+            S.desc = d_sd;
+            hipLaunchKernelGGL(spec->kernel, dim3((unsigned)((size + AIRQ_THREADS - 1) / AIRQ_THREADS)), dim3(AIRQ_THREADS), 0, ctx->stream, S);
+            if (crosscheck) {
+                u64* qv2 = mem.alloc(2 * size);
+                run_interpreter(qv2);
+                unsigned* d_flag = (unsigned*)mem.alloc(1);
+                HIP_CHECK(hipMemsetAsync(d_flag, 0, 8, ctx->stream));
+                hipLaunchKernelGGL(any_diff_kernel, dim3((unsigned)((2 * size + 255) / 256)), dim3(256), 0, ctx->stream, qv, qv2, 2 * size, d_flag);
+                unsigned flag = 0;
+                HIP_CHECK(hipMemcpyAsync(&flag, d_flag, 4, hipMemcpyDeviceToHost, ctx->stream));
+                HIP_CHECK(hipStreamSynchronize(ctx->stream));
+                if (flag) throw OlaError(OLA_E_INTERNAL, std::string("specialised quotient kernel disagrees with the interpreter: ") + spec->name);
+            }
+        }
     }
     // qv is in bit-reversed order of the size-domain: un-reverse, coset iNTT (prover.rs:700-704)
     const int size_bits = degree_bits + qdb;
