@@ -3,8 +3,13 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <map>
 #include <stdexcept>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 namespace ola {
@@ -22,29 +27,88 @@ struct OlaError : public std::runtime_error {
                                           ":" + std::to_string(__LINE__));                                \
     } while (0)
 
+// All device work of a context is issued on ONE stream, so a block returned to the cache may be handed out again
+// without synchronising: whatever still reads it was enqueued earlier on the same stream.  Scratch buffers of a 2^22-row
+// proof are tens of GB; going back to hipMalloc/hipFree for each of them costs more than the kernels (and hipFree
+// synchronises the device), hence the cache.  It is released on out-of-memory and when the context is destroyed.
 struct DeviceCtx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool owns_stream = false;
+    bool timing = false;                       // OLA_TIMING=1: per-phase wall-clock on stderr (synchronises at phase edges)
     std::vector<void*> persistent;
+    std::multimap<size_t, void*> cache;        // free blocks by size
+    std::unordered_map<void*, size_t> live;    // blocks handed out
+    size_t cached_bytes = 0;
 
+    static size_t round_size(size_t bytes) {
+        const size_t g = bytes >= (1u << 20) ? (2u << 20) : 256;
+        return ((bytes ? bytes : 8) + g - 1) / g * g;
+    }
     void* alloc_persistent(size_t bytes) {
         void* p = nullptr;
         HIP_CHECK(hipMalloc(&p, bytes ? bytes : 8));
         persistent.push_back(p);
         return p;
     }
+    void release_cache() {
+        if (cache.empty()) return;
+        (void)hipStreamSynchronize(stream);
+        for (auto& kv : cache) (void)hipFree(kv.second);
+        cache.clear();
+        cached_bytes = 0;
+    }
     void* alloc(size_t bytes) {
+        const size_t want = round_size(bytes);
+        auto it = cache.lower_bound(want);
+        if (it != cache.end() && it->first <= want + want / 4) {   // close enough fit
+            void* p = it->second;
+            live[p] = it->first;
+            cached_bytes -= it->first;
+            cache.erase(it);
+            return p;
+        }
         void* p = nullptr;
-        HIP_CHECK(hipMalloc(&p, bytes ? bytes : 8));
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            release_cache();
+            e = hipMalloc(&p, want);
+        }
+        if (e != hipSuccess) throw OlaError(-3, std::string("hipMalloc(") + std::to_string(want) + "): " + hipGetErrorString(e));
+        live[p] = want;
         return p;
     }
     void free(void* p) {
-        if (p) (void)hipFree(p);
+        if (!p) return;
+        auto it = live.find(p);
+        if (it == live.end()) { (void)hipFree(p); return; }
+        cache.emplace(it->second, p);
+        cached_bytes += it->second;
+        live.erase(it);
     }
     ~DeviceCtx() {
+        if (stream) (void)hipStreamSynchronize(stream);
+        for (auto& kv : cache) (void)hipFree(kv.second);
+        for (auto& kv : live) (void)hipFree(kv.first);
         for (void* p : persistent) (void)hipFree(p);
         if (owns_stream && stream) (void)hipStreamDestroy(stream);
+    }
+};
+
+// wall-clock of one phase of the prover (the reference's `timed!` scopes, prover.rs), printed when ctx->timing is set
+struct PhaseTimer {
+    DeviceCtx* ctx;
+    std::string name;
+    std::chrono::steady_clock::time_point t0;
+    PhaseTimer(DeviceCtx* c, const std::string& n) : ctx(c), name(n) {
+        if (ctx->timing) { (void)hipStreamSynchronize(ctx->stream); t0 = std::chrono::steady_clock::now(); }
+    }
+    ~PhaseTimer() {
+        if (!ctx->timing) return;
+        (void)hipStreamSynchronize(ctx->stream);
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        fprintf(stderr, "[ola-timing] %-44s %9.3f ms\n", name.c_str(), ms);
     }
 };
 

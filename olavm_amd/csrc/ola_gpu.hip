@@ -61,6 +61,7 @@ int32_t ola_gpu_init(const OlaGpuConfig* cfg, OlaCtx** out_ctx) {
     HIP_CHECK(hipGetDevice(&c->dev.device));
     if (c->cfg.stream) { c->dev.stream = (hipStream_t)c->cfg.stream; c->dev.owns_stream = false; }
     else { HIP_CHECK(hipStreamCreateWithFlags(&c->dev.stream, hipStreamNonBlocking)); c->dev.owns_stream = true; }
+    { const char* t = getenv("OLA_TIMING"); c->dev.timing = t && *t && *t != '0'; }
     poseidon_init(&c->dev);
     c->tables = ntt_tables_create(&c->dev);
     *out_ctx = c.release();

@@ -2,11 +2,11 @@
 //
 // Computes the same function as the reference's Poseidon::poseidon
 //   plonky2/plonky2/src/hash/poseidon.rs:593-603 (full_rounds :560-567, partial_rounds :570-590)
-// pinned by the known-answer vectors of poseidon_goldilocks.rs:293-314.  The partial rounds use OUR OWN sparse
-// factorisation of the linear layers (tables derived by tools/gen_poseidon_tables.py), the full-round MDS layer
-// (circulant [17,15,41,16,2,28,13,13,39,18,34,20] + diag [8,0..]) is accumulated un-reduced in 32-bit halves and
-// reduced once per lane.  Round constants sit in __constant__ memory: every lane reads the same address, so they
-// arrive through the scalar cache.
+// pinned by the known-answer vectors of poseidon_goldilocks.rs:293-314.  All 30 rounds use the dense MDS layer: its
+// coefficients are below 2^6, so on the 32-bit integer ALU it costs 288 single-instruction multiply-adds, less than
+// the 64x64-bit products of a sparse partial-round factorisation (measured: 855 -> ~540 VALU instructions per partial
+// round).  Round constants sit in __constant__ memory: every lane reads the same address, so they arrive through the
+// scalar cache.
 #pragma once
 #include "gl.cuh"
 #include "../../include/ola_poseidon_constants.h"
@@ -15,119 +15,101 @@ namespace ola {
 
 #if defined(__HIPCC__)
 __constant__ u64 c_rc[360];
-__constant__ u64 c_first_c[12];
-__constant__ u64 c_post_c[22];
-__constant__ u64 c_vhat[22 * 11];
-__constant__ u64 c_w[22 * 11];
-__constant__ u64 c_init[11 * 11];
+__constant__ u64 c_lane0[22];
+__constant__ u64 c_round26[12];
 
 static inline void poseidon_upload_constants() {
     HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_rc), OLA_POSEIDON_RC, sizeof(c_rc)));
-    HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_first_c), OLA_POSEIDON_FAST_FIRST_C, sizeof(c_first_c)));
-    HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_post_c), OLA_POSEIDON_FAST_POST_C, sizeof(c_post_c)));
-    HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_vhat), OLA_POSEIDON_FAST_VHAT, sizeof(c_vhat)));
-    HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_w), OLA_POSEIDON_FAST_W, sizeof(c_w)));
-    HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_init), OLA_POSEIDON_FAST_INIT, sizeof(c_init)));
+    HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_lane0), OLA_POSEIDON_LANE0_C, sizeof(c_lane0)));
+    HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_round26), OLA_POSEIDON_ROUND26_C, sizeof(c_round26)));
 }
 
-__device__ __forceinline__ u64 sbox7(u64 x) {
-    const u64 x2 = gl_sqr(x), x4 = gl_sqr(x2), x3 = gl_mul(x, x2);
-    return gl_mul(x3, x4);
+// ---- weakly reduced arithmetic: values are any u64 congruent to the field element; only the permutation's output is
+// canonicalised.  Saves the final conditional subtraction of every reduction (the reference's CPU code does the same,
+// goldilocks_field.rs:329-345 returns non-canonical u64).
+__device__ __forceinline__ void mul_wide32(u64 a, u64 b, u64& lo, u64& hi) {
+    const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+    const u64 t = (u64)a0 * b0;
+    const u64 u = (u64)a0 * b1 + (t >> 32);
+    const u64 v = (u64)a1 * b0 + (u32)u;
+    hi = (u64)a1 * b1 + (u >> 32) + (v >> 32);
+    lo = (v << 32) | (u32)t;
+}
+__device__ __forceinline__ u64 reduce128_weak(u64 lo, u64 hi) {
+    const u32 hh = (u32)(hi >> 32), hl = (u32)hi;
+    u64 t0 = lo - hh;
+    t0 -= (lo < (u64)hh) ? GL_EPS : 0;     // borrowed: + p
+    const u64 t1 = (u64)hl * 0xFFFFFFFFu;  // hl * (2^32 - 1)
+    u64 t2 = t0 + t1;
+    t2 += (t2 < t1) ? GL_EPS : 0;          // wrapped: 2^64 = EPS (mod p); cannot wrap twice
+    return t2;
+}
+__device__ __forceinline__ u64 mul_weak(u64 a, u64 b) {
+    u64 lo, hi;
+    mul_wide32(a, b, lo, hi);
+    return reduce128_weak(lo, hi);
+}
+// x weak, c canonical -> weak
+__device__ __forceinline__ u64 add_weak(u64 x, u64 c) {
+    u64 s = x + c;
+    s += (s < c) ? GL_EPS : 0;             // wrapped sum is < c < p, so adding EPS cannot wrap again
+    return s;
+}
+__device__ __forceinline__ u64 sbox7_weak(u64 x) {
+    const u64 x2 = mul_weak(x, x), x4 = mul_weak(x2, x2), x3 = mul_weak(x, x2);
+    return mul_weak(x3, x4);
 }
 
-// 128-bit accumulate helpers
-__device__ __forceinline__ void acc128_mul(u64& lo, u64& hi, u64 a, u64 b) {
-    u64 pl, ph;
-    mul_wide(a, b, pl, ph);
-    lo += pl;
-    hi += ph + (lo < pl);
-}
-
-__device__ __forceinline__ void mds_full(u64 (&s)[12]) {
+// MDS layer (poseidon.rs:170-190): circulant [17,15,41,16,2,28,13,13,39,18,34,20] + diag [8,0,..].  Every coefficient is
+// below 2^6, so the 32-bit halves of the (weak) state are accumulated un-reduced with one v_mad_u64_u32 per term and
+// each lane is folded once: value = al + ah*2^32 with al, ah < 2^42.
+__device__ __forceinline__ void mds_weak(u64 (&s)[12]) {
     constexpr u32 C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
     u32 l[12], h[12];
 #pragma unroll
     for (int i = 0; i < 12; i++) { l[i] = (u32)s[i]; h[i] = (u32)(s[i] >> 32); }
 #pragma unroll
     for (int r = 0; r < 12; r++) {
-        u64 al = 0, ah = 0;  // sums of 32-bit halves times constants < 2^6: each < 12*41*2^32 < 2^41
+        u64 al = 0, ah = 0;
 #pragma unroll
         for (int i = 0; i < 12; i++) {
-            al += (u64)l[(i + r) % 12] * C[i];
-            ah += (u64)h[(i + r) % 12] * C[i];
+            const u32 c = C[i] + ((r == 0 && i == 0) ? 8u : 0u);
+            al += (u64)l[(i + r) % 12] * c;
+            ah += (u64)h[(i + r) % 12] * c;
         }
-        if (r == 0) { al += (u64)l[0] * 8; ah += (u64)h[0] * 8; }
-        // value = al + ah * 2^32  (< 2^74)
-        const u64 lo = al + (ah << 32);
-        const u64 hi = (ah >> 32) + (lo < al);
-        s[r] = gl_reduce128(lo, hi);
+        // ah = ah_lo + ah_hi*2^32 (ah_hi < 2^10):  value = (al + ah_hi*EPS) + ah_lo*2^32  (mod p)
+        const u64 m = al + (u64)(u32)(ah >> 32) * 0xFFFFFFFFu;   // < 2^43
+        const u32 m_hi = (u32)(m >> 32), a_lo = (u32)ah;
+        const u32 r_hi = m_hi + a_lo;
+        u64 v = ((u64)r_hi << 32) | (u32)m;
+        v += (r_hi < a_lo) ? GL_EPS : 0;                          // wrapped: r_hi is small, no second wrap
+        s[r] = v;
     }
 }
 
+// Same function as the reference's Poseidon::poseidon (poseidon.rs:593-603).  The partial rounds are the reference's
+// dense form (constant layer, x^7 on lane 0, MDS layer; partial_rounds_naive) with the constants pushed onto lane 0 by
+// tools/gen_poseidon_tables.py derive_lane0; output is canonical.
 __device__ __forceinline__ void poseidon_permute(u64 (&s)[12]) {
-    // first 4 full rounds
 #pragma unroll 1
     for (int r = 0; r < 4; r++) {
 #pragma unroll
-        for (int i = 0; i < 12; i++) s[i] = sbox7(gl_add(s[i], c_rc[r * 12 + i]));
-        mds_full(s);
-    }
-    // partial rounds, sparse form
-#pragma unroll
-    for (int i = 0; i < 12; i++) s[i] = gl_add(s[i], c_first_c[i]);
-    {
-        u64 t[11];
-#pragma unroll
-        for (int r = 0; r < 11; r++) {
-            u64 lo = 0, hi = 0, top = 0;  // 11 products < 2^128 each
-#pragma unroll
-            for (int c = 0; c < 11; c++) {
-                u64 pl, ph;
-                mul_wide(c_init[r * 11 + c], s[c + 1], pl, ph);
-                lo += pl;
-                const u64 cy = (lo < pl);
-                hi += cy; top += (hi < cy);
-                hi += ph; top += (hi < ph);
-            }
-            // value = top*2^128 + hi*2^64 + lo ; 2^128 = -2^32 (mod p)
-            u64 v = gl_reduce128(lo, hi);
-            t[r] = gl_sub(v, gl_reduce128(top << 32, 0));
-        }
-#pragma unroll
-        for (int r = 0; r < 11; r++) s[r + 1] = t[r];
+        for (int i = 0; i < 12; i++) s[i] = sbox7_weak(add_weak(s[i], c_rc[r * 12 + i]));
+        mds_weak(s);
     }
 #pragma unroll 1
     for (int r = 0; r < 22; r++) {
-        const u64 x0 = gl_add(sbox7(s[0]), c_post_c[r]);
-        // d = 25*x0 + sum vhat[j]*s[j+1]
-        u64 lo = x0 * 25, hi = __umul64hi(x0, 25), top = 0;
-#pragma unroll
-        for (int j = 0; j < 11; j++) {
-            u64 pl, ph;
-            mul_wide(c_vhat[r * 11 + j], s[j + 1], pl, ph);
-            lo += pl;
-            const u64 cy = (lo < pl);
-            hi += cy; top += (hi < cy);
-            hi += ph; top += (hi < ph);
-        }
-        const u64 d = gl_sub(gl_reduce128(lo, hi), gl_reduce128(top << 32, 0));
-#pragma unroll
-        for (int j = 0; j < 11; j++) {
-            u64 pl, ph;
-            mul_wide(x0, c_w[r * 11 + j], pl, ph);
-            pl += s[j + 1];
-            ph += (pl < s[j + 1]);  // < 2^128: x0*w <= (p-1)^2, + s < 2^128
-            s[j + 1] = gl_reduce128(pl, ph);
-        }
-        s[0] = d;
+        s[0] = sbox7_weak(add_weak(s[0], c_lane0[r]));
+        mds_weak(s);
     }
-    // last 4 full rounds
 #pragma unroll 1
     for (int r = 26; r < 30; r++) {
 #pragma unroll
-        for (int i = 0; i < 12; i++) s[i] = sbox7(gl_add(s[i], c_rc[r * 12 + i]));
-        mds_full(s);
+        for (int i = 0; i < 12; i++) s[i] = sbox7_weak(add_weak(s[i], r == 26 ? c_round26[i] : c_rc[r * 12 + i]));
+        mds_weak(s);
     }
+#pragma unroll
+    for (int i = 0; i < 12; i++) s[i] = gl_canon(s[i]);
 }
 #endif  // __HIPCC__
 

@@ -491,6 +491,7 @@ static void prove_single_table(DeviceCtx* ctx, NttTables& tables, const OlaGpuCo
         if (bad) throw OlaError(OLA_E_INVALID_ARG, "Non-binary filter?");
     }
     // ---- Zs commitment ----
+    std::unique_ptr<PhaseTimer> ph(new PhaseTimer(ctx, "    compute permutation/CTL Z commitment"));
     BatchHolder zs_c(ctx);
     zs_c.b = batch_commit(ctx, tables, nullptr, zvals, (uint32_t)nz, (uint32_t)degree_bits, cfg.rate_bits, cfg.cap_height, true);
     std::vector<u64> zs_cap(len_cap * 4);
@@ -499,6 +500,8 @@ static void prove_single_table(DeviceCtx* ctx, NttTables& tables, const OlaGpuCo
     const u64 alpha0 = challenger_get(ch), alpha1 = challenger_get(ch);
 
     // ---- quotient (prover.rs:571-705) ----
+    ph.reset();
+    ph.reset(new PhaseTimer(ctx, "    compute quotient polys"));
     const int q = air.quotient_degree_factor();
     int qdb = 0;
     while ((1 << qdb) < q) qdb++;
@@ -628,6 +631,8 @@ static void prove_single_table(DeviceCtx* ctx, NttTables& tables, const OlaGpuCo
     u64* chunks = mem.alloc((size_t)2 * q * n);
     for (int c = 0; c < 2; c++)
         HIP_CHECK(hipMemcpyAsync(chunks + (size_t)c * q * n, qcoef + (size_t)c * size, keep * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    ph.reset();
+    ph.reset(new PhaseTimer(ctx, "    compute quotient commitment"));
     BatchHolder q_c(ctx);
     q_c.b = batch_commit(ctx, tables, nullptr, chunks, (uint32_t)(2 * q), (uint32_t)degree_bits, cfg.rate_bits, cfg.cap_height, false);
     std::vector<u64> q_cap(len_cap * 4);
@@ -640,6 +645,8 @@ static void prove_single_table(DeviceCtx* ctx, NttTables& tables, const OlaGpuCo
     write_cap(w, zs_cap);
     write_cap(w, q_cap);
     size_t olen = 0;
+    ph.reset();
+    ph.reset(new PhaseTimer(ctx, "    openings + FRI"));
     open_and_prove(ctx, tables, cfg, trace_c, *zs_c.b, *q_c.b, (uint32_t)nperm, ch, bytes, olen);
 }
 
@@ -657,12 +664,17 @@ void prove_with_traces(DeviceCtx* ctx, NttTables& tables, const OlaGpuConfig& cf
     std::vector<std::vector<u64>> caps(nt, std::vector<u64>(len_cap * 4));
     OlaChallenger ch;
     memset(&ch, 0, sizeof(ch));
+    PhaseTimer t_all(ctx, "prove_with_traces total");
     for (size_t t = 0; t < nt; t++) {
         if (log_n[t] + cfg.rate_bits > 32 || log_n[t] + cfg.rate_bits < cfg.cap_height) throw OlaError(OLA_E_INVALID_ARG, "table size out of range");
         dev[t].log_n = log_n[t];
         const size_t elems = (size_t)set.tables[t].ncols << log_n[t];
         dev[t].vals = mem.alloc(elems);
-        HIP_CHECK(hipMemcpyAsync(dev[t].vals, traces[t], elems * 8, hipMemcpyHostToDevice, ctx->stream));
+        {
+            PhaseTimer tt(ctx, "  table " + std::to_string(t) + " trace H2D");
+            HIP_CHECK(hipMemcpyAsync(dev[t].vals, traces[t], elems * 8, hipMemcpyHostToDevice, ctx->stream));
+        }
+        PhaseTimer tt(ctx, "  table " + std::to_string(t) + " compute trace commitment");
         canonicalize(ctx, dev[t].vals, elems);
         commits.emplace_back(new BatchHolder(ctx));
         commits[t]->b = batch_commit(ctx, tables, nullptr, dev[t].vals, (uint32_t)set.tables[t].ncols, log_n[t], cfg.rate_bits, cfg.cap_height, true);
@@ -686,6 +698,7 @@ void prove_with_traces(DeviceCtx* ctx, NttTables& tables, const OlaGpuConfig& cf
         const u64* pr = params ? params + poff : zero_params.data();
         if (!params && set.tables[t].n_params > 64) throw OlaError(OLA_E_INVALID_ARG, "params required");
         poff += set.tables[t].n_params;
+        PhaseTimer tt(ctx, "  table " + std::to_string(t) + " prove_single_table");
         prove_single_table(ctx, tables, cfg, set.tables[t], dev[t], *commits[t]->b, caps[t], jobs[t], pr, ch, bytes);
     }
     // compress_challenges (prover.rs:307-320) -- produced by trace generation, carried through

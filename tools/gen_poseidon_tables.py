@@ -114,6 +114,39 @@ def derive_fast(rc, M):
     return first_c, post, vhat, wcol, init
 
 
+def derive_lane0(rc, M):
+    """Rewrite the 22 partial rounds  x <- M * S0(x + c_r)  so that only lane 0 receives a constant:
+         x'_{r+1} = M * S0(x'_r + k_r e_0),  x_r = x'_r + d_r  with  d_4 = 0,  u_r = d_r + c_r,  k_r = u_r[0],
+         d_{r+1} = M * (0, u_r[1..11]).
+    The accumulated offset d_26 is folded into the constants of the next full round.  The MDS matrix of this field
+    has entries < 2^6, so the dense layer costs shifts/small multiply-adds only -- cheaper on a 32-bit integer ALU than
+    the 64x64-bit multiplications of a sparse factorisation."""
+    d = [0] * W
+    lane0 = []
+    for i in range(N_PART):
+        c = rc[(4 + i) * W:(5 + i) * W]
+        u = [(a + b) % P for a, b in zip(d, c)]
+        lane0.append(u[0])
+        d = mat_vec(M, [0] + u[1:])
+    tail_rc = [(a + b) % P for a, b in zip(d, rc[26 * W:27 * W])]
+    return lane0, tail_rc
+
+
+def perm_lane0(x, rc, M, lane0, tail_rc):
+    x = list(x)
+    r = 0
+    for _ in range(4):
+        x = mat_vec(M, [sbox((a + rc[r * W + i]) % P) for i, a in enumerate(x)]); r += 1
+    for i in range(N_PART):
+        x[0] = sbox((x[0] + lane0[i]) % P)
+        x = mat_vec(M, x)
+    r += N_PART
+    for j in range(4):
+        cs = tail_rc if j == 0 else rc[r * W:(r + 1) * W]
+        x = mat_vec(M, [sbox((a + cs[i]) % P) for i, a in enumerate(x)]); r += 1
+    return x
+
+
 # ---- plain-python permutation used only to self-check the tables at generation time ----
 def sbox(x):
     x2 = x * x % P
@@ -168,6 +201,9 @@ def main():
     for kat in kats:
         assert perm_naive(kat["input"], rc, M) == kat["output"], "naive permutation fails KAT"
         assert perm_fast(kat["input"], rc, M, fast) == kat["output"], "fast permutation fails KAT"
+    lane0, tail_rc = derive_lane0(rc, M)
+    for kat in kats:
+        assert perm_lane0(kat["input"], rc, M, lane0, tail_rc) == kat["output"], "lane-0 permutation fails KAT"
     first_c, post, vhat, wcol, init = fast
     h = ["// GENERATED by tools/gen_poseidon_tables.py -- do not edit.",
          "// Poseidon-Goldilocks (width 12, x^7, 8 full + 22 partial rounds) parameter tables.",
@@ -184,13 +220,17 @@ def main():
          c_array("OLA_POSEIDON_FAST_VHAT", [x for r in vhat for x in r], 11), "",
          c_array("OLA_POSEIDON_FAST_W", [x for r in wcol for x in r], 11), "",
          "// 11x11 initial dense matrix, row-major: y[r] = sum_c INIT[r][c] * x[c] on lanes 1..11",
-         c_array("OLA_POSEIDON_FAST_INIT", [x for r in init for x in r], 11), ""]
+         c_array("OLA_POSEIDON_FAST_INIT", [x for r in init for x in r], 11), "",
+         "// dense partial rounds with the constants pushed onto lane 0 (see derive_lane0): per-round lane-0 constant, and",
+         "// the constants of full round 26 with the accumulated offset folded in",
+         c_array("OLA_POSEIDON_LANE0_C", lane0), "",
+         c_array("OLA_POSEIDON_ROUND26_C", tail_rc), ""]
     os.makedirs(os.path.join(ROOT, "include"), exist_ok=True)
     open(os.path.join(ROOT, "include", "ola_poseidon_constants.h"), "w").write("\n".join(h))
     os.makedirs(os.path.join(ROOT, "tests", "golden"), exist_ok=True)
     json.dump({"source": "plonky2/plonky2/src/hash/poseidon_goldilocks.rs:293-314 (test_vectors12)",
                "vectors": kats}, open(os.path.join(ROOT, "tests", "golden", "poseidon_kat.json"), "w"), indent=1)
-    print("ok: tables + KATs written; naive and fast permutations match all 4 KATs")
+    print("ok: tables + KATs written; naive, sparse and lane-0 permutations match all 4 KATs")
 
 
 if __name__ == "__main__":
