@@ -165,6 +165,13 @@ int32_t ola_prove_with_traces(OlaCtx* ctx, const uint64_t* airset, size_t airset
                               const uint32_t* log_n, const uint64_t* params, const uint64_t* compress_challenges,
                               uint8_t* out, size_t cap, size_t* out_len);
 
+/* Which tables of `airset` have an ahead-of-time specialised constraint-quotient kernel in this build (the counterpart of
+ * the reference compiling each table's eval_packed_generic, e.g. cpu/cpu_stark.rs:325): has_kernel[t] = 1 or 0 for every
+ * table.  Tables without one are proven with the generic interpreter kernel -- same bytes, fewer points per second.
+ * The environment variable OLA_AIR_KERNELS=interpreter disables the specialised kernels, =crosscheck runs both and fails
+ * with OLA_E_INTERNAL if they disagree (test hooks). */
+int32_t ola_air_kernels_available(const uint64_t* airset, size_t airset_words, uint8_t* has_kernel, size_t ntables);
+
 #ifdef __cplusplus
 }
 #endif

@@ -82,6 +82,7 @@ def load_library():
                                      C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
     L.ola_prove_with_traces.argtypes = [C.c_void_p, U64P, C.c_size_t, C.POINTER(U64P), C.POINTER(C.c_uint32), U64P, U64P,
                                         C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.ola_air_kernels_available.argtypes = [U64P, C.c_size_t, C.POINTER(C.c_uint8), C.c_size_t]
     _lib = L
     return L
 
@@ -92,6 +93,7 @@ EXPORTS = [
     "ola_commit_values_dev", "ola_commit_coeffs_dev", "ola_batch_free", "ola_batch_shape", "ola_batch_get_coeffs",
     "ola_batch_get_leaf", "ola_batch_get_lde_row", "ola_challenger_init", "ola_challenger_observe",
     "ola_challenger_get", "ola_challenger_compact", "ola_open_and_prove", "ola_pow", "ola_prove_with_traces",
+    "ola_air_kernels_available",
 ]
 
 
@@ -270,6 +272,13 @@ class Backend:
                 continue
             self._chk(rc)
             return bytes(buf.raw[:need.value])
+
+    def air_kernels_available(self, airset_blob, ntables):
+        """-> list of bool: which tables of the AIR set have a specialised quotient kernel in this build."""
+        blob = np.ascontiguousarray(airset_blob, dtype=np.uint64)
+        flags = (C.c_uint8 * ntables)()
+        self._chk(self.lib.ola_air_kernels_available(_p(blob), blob.size, flags, ntables))
+        return [bool(x) for x in flags]
 
     def open_and_prove(self, trace, zs, quot, num_permutation_zs, challenger):
         need, olen = C.c_size_t(0), C.c_size_t(0)

@@ -347,4 +347,11 @@ int32_t ola_prove_with_traces(OlaCtx* ctx, const uint64_t* airset, size_t airset
     OLA_CATCH
 }
 
+int32_t ola_air_kernels_available(const uint64_t* airset, size_t airset_words, uint8_t* has_kernel, size_t ntables) {
+    OLA_TRY
+    require(airset && has_kernel, "null pointer");
+    air_kernels_available((const u64*)airset, airset_words, has_kernel, ntables);
+    OLA_CATCH
+}
+
 }  // extern "C"

@@ -706,4 +706,17 @@ void prove_with_traces(DeviceCtx* ctx, NttTables& tables, const OlaGpuConfig& cf
     for (size_t t = 0; t < nt; t++) w.field(compress ? compress[t] : 0);
 }
 
+// ola_air_kernels_available
+void air_kernels_available(const u64* airset, size_t airset_words, uint8_t* has_kernel, size_t ntables) {
+    HAirSet set = parse_airset(airset, airset_words);
+    if (ntables != set.tables.size()) throw OlaError(OLA_E_INVALID_ARG, "ntables does not match the AIR set");
+    std::vector<std::vector<const HTwc*>> jobs(set.tables.size());
+    for (const HCtl& ctl : set.ctls)
+        for (int c = 0; c < 2; c++) {
+            for (const HTwc& twc : ctl.looking) jobs[twc.table].push_back(&twc);
+            jobs[ctl.looked.table].push_back(&ctl.looked);
+        }
+    for (size_t t = 0; t < set.tables.size(); t++) has_kernel[t] = find_air_kernel(air_signature(set.tables[t], jobs[t])) ? 1 : 0;
+}
+
 }  // namespace ola

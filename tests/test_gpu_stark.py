@@ -126,3 +126,62 @@ def test_non_binary_ctl_filter_is_refused(be, oracle):
         be.prove_with_traces(blob, [cmp_t, rc_t])
     with pytest.raises(RuntimeError, match="Non-binary filter"):
         oracle.prove_with_traces(blob, [cmp_t, rc_t])
+
+
+def _random_rows_with_binary_filters(rng, airset, t, n):
+    """Uniform random trace for table t, except that the columns its CTL filters read are zero or one-hot per row, chosen
+    among the assignments for which every filter (sums / differences / `1 - col` of selector columns) evaluates to 0 or
+    1, as cross_table_lookup.rs:303 demands."""
+    tab = airset.tables[t]
+    tr = rng.integers(0, tracegen.P, size=(tab.ncols, n), dtype=np.uint64)
+    filters = [j.filter_column for j in airset.ctl_jobs(t, 1) if j.filter_column is not None]
+    cols = sorted({c for f in filters for c, _ in f.terms})
+    if not cols:
+        return tr
+
+    def ok(hot):
+        return all((sum(k for c, k in f.terms if c == hot) + f.constant) % tracegen.P in (0, 1) for f in filters)
+    options = [h for h in [None] + cols if ok(h)]
+    assert len(options) > 1, "no non-trivial binary filter assignment"
+    tr[cols] = 0
+    for r in range(n):
+        h = options[int(rng.integers(0, len(options)))]
+        if h is not None:
+            tr[h, r] = 1
+    return tr
+
+
+@pytest.mark.parametrize("t", range(12))
+def test_specialised_quotient_kernels_match_interpreter_on_random_rows(be, t, monkeypatch):
+    """Every generated straight-line kernel against the interpreter on generic data (OLA_AIR_KERNELS=crosscheck compares
+    all quotient values on the device).  Table t is the real one; the tables before it are replaced by constraint-free
+    stand-ins of the same width (their vanishing polynomial -- CTL checks only -- is divisible for any trace), so the
+    prover reaches table t.  The run may still end in the quotient-degree error for table t (random rows do not satisfy
+    its constraints), which is raised after the comparison."""
+    from olavm_amd.air.dsl import AirTable
+    from olavm_amd.backend import OlaGpuError
+    full = T.ola_stark(range_bits=4, limb_bits=2)
+    tabs = [full.tables[i] if i >= t else AirTable("standin%d" % i, full.tables[i].ncols, 3) for i in range(12)]
+    s = AirSet(tabs, full.ctls)
+    assert s.signature(t) == full.signature(t)
+    blob = s.blob()
+    avail = be.air_kernels_available(blob, 12)
+    assert avail[t] and not any(avail[:t])
+    rng = np.random.default_rng(100 + t)
+    traces = [_random_rows_with_binary_filters(rng, s, i, 32) for i in range(12)]
+    params = [int(x) for tab in tabs for x in rng.integers(0, tracegen.P, size=tab.n_params, dtype=np.uint64)] or None
+    monkeypatch.setenv("OLA_AIR_KERNELS", "crosscheck")
+    try:
+        be.prove_with_traces(blob, traces, params)
+    except OlaGpuError as e:
+        assert "Quotient has failed" in str(e), str(e)
+
+
+def test_interpreter_and_specialised_kernels_give_the_same_proof(be, monkeypatch):
+    s = T.ola_stark(range_bits=4, limb_bits=2)
+    blob = s.blob()
+    assert all(be.air_kernels_available(blob, 12))
+    traces, params, compress = tracegen.empty_program_instance()
+    fast = be.prove_with_traces(blob, traces, params, compress)
+    monkeypatch.setenv("OLA_AIR_KERNELS", "interpreter")
+    assert be.prove_with_traces(blob, traces, params, compress) == fast
