@@ -13,7 +13,12 @@ with open(os.path.join(root, "profiles", f"{tag}_kernel_stats.csv"), "w", newlin
     for r in rows:
         r[0] = re.sub(r"\(anonymous namespace\)::", "", r[0])[:120]
         w.writerow(r)
-log = open(os.path.join(d, "bench.log")).read().splitlines()
-js = [l for l in log if l.startswith("{")]
-open(os.path.join(root, "profiles", f"{tag}_bench.json"), "w").write((js[-1] if js else "") + "\n")
+for name in ("bench.log", "cmd.log"):
+    if os.path.exists(os.path.join(d, name)):
+        log = [l for l in open(os.path.join(d, name)).read().splitlines() if not re.match(r"^[EWI]\d{8} ", l)]
+        js = [l for l in log if l.startswith("{")]
+        if js:
+            open(os.path.join(root, "profiles", f"{tag}_bench.json"), "w").write(js[-1] + "\n")
+        else:
+            open(os.path.join(root, "profiles", f"{tag}_run.log"), "w").write("\n".join(log[-20:]) + "\n")
 print("saved", tag, len(rows) - 1, "kernels")
