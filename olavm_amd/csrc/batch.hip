@@ -124,7 +124,7 @@ OlaBatch* batch_commit(DeviceCtx* ctx, NttTables& t, const uint64_t* const* cols
         }
         ntt_lde_leaf_order(t, b->coeffs, b->lde, log_n, rate_bits, ncols);
         launch_leaf_hash_colmajor(ctx, b->lde, N, (int)ncols, N, b->heap + 4 * N);
-        launch_merkle_build(ctx, b->heap, N);
+        launch_merkle_build(ctx, b->heap, N, cap_height);
         HIP_CHECK(hipStreamSynchronize(ctx->stream));
         if (tmp) ctx->free(tmp);
     } catch (...) {

@@ -195,12 +195,31 @@ __global__ __launch_bounds__(256) void scan_local_kernel(u64* __restrict__ d, si
 }
 // single block: exclusive suffix scan of nblocks totals in place
 __global__ __launch_bounds__(256) void scan_totals_kernel(u64* __restrict__ tot, size_t nblocks) {
-    if (threadIdx.x != 0) return;
+    // exclusive suffix sum of the block totals, one workgroup: thread t owns a contiguous chunk (chunks in reverse order)
+    __shared__ u64 sh[256];
+    const int t = threadIdx.x;
+    const size_t per = (nblocks + 255) / 256;
+    // chunk of thread t counted from the END: indices [nblocks - hi_off, nblocks - lo_off)
+    const size_t lo_off = (size_t)t * per < nblocks ? (size_t)t * per : nblocks;
+    const size_t hi_off = lo_off + per < nblocks ? lo_off + per : nblocks;
     u64 run = 0;
-    for (size_t i = nblocks; i-- > 0;) {
+    for (size_t o = lo_off; o < hi_off; o++) run = gl_add(run, tot[nblocks - 1 - o]);
+    sh[t] = run;
+    __syncthreads();
+    u64 incl = run;
+    for (int s = 1; s < 256; s <<= 1) {
+        const u64 other = (t >= s) ? sh[t - s] : 0;
+        __syncthreads();
+        incl = gl_add(incl, other);
+        sh[t] = incl;
+        __syncthreads();
+    }
+    u64 acc = (t > 0) ? sh[t - 1] : 0;
+    for (size_t o = lo_off; o < hi_off; o++) {
+        const size_t i = nblocks - 1 - o;
         const u64 v = tot[i];
-        tot[i] = run;
-        run = gl_add(run, v);
+        tot[i] = acc;
+        acc = gl_add(acc, v);
     }
 }
 __global__ __launch_bounds__(256) void scan_add_kernel(u64* __restrict__ d, size_t n, const u64* __restrict__ tot) {
@@ -450,7 +469,7 @@ void open_and_prove(DeviceCtx* ctx, NttTables& tables, const OlaGpuConfig& cfg, 
         const size_t nleaves = len >> ab;
         L.heap = mem.alloc(2 * nleaves * 4);
         launch_leaf_hash_ext(ctx, L.va, L.vb, arity, nleaves, L.heap + 4 * nleaves);
-        launch_merkle_build(ctx, L.heap, nleaves);
+        launch_merkle_build(ctx, L.heap, nleaves, cfg.cap_height);
         L.cap.resize(len_cap * 4);
         HIP_CHECK(hipMemcpyAsync(L.cap.data(), L.heap + 4 * len_cap, len_cap * 32, hipMemcpyDeviceToHost, ctx->stream));
         HIP_CHECK(hipStreamSynchronize(ctx->stream));

@@ -135,9 +135,10 @@ void launch_leaf_hash_ext(DeviceCtx* ctx, const u64* pa, const u64* pb, int arit
     const unsigned blocks = (unsigned)((num_leaves + 255) / 256);
     hipLaunchKernelGGL(leaf_hash_ext_kernel, dim3(blocks), dim3(256), 0, ctx->stream, pa, pb, arity, num_leaves, out);
 }
-// heap[N..2N) must hold the leaf digests; fills heap[1..N)
-void launch_merkle_build(DeviceCtx* ctx, u64* heap, size_t num_leaves) {
-    for (size_t level = num_leaves / 2; level >= 1; level /= 2) {
+// heap[N..2N) must hold the leaf digests; fills heap[2^cap_height .. N): like the reference (merkle_tree/mod.rs:228-233)
+// nothing above the cap is ever hashed
+void launch_merkle_build(DeviceCtx* ctx, u64* heap, size_t num_leaves, uint32_t cap_height) {
+    for (size_t level = num_leaves / 2; level >= ((size_t)1 << cap_height); level /= 2) {
         const unsigned blocks = (unsigned)((level + 255) / 256);
         hipLaunchKernelGGL(merkle_level_kernel, dim3(blocks), dim3(256), 0, ctx->stream, heap, level, level);
     }

@@ -207,7 +207,7 @@ int32_t ola_merkle_cap(OlaCtx* ctx, const uint64_t* leaves, size_t num_leaves, s
     try {
         HIP_CHECK(hipMemcpyAsync(d_rows, leaves, num_leaves * leaf_len * 8, hipMemcpyHostToDevice, ctx->dev.stream));
         launch_leaf_hash_rowmajor(&ctx->dev, d_rows, leaf_len, num_leaves, heap + 4 * num_leaves);
-        launch_merkle_build(&ctx->dev, heap, num_leaves);
+        launch_merkle_build(&ctx->dev, heap, num_leaves, cap_height);
         const size_t len_cap = (size_t)1 << cap_height;
         HIP_CHECK(hipMemcpyAsync(cap_out, heap + 4 * len_cap, len_cap * 32, hipMemcpyDeviceToHost, ctx->dev.stream));
         HIP_CHECK(hipStreamSynchronize(ctx->dev.stream));

@@ -216,13 +216,30 @@ __global__ __launch_bounds__(256) void pscan_local_kernel(u64* __restrict__ d, s
     }
     if (t == 255) block_tot[blockIdx.x] = incl;
 }
-__global__ void pscan_totals_kernel(u64* __restrict__ tot, size_t nblocks) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// exclusive running product of the block totals, one workgroup: each thread owns a contiguous chunk, chunk totals
+// are combined with a Hillis-Steele scan in LDS
+__global__ __launch_bounds__(256) void pscan_totals_kernel(u64* __restrict__ tot, size_t nblocks) {
+    __shared__ u64 sh[256];
+    const int t = threadIdx.x;
+    const size_t per = (nblocks + 255) / 256;
+    const size_t lo = (size_t)t * per, hi = lo + per < nblocks ? lo + per : nblocks;
     u64 run = 1;
-    for (size_t i = 0; i < nblocks; i++) {
+    for (size_t i = lo; i < hi; i++) run = gl_mul(run, tot[i]);
+    sh[t] = run;
+    __syncthreads();
+    u64 incl = run;
+    for (int s = 1; s < 256; s <<= 1) {
+        const u64 other = (t >= s) ? sh[t - s] : 1;
+        __syncthreads();
+        incl = gl_mul(incl, other);
+        sh[t] = incl;
+        __syncthreads();
+    }
+    u64 acc = (t > 0) ? sh[t - 1] : 1;
+    for (size_t i = lo; i < hi; i++) {
         const u64 v = tot[i];
-        tot[i] = run;
-        run = gl_mul(run, v);
+        tot[i] = acc;
+        acc = gl_mul(acc, v);
     }
 }
 __global__ __launch_bounds__(256) void pscan_apply_kernel(u64* __restrict__ d, size_t n, const u64* __restrict__ tot) {
@@ -241,7 +258,7 @@ static void product_scan_inclusive(DeviceCtx* ctx, u64* col, size_t n, u64* tot)
     const size_t nblocks = (n + PSCAN_B - 1) / PSCAN_B;
     hipLaunchKernelGGL(pscan_local_kernel, dim3((unsigned)nblocks), dim3(256), 0, ctx->stream, col, n, tot);
     if (nblocks > 1) {
-        hipLaunchKernelGGL(pscan_totals_kernel, dim3(1), dim3(64), 0, ctx->stream, tot, nblocks);
+        hipLaunchKernelGGL(pscan_totals_kernel, dim3(1), dim3(256), 0, ctx->stream, tot, nblocks);
         hipLaunchKernelGGL(pscan_apply_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, col, n, tot);
     }
 }
