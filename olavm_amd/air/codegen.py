@@ -74,8 +74,16 @@ def num_emits(airset, t, num_challenges=2):
     return len(tab.emits) + 2 * tab.num_permutation_batches(num_challenges) + 2 * len(airset.ctl_jobs(t, num_challenges))
 
 
+SEGMENT_OPS = 96     # field operations between two code-motion barriers
+
+
 def table_kernel(airset, t, name, num_challenges=2):
-    """-> (source text of the kernel, K)."""
+    """-> (source text of the kernel, K).
+
+    Register pressure is what limits these kernels (the CPU table keeps ~90 trace cells and ~65 shared subexpressions
+    alive if every value is computed once), so the code is cut into segments separated by compiler barriers: trace
+    cells, constants and one-operation combinations of them ("cheap" nodes) are re-loaded / recomputed in every segment
+    that uses them instead of being kept in registers; only multi-operation subexpressions stay live across segments."""
     tab = airset.tables[t]
     jobs = airset.ctl_jobs(t, num_challenges)
     nperm = tab.num_permutation_batches(num_challenges)
@@ -86,32 +94,76 @@ def table_kernel(airset, t, name, num_challenges=2):
     d_ctl = d_perm + 2 * nperm * bs
     e = _Emitter(K)
     e.add("AIRQ_PROLOGUE(%d)" % K)
+    nodes = tab.nodes
+    LEAF = (OP_LOCAL, OP_NEXT, OP_CONST, OP_PARAM)
+
+    def is_cheap(j):
+        op, a, b = nodes[j]
+        if op in LEAF:
+            return True
+        return op in (OP_ADD, OP_SUB) and nodes[a][0] in LEAF and nodes[b][0] in LEAF
+
+    state = {"seg": 0, "ops": 0, "local": {}}
+
+    def barrier():
+        e.add("AIRQ_SEGMENT_BARRIER;")
+        state["seg"] += 1
+        state["ops"] = 0
+        state["local"] = {}
+
+    def leaf_expr(j):
+        op, a, _ = nodes[j]
+        if op == OP_LOCAL:
+            return "LC(%d)" % a
+        if op == OP_NEXT:
+            return "NC(%d)" % a
+        if op == OP_CONST:
+            return _lit(a)
+        return "D[%d]" % (d_params + a)
+
+    def ref(j):
+        """Name of node j's value, materialising cheap nodes in the current segment."""
+        if not is_cheap(j):
+            return "t%d" % j
+        op, a, b = nodes[j]
+        if op == OP_CONST:
+            return _lit(a)
+        if j in state["local"]:
+            return state["local"][j]
+        nm = "s%d_%d" % (state["seg"], j)
+        if op in LEAF:
+            e.add("const u64 %s = %s;" % (nm, leaf_expr(j)))
+        else:
+            e.add("const u64 %s = %s(%s, %s);" % (nm, "gl_add" if op == OP_ADD else "gl_sub", ref(a), ref(b)))
+            state["ops"] += 1
+        state["local"][j] = nm
+        return nm
+
     # ---- the table's constraint program ----
     for it in tab.schedule():
         if it[0] == "emit":
-            e.emit(it[1], "t%d" % it[2])
+            e.emit(it[1], ref(it[2]))
+            state["ops"] += 2
+            if state["ops"] >= SEGMENT_OPS:
+                barrier()
             continue
         j = it[1]
-        op, a, b = tab.nodes[j]
-        if op == OP_LOCAL:
-            rhs = "LC(%d)" % a
-        elif op == OP_NEXT:
-            rhs = "NC(%d)" % a
-        elif op == OP_CONST:
-            rhs = _lit(a)
-        elif op == OP_PARAM:
-            rhs = "D[%d]" % (d_params + a)
-        elif op == OP_ADD:
-            rhs = "gl_add(t%d, t%d)" % (a, b)
+        if is_cheap(j):
+            continue            # materialised where it is used
+        op, a, b = nodes[j]
+        if op == OP_ADD:
+            rhs = "gl_add(%s, %s)" % (ref(a), ref(b))
         elif op == OP_SUB:
-            rhs = "gl_sub(t%d, t%d)" % (a, b)
+            rhs = "gl_sub(%s, %s)" % (ref(a), ref(b))
         elif op == OP_MUL:
-            rhs = "gl_mul(t%d, t%d)" % (a, b)
+            rhs = "gl_mul(%s, %s)" % (ref(a), ref(b))
         elif op == OP_ISZERO:
-            rhs = "(t%d == 0 ? 1ull : 0ull)" % a
+            rhs = "(%s == 0 ? 1ull : 0ull)" % ref(a)
         else:
             raise ValueError(op)
         e.add("const u64 t%d = %s;" % (j, rhs))
+        state["ops"] += 1
+    barrier()
     # ---- permutation checks (permutation.rs:302-360) ----
     for b in range(nperm):
         e.emit(KIND_FIRST, "gl_sub(ZL(%d), 1)" % b)
@@ -135,33 +187,47 @@ def table_kernel(airset, t, name, num_challenges=2):
             inst += 1
         e.emit(KIND_ALL, "gl_sub(gl_mul(ZN(%d), pr), gl_mul(ZL(%d), pl))" % (b, b))
         e.add("}")
+        e.add("AIRQ_SEGMENT_BARRIER;")
     # ---- cross-table lookup checks (cross_table_lookup.rs:380-421) ----
-    evals = {}   # id(twc) -> per-column temporaries (shared by the jobs of the challenges of one lookup)
+    # Emits are indexed, so evaluation order is free: the Z columns that look at the same columns (one per challenge)
+    # are evaluated together, streaming the column values through one Horner step per challenge.
+    first_idx = e.idx
+    groups = {}
     for i, twc in enumerate(jobs):
-        key = id(twc)
-        if key not in evals:
-            g = len(evals)
-            names = []
-            for k, col in enumerate(twc.columns):
-                e.add("const u64 c%d_%dl = %s, c%d_%dn = %s;" % (g, k, _lincol(col, "L"), g, k, _lincol(col, "N")))
-                names.append("c%d_%d" % (g, k))
-            fname = None
-            if twc.filter_column is not None:
-                fname = "f%d" % g
-                e.add("const u64 %sl = %s, %sn = %s;" % (fname, _lincol(twc.filter_column, "L"), fname, _lincol(twc.filter_column, "N")))
-            evals[key] = (names, fname)
-        names, fname = evals[key]
-        e.add("{ const u64 beta = D[%d], gamma = D[%d];" % (d_ctl + 2 * i, d_ctl + 2 * i + 1))
-        e.add("  u64 cl = %sl, cn = %sn;" % (names[-1], names[-1]))
-        for k in range(len(names) - 2, -1, -1):
-            e.add("  cl = gl_add(gl_mul(cl, beta), %sl); cn = gl_add(gl_mul(cn, beta), %sn);" % (names[k], names[k]))
-        e.add("  cl = gl_add(cl, gamma); cn = gl_add(cn, gamma);")
-        if fname is not None:   # select(f, x) = f*x + 1 - f
-            e.add("  cl = gl_sub(gl_add(gl_mul(%sl, cl), 1), %sl); cn = gl_sub(gl_add(gl_mul(%sn, cn), 1), %sn);" % (fname, fname, fname, fname))
-        e.add("  const u64 zl = ZL(%d), zn = ZN(%d);" % (nperm + i, nperm + i))
-        e.emit(KIND_FIRST, "gl_sub(zl, cl)")
-        e.emit(KIND_TRANSITION, "gl_sub(zn, gl_mul(zl, cn))")
+        groups.setdefault(id(twc), (twc, []))[1].append(i)
+    for twc, idxs in groups.values():
+        e.add("{")
+        for i in idxs:
+            e.add("  const u64 beta%d = D[%d], gamma%d = D[%d];" % (i, d_ctl + 2 * i, i, d_ctl + 2 * i + 1))
+        ncol = len(twc.columns)
+        for k in range(ncol - 1, -1, -1):
+            e.add("  { const u64 el = %s, en = %s;" % (_lincol(twc.columns[k], "L"), _lincol(twc.columns[k], "N")))
+            for i in idxs:
+                if k == ncol - 1:
+                    e.add("    cl%d = el; cn%d = en;" % (i, i))
+                else:
+                    e.add("    cl%d = gl_add(gl_mul(cl%d, beta%d), el); cn%d = gl_add(gl_mul(cn%d, beta%d), en);" % (i, i, i, i, i, i))
+            e.add("  }")
+        # declarations have to precede the streaming block
+        decl = "  u64 " + ", ".join("cl%d, cn%d" % (i, i) for i in idxs) + ";"
+        pos = len(e.lines) - 1
+        while "const u64 beta%d" % idxs[-1] not in e.lines[pos]:
+            pos -= 1
+        e.lines.insert(pos + 1, "    " + decl)
+        if twc.filter_column is not None:
+            e.add("  const u64 fl = %s, fn = %s;" % (_lincol(twc.filter_column, "L"), _lincol(twc.filter_column, "N")))
+        for i in idxs:
+            e.add("  cl%d = gl_add(cl%d, gamma%d); cn%d = gl_add(cn%d, gamma%d);" % (i, i, i, i, i, i))
+            if twc.filter_column is not None:   # select(f, x) = f*x + 1 - f
+                e.add("  cl%d = gl_sub(gl_add(gl_mul(fl, cl%d), 1), fl); cn%d = gl_sub(gl_add(gl_mul(fn, cn%d), 1), fn);" % (i, i, i, i))
+            e.add("  { const u64 zl = ZL(%d), zn = ZN(%d);" % (nperm + i, nperm + i))
+            e.idx = first_idx + 2 * i
+            e.emit(KIND_FIRST, "gl_sub(zl, cl%d)" % i)
+            e.emit(KIND_TRANSITION, "gl_sub(zn, gl_mul(zl, cn%d))" % i)
+            e.add("  }")
         e.add("}")
+        e.add("AIRQ_SEGMENT_BARRIER;")
+    e.idx = first_idx + 2 * len(jobs)
     assert e.idx == K, (e.idx, K)
     e.add("AIRQ_EPILOGUE")
     head = "// table %d (%s): %d columns, %d constraints, %d permutation Zs, %d CTL Zs, K = %d\n" % (

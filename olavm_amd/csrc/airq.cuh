@@ -36,32 +36,48 @@ __device__ __forceinline__ u64 acc_reduce(const Acc160& a) { return gl_sub(gl_re
 
 #define AIRQ_THREADS 256
 #ifdef AIRQ_GENERATED_TU
+typedef const u64 __attribute__((address_space(1)))* airq_gptr;
+typedef const u64 __attribute__((address_space(4)))* airq_cptr;
+// Requires n >= 256 (the launcher sends smaller tables to the interpreter): a workgroup then covers 256 consecutive leaves
+// of one coset, and both the local rows (leaf j) and the next rows (leaf jn, see stark.hip quotient_kernel) of the
+// workgroup are 256-aligned runs -- so every load is "uniform base + small lane offset" and its address lives in SGPRs
+// (global_load ... v_off, s[base]) instead of one VGPR pair per column and row.
 #define AIRQ_PROLOGUE(K_)                                                                                                  \
     const size_t size = P.n << P.qdb;                                                                                      \
-    const size_t j = (size_t)blockIdx.x * AIRQ_THREADS + threadIdx.x;                                                      \
-    const bool active = j < size;                                                                                          \
-    const size_t jj = active ? j : 0;                                                                                      \
-    const size_t c_ = jj >> P.log_n, r_ = jj & (P.n - 1);                                                                  \
+    const u32 lane_ = threadIdx.x;                                                                                         \
+    const size_t jb_ = (size_t)blockIdx.x * AIRQ_THREADS;                                                                  \
+    const size_t j = jb_ + lane_;                                                                                          \
+    const size_t c_ = jb_ >> P.log_n, r_ = j & (P.n - 1);                                                                  \
     const u32 rr_ = bitrev32((u32)r_, P.log_n);                                                                            \
-    const size_t jn = (c_ << P.log_n) + bitrev32((rr_ + 1) & (u32)(P.n - 1), P.log_n);                                     \
+    const size_t jn_ = (c_ << P.log_n) + bitrev32((rr_ + 1) & (u32)(P.n - 1), P.log_n);                                    \
+    const u32 noff_ = (u32)jn_ & (AIRQ_THREADS - 1);                                                                       \
+    const size_t nb_ = ((size_t)__builtin_amdgcn_readfirstlane((u32)(jn_ >> 32)) << 32) |                                  \
+                       (__builtin_amdgcn_readfirstlane((u32)jn_) & ~(u32)(AIRQ_THREADS - 1));                              \
     const u64 m_ = ((u64)rr_ << (P.log_N - P.log_n)) + bitrev32((u32)c_, P.log_N - P.log_n);                               \
     const u64 x_ = gl_mul(GL_GENERATOR, gl_mul(P.gN_lo[m_ & (((u64)1 << P.gN_h) - 1)], P.gN_hi[m_ >> P.gN_h]));            \
     const u64 z_last = gl_sub(x_, P.g_inv);                                                                                \
     const size_t N = P.N;                                                                                                  \
-    const u64 lag_first = P.lag_lde[jj], lag_last = P.lag_lde[N + jj];                                                     \
-    const u64* __restrict__ D = P.desc;                                                                                    \
-    const u64* __restrict__ T_ = P.trace_lde;                                                                              \
-    const u64* __restrict__ Z_ = P.zs_lde;                                                                                 \
+    const u64 lag_first = P.lag_lde[j], lag_last = P.lag_lde[N + j];                                                       \
+    airq_cptr D = (airq_cptr)P.desc;                                                                                       \
+    airq_gptr T_ = (airq_gptr)P.trace_lde;                                                                                 \
+    airq_gptr Z_ = (airq_gptr)P.zs_lde;                                                                                    \
     constexpr int AIRQ_K = (K_);                                                                                           \
     Acc160 accA0 = {0, 0, 0}, accA1 = {0, 0, 0}, accT0 = {0, 0, 0}, accT1 = {0, 0, 0};
-#define LC(c) gl_canon(T_[(size_t)(c) * N + jj])
-#define NC(c) gl_canon(T_[(size_t)(c) * N + jn])
-#define ZL(c) Z_[(size_t)(c) * N + jj]
-#define ZN(c) Z_[(size_t)(c) * N + jn]
+#define LC(c) gl_canon((T_ + ((size_t)(c) * N + jb_))[lane_])
+#define NC(c) gl_canon((T_ + ((size_t)(c) * N + nb_))[noff_])
+#define ZL(c) (Z_ + ((size_t)(c) * N + jb_))[lane_]
+#define ZN(c) (Z_ + ((size_t)(c) * N + nb_))[noff_]
 #define AIRQ_EMIT_ALL(i, v) { const u64 v_ = (v); acc_mad(accA0, v_, D[8 + (i)]); acc_mad(accA1, v_, D[8 + AIRQ_K + (i)]); }
 #define AIRQ_EMIT_TRANS(i, v) { const u64 v_ = (v); acc_mad(accT0, v_, D[8 + (i)]); acc_mad(accT1, v_, D[8 + AIRQ_K + (i)]); }
+// Segment boundary: the base pointers and the running accumulators pass through one opaque (empty) volatile asm.  The
+// compiler can then neither merge a re-load of a trace cell with the load of an earlier segment, nor start the loads of
+// this segment before the emits of the previous one are done -- the live ranges of re-loaded cells stay inside their
+// segment.  (A plain memory clobber does not do it: loads through the kernel's read-only arguments are treated as
+// invariant and all ~300 of them were hoisted to the top of the kernel.)  The pointers keep their address spaces
+// (global for the trace / Z tables, constant for the descriptor, which is read with scalar loads).
+#define AIRQ_SEGMENT_BARRIER asm volatile("" : "+s"(T_), "+s"(Z_), "+s"(D), "+v"(accA0.lo), "+v"(accT0.lo))
 #define AIRQ_EPILOGUE                                                                                                      \
-    if (active) {                                                                                                          \
+    {                                                                                                                      \
         const u64 zh_inv = D[c_];                                                                                          \
         P.out[j] = gl_mul(gl_add(acc_reduce(accA0), gl_mul(z_last, acc_reduce(accT0))), zh_inv);                           \
         P.out[size + j] = gl_mul(gl_add(acc_reduce(accA1), gl_mul(z_last, acc_reduce(accT1))), zh_inv);                    \

@@ -43,8 +43,13 @@ GL_HD u64 gl_neg(u64 a) { return a ? GL_P - a : 0; }
 // 64x64 -> 128 multiply
 GL_HD void mul_wide(u64 a, u64 b, u64& lo, u64& hi) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    lo = a * b;
-    hi = __umul64hi(a, b);
+    // schoolbook on 32-bit halves: four v_mad_u64_u32 (full rate on gfx950), the partial sums cannot overflow 64 bits
+    const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+    const u64 t = (u64)a0 * b0;
+    const u64 u = (u64)a0 * b1 + (t >> 32);
+    const u64 v = (u64)a1 * b0 + (u32)u;
+    hi = (u64)a1 * b1 + (u >> 32) + (v >> 32);
+    lo = (v << 32) | (u32)t;
 #else
     unsigned __int128 p = (unsigned __int128)a * b;
     lo = (u64)p;

@@ -576,7 +576,8 @@ static void prove_single_table(DeviceCtx* ctx, NttTables& tables, const OlaGpuCo
         const bool force_interp = mode && !strcmp(mode, "interpreter"), crosscheck = mode && !strcmp(mode, "crosscheck");
         std::vector<const HTwc*> twcs;
         for (auto& jb : ctl) twcs.push_back(jb.twc);
-        const AirKernelEntry* spec = force_interp ? nullptr : find_air_kernel(air_signature(air, twcs));
+        // the specialised kernels address rows as "workgroup base + lane" and need n >= AIRQ_THREADS (airq.cuh)
+        const AirKernelEntry* spec = (force_interp || n < AIRQ_THREADS) ? nullptr : find_air_kernel(air_signature(air, twcs));
         auto run_interpreter = [&](u64* out) {
             P.out = out;
             const size_t lds = (size_t)air.n_regs * QW * 8;

@@ -65,12 +65,13 @@ def test_twelve_table_all_proof_bytes_match_oracle(be, oracle):
     with miniature fixed tables: AllProof bytes identical to the oracle's and accepted by its verifier."""
     s = T.ola_stark(range_bits=4, limb_bits=2)
     blob = s.blob()
-    traces, params, compress = tracegen.empty_program_instance()
-    got = be.prove_with_traces(blob, traces, params, compress)
-    want = oracle.prove_with_traces(blob, traces, params, compress)
-    assert got == want
-    rc, why = oracle.verify_all_proof(blob, got, params)
-    assert rc == 0, why
+    for log_n in (3, 8):        # 2^3 rows: interpreter kernel (tables below 256 rows); 2^8: the generated kernels
+        traces, params, compress = tracegen.empty_program_instance(log_n=log_n)
+        got = be.prove_with_traces(blob, traces, params, compress)
+        want = oracle.prove_with_traces(blob, traces, params, compress)
+        assert got == want
+        rc, why = oracle.verify_all_proof(blob, got, params)
+        assert rc == 0, why
 
 
 def test_twelve_table_larger_traces_verify(be, oracle):
@@ -168,7 +169,7 @@ def test_specialised_quotient_kernels_match_interpreter_on_random_rows(be, t, mo
     avail = be.air_kernels_available(blob, 12)
     assert avail[t] and not any(avail[:t])
     rng = np.random.default_rng(100 + t)
-    traces = [_random_rows_with_binary_filters(rng, s, i, 32) for i in range(12)]
+    traces = [_random_rows_with_binary_filters(rng, s, i, 512) for i in range(12)]
     params = [int(x) for tab in tabs for x in rng.integers(0, tracegen.P, size=tab.n_params, dtype=np.uint64)] or None
     monkeypatch.setenv("OLA_AIR_KERNELS", "crosscheck")
     try:
@@ -181,7 +182,7 @@ def test_interpreter_and_specialised_kernels_give_the_same_proof(be, monkeypatch
     s = T.ola_stark(range_bits=4, limb_bits=2)
     blob = s.blob()
     assert all(be.air_kernels_available(blob, 12))
-    traces, params, compress = tracegen.empty_program_instance()
+    traces, params, compress = tracegen.empty_program_instance(log_n=9)
     fast = be.prove_with_traces(blob, traces, params, compress)
     monkeypatch.setenv("OLA_AIR_KERNELS", "interpreter")
     assert be.prove_with_traces(blob, traces, params, compress) == fast
