@@ -195,35 +195,33 @@ def table_kernel(airset, t, name, num_challenges=2):
     groups = {}
     for i, twc in enumerate(jobs):
         groups.setdefault(id(twc), (twc, []))[1].append(i)
+    # descriptor slice of CTL job i: [gamma_i, beta_i^0 .. beta_i^(ncol-1)]; the combination sum_k beta^k e_k
+    # (= reduce_with_powers, plonk_common.rs:116-128) is accumulated un-reduced like the constraint sum
+    d_job, off = {}, d_ctl
+    for i, twc in enumerate(jobs):
+        d_job[i] = off
+        off += 1 + len(twc.columns)
     for twc, idxs in groups.values():
         e.add("{")
-        for i in idxs:
-            e.add("  const u64 beta%d = D[%d], gamma%d = D[%d];" % (i, d_ctl + 2 * i, i, d_ctl + 2 * i + 1))
-        ncol = len(twc.columns)
-        for k in range(ncol - 1, -1, -1):
-            e.add("  { const u64 el = %s, en = %s;" % (_lincol(twc.columns[k], "L"), _lincol(twc.columns[k], "N")))
+        e.add("  const u64 el0 = %s, en0 = %s;" % (_lincol(twc.columns[0], "L"), _lincol(twc.columns[0], "N")))   # beta^0 term
+        e.add("  Acc160 " + ", ".join("al%d = {el0, 0, 0}, an%d = {en0, 0, 0}" % (i, i) for i in idxs) + ";")
+        for k, col in enumerate(twc.columns):
+            if k == 0:
+                continue
+            e.add("  { const u64 el = %s, en = %s;" % (_lincol(col, "L"), _lincol(col, "N")))
             for i in idxs:
-                if k == ncol - 1:
-                    e.add("    cl%d = el; cn%d = en;" % (i, i))
-                else:
-                    e.add("    cl%d = gl_add(gl_mul(cl%d, beta%d), el); cn%d = gl_add(gl_mul(cn%d, beta%d), en);" % (i, i, i, i, i, i))
+                e.add("    acc_mad(al%d, el, D[%d]); acc_mad(an%d, en, D[%d]);" % (i, d_job[i] + 1 + k, i, d_job[i] + 1 + k))
             e.add("  }")
-        # declarations have to precede the streaming block
-        decl = "  u64 " + ", ".join("cl%d, cn%d" % (i, i) for i in idxs) + ";"
-        pos = len(e.lines) - 1
-        while "const u64 beta%d" % idxs[-1] not in e.lines[pos]:
-            pos -= 1
-        e.lines.insert(pos + 1, "    " + decl)
         if twc.filter_column is not None:
             e.add("  const u64 fl = %s, fn = %s;" % (_lincol(twc.filter_column, "L"), _lincol(twc.filter_column, "N")))
         for i in idxs:
-            e.add("  cl%d = gl_add(cl%d, gamma%d); cn%d = gl_add(cn%d, gamma%d);" % (i, i, i, i, i, i))
+            e.add("  { u64 cl = gl_add(acc_reduce(al%d), D[%d]), cn = gl_add(acc_reduce(an%d), D[%d]);" % (i, d_job[i], i, d_job[i]))
             if twc.filter_column is not None:   # select(f, x) = f*x + 1 - f
-                e.add("  cl%d = gl_sub(gl_add(gl_mul(fl, cl%d), 1), fl); cn%d = gl_sub(gl_add(gl_mul(fn, cn%d), 1), fn);" % (i, i, i, i))
-            e.add("  { const u64 zl = ZL(%d), zn = ZN(%d);" % (nperm + i, nperm + i))
+                e.add("    cl = gl_sub(gl_add(gl_mul(fl, cl), 1), fl); cn = gl_sub(gl_add(gl_mul(fn, cn), 1), fn);")
+            e.add("    const u64 zl = ZL(%d), zn = ZN(%d);" % (nperm + i, nperm + i))
             e.idx = first_idx + 2 * i
-            e.emit(KIND_FIRST, "gl_sub(zl, cl%d)" % i)
-            e.emit(KIND_TRANSITION, "gl_sub(zn, gl_mul(zl, cn%d))" % i)
+            e.emit(KIND_FIRST, "gl_sub(zl, cl)")
+            e.emit(KIND_TRANSITION, "gl_sub(zn, gl_mul(zl, cn))")
             e.add("  }")
         e.add("}")
         e.add("AIRQ_SEGMENT_BARRIER;")

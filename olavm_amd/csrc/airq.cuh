@@ -21,7 +21,7 @@ struct QuotParams {
 
 // Straight-line kernels printed by olavm_amd/air/codegen.py, one per table signature.  Descriptor D (u64 words):
 //   [0,8) 1/Z_H per coset | [8, 8+2K) alpha weights alpha_c^(K-1-i), challenge-major | params | permutation (beta,gamma)
-//   per batch slot | CTL (beta,gamma) per Z column.
+//   per batch slot | per CTL Z column: gamma, beta^0 .. beta^(ncol-1).
 struct Acc160 { u64 lo, hi; u32 top; };   // sum of < 2^32 products of two u64
 __device__ __forceinline__ void acc_mad(Acc160& a, u64 x, u64 w) {
     u64 plo, phi;
@@ -63,8 +63,9 @@ typedef const u64 __attribute__((address_space(4)))* airq_cptr;
     airq_gptr Z_ = (airq_gptr)P.zs_lde;                                                                                    \
     constexpr int AIRQ_K = (K_);                                                                                           \
     Acc160 accA0 = {0, 0, 0}, accA1 = {0, 0, 0}, accT0 = {0, 0, 0}, accT1 = {0, 0, 0};
-#define LC(c) gl_canon((T_ + ((size_t)(c) * N + jb_))[lane_])
-#define NC(c) gl_canon((T_ + ((size_t)(c) * N + nb_))[noff_])
+// LDE values are canonical (the NTT writes canonical words)
+#define LC(c) (T_ + ((size_t)(c) * N + jb_))[lane_]
+#define NC(c) (T_ + ((size_t)(c) * N + nb_))[noff_]
 #define ZL(c) (Z_ + ((size_t)(c) * N + jb_))[lane_]
 #define ZN(c) (Z_ + ((size_t)(c) * N + nb_))[noff_]
 #define AIRQ_EMIT_ALL(i, v) { const u64 v_ = (v); acc_mad(accA0, v_, D[8 + (i)]); acc_mad(accA1, v_, D[8 + AIRQ_K + (i)]); }

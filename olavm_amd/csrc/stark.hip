@@ -605,7 +605,11 @@ static void prove_single_table(DeviceCtx* ctx, NttTables& tables, const OlaGpuCo
                         const bool live = inst < (int)air.perm_pairs.size() * nch;
                         sd.push_back(live ? (k ? perm_sets[i][inst % nch].gamma : perm_sets[i][inst % nch].beta) : 0);
                     }
-            for (auto& jb : ctl) { sd.push_back(jb.ch.beta); sd.push_back(jb.ch.gamma); }
+            for (auto& jb : ctl) {
+                sd.push_back(jb.ch.gamma);
+                u64 bp = 1;
+                for (size_t k = 0; k < jb.twc->columns.size(); k++) { sd.push_back(bp); bp = gl_mul(bp, jb.ch.beta); }
+            }
             u64* d_sd = mem.alloc(sd.size());
             HIP_CHECK(hipMemcpyAsync(d_sd, sd.data(), sd.size() * 8, hipMemcpyHostToDevice, ctx->stream));
             HIP_CHECK(hipStreamSynchronize(ctx->stream));   // sd is a stack-lifetime staging buffer
