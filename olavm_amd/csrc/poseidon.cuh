@@ -87,9 +87,49 @@ __device__ __forceinline__ void mds_weak(u64 (&s)[12]) {
     }
 }
 
+// Fold al + ah*2^32 (al, ah < 2^63) into a weak u64: ah = ah_lo + ah_hi*2^32, 2^64 = EPS (mod p).
+__device__ __forceinline__ u64 fold_halves(u64 al, u64 ah) {
+    const u64 m = al + (u64)(u32)(ah >> 32) * 0xFFFFFFFFu;   // < 2^63 + 2^63
+    const u32 m_hi = (u32)(m >> 32), a_lo = (u32)ah;
+    const u32 r_hi = m_hi + a_lo;
+    u64 v = ((u64)r_hi << 32) | (u32)m;
+    v += (r_hi < a_lo) ? GL_EPS : 0;                          // wrapped once at most (see derive_fused3)
+    return v;
+}
+
+// Three partial rounds as one small-integer linear layer (tools/gen_poseidon_tables.py derive_fused3): 386 multiply-adds
+// instead of 3 x 288, one fold per lane instead of three.
+__device__ __forceinline__ void partial3_weak(u64 (&s)[12], u64 k0, u64 k1, u64 k2) {
+    constexpr u32 R1[12] = OLA_POSEIDON_FUSED3_R1_INIT;
+    constexpr u32 R2[13] = OLA_POSEIDON_FUSED3_R2_INIT;
+    constexpr u32 F[168] = OLA_POSEIDON_FUSED3_F_INIT;
+    u32 l[14], h[14];   // halves of s[1..11], then t0, t1, t2
+#pragma unroll
+    for (int i = 0; i < 11; i++) { l[i] = (u32)s[i + 1]; h[i] = (u32)(s[i + 1] >> 32); }
+    const u64 t0 = sbox7_weak(add_weak(s[0], k0));
+    l[11] = (u32)t0; h[11] = (u32)(t0 >> 32);
+    u64 al = 0, ah = 0;
+#pragma unroll
+    for (int i = 0; i < 12; i++) { al += (u64)l[i] * R1[i]; ah += (u64)h[i] * R1[i]; }
+    const u64 t1 = sbox7_weak(add_weak(fold_halves(al, ah), k1));
+    l[12] = (u32)t1; h[12] = (u32)(t1 >> 32);
+    al = 0; ah = 0;
+#pragma unroll
+    for (int i = 0; i < 13; i++) { al += (u64)l[i] * R2[i]; ah += (u64)h[i] * R2[i]; }
+    const u64 t2 = sbox7_weak(add_weak(fold_halves(al, ah), k2));
+    l[13] = (u32)t2; h[13] = (u32)(t2 >> 32);
+#pragma unroll
+    for (int o = 0; o < 12; o++) {
+        al = 0; ah = 0;
+#pragma unroll
+        for (int i = 0; i < 14; i++) { al += (u64)l[i] * F[14 * o + i]; ah += (u64)h[i] * F[14 * o + i]; }
+        s[o] = fold_halves(al, ah);
+    }
+}
+
 // Same function as the reference's Poseidon::poseidon (poseidon.rs:593-603).  The partial rounds are the reference's
-// dense form (constant layer, x^7 on lane 0, MDS layer; partial_rounds_naive) with the constants pushed onto lane 0 by
-// tools/gen_poseidon_tables.py derive_lane0; output is canonical.
+// dense form (constant layer, x^7 on lane 0, MDS layer; partial_rounds_naive) with the constants pushed onto lane 0
+// (tools/gen_poseidon_tables.py derive_lane0) and fused three at a time (derive_fused3); output is canonical.
 __device__ __forceinline__ void poseidon_permute(u64 (&s)[12]) {
 #pragma unroll 1
     for (int r = 0; r < 4; r++) {
@@ -97,11 +137,11 @@ __device__ __forceinline__ void poseidon_permute(u64 (&s)[12]) {
         for (int i = 0; i < 12; i++) s[i] = sbox7_weak(add_weak(s[i], c_rc[r * 12 + i]));
         mds_weak(s);
     }
+    // 22 partial rounds = 7 fused triples + 1 plain round
 #pragma unroll 1
-    for (int r = 0; r < 22; r++) {
-        s[0] = sbox7_weak(add_weak(s[0], c_lane0[r]));
-        mds_weak(s);
-    }
+    for (int g = 0; g < 7; g++) partial3_weak(s, c_lane0[3 * g], c_lane0[3 * g + 1], c_lane0[3 * g + 2]);
+    s[0] = sbox7_weak(add_weak(s[0], c_lane0[21]));
+    mds_weak(s);
 #pragma unroll 1
     for (int r = 26; r < 30; r++) {
 #pragma unroll

@@ -132,6 +132,56 @@ def derive_lane0(rc, M):
     return lane0, tail_rc
 
 
+def derive_fused3(M):
+    """Three consecutive partial rounds as ONE small-integer linear layer.  With Mt = M with column 0 zeroed and m0 =
+    column 0 of M, a partial round is  s <- Mt*s + m0*t  (t = (s0 + k)^7), hence
+        s1_0 = row0(Mt).s + m0[0] t0
+        s2_0 = row0(Mt^2).s + (Mt m0)[0] t0 + m0[0] t1
+        s3   = Mt^3 s + (Mt^2 m0) t0 + (Mt m0) t1 + m0 t2
+    over the integers; every coefficient stays below 2^27, so the 32-bit halves of the state can still be accumulated
+    un-reduced in 64 bits (14 terms < 2^63)."""
+    Mt = [[0 if c == 0 else M[r][c] for c in range(W)] for r in range(W)]
+    m0 = [M[r][0] for r in range(W)]
+    imul = lambda A, B: [[sum(A[i][k] * B[k][j] for k in range(W)) for j in range(W)] for i in range(W)]
+    ivec = lambda A, v: [sum(A[i][k] * v[k] for k in range(W)) for i in range(W)]
+    Mt2 = imul(Mt, Mt)
+    Mt3 = imul(Mt2, Mt)
+    v1, v2 = ivec(Mt, m0), ivec(Mt2, m0)
+    tabs = {
+        "R1": Mt[0][1:] + [m0[0]],                       # 11 state coefficients, then t0
+        "R2": Mt2[0][1:] + [v1[0], m0[0]],               # 11 state coefficients, then t0, t1
+        "F": [x for r in range(W) for x in (Mt3[r][1:] + [v2[r], v1[r], m0[r]])],   # per output lane: 11 + t0,t1,t2
+    }
+    assert max(max(v) for v in tabs.values()) < 2**27
+    return tabs
+
+
+def perm_fused3(x, rc, M, lane0, tail_rc, tabs):
+    x = list(x)
+    r = 0
+    for _ in range(4):
+        x = mat_vec(M, [sbox((a + rc[r * W + i]) % P) for i, a in enumerate(x)]); r += 1
+    i = 0
+    while i + 3 <= N_PART - 1:
+        s = x[1:]
+        t0 = sbox((x[0] + lane0[i]) % P)
+        s1 = (sum(a * b for a, b in zip(tabs["R1"], s + [t0]))) % P
+        t1 = sbox((s1 + lane0[i + 1]) % P)
+        s2 = (sum(a * b for a, b in zip(tabs["R2"], s + [t0, t1]))) % P
+        t2 = sbox((s2 + lane0[i + 2]) % P)
+        x = [sum(a * b for a, b in zip(tabs["F"][14 * o:14 * o + 14], s + [t0, t1, t2])) % P for o in range(W)]
+        i += 3
+    while i < N_PART:
+        x[0] = sbox((x[0] + lane0[i]) % P)
+        x = mat_vec(M, x)
+        i += 1
+    r += N_PART
+    for j in range(4):
+        cs = tail_rc if j == 0 else rc[r * W:(r + 1) * W]
+        x = mat_vec(M, [sbox((a + cs[i]) % P) for i, a in enumerate(x)]); r += 1
+    return x
+
+
 def perm_lane0(x, rc, M, lane0, tail_rc):
     x = list(x)
     r = 0
@@ -204,6 +254,9 @@ def main():
     lane0, tail_rc = derive_lane0(rc, M)
     for kat in kats:
         assert perm_lane0(kat["input"], rc, M, lane0, tail_rc) == kat["output"], "lane-0 permutation fails KAT"
+    tabs = derive_fused3(M)
+    for kat in kats:
+        assert perm_fused3(kat["input"], rc, M, lane0, tail_rc, tabs) == kat["output"], "fused partial rounds fail KAT"
     first_c, post, vhat, wcol, init = fast
     h = ["// GENERATED by tools/gen_poseidon_tables.py -- do not edit.",
          "// Poseidon-Goldilocks (width 12, x^7, 8 full + 22 partial rounds) parameter tables.",
@@ -224,7 +277,16 @@ def main():
          "// dense partial rounds with the constants pushed onto lane 0 (see derive_lane0): per-round lane-0 constant, and",
          "// the constants of full round 26 with the accumulated offset folded in",
          c_array("OLA_POSEIDON_LANE0_C", lane0), "",
-         c_array("OLA_POSEIDON_ROUND26_C", tail_rc), ""]
+         c_array("OLA_POSEIDON_ROUND26_C", tail_rc), "",
+         "// three partial rounds fused into one small-integer linear layer (see derive_fused3); coefficients < 2^27",
+         "// (initialiser lists as macros: the device code declares them as local constexpr arrays so that the unrolled",
+         "// multiply-adds take them as immediates)",
+         "#define OLA_POSEIDON_FUSED3_R1_INIT {" + ", ".join(map(str, tabs["R1"])) + "}",
+         "#define OLA_POSEIDON_FUSED3_R2_INIT {" + ", ".join(map(str, tabs["R2"])) + "}",
+         "#define OLA_POSEIDON_FUSED3_F_INIT {" + ", ".join(map(str, tabs["F"])) + "}",
+         "static const uint32_t OLA_POSEIDON_FUSED3_R1[12] = OLA_POSEIDON_FUSED3_R1_INIT;",
+         "static const uint32_t OLA_POSEIDON_FUSED3_R2[13] = OLA_POSEIDON_FUSED3_R2_INIT;",
+         "static const uint32_t OLA_POSEIDON_FUSED3_F[168] = OLA_POSEIDON_FUSED3_F_INIT;", ""]
     os.makedirs(os.path.join(ROOT, "include"), exist_ok=True)
     open(os.path.join(ROOT, "include", "ola_poseidon_constants.h"), "w").write("\n".join(h))
     os.makedirs(os.path.join(ROOT, "tests", "golden"), exist_ok=True)
