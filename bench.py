@@ -54,6 +54,20 @@ def cpu_baseline(log_n, seconds_budget=20.0):
             "sample": f"{cols} columns x 2^{log_n} forward NTT (oracle evaluate_poly, OpenMP over columns) in {dt:.2f}s"}
 
 
+def pmc_traffic(log_n, cols):
+    """HBM bytes per launch of the NTT pass kernel from the committed rocprofv3 PMC summary (tools/pmc.sh; FETCH_SIZE with the
+    gfx950 x2 correction + WRITE_SIZE, separate passes).  bench.py cannot run the profiler on itself, so this is the
+    figure of the last profiled run of the same shape, or None."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r01_ntt_pmc.json")))
+        if (log_n, cols) != (22, 94):
+            return None, None
+        p = d["ntt_94x2^22_per_pass"]
+        return (p["fetch_kib_corrected"] + p["write_kib"]) * 1024.0, "profiles/r01_ntt_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
+    except (OSError, KeyError, ValueError):
+        return None, None
+
+
 def prove_time(be, log_n, reps=3):
     """Second half of BASELINE.json's metric: wall-clock of the whole multi-table proof (ola_prove_with_traces, host
     traces in, AllProof bytes out -- so H2D of the traces is inside the timed region) for the 12-table OlaStark with a
@@ -139,6 +153,7 @@ def main():
         passes = 1 if args.log_n <= 13 else (2 if args.log_n <= 18 else 3)
         launch_ms = dev_ms / args.steps / passes
         achieved = bytes_per_step / passes / (launch_ms * 1e-3) / 1e9
+        traffic, traffic_src = pmc_traffic(args.log_n, cols)
         res = {
             "metric": "goldilocks_ntt_throughput", "value": round(value, 2), "unit": "GB/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
@@ -147,9 +162,13 @@ def main():
                                    f"{cols} columns x 2^{args.log_n} rows per GPU, inputs resident in HBM",
                        "log_n": args.log_n, "columns_per_gpu": cols, "parallelism": f"columns sharded over {world} GPU(s), no collective"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
-                         "kernel": "ntt_pass_kernel", "launches_per_step": passes,
-                         "avg_launch_ms": round(launch_ms, 4)},
+                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                         "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
+                         "algorithmic_bytes_per_launch": bytes_per_step / passes,
+                         "kernel": "ntt2_pass_kernel", "launches_per_step": passes,
+                         "avg_launch_ms": round(launch_ms, 4),
+                         "note": "every pass streams the whole batch once (traffic = 3 x algorithmic per launch); the kernel is "
+                                 "VALU-issue bound (64-bit modular arithmetic on the 32-bit integer pipe), see DESIGN.md"},
         }
         if world == 1 and not args.no_prove:
             del data, out, scratch
