@@ -110,6 +110,17 @@ int32_t ola_commit_values_dev(OlaCtx* ctx, const uint64_t* cols_dev, uint32_t nc
                               OlaBatch** out_batch, uint64_t* cap_out);
 int32_t ola_commit_coeffs_dev(OlaCtx* ctx, const uint64_t* cols_dev, uint32_t ncols, uint32_t log_n,
                               OlaBatch** out_batch, uint64_t* cap_out);
+/* One GPU's share of PolynomialBatch::from_values under the coset partition: with rate_bits = 3 the LDE is 8
+ * independent cosets that are also contiguous blocks of n commitment leaves.  Shard `rank` of `world`
+ * (1, 2, 4 or 8) interpolates all columns (replicated), extends them onto cosets [rank*8/world, (rank+1)*8/world), hashes
+ * those leaves and builds their sub-trees; cap_slice_out receives entries [rank*16/world, (rank+1)*16/world) of the
+ * commitment's Merkle cap (2^cap_height/world digests).  Concatenating the slices of all ranks in rank order -- one
+ * all-gather of 512/world bytes -- gives exactly the cap ola_commit_values returns.  The batch answers
+ * ola_batch_get_leaf for local leaf indices (global index - rank*N/world) with paths up to its own cap slice. */
+int32_t ola_commit_values_shard(OlaCtx* ctx, const uint64_t* const* cols, uint32_t ncols, uint32_t log_n, uint32_t rank,
+                                uint32_t world, OlaBatch** out_batch, uint64_t* cap_slice_out);
+int32_t ola_commit_values_shard_dev(OlaCtx* ctx, const uint64_t* cols_dev, uint32_t ncols, uint32_t log_n, uint32_t rank,
+                                    uint32_t world, OlaBatch** out_batch, uint64_t* cap_slice_out);
 int32_t ola_batch_free(OlaCtx* ctx, OlaBatch* batch);
 /* accessors (PolynomialBatch.polynomials, MerkleTree::get / prove, merkle_tree/mod.rs:268-308) */
 int32_t ola_batch_shape(const OlaBatch* batch, uint32_t* ncols, uint32_t* log_n, uint32_t* rate_bits);

@@ -82,6 +82,10 @@ def load_library():
                                      C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
     L.ola_prove_with_traces.argtypes = [C.c_void_p, U64P, C.c_size_t, C.POINTER(U64P), C.POINTER(C.c_uint32), U64P, U64P,
                                         C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.ola_commit_values_shard.argtypes = [C.c_void_p, C.POINTER(U64P), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                          C.POINTER(C.c_void_p), U64P]
+    L.ola_commit_values_shard_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                              C.POINTER(C.c_void_p), U64P]
     L.ola_air_kernels_available.argtypes = [U64P, C.c_size_t, C.POINTER(C.c_uint8), C.c_size_t]
     _lib = L
     return L
@@ -93,7 +97,7 @@ EXPORTS = [
     "ola_commit_values_dev", "ola_commit_coeffs_dev", "ola_batch_free", "ola_batch_shape", "ola_batch_get_coeffs",
     "ola_batch_get_leaf", "ola_batch_get_lde_row", "ola_challenger_init", "ola_challenger_observe",
     "ola_challenger_get", "ola_challenger_compact", "ola_open_and_prove", "ola_pow", "ola_prove_with_traces",
-    "ola_air_kernels_available",
+    "ola_air_kernels_available", "ola_commit_values_shard", "ola_commit_values_shard_dev",
 ]
 
 
@@ -133,8 +137,8 @@ class Challenger:
 class Batch:
     """A committed PolynomialBatch resident in HBM (fri/oracle.rs:31-39)."""
 
-    def __init__(self, be, handle, cap):
-        self.be, self.h, self._cap = be, handle, cap
+    def __init__(self, be, handle, cap, shard_log_world=0):
+        self.be, self.h, self._cap, self.shard_log_world = be, handle, cap, shard_log_world
         a, b, c = C.c_uint32(), C.c_uint32(), C.c_uint32()
         be._chk(be.lib.ola_batch_shape(handle, C.byref(a), C.byref(b), C.byref(c)))
         self.ncols, self.log_n, self.rate_bits = a.value, b.value, c.value
@@ -148,7 +152,7 @@ class Batch:
         return out
 
     def leaf(self, index):
-        depth = self.log_n + self.rate_bits - self.be.cap_height
+        depth = self.log_n + self.rate_bits + self.shard_log_world - self.be.cap_height   # rate_bits is the local one
         row = np.empty(self.ncols, dtype=np.uint64)
         sib = np.empty((max(depth, 0), 4), dtype=np.uint64)
         self.be._chk(self.be.lib.ola_batch_get_leaf(self.be.ctx, self.h, index, _p(row), _p(sib) if depth > 0 else None))
@@ -252,6 +256,22 @@ class Backend:
         f = self.lib.ola_commit_coeffs_dev if from_coeffs else self.lib.ola_commit_values_dev
         self._chk(f(self.ctx, dev_ptr, ncols, log_n, C.byref(h), _p(cap)))
         return Batch(self, h, cap)
+
+    def commit_shard(self, cols, rank, world, dev_ptr=None, ncols=None, log_n=None):
+        """This GPU's share of a commitment under the coset partition (ola_commit_values_shard): -> Batch whose cap() is
+        the slice [rank*16/world, (rank+1)*16/world) of the full Merkle cap.  Pass `cols` (host array) or dev_ptr/ncols/
+        log_n (device-resident column-major values)."""
+        lw = int(world).bit_length() - 1
+        h = C.c_void_p()
+        cap = np.empty(((1 << self.cap_height) >> lw, 4), dtype=np.uint64)
+        if dev_ptr is not None:
+            self._chk(self.lib.ola_commit_values_shard_dev(self.ctx, dev_ptr, ncols, log_n, rank, world, C.byref(h), _p(cap)))
+        else:
+            cols = np.ascontiguousarray(cols, dtype=np.uint64)
+            ncols, n = cols.shape
+            ptrs = (U64P * ncols)(*[cols[i].ctypes.data_as(U64P) for i in range(ncols)])
+            self._chk(self.lib.ola_commit_values_shard(self.ctx, ptrs, ncols, int(n).bit_length() - 1, rank, world, C.byref(h), _p(cap)))
+        return Batch(self, h, cap, shard_log_world=lw)
 
     def prove_with_traces(self, airset_blob, traces, params=None, compress=None):
         """AllProof bytes for the multi-table STARK described by `airset_blob` (olavm_amd.air.AirSet.blob())."""

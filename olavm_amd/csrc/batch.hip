@@ -12,8 +12,13 @@
 #include "device_ctx.h"
 #include "gl.cuh"
 
+// A batch may be one GPU's SHARE of a commitment (coset partition): leaf blocks (cosets)
+// [coset_first, coset_first + 2^rate_bits) of a 2^full_rate_bits-coset LDE.  `rate_bits` and `cap_height` then describe the
+// local tree (full values minus log2 of the number of shards), whose cap is this shard's contiguous slice of the full cap.
 struct OlaBatch {
     uint32_t ncols = 0, log_n = 0, rate_bits = 0, cap_height = 0;
+    uint32_t full_rate_bits = 0, coset_first = 0;
+    bool is_shard() const { return rate_bits != full_rate_bits; }
     ola::u64* coeffs = nullptr;  // [ncols][n], natural coefficient order
     ola::u64* lde = nullptr;     // [ncols][N], leaf order
     ola::u64* heap = nullptr;    // 2N digests of 4 u64, heap[N + j] = leaf j, root at 1
@@ -88,9 +93,17 @@ void batch_destroy(DeviceCtx* ctx, OlaBatch* b) {
 }
 
 OlaBatch* batch_commit(DeviceCtx* ctx, NttTables& t, const uint64_t* const* cols_host, const u64* cols_dev, uint32_t ncols,
-                       uint32_t log_n, uint32_t rate_bits, uint32_t cap_height, bool from_values) {
+                       uint32_t log_n, uint32_t rate_bits, uint32_t cap_height, bool from_values, uint32_t shard_rank = 0,
+                       uint32_t shard_log_world = 0) {
+    if (shard_log_world > rate_bits || shard_log_world > cap_height || shard_rank >= (1u << shard_log_world))
+        throw OlaError(-1, "shard count must divide both the number of cosets and the cap");
     OlaBatch* b = new OlaBatch();
-    b->ncols = ncols; b->log_n = log_n; b->rate_bits = rate_bits; b->cap_height = cap_height;
+    b->ncols = ncols; b->log_n = log_n; b->full_rate_bits = rate_bits;
+    const uint32_t full_rate_bits = rate_bits;
+    rate_bits -= shard_log_world;          // from here on: the local tree
+    cap_height -= shard_log_world;
+    b->rate_bits = rate_bits; b->cap_height = cap_height;
+    b->coset_first = shard_rank << rate_bits;
     const size_t n = b->n(), N = b->num_leaves();
     u64* tmp = nullptr;
     try {
@@ -122,7 +135,7 @@ OlaBatch* batch_commit(DeviceCtx* ctx, NttTables& t, const uint64_t* const* cols
             }
             canonicalize(ctx, b->coeffs, (size_t)ncols * n);
         }
-        ntt_lde_leaf_order(t, b->coeffs, b->lde, log_n, rate_bits, ncols);
+        ntt_lde_leaf_order(t, b->coeffs, b->lde, log_n, full_rate_bits, ncols, b->coset_first, (size_t)1 << rate_bits);
         launch_leaf_hash_colmajor(ctx, b->lde, N, (int)ncols, N, b->heap + 4 * N);
         launch_merkle_build(ctx, b->heap, N, cap_height);
         HIP_CHECK(hipStreamSynchronize(ctx->stream));

@@ -447,7 +447,7 @@ void ntt_run(NttTables& t, const u64* in, size_t in_col_stride, u64* out, size_t
 // Transforms of 2^14 points and more run on the second-generation passes (ntt2.hip); smaller ones fit one tile here.
 void ntt2_run(NttTables& t, const u64* in, size_t in_col_stride, u64* out, size_t out_col_stride, u64* scratch,
               size_t scratch_col_stride, int L, size_t cols, bool inverse, bool natural_out, int sc_rate_bits, u64 sc_shift,
-              size_t cosets, size_t out_coset_stride);
+              size_t cosets, size_t out_coset_stride, size_t coset_first = 0);
 static const int NTT2_MIN_LOG = 14;
 
 // values (natural) -> coefficients (natural), per column.  scratch must hold cols * 2^L elements when L > 13.
@@ -464,15 +464,22 @@ void ntt_evaluate(NttTables& t, const u64* coeffs, u64* values, u64* scratch, in
 }
 // coefficients (natural, n per column) -> LDE on 7*<g>, in commitment leaf order: out[col][c*n + r] =
 // P(7 * g^bitrev(c) * w_n^bitrev_n(r)); equals natural LDE row bitrev_N(c*n + r).
-void ntt_lde_leaf_order(NttTables& t, const u64* coeffs, u64* lde, int L, int rate_bits, size_t cols) {
+void ntt_lde_leaf_order(NttTables& t, const u64* coeffs, u64* lde, int L, int rate_bits, size_t cols, size_t coset_first,
+                        size_t coset_count) {
+    // cosets [coset_first, coset_first + coset_count) of the 2^rate_bits (leaf-order blocks of n); lde holds only those
     const size_t n = (size_t)1 << L;
     if (L >= NTT2_MIN_LOG) {
-        ntt2_run(t, coeffs, n, lde, n << rate_bits, nullptr, 0, L, cols, false, false, rate_bits, 0, (size_t)1 << rate_bits, n);
+        ntt2_run(t, coeffs, n, lde, n * coset_count, nullptr, 0, L, cols, false, false, rate_bits, 0, coset_count, n, coset_first);
         return;
     }
     size_t stride = 0;
     TwoLevel sc = get_coset(t, L, rate_bits, &stride);
-    ntt_run(t, coeffs, n, lde, n << rate_bits, nullptr, 0, L, cols, false, false, &sc, stride, (size_t)1 << rate_bits, n, 1);
+    sc.lo += coset_first * stride;
+    sc.hi += coset_first * stride;
+    ntt_run(t, coeffs, n, lde, n * coset_count, nullptr, 0, L, cols, false, false, &sc, stride, coset_count, n, 1);
+}
+void ntt_lde_leaf_order(NttTables& t, const u64* coeffs, u64* lde, int L, int rate_bits, size_t cols) {
+    ntt_lde_leaf_order(t, coeffs, lde, L, rate_bits, cols, 0, (size_t)1 << rate_bits);
 }
 // coefficients -> values on shift*<w_n> in natural order (coset_fft with blowup 1), or bit-reversed order
 void ntt_coset_evaluate(NttTables& t, const u64* coeffs, u64* values, u64* scratch, int L, size_t cols, u64 shift,

@@ -288,10 +288,11 @@ struct Ntt2StepCacheKey {
 static std::map<std::pair<NttTables*, Ntt2StepCacheKey>, const u64*> g_step_cache;
 
 // Same contract as ntt_run (ntt.hip) for L >= 14.  prescale: rate_bits >= 0 selects the LDE coset family
-// (7*g^bitrev(c)), rate_bits = -1 with `shift` a single coset, -2 none.
+// (7*g^bitrev(c)) of which cosets [coset_first, coset_first + cosets) are produced, rate_bits = -1 with `shift` a single
+// coset, -2 none.
 void ntt2_run(NttTables& t, const u64* in, size_t in_col_stride, u64* out, size_t out_col_stride, u64* scratch,
               size_t scratch_col_stride, int L, size_t cols, bool inverse, bool natural_out, int sc_rate_bits, u64 sc_shift,
-              size_t cosets, size_t out_coset_stride) {
+              size_t cosets, size_t out_coset_stride, size_t coset_first) {
     if (cols == 0) return;
     hipStream_t stream = t.ctx->stream;
     const int P = (L + 7) / 8;
@@ -324,12 +325,13 @@ void ntt2_run(NttTables& t, const u64* in, size_t in_col_stride, u64* out, size_
                 size_t stride = 0;
                 if (sc_rate_bits >= 0) sc = get_coset(t, L, sc_rate_bits, &stride);
                 else sc = get_shift(t, L, sc_shift);
-                p.sc_lo = sc.lo; p.sc_hi = sc.hi; p.sc_h = sc.h; p.sc_coset_stride = stride;
+                // a coset sub-range (one GPU's share of the LDE) starts `coset_first` entries into the per-coset tables
+                p.sc_lo = sc.lo + coset_first * stride; p.sc_hi = sc.hi + coset_first * stride; p.sc_h = sc.h; p.sc_coset_stride = stride;
                 Ntt2StepCacheKey key{L, sc_rate_bits, lo + R - 4, sc_rate_bits >= 0 ? 0 : sc_shift};
                 auto ck = std::make_pair(&t, key);
                 auto it = g_step_cache.find(ck);
                 if (it == g_step_cache.end()) it = g_step_cache.emplace(ck, get_coset_steps(t, L, sc_rate_bits, lo + R - 4, sc_shift)).first;
-                p.sc_step = it->second;
+                p.sc_step = it->second + coset_first;
             }
             ntt2_dispatch(R, N2_STRIDED, inverse, p, cols, cosets, stream);
             cur_in = work; cur_in_stride = work_col_stride; cur_in_coset = work_coset_stride;

@@ -227,14 +227,18 @@ int32_t ola_pow(OlaCtx* ctx, const uint64_t h[4], uint32_t bits, uint64_t* witne
 
 // ------------------------------------------------------------------------------------------------ commitment
 static int32_t commit_common(OlaCtx* ctx, const uint64_t* const* cols_host, const uint64_t* cols_dev, uint32_t ncols,
-                             uint32_t log_n, bool from_values, OlaBatch** out_batch, uint64_t* cap_out) {
+                             uint32_t log_n, bool from_values, OlaBatch** out_batch, uint64_t* cap_out, uint32_t shard_rank = 0,
+                             uint32_t shard_world = 1) {
     OLA_TRY
+    require(shard_world >= 1 && (shard_world & (shard_world - 1)) == 0 && shard_rank < shard_world, "shard rank / world");
+    uint32_t log_world = 0;
+    while ((1u << log_world) < shard_world) log_world++;
     require(ctx && out_batch && cap_out && (cols_host || cols_dev), "null pointer");
     require(ncols >= 1, "ncols");
     require(log_n + ctx->cfg.rate_bits <= 32, "log_n too large");
     require(log_n + ctx->cfg.rate_bits >= ctx->cfg.cap_height, "cap height should be at most log2(leaves.len())");
     std::unique_ptr<OlaBatch> b(batch_commit(&ctx->dev, *ctx->tables, cols_host, (const u64*)cols_dev, ncols, log_n,
-                                             ctx->cfg.rate_bits, ctx->cfg.cap_height, from_values));
+                                             ctx->cfg.rate_bits, ctx->cfg.cap_height, from_values, shard_rank, log_world));
     batch_read_cap(&ctx->dev, *b, (u64*)cap_out);
     *out_batch = b.release();
     OLA_CATCH
@@ -250,6 +254,14 @@ int32_t ola_commit_values_dev(OlaCtx* ctx, const uint64_t* cols_dev, uint32_t nc
 }
 int32_t ola_commit_coeffs_dev(OlaCtx* ctx, const uint64_t* cols_dev, uint32_t ncols, uint32_t log_n, OlaBatch** ob, uint64_t* cap) {
     return commit_common(ctx, nullptr, cols_dev, ncols, log_n, false, ob, cap);
+}
+int32_t ola_commit_values_shard(OlaCtx* ctx, const uint64_t* const* cols, uint32_t ncols, uint32_t log_n, uint32_t rank,
+                                uint32_t world, OlaBatch** ob, uint64_t* cap_slice) {
+    return commit_common(ctx, cols, nullptr, ncols, log_n, true, ob, cap_slice, rank, world);
+}
+int32_t ola_commit_values_shard_dev(OlaCtx* ctx, const uint64_t* cols_dev, uint32_t ncols, uint32_t log_n, uint32_t rank,
+                                    uint32_t world, OlaBatch** ob, uint64_t* cap_slice) {
+    return commit_common(ctx, nullptr, cols_dev, ncols, log_n, true, ob, cap_slice, rank, world);
 }
 int32_t ola_batch_free(OlaCtx* ctx, OlaBatch* batch) {
     OLA_TRY
@@ -279,9 +291,14 @@ int32_t ola_batch_get_leaf(OlaCtx* ctx, const OlaBatch* b, size_t leaf_index, ui
     batch_get_leaf(&ctx->dev, *b, leaf_index, (u64*)row_out, (u64*)siblings_out);
     OLA_CATCH
 }
+static void require_full(const OlaBatch* b) {
+    if (b && b->is_shard()) throw OlaError(OLA_E_INVALID_ARG, "this entry point needs a complete commitment, not one GPU's coset share");
+}
+
 int32_t ola_batch_get_lde_row(OlaCtx* ctx, const OlaBatch* b, size_t index, size_t step, uint64_t* row_out) {
     OLA_TRY
     require(ctx && b && row_out, "null pointer");
+    require_full(b);   // natural-order LDE rows interleave the cosets of all shards
     const size_t nat = index * step;
     require(nat < b->num_leaves(), "row index out of range");
     batch_get_leaf(&ctx->dev, *b, bitrev32((u32)nat, b->log_n + b->rate_bits), (u64*)row_out, nullptr);
@@ -319,6 +336,7 @@ int32_t ola_open_and_prove(OlaCtx* ctx, const OlaBatch* trace, const OlaBatch* z
                            size_t* out_len, size_t* openings_len) {
     OLA_TRY
     require(ctx && trace && zs && quotient && challenger && out_len, "null pointer");
+    require_full(trace); require_full(zs); require_full(quotient);
     require(trace->log_n == zs->log_n && trace->log_n == quotient->log_n, "degree mismatch between commitments");
     require(num_permutation_zs <= zs->ncols, "num_permutation_zs");
     OlaChallenger ch = *challenger;  // only committed on success

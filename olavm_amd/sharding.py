@@ -13,9 +13,28 @@ def shard_range(total, rank, world):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
-def coset_owner(coset, world):
-    """LDE coset -> rank for world in {1,2,4,8} with rate_bits = 3 (8 cosets): coset c lives on rank c mod world."""
-    return coset % world
+def coset_range(rank, world, rate_bits=3):
+    """Leaf-order cosets (blocks of n commitment leaves) owned by `rank`: a contiguous run, so that the rank's Merkle
+    sub-trees are a contiguous slice of the cap (ola_commit_values_shard)."""
+    per = (1 << rate_bits) // world
+    assert per * world == (1 << rate_bits), "world must divide the number of cosets"
+    return rank * per, (rank + 1) * per
+
+
+def coset_owner(coset, world, rate_bits=3):
+    """LDE coset (leaf-order block) -> owning rank for world in {1,2,4,8}."""
+    return coset * world >> rate_bits
+
+
+def commit_sharded(be, rank, world, cols=None, dev_ptr=None, ncols=None, log_n=None, device="cpu"):
+    """PolynomialBatch::from_values across `world` GPUs: this rank commits its cosets (Backend.commit_shard), the cap
+    slices are all-gathered (the only collective of the commitment: 512 bytes in total) and concatenated in rank order.
+    -> (local Batch, full cap as a (16, 4) uint64 array, identical on every rank and to the single-GPU commitment)."""
+    import numpy as np
+    b = be.commit_shard(cols, rank, world, dev_ptr=dev_ptr, ncols=ncols, log_n=log_n)
+    parts = all_gather_caps(b.cap().view(np.int64), device=device)
+    cap = np.concatenate([p.cpu().numpy().view(np.uint64) for p in parts])
+    return b, cap
 
 
 def max_over_ranks(values, device="cpu"):

@@ -56,7 +56,8 @@ def test_two_rank_gloo_plumbing():
         for e in rank_slice:
             full[e[0]] = e[1]
     assert sorted(full) == list(range(16))                    # all 16 cap entries present exactly once
-    assert all(full[i] == (i // 2) % 2 for i in range(16))    # entry 2c,2c+1 came from the owner of coset c
+    assert all(full[i] == (i // 2) * 2 // 8 for i in range(16))   # entries 2c, 2c+1 came from the owner of coset c
+    assert [e[0] for rank_slice in g0 for e in rank_slice] == list(range(16))   # rank-ordered concatenation IS the cap
 
 
 def test_partition_and_aggregate():

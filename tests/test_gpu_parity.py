@@ -228,3 +228,42 @@ def test_open_and_prove_large_verifies(be, oracle):
     caps = np.stack([gt.cap(), gz.cap(), gq.cap()])
     rc, why = oracle.verify_opening(caps, cols, log_n, nperm, g_open + g_fri, och)
     assert rc == 0, why
+
+
+# ------------------------------------------------------------------------------------------------ coset-sharded commitment
+@pytest.mark.parametrize("log_n,ncols", [(6, 5), (10, 9), (15, 3)])
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_coset_sharded_commit_reassembles_the_full_commitment(be, log_n, ncols, world):
+    """every rank commits its own leaf blocks (cosets); the rank-ordered concatenation of the cap slices is the
+    cap of the unsharded commitment, and every leaf row / Merkle path agrees with the unsharded tree (all ranks are run
+    one after the other on the single test GPU)."""
+    rng = np.random.default_rng(log_n * 10 + world)
+    vals = rand_field(rng, (ncols, 1 << log_n))
+    full = be.commit(vals)
+    N = 8 << log_n
+    slices = []
+    for rank in range(world):
+        sh = be.commit_shard(vals, rank, world)
+        assert sh.rate_bits == 3 - (world.bit_length() - 1)
+        slices.append(sh.cap())
+        assert np.array_equal(sh.coeffs(), full.coeffs())
+        for local in (0, 1, N // world - 1, int(rng.integers(0, N // world))):
+            row, sib = sh.leaf(local)
+            frow, fsib = full.leaf(rank * (N // world) + local)
+            assert np.array_equal(row, frow) and np.array_equal(sib, fsib)
+        sh.free()
+    assert np.array_equal(np.concatenate(slices), full.cap())
+    full.free()
+
+
+def test_shard_batches_are_refused_where_a_full_commitment_is_needed(be):
+    from olavm_amd.backend import OlaGpuError
+    vals = rand_field(np.random.default_rng(1), (2, 64))
+    sh = be.commit_shard(vals, 1, 2)
+    with pytest.raises(OlaGpuError, match="complete commitment"):
+        sh.lde_row(3)
+    sh.free()
+    with pytest.raises(OlaGpuError):
+        be.commit_shard(vals, 2, 2)
+    with pytest.raises(OlaGpuError):
+        be.commit_shard(vals, 0, 3)
