@@ -66,7 +66,7 @@ def test_twelve_table_all_proof_bytes_match_oracle(be, oracle):
     s = T.ola_stark(range_bits=4, limb_bits=2)
     blob = s.blob()
     for log_n in (3, 8):        # 2^3 rows: interpreter kernel (tables below 256 rows); 2^8: the generated kernels
-        traces, params, compress = tracegen.empty_program_instance(log_n=log_n)
+        traces, params, compress = tracegen.empty_program_instance(log_n=log_n, live=np.random.default_rng(log_n))
         got = be.prove_with_traces(blob, traces, params, compress)
         want = oracle.prove_with_traces(blob, traces, params, compress)
         assert got == want
@@ -79,7 +79,7 @@ def test_twelve_table_larger_traces_verify(be, oracle):
     verifier accepts the GPU proof."""
     s = T.ola_stark(range_bits=8, limb_bits=8)
     blob = s.blob()
-    traces, params, compress = tracegen.empty_program_instance(log_n=10, range_bits=8, limb_bits=8)
+    traces, params, compress = tracegen.empty_program_instance(log_n=10, range_bits=8, limb_bits=8, live=np.random.default_rng(10))
     assert traces[2].shape == (59, 1 << 18)
     proof = be.prove_with_traces(blob, traces, params, compress)
     rc, why = oracle.verify_all_proof(blob, proof, params)

@@ -104,7 +104,10 @@ def test_all_twelve_tables_vanish_on_the_empty_program_instance(oracle):
 def test_twelve_table_all_proof_verifies(oracle):
     s = T.ola_stark(range_bits=4, limb_bits=2)
     blob = s.blob()
-    traces, params, compress = tracegen.empty_program_instance()
+    # padding rows everywhere plus live range-check, bitwise and Poseidon rows (tracegen.empty_program_instance)
+    traces, params, compress = tracegen.empty_program_instance(live=np.random.default_rng(5))
+    for i, (tr, pr) in enumerate(zip(traces, _per_table_params(s, params))):
+        assert oracle.check_constraints(blob, i, tr, pr) == -1, s.tables[i].name
     proof = oracle.prove_with_traces(blob, traces, params, compress)
     rc, why = oracle.verify_all_proof(blob, proof, params)
     assert rc == 0, why

@@ -131,10 +131,14 @@ def memory_padding_trace(n):
     return t
 
 
-def bitwise_padding_trace(beta, limb_bits=8):
+def bitwise_trace(beta, limb_bits=8, ops=()):
+    """generation/builtin.rs:35-205 with `limb_bits`-wide limbs: the fixed AND/OR/XOR table, and one row per operation in
+    `ops` = [(name, op0, op1)] (operands of 4 limbs) with its limbs, compressed limbs and the permuted lookup columns.
+    The rows carry FILTER = 0: nothing in the CPU table looks them up, but every bitwise constraint and in-table lookup
+    is live on them."""
     size = 1 << limb_bits
     per = size * size
-    n = next_pow2(max(size, 3 * per))
+    n = next_pow2(max(size, 3 * per, len(ops)))
     t = np.zeros((T.COL_NUM_BITWISE, n), dtype=np.uint64)
     index = 0
     for op0 in range(size):
@@ -145,24 +149,44 @@ def bitwise_padding_trace(beta, limb_bits=8):
                 t[T.BW_FIX_BITWSIE_OP0, r], t[T.BW_FIX_BITWSIE_OP1, r], t[T.BW_FIX_BITWSIE_RES, r], t[T.BW_FIX_TAG, r] = op0, op1, res, tag
             index += 1
     b = int(beta) % P
-    fix = [(int(t[T.BW_FIX_TAG, i]) + int(t[T.BW_FIX_BITWSIE_OP0, i]) * b + int(t[T.BW_FIX_BITWSIE_OP1, i]) * b * b
-            + int(t[T.BW_FIX_BITWSIE_RES, i]) * b * b * b) % P for i in range(n)]
+    compress = lambda tag, x, y, z: (tag + x * b + y * b * b + z * b * b * b) % P
+    fix = [compress(int(t[T.BW_FIX_TAG, i]), int(t[T.BW_FIX_BITWSIE_OP0, i]), int(t[T.BW_FIX_BITWSIE_OP1, i]), int(t[T.BW_FIX_BITWSIE_RES, i]))
+           for i in range(n)]
     t[T.BW_FIX_COMPRESS] = fix
-    zeros = [0] * n
+    fn = {"AND": lambda x, y: x & y, "OR": lambda x, y: x | y, "XOR": lambda x, y: x ^ y}
+    limbs = lambda v: [(v >> (limb_bits * i)) & (size - 1) for i in range(4)]
+    for r, (name, x, y) in enumerate(ops):
+        assert x < size ** 4 and y < size ** 4
+        z = fn[name](x, y)
+        tag = T.op_mask(name)
+        t[T.BW_TAG, r], t[T.BW_OP0, r], t[T.BW_OP1, r], t[T.BW_RES, r] = tag, x, y, z
+        for i, (lx, ly, lz) in enumerate(zip(limbs(x), limbs(y), limbs(z))):
+            t[T.BW_OP0_LIMBS.start + i, r], t[T.BW_OP1_LIMBS.start + i, r], t[T.BW_RES_LIMBS.start + i, r] = lx, ly, lz
+            t[T.BW_COMPRESS_LIMBS.start + i, r] = compress(tag, lx, ly, lz)
     rc8 = [int(x) for x in t[T.BW_FIX_RANGE_CHECK_U8]]
     for i in range(4):
-        for limbs_perm, off in ((T.BW_OP0_LIMBS_PERMUTED, 0), (T.BW_OP1_LIMBS_PERMUTED, 4), (T.BW_RES_LIMBS_PERMUTED, 8)):
-            pi, pt = permuted_cols(zeros, rc8)
+        for src, limbs_perm, off in ((T.BW_OP0_LIMBS, T.BW_OP0_LIMBS_PERMUTED, 0), (T.BW_OP1_LIMBS, T.BW_OP1_LIMBS_PERMUTED, 4),
+                                     (T.BW_RES_LIMBS, T.BW_RES_LIMBS_PERMUTED, 8)):
+            pi, pt = permuted_cols([int(v) for v in t[src.start + i]], rc8)
             t[limbs_perm.start + i], t[T.BW_FIX_RANGE_CHECK_U8_PERMUTED.start + off + i] = pi, pt
-        pi, pt = permuted_cols(zeros, fix)          # COMPRESS_LIMBS are all zero (tag 0, limbs 0)
+        pi, pt = permuted_cols([int(v) for v in t[T.BW_COMPRESS_LIMBS.start + i]], fix)
         t[T.BW_COMPRESS_PERMUTED.start + i], t[T.BW_FIX_COMPRESS_PERMUTED.start + i] = pi, pt
     return t
 
 
-def poseidon_padding_trace(n):
+def bitwise_padding_trace(beta, limb_bits=8):
+    return bitwise_trace(beta, limb_bits)
+
+
+def poseidon_padding_trace(n, live_rows=0):
+    """ZERO-hash padding rows (generation/poseidon.rs); the first `live_rows` rows are the reference's golden row of
+    hashing [1000, 1001, ...] instead -- a full non-trivial permutation, with its looked-up filters at 0."""
     import json, os
-    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "poseidon_air_rows.json")))["rows"]["ZERO"]
-    return np.tile(np.array(g, dtype=np.uint64)[:, None], (1, n))
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "poseidon_air_rows.json")))["rows"]
+    t = np.tile(np.array(g["ZERO"], dtype=np.uint64)[:, None], (1, n))
+    for r in range(min(live_rows, n)):
+        t[:, r] = np.array(g["1000"], dtype=np.uint64)
+    return t
 
 
 def flag_padding_trace(ncols, n, flag_col):
@@ -181,14 +205,24 @@ def program_padding_trace(n):
     return np.zeros((T.NUM_PROG_COLS, n), dtype=np.uint64)   # all-zero rows: compress = 0, lookups trivially hold
 
 
-def empty_program_instance(log_n=3, range_bits=4, limb_bits=2, bitwise_beta=12345, program_beta=67890, log_n_cpu=None, log_n_mem=None):
+def empty_program_instance(log_n=3, range_bits=4, limb_bits=2, bitwise_beta=12345, program_beta=67890, log_n_cpu=None, log_n_mem=None,
+                           live=None):
     """12 traces in `enum Table` order + per-table params + compress_challenges, for ola_stark(range_bits, limb_bits).
     log_n_cpu / log_n_mem override the height of the two tables that dominate a real execution."""
     n = 1 << log_n
+    # `live` (a numpy Generator): on top of the padding rows, the tables that can carry real rows without a CPU row
+    # looking at them do so -- range-checked values, bitwise operations and full Poseidon permutations.  (Cmp rows cannot:
+    # their filter column also drives the lookup from the CPU table, cmp_stark.rs:95-97.)
+    cmp_rows_, rc_rows, bw_ops, pos_live = [], [], (), 0
+    if live is not None:
+        rc_rows = [(int(live.integers(0, 1 << (2 * range_bits))), 0, 0, 0, 0) for _ in range(6)]
+        top = 1 << (4 * limb_bits)
+        bw_ops = [(name, int(live.integers(0, top)), int(live.integers(0, top))) for name in ("AND", "OR", "XOR", "XOR", "AND")]
+        pos_live = max(1, n // 2)
     traces = [
         cpu_padding_trace(1 << (log_n_cpu or log_n)), memory_padding_trace(1 << (log_n_mem or log_n)),
-        bitwise_padding_trace(bitwise_beta, limb_bits),
-        generate_cmp_trace([]), generate_rc_trace([], range_bits), poseidon_padding_trace(n),
+        bitwise_trace(bitwise_beta, limb_bits, bw_ops),
+        generate_cmp_trace(cmp_rows_), generate_rc_trace(rc_rows, range_bits), poseidon_padding_trace(n, pos_live),
         flag_padding_trace(T.NUM_POSEIDON_CHUNK_COLS, n, T.COL_POSEIDON_CHUNK_IS_PADDING_LINE),
         flag_padding_trace(T.NUM_COL_ST, n, T.COL_ST_IS_PADDING),
         tape_padding_trace(n),
