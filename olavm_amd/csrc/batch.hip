@@ -7,6 +7,8 @@
 //   lde[col][c*n + r] = P_col(7 * g^bitrev(c) * w_n^bitrev_n(r))  ==  natural LDE row bitrev_N(c*n + r).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <functional>
 #include <vector>
 
 #include "device_ctx.h"
@@ -92,9 +94,17 @@ void batch_destroy(DeviceCtx* ctx, OlaBatch* b) {
     delete b;
 }
 
+// Columns of a device-resident table may still be arriving (prove_with_traces uploads the traces from a helper thread):
+// the interpolation then runs in groups of `chunk_cols` columns and calls before_chunk(c0, c1) -- wait for the upload,
+// canonicalise -- ahead of each group.
+struct ColumnFeed {
+    uint32_t chunk_cols = 0;
+    std::function<void(uint32_t, uint32_t)> before_chunk;
+};
+
 OlaBatch* batch_commit(DeviceCtx* ctx, NttTables& t, const uint64_t* const* cols_host, const u64* cols_dev, uint32_t ncols,
                        uint32_t log_n, uint32_t rate_bits, uint32_t cap_height, bool from_values, uint32_t shard_rank = 0,
-                       uint32_t shard_log_world = 0) {
+                       uint32_t shard_log_world = 0, const ColumnFeed* feed = nullptr) {
     if (shard_log_world > rate_bits || shard_log_world > cap_height || shard_rank >= (1u << shard_log_world))
         throw OlaError(-1, "shard count must divide both the number of cosets and the cap");
     OlaBatch* b = new OlaBatch();
@@ -106,6 +116,7 @@ OlaBatch* batch_commit(DeviceCtx* ctx, NttTables& t, const uint64_t* const* cols
     b->coset_first = shard_rank << rate_bits;
     const size_t n = b->n(), N = b->num_leaves();
     u64* tmp = nullptr;
+    bool lde_done = false;
     try {
         b->coeffs = (u64*)ctx->alloc((size_t)ncols * n * 8);
         b->lde = (u64*)ctx->alloc((size_t)ncols * N * 8);
@@ -121,8 +132,18 @@ OlaBatch* batch_commit(DeviceCtx* ctx, NttTables& t, const uint64_t* const* cols
                     HIP_CHECK(hipMemcpyAsync(stage + (size_t)c * n, cols_host[c], n * 8, hipMemcpyHostToDevice, ctx->stream));
                 vals = stage;
             }
-            if (rate_bits == 0 && cols_host) {  // stage and lde coincide with the LDE output: go through tmp
-                ntt_interpolate(t, vals, b->coeffs, scratch, log_n, ncols);
+            if (feed && feed->chunk_cols && !cols_host) {
+                // interpolate AND extend each group as it arrives, so that only the leaf hashing waits for the last column
+                // (the transform scratch cannot live inside the LDE buffer here: earlier groups already wrote theirs)
+                if (!tmp) tmp = (u64*)ctx->alloc((size_t)feed->chunk_cols * n * 8);
+                for (uint32_t c0 = 0; c0 < ncols; c0 += feed->chunk_cols) {
+                    const uint32_t c1 = std::min(ncols, c0 + feed->chunk_cols);
+                    feed->before_chunk(c0, c1);
+                    ntt_interpolate(t, vals + (size_t)c0 * n, b->coeffs + (size_t)c0 * n, tmp, log_n, c1 - c0);
+                    ntt_lde_leaf_order(t, b->coeffs + (size_t)c0 * n, b->lde + (size_t)c0 * N, log_n, full_rate_bits, c1 - c0, b->coset_first,
+                                       (size_t)1 << rate_bits);
+                }
+                lde_done = true;
             } else {
                 ntt_interpolate(t, vals, b->coeffs, scratch, log_n, ncols);
             }
@@ -135,7 +156,7 @@ OlaBatch* batch_commit(DeviceCtx* ctx, NttTables& t, const uint64_t* const* cols
             }
             canonicalize(ctx, b->coeffs, (size_t)ncols * n);
         }
-        ntt_lde_leaf_order(t, b->coeffs, b->lde, log_n, full_rate_bits, ncols, b->coset_first, (size_t)1 << rate_bits);
+        if (!lde_done) ntt_lde_leaf_order(t, b->coeffs, b->lde, log_n, full_rate_bits, ncols, b->coset_first, (size_t)1 << rate_bits);
         launch_leaf_hash_colmajor(ctx, b->lde, N, (int)ncols, N, b->heap + 4 * N);
         launch_merkle_build(ctx, b->heap, N, cap_height);
         HIP_CHECK(hipStreamSynchronize(ctx->stream));

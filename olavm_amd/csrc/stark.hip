@@ -17,10 +17,14 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/ola_gpu.h"
@@ -672,6 +676,64 @@ static void prove_single_table(DeviceCtx* ctx, NttTables& tables, const OlaGpuCo
     open_and_prove(ctx, tables, cfg, trace_c, *zs_c.b, *q_c.b, (uint32_t)nperm, ch, bytes, olen);
 }
 
+// Host -> device transfer of the trace tables on a helper thread and a dedicated stream, in groups of columns of about
+// 64 MB; wait(t, c) blocks until columns [0, c) of table t are on the device.
+class TraceUploader {
+  public:
+    TraceUploader(DeviceCtx* ctx, size_t ntables) : ctx_(ctx), jobs_(ntables), done_(ntables) {
+        for (auto& d : done_) d.store(0);
+    }
+    ~TraceUploader() { cancel_.store(true); if (th_.joinable()) th_.join(); if (stream_) (void)hipStreamDestroy(stream_); }
+    void add(size_t t, const u64* src, u64* dst, uint32_t ncols, size_t n) {
+        const size_t target = (size_t)64 << 20;
+        uint32_t cc = (uint32_t)std::max<size_t>(1, target / (n * 8));
+        jobs_[t] = {src, dst, ncols, n, std::min(cc, ncols)};
+    }
+    uint32_t chunk_cols(size_t t) const { return jobs_[t].chunk; }
+    void start() {
+        HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+        th_ = std::thread([this] { run(); });
+    }
+    void wait(size_t t, uint32_t cols) {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [&] { return done_[t].load() >= cols || failed_; });
+        if (failed_) throw OlaError(OLA_E_HIP, "trace upload failed: " + error_);
+    }
+    void finish() {
+        if (th_.joinable()) th_.join();
+        if (failed_) throw OlaError(OLA_E_HIP, "trace upload failed: " + error_);
+    }
+
+  private:
+    struct Job { const u64* src; u64* dst; uint32_t ncols; size_t n; uint32_t chunk; };
+    void run() {
+        (void)hipSetDevice(ctx_->device);
+        for (size_t t = 0; t < jobs_.size() && !cancel_.load(); t++) {
+            const Job& j = jobs_[t];
+            for (uint32_t c0 = 0; c0 < j.ncols && !cancel_.load(); c0 += j.chunk) {
+                const uint32_t c1 = std::min(j.ncols, c0 + j.chunk);
+                hipError_t e = hipMemcpyAsync(j.dst + (size_t)c0 * j.n, j.src + (size_t)c0 * j.n, (size_t)(c1 - c0) * j.n * 8,
+                                              hipMemcpyHostToDevice, stream_);
+                if (e == hipSuccess) e = hipStreamSynchronize(stream_);
+                std::lock_guard<std::mutex> lk(mu_);
+                if (e != hipSuccess) { failed_ = true; error_ = hipGetErrorString(e); cv_.notify_all(); return; }
+                done_[t].store(c1);
+                cv_.notify_all();
+            }
+        }
+    }
+    DeviceCtx* ctx_;
+    std::vector<Job> jobs_;
+    std::vector<std::atomic<uint32_t>> done_;
+    std::thread th_;
+    std::mutex mu_;
+    std::condition_variable cv_;
+    std::atomic<bool> cancel_{false};
+    bool failed_ = false;
+    std::string error_;
+    hipStream_t stream_ = nullptr;
+};
+
 // prove_with_traces (prover.rs:79-327).  traces[t]: host pointer to a column-major ncols x 2^log_n[t] table.
 void prove_with_traces(DeviceCtx* ctx, NttTables& tables, const OlaGpuConfig& cfg, const u64* airset, size_t airset_words,
                        const u64* const* traces, const uint32_t* log_n, const u64* params, const u64* compress,
@@ -690,18 +752,28 @@ void prove_with_traces(DeviceCtx* ctx, NttTables& tables, const OlaGpuConfig& cf
     for (size_t t = 0; t < nt; t++) {
         if (log_n[t] + cfg.rate_bits > 32 || log_n[t] + cfg.rate_bits < cfg.cap_height) throw OlaError(OLA_E_INVALID_ARG, "table size out of range");
         dev[t].log_n = log_n[t];
-        const size_t elems = (size_t)set.tables[t].ncols << log_n[t];
-        dev[t].vals = mem.alloc(elems);
-        {
-            PhaseTimer tt(ctx, "  table " + std::to_string(t) + " trace H2D");
-            HIP_CHECK(hipMemcpyAsync(dev[t].vals, traces[t], elems * 8, hipMemcpyHostToDevice, ctx->stream));
-        }
-        PhaseTimer tt(ctx, "  table " + std::to_string(t) + " compute trace commitment");
-        canonicalize(ctx, dev[t].vals, elems);
+        dev[t].vals = mem.alloc((size_t)set.tables[t].ncols << log_n[t]);
+    }
+    // The traces are pageable host memory: a helper thread pushes them to the device in column groups on its own stream
+    // while this thread already interpolates / extends / hashes what has arrived (H2D of a 2^22-row instance is ~75 ms).
+    TraceUploader up(ctx, nt);
+    for (size_t t = 0; t < nt; t++) up.add(t, traces[t], dev[t].vals, (uint32_t)set.tables[t].ncols, (size_t)1 << log_n[t]);
+    up.start();
+    for (size_t t = 0; t < nt; t++) {
+        PhaseTimer tt(ctx, "  table " + std::to_string(t) + " compute trace commitment (upload overlapped)");
+        const size_t n_t = (size_t)1 << log_n[t];
+        ColumnFeed feed;
+        feed.chunk_cols = up.chunk_cols(t);
+        feed.before_chunk = [&, t, n_t](uint32_t c0, uint32_t c1) {
+            up.wait(t, c1);
+            canonicalize(ctx, dev[t].vals + (size_t)c0 * n_t, (size_t)(c1 - c0) * n_t);
+        };
         commits.emplace_back(new BatchHolder(ctx));
-        commits[t]->b = batch_commit(ctx, tables, nullptr, dev[t].vals, (uint32_t)set.tables[t].ncols, log_n[t], cfg.rate_bits, cfg.cap_height, true);
+        commits[t]->b = batch_commit(ctx, tables, nullptr, dev[t].vals, (uint32_t)set.tables[t].ncols, log_n[t], cfg.rate_bits, cfg.cap_height, true,
+                                     0, 0, &feed);
         batch_read_cap(ctx, *commits[t]->b, caps[t].data());
     }
+    up.finish();
     for (size_t t = 0; t < nt; t++) challenger_observe(ch, caps[t].data(), caps[t].size());
     // CTL challenges and per-table job lists, in cross_table_lookup_data order
     std::vector<GpChallenge> ctl_ch;
