@@ -19,12 +19,16 @@
 namespace ola {
 
 enum { N2_STRIDED = 0, N2_BITREV_LAST = 1, N2_NATURAL_LAST = 2 };
+#ifndef NTT2_STRIDED_COLS
+#define NTT2_STRIDED_COLS 4   // columns per workgroup of a strided pass (see ntt2_pass_kernel)
+#endif
 
 struct Ntt2Params {
     const u64* in;
     u64* out;
     size_t in_col_stride, out_col_stride, in_coset_stride, out_coset_stride;
     int log_n;  // L
+    size_t ncols;  // columns of the batch (a workgroup handles CB of them)
     int lo;     // pass handles index bits [lo, lo+R)
     const u64* tw_r;   // w_{2^R}^e, e < 2^R
     const u64* tw_lo;  // two-level powers of w_{2^(lo+R)}
@@ -74,8 +78,12 @@ constexpr int ntt2_lds_elems() {
     return (1 << (8 - R)) * 16 * ((1 << R) + 1);
 }
 
-template <int R, int MODE, bool INV>
+// CB = columns per workgroup.  Everything that depends only on the position inside the transform -- the pass twiddles and
+// the coset pre-scale weights, 2-3 of the ~5 general multiplications per element of a strided pass -- is computed once
+// and reused for the workgroup's CB columns.
+template <int R, int MODE, bool INV, int CB, bool PRE>
 __global__ __launch_bounds__(256) void ntt2_pass_kernel(Ntt2Params p) {
+    static_assert(!PRE || MODE == N2_STRIDED, "only the first (strided) pass of a coset transform pre-scales");
     static_assert(R >= 4 && R <= 8, "pass width");
     constexpr int K2 = R - 4;     // bits of the second round
     constexpr int D = 8 - R;      // log2(tiles per workgroup)
@@ -87,9 +95,7 @@ __global__ __launch_bounds__(256) void ntt2_pass_kernel(Ntt2Params p) {
 
     const int tid = threadIdx.x;
     const u32 blk = blockIdx.x;
-    const size_t col = blockIdx.y, coset = blockIdx.z;
-    const u64* __restrict__ in = p.in + col * p.in_col_stride + coset * p.in_coset_stride;
-    u64* __restrict__ out = p.out + col * p.out_col_stride + coset * p.out_coset_stride;
+    const size_t col0 = (size_t)blockIdx.y * CB, coset = blockIdx.z;
     const int L = p.log_n, lo = p.lo;
 
     if (R > 4) {
@@ -98,124 +104,169 @@ __global__ __launch_bounds__(256) void ntt2_pass_kernel(Ntt2Params p) {
 
     auto pad1 = [](int e) -> int { return K2 >= 1 ? e + ((e >> (K2 + 4)) << 4) : e; };
 
-    // ---------------------------------------------------------------- phase A: load + radix-16 round
+    // ---- phase A thread -> element map
+    int uA, m_low, tA;
+    if (MODE == N2_STRIDED) {
+        uA = tid & 15;
+        const int rest = tid >> 4;
+        m_low = rest & ((1 << K2) - 1);
+        tA = rest >> K2;
+    } else {
+        m_low = tid & ((1 << K2) - 1);
+        uA = (tid >> K2) & 15;
+        tA = tid >> R;
+    }
+    size_t a0;       // address of register element j = 0
+    size_t jstride;  // address distance between consecutive register elements
+    // STRIDED: a0 = a0_uni (same for the whole workgroup, lives in SGPRs) + a0_lane (< 2^(lo+K2+1)); with the column base and
+    // j*jstride also uniform, every load/store is "SGPR base + 32-bit lane offset" and needs no per-element address registers
+    size_t a0_uni = 0;
+    u32 a0_lane = 0;
     {
-        int u, m_low, t;
-        if (MODE == N2_STRIDED) {
-            u = tid & 15;
-            const int rest = tid >> 4;
-            m_low = rest & ((1 << K2) - 1);
-            t = rest >> K2;
-        } else {
-            m_low = tid & ((1 << K2) - 1);
-            u = (tid >> K2) & 15;
-            t = tid >> R;
-        }
-        const u32 ntile = (blk << D) + t;
-        size_t a0;       // address of register element j = 0
-        size_t jstride;  // address distance between consecutive register elements
+        const u32 ntile = (blk << D) + tA;
         if (MODE == N2_STRIDED) {
             const u32 lowblks = 1u << (lo - 4);
             const u32 lb = ntile & (lowblks - 1), hi = ntile >> (lo - 4);
-            a0 = ((size_t)hi << (lo + R)) + ((size_t)lb << 4) + ((size_t)m_low << lo) + u;
+            a0 = ((size_t)hi << (lo + R)) + ((size_t)lb << 4) + ((size_t)m_low << lo) + uA;
             jstride = (size_t)1 << (lo + K2);
+            // from blk alone (provably uniform): with lo - 4 >= D the workgroup's 2^D tiles share `hi` and are consecutive
+            const u32 ntile0 = blk << D;
+            a0_uni = ((size_t)(ntile0 >> (lo - 4)) << (lo + R)) + ((size_t)(ntile0 & (lowblks - 1)) << 4);
+            a0_lane = ((u32)tA << 4) + ((u32)m_low << lo) + (u32)uA;
         } else if (MODE == N2_BITREV_LAST) {
-            a0 = ((((size_t)ntile << 4) + u) << R) + m_low;
+            a0 = ((((size_t)ntile << 4) + uA) << R) + m_low;
             jstride = (size_t)1 << K2;
         } else {
             const int ub = L - R - 4;
-            const size_t row = ((size_t)rev_bits_c(u, 4) << ub) + (ub ? bitrev32(ntile, ub) : 0);
+            const size_t row = ((size_t)rev_bits_c(uA, 4) << ub) + (ub ? bitrev32(ntile, ub) : 0);
             a0 = (row << R) + m_low;
             jstride = (size_t)1 << K2;
         }
-        u64 x[16];
-#pragma unroll
-        for (int j = 0; j < 16; j++) x[j] = gl_canon(in[a0 + j * jstride]);
-        if (MODE == N2_STRIDED && p.sc_lo) {
-            const u64 sb = two_level(p.sc_lo + coset * p.sc_coset_stride, p.sc_hi + coset * p.sc_coset_stride, p.sc_h, a0);
-            const u64 st = p.sc_step[coset];
-            u64 w = sb;
-#pragma unroll
-            for (int j = 0; j < 16; j++) {
-                x[j] = gl_mul(x[j], w);
-                if (j < 15) w = gl_mul(w, st);
-            }
-        }
-        dft_pow2<4, INV>(x);
-        if (R > 4) __syncthreads();  // tw1 visible
+    }
+    // ---- phase B thread -> element map
+    const int uB = tid & 15, m_hi = tid >> 4;
+
+    // ---- column-independent multipliers
+    constexpr bool prescale = PRE;
+    u64 ws[PRE ? 16 : 1];   // coset pre-scale s_c^(position) of the 16 phase-A elements
+    if (prescale) {
+        const u64 sb = two_level(p.sc_lo + coset * p.sc_coset_stride, p.sc_hi + coset * p.sc_coset_stride, p.sc_h, a0);
+        const u64 st = p.sc_step[coset];
+        u64 w = sb;
 #pragma unroll
         for (int j = 0; j < 16; j++) {
-            const int q1 = rev_bits_c(j, 4);
-            u64 v = x[j];
-            if (R > 4 && q1 != 0) {
-                const int idx = m_low * q1;  // < 2^R
-                if (idx) v = gl_mul(v, tw1[idx]);
-            }
-            const int m = (j << K2) + m_low;
-            if (MODE == N2_STRIDED) lds[pad1((((t << R) + m) << 4) + u)] = v;
-            else lds[((t << 4) + u) * ROW + m] = v;
+            ws[j] = w;
+            if (j < 15) w = gl_mul(w, st);
         }
     }
-    __syncthreads();
-
-    // ---------------------------------------------------------------- phase B: second round + store
-    {
-        const int u = tid & 15, m_hi = tid >> 4;
-        u64 y[16];
+    u64 wt[16];   // pass twiddle w_B^(low*q) (times the final scale) of the 16 phase-B elements, in store order
+    if (MODE == N2_STRIDED) {
+        // q = rev_R(m) = rev_K2(j2)*16 + rev4(m_hi):  base * step^rev_K2(j2)
+        const u32 lowblks = 1u << (lo - 4);
 #pragma unroll
         for (int t = 0; t < (1 << D); t++) {
+            const u32 ntile = (blk << D) + t;
+            const u64 low = ((u64)(ntile & (lowblks - 1)) << 4) + uB;
+            const u64 base = gl_mul(two_level(p.tw_lo, p.tw_hi, p.tw_h, low * (u64)rev_bits_c(m_hi & 15, 4)), p.post_scale);
+            const u64 step = (K2 >= 1) ? two_level(p.tw_lo, p.tw_hi, p.tw_h, low << 4) : 1;
+            u64 w = base;
 #pragma unroll
-            for (int j2 = 0; j2 < G2; j2++) {
-                const int m = (m_hi << K2) + j2;
-                y[t * G2 + j2] = (MODE == N2_STRIDED) ? lds[pad1((((t << R) + m) << 4) + u)] : lds[((t << 4) + u) * ROW + m];
+            for (int k = 0; k < G2; k++) {
+                wt[t * G2 + k] = w;
+                if (k + 1 < G2) w = gl_mul(w, step);
             }
         }
-        if (MODE == N2_STRIDED) {
-            // pass twiddle w_B^(low*q), q = rev_R(m) = rev_K2(j2)*16 + rev4(m_hi):  base * step^rev_K2(j2)
-            u64 base[1 << D], step[1 << D];
-            const u32 lowblks = 1u << (lo - 4);
+    }
+
+#pragma unroll 1
+    for (int cc = 0; cc < CB; cc++) {
+        const size_t col = col0 + cc;
+        if (col >= p.ncols) break;
+        const u64* __restrict__ in = p.in + col * p.in_col_stride + coset * p.in_coset_stride;
+        u64* __restrict__ out = p.out + col * p.out_col_stride + coset * p.out_coset_stride;
+        // An opaque per-iteration zero in the lane offsets: the accesses then stay "uniform base (SGPRs) + 32-bit lane
+        // offset"; without it LICM hoists 32 per-lane 64-bit addresses out of the column loop (64 VGPRs).
+        u32 zlane = 0;
+        asm volatile("" : "+v"(zlane));
+
+        // ------------------------------------------------------------ phase A: load + radix-16 round
+        {
+            u64 x[16];
+            if (MODE == N2_STRIDED) {   // the host guarantees lo - 4 >= D (ntt2_run)
+                const char* __restrict__ base = reinterpret_cast<const char*>(in + a0_uni);
+                const u32 off = (a0_lane + zlane) * 8u;   // a0_lane < 2^(lo+K2+1) <= 2^(L-3): the byte offset fits 32 bits
 #pragma unroll
-            for (int t = 0; t < (1 << D); t++) {
-                const u32 ntile = (blk << D) + t;
-                const u64 low = ((u64)(ntile & (lowblks - 1)) << 4) + u;
-                base[t] = gl_mul(two_level(p.tw_lo, p.tw_hi, p.tw_h, low * (u64)rev_bits_c(m_hi & 15, 4)), p.post_scale);
-                step[t] = (K2 >= 1) ? two_level(p.tw_lo, p.tw_hi, p.tw_h, low << 4) : 1;
+                for (int j = 0; j < 16; j++) x[j] = gl_canon(*reinterpret_cast<const u64*>(base + j * jstride * 8 + off));
+            } else {
+#pragma unroll
+                for (int j = 0; j < 16; j++) x[j] = gl_canon(in[a0 + j * jstride]);
             }
+            if (prescale) {
+#pragma unroll
+                for (int j = 0; j < 16; j++) x[j] = gl_mul(x[j], ws[j]);
+            }
+            dft_pow2<4, INV>(x);
+            if (R > 4 && cc == 0) __syncthreads();  // tw1 visible
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                const int q1 = rev_bits_c(j, 4);
+                u64 v = x[j];
+                if (R > 4 && q1 != 0) {
+                    const int idx = m_low * q1;  // < 2^R
+                    if (idx) v = gl_mul(v, tw1[idx]);
+                }
+                const int m = (j << K2) + m_low;
+                if (MODE == N2_STRIDED) lds[pad1((((tA << R) + m) << 4) + uA)] = v;
+                else lds[((tA << 4) + uA) * ROW + m] = v;
+            }
+        }
+        __syncthreads();
+
+        // ------------------------------------------------------------ phase B: second round + store
+        {
+            u64 y[16];
 #pragma unroll
             for (int t = 0; t < (1 << D); t++) {
-                if (K2 >= 1) dft_pow2<(K2 >= 1 ? K2 : 1), INV>(y + t * G2);
-                const u32 ntile = (blk << D) + t;
-                const u32 lb = ntile & (lowblks - 1), hi = ntile >> (lo - 4);
-                const size_t b0 = ((size_t)hi << (lo + R)) + ((size_t)lb << 4) + u;
-                u64 w = base[t];
 #pragma unroll
-                for (int k = 0; k < G2; k++) {
-                    const int j2 = rev_bits_c(k, K2);
-                    const u64 v = gl_mul(y[t * G2 + j2], w);
-                    if (k + 1 < G2) w = gl_mul(w, step[t]);
-                    out[b0 + ((size_t)((m_hi << K2) + j2) << lo)] = v;
+                for (int j2 = 0; j2 < G2; j2++) {
+                    const int m = (m_hi << K2) + j2;
+                    y[t * G2 + j2] = (MODE == N2_STRIDED) ? lds[pad1((((t << R) + m) << 4) + uB)] : lds[((t << 4) + uB) * ROW + m];
                 }
             }
-        } else {
 #pragma unroll
             for (int t = 0; t < (1 << D); t++)
                 if (K2 >= 1) dft_pow2<(K2 >= 1 ? K2 : 1), INV>(y + t * G2);
-            if (MODE == N2_NATURAL_LAST) {
+            if (MODE == N2_STRIDED) {
+                const u32 lowblks = 1u << (lo - 4);
+#pragma unroll
+                for (int t = 0; t < (1 << D); t++) {
+                    const u32 ntile = (blk << D) + t;   // t is an unrolled constant: uniform
+                    const u32 lb = ntile & (lowblks - 1), hi = ntile >> (lo - 4);
+                    char* __restrict__ obase = reinterpret_cast<char*>(out + ((size_t)hi << (lo + R)) + ((size_t)lb << 4));   // uniform
+                    const u32 ooff = (((u32)m_hi << (K2 + lo)) + (u32)uB + zlane) * 8u;
+#pragma unroll
+                    for (int k = 0; k < G2; k++) {
+                        const int j2 = rev_bits_c(k, K2);
+                        *reinterpret_cast<u64*>(obase + ((size_t)j2 << (lo + 3)) + ooff) = gl_mul(y[t * G2 + j2], wt[t * G2 + k]);
+                    }
+                }
+            } else if (MODE == N2_NATURAL_LAST) {
 #pragma unroll
                 for (int t = 0; t < (1 << D); t++) {
                     const u32 A = (blk << D) + t;
 #pragma unroll
                     for (int j2 = 0; j2 < G2; j2++) {
                         const u32 q = ((u32)rev_bits_c(j2, K2) << 4) + (u32)rev_bits_c(m_hi & 15, 4);
-                        out[((size_t)A << 4) + u + ((size_t)q << (L - R))] = y[t * G2 + j2];
+                        out[((size_t)A << 4) + uB + ((size_t)q << (L - R))] = y[t * G2 + j2];
                     }
                 }
             } else {
                 // bit-reversed (in-place) order: exchange through LDS once more so that the stores are contiguous
+                __syncthreads();
 #pragma unroll
                 for (int t = 0; t < (1 << D); t++)
 #pragma unroll
-                    for (int j2 = 0; j2 < G2; j2++) lds[((t << 4) + u) * ROW + (m_hi << K2) + j2] = y[t * G2 + j2];
+                    for (int j2 = 0; j2 < G2; j2++) lds[((t << 4) + uB) * ROW + (m_hi << K2) + j2] = y[t * G2 + j2];
                 __syncthreads();
                 const size_t b0 = (size_t)blk << 12;
 #pragma unroll
@@ -225,15 +276,20 @@ __global__ __launch_bounds__(256) void ntt2_pass_kernel(Ntt2Params p) {
                 }
             }
         }
+        if (cc + 1 < CB) __syncthreads();  // the exchange buffer is reused by the next column
     }
 }
 
 // ------------------------------------------------------------------------------------------------ host side
 template <int R, int MODE, bool INV>
-static void ntt2_launch(const Ntt2Params& p, size_t cols, size_t cosets, hipStream_t stream) {
+static void ntt2_launch(const Ntt2Params& p0, size_t cols, size_t cosets, hipStream_t stream) {
+    constexpr int CB = (MODE == N2_STRIDED) ? NTT2_STRIDED_COLS : 1;
+    Ntt2Params p = p0;
+    p.ncols = cols;
     const size_t lds_bytes = (size_t)(ntt2_lds_elems<R, MODE>() + (R > 4 ? (1 << R) : 0)) * 8;
-    dim3 grid((unsigned)(((size_t)1 << p.log_n) >> 12), (unsigned)cols, (unsigned)cosets);
-    hipLaunchKernelGGL((ntt2_pass_kernel<R, MODE, INV>), grid, dim3(256), lds_bytes, stream, p);
+    dim3 grid((unsigned)(((size_t)1 << p.log_n) >> 12), (unsigned)((cols + CB - 1) / CB), (unsigned)cosets);
+    if (MODE == N2_STRIDED && p.sc_lo) hipLaunchKernelGGL((ntt2_pass_kernel<R, MODE, INV, CB, MODE == N2_STRIDED>), grid, dim3(256), lds_bytes, stream, p);
+    else hipLaunchKernelGGL((ntt2_pass_kernel<R, MODE, INV, CB, false>), grid, dim3(256), lds_bytes, stream, p);
 }
 template <int MODE, bool INV>
 static void ntt2_dispatch_r(int R, const Ntt2Params& p, size_t cols, size_t cosets, hipStream_t s) {
@@ -333,6 +389,8 @@ void ntt2_run(NttTables& t, const u64* in, size_t in_col_stride, u64* out, size_
                 if (it == g_step_cache.end()) it = g_step_cache.emplace(ck, get_coset_steps(t, L, sc_rate_bits, lo + R - 4, sc_shift)).first;
                 p.sc_step = it->second + coset_first;
             }
+            // the strided kernel addresses a workgroup's 2^(8-R) tiles as one uniform base + lane offsets
+            if (lo - 4 < 8 - R) throw OlaError(-7, "ntt2: pass split leaves a strided pass with lo + R < 12");
             ntt2_dispatch(R, N2_STRIDED, inverse, p, cols, cosets, stream);
             cur_in = work; cur_in_stride = work_col_stride; cur_in_coset = work_coset_stride;
         } else {
