@@ -176,6 +176,19 @@ int32_t ola_prove_with_traces(OlaCtx* ctx, const uint64_t* airset, size_t airset
                               const uint32_t* log_n, const uint64_t* params, const uint64_t* compress_challenges,
                               uint8_t* out, size_t cap, size_t* out_len);
 
+/* ---- coset-partitioned proving over several GPUs ---------------------------------------------------------
+ * One process per GPU; every process calls ola_prove_with_traces with the SAME traces.  Because the transcript is a
+ * function of the (identical) commitments, all ranks draw the same challenges without talking to each other; only the
+ * heavy work is divided: for every table with at least 2^12 rows whose quotient domain is the whole LDE (CPU, memory and
+ * Poseidon tables), rank r extends / hashes / evaluates the quotient on cosets [r*8/world, (r+1)*8/world) only.  Three
+ * exchanges go through `all_gather` -- Merkle cap slices (512 B per tree), the quotient values (16 * 8n bytes per table)
+ * and the opened rows of the 28 queries -- and every rank ends up with the complete, identical AllProof bytes.
+ * all_gather(user, send_dev, recv_dev, bytes): gather `bytes` bytes of DEVICE memory from every rank into recv_dev in rank
+ * order (world * bytes); return 0 when recv_dev is complete.  The library synchronises its stream before the call.
+ * world must be 1, 2, 4 or 8; world = 1 (or a NULL callback) restores single-GPU proving. */
+typedef int32_t (*ola_all_gather_fn)(void* user, const void* send_dev, void* recv_dev, size_t bytes);
+int32_t ola_set_shard(OlaCtx* ctx, uint32_t rank, uint32_t world, ola_all_gather_fn all_gather, void* user);
+
 /* Which tables of `airset` have an ahead-of-time specialised constraint-quotient kernel in this build (the counterpart of
  * the reference compiling each table's eval_packed_generic, e.g. cpu/cpu_stark.rs:325): has_kernel[t] = 1 or 0 for every
  * table.  Tables without one are proven with the generic interpreter kernel -- same bytes, fewer points per second.

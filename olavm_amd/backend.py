@@ -86,6 +86,7 @@ def load_library():
                                           C.POINTER(C.c_void_p), U64P]
     L.ola_commit_values_shard_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                               C.POINTER(C.c_void_p), U64P]
+    L.ola_set_shard.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, ALL_GATHER_FN, C.c_void_p]
     L.ola_air_kernels_available.argtypes = [U64P, C.c_size_t, C.POINTER(C.c_uint8), C.c_size_t]
     _lib = L
     return L
@@ -97,12 +98,22 @@ EXPORTS = [
     "ola_commit_values_dev", "ola_commit_coeffs_dev", "ola_batch_free", "ola_batch_shape", "ola_batch_get_coeffs",
     "ola_batch_get_leaf", "ola_batch_get_lde_row", "ola_challenger_init", "ola_challenger_observe",
     "ola_challenger_get", "ola_challenger_compact", "ola_open_and_prove", "ola_pow", "ola_prove_with_traces",
-    "ola_air_kernels_available", "ola_commit_values_shard", "ola_commit_values_shard_dev",
+    "ola_air_kernels_available", "ola_commit_values_shard", "ola_commit_values_shard_dev", "ola_set_shard",
 ]
+
+
+ALL_GATHER_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)
 
 
 def _p(a):
     return a.ctypes.data_as(U64P)
+
+
+class _DeviceBytes:
+    """View of raw device memory for torch (CUDA array interface): lets torch.distributed operate on the library's buffers."""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False), "version": 3}
 
 
 class Challenger:
@@ -272,6 +283,41 @@ class Backend:
             ptrs = (U64P * ncols)(*[cols[i].ctypes.data_as(U64P) for i in range(ncols)])
             self._chk(self.lib.ola_commit_values_shard(self.ctx, ptrs, ncols, int(n).bit_length() - 1, rank, world, C.byref(h), _p(cap)))
         return Batch(self, h, cap, shard_log_world=lw)
+
+    def set_shard(self, rank, world, group=None):
+        """Coset-partitioned proving (ola_set_shard): this context is rank `rank` of `world` GPUs.  The all-gather the
+        library asks for runs through torch.distributed on `group` -- RCCL when the process group is "nccl" (device
+        buffers are handed over as they are), host staging for "gloo" (tests).  world = 1 switches back."""
+        if world == 1:
+            self._chk(self.lib.ola_set_shard(self.ctx, 0, 1, ALL_GATHER_FN(0), None))
+            self._shard_cb = None
+            return
+        import torch
+        import torch.distributed as dist
+        on_device = dist.get_backend(group) == "nccl"
+
+        self.shard_calls = 0          # exchanges performed so far (observability / tests)
+
+        def all_gather(_user, send, recv, nbytes):
+            self.shard_calls += 1
+            try:
+                src = torch.as_tensor(_DeviceBytes(send, nbytes), device="cuda")
+                dst = torch.as_tensor(_DeviceBytes(recv, nbytes * world), device="cuda")
+                if on_device:
+                    dist.all_gather_into_tensor(dst, src, group=group)
+                else:
+                    parts = [torch.empty(nbytes, dtype=torch.uint8) for _ in range(world)]
+                    dist.all_gather(parts, src.cpu(), group=group)
+                    dst.copy_(torch.cat(parts))
+                torch.cuda.synchronize()
+                return 0
+            except Exception as e:          # noqa: BLE001 -- must not unwind through the C frame
+                import sys
+                print("ola all_gather callback failed:", repr(e), file=sys.stderr)
+                return 1
+
+        self._shard_cb = ALL_GATHER_FN(all_gather)      # keep the trampoline alive as long as the context uses it
+        self._chk(self.lib.ola_set_shard(self.ctx, rank, world, self._shard_cb, None))
 
     def prove_with_traces(self, airset_blob, traces, params=None, compress=None):
         """AllProof bytes for the multi-table STARK described by `airset_blob` (olavm_amd.air.AirSet.blob())."""

@@ -17,6 +17,10 @@ struct QuotParams {
     u64 g_inv;                                      // last = g^-1 (prover.rs:617)
     u64* out;                                       // [num_challenges][size]
     int n_regs;
+    // a rank's share (coset partition): the buffers hold cosets [coset_first, ...), N is their column stride, `out` holds
+    // `out_plane` values per challenge, and leaf j of the buffers is global leaf j + coset_first * n
+    u32 coset_first;
+    size_t out_plane;
 };
 
 // Straight-line kernels printed by olavm_amd/air/codegen.py, one per table signature.  Descriptor D (u64 words):
@@ -43,13 +47,12 @@ typedef const u64 __attribute__((address_space(4)))* airq_cptr;
 // workgroup are 256-aligned runs -- so every load is "uniform base + small lane offset" and its address lives in SGPRs
 // (global_load ... v_off, s[base]) instead of one VGPR pair per column and row.
 #define AIRQ_PROLOGUE(K_)                                                                                                  \
-    const size_t size = P.n << P.qdb;                                                                                      \
     const u32 lane_ = threadIdx.x;                                                                                         \
     const size_t jb_ = (size_t)blockIdx.x * AIRQ_THREADS;                                                                  \
     const size_t j = jb_ + lane_;                                                                                          \
-    const size_t c_ = jb_ >> P.log_n, r_ = j & (P.n - 1);                                                                  \
+    const size_t c_ = (jb_ >> P.log_n) + P.coset_first, r_ = j & (P.n - 1);                                                                  \
     const u32 rr_ = bitrev32((u32)r_, P.log_n);                                                                            \
-    const size_t jn_ = (c_ << P.log_n) + bitrev32((rr_ + 1) & (u32)(P.n - 1), P.log_n);                                    \
+    const size_t jn_ = ((jb_ >> P.log_n) << P.log_n) + bitrev32((rr_ + 1) & (u32)(P.n - 1), P.log_n);                                    \
     const u32 noff_ = (u32)jn_ & (AIRQ_THREADS - 1);                                                                       \
     const size_t nb_ = ((size_t)__builtin_amdgcn_readfirstlane((u32)(jn_ >> 32)) << 32) |                                  \
                        (__builtin_amdgcn_readfirstlane((u32)jn_) & ~(u32)(AIRQ_THREADS - 1));                              \
@@ -81,7 +84,7 @@ typedef const u64 __attribute__((address_space(4)))* airq_cptr;
     {                                                                                                                      \
         const u64 zh_inv = D[c_];                                                                                          \
         P.out[j] = gl_mul(gl_add(acc_reduce(accA0), gl_mul(z_last, acc_reduce(accT0))), zh_inv);                           \
-        P.out[size + j] = gl_mul(gl_add(acc_reduce(accA1), gl_mul(z_last, acc_reduce(accT1))), zh_inv);                    \
+        P.out[P.out_plane + j] = gl_mul(gl_add(acc_reduce(accA1), gl_mul(z_last, acc_reduce(accT1))), zh_inv);                    \
     }
 
 #endif  // AIRQ_GENERATED_TU

@@ -31,7 +31,21 @@ struct OlaError : public std::runtime_error {
 // without synchronising: whatever still reads it was enqueued earlier on the same stream.  Scratch buffers of a 2^22-row
 // proof are tens of GB; going back to hipMalloc/hipFree for each of them costs more than the kernels (and hipFree
 // synchronises the device), hence the cache.  It is released on out-of-memory and when the context is destroyed.
+// Coset partition of a proof over `world` GPUs: every rank runs the same host code on the same (replicated)
+// traces, so transcripts agree without exchanging challenges; LDEs, leaf hashing, Merkle sub-trees and quotient
+// evaluation are restricted to the rank's cosets, and three small exchanges go through `all_gather`: cap slices, the
+// quotient values, and the opened rows / paths of the queries.  The callback is supplied by the host (torch.distributed
+// over RCCL in olavm_amd/backend.py): it must gather `bytes` bytes of device memory from every rank into recv (rank
+// order) and return 0 once recv is complete.
+struct ShardInfo {
+    uint32_t rank = 0, world = 1, log_world = 0;
+    uint32_t min_log_n = 12;   // smaller tables are proven replicated: sharding them costs more latency than it saves
+    int32_t (*all_gather)(void* user, const void* send_dev, void* recv_dev, size_t bytes) = nullptr;
+    void* user = nullptr;
+};
+
 struct DeviceCtx {
+    ShardInfo shard;
     int device = 0;
     hipStream_t stream = nullptr;
     bool owns_stream = false;
@@ -95,6 +109,14 @@ struct DeviceCtx {
         if (owns_stream && stream) (void)hipStreamDestroy(stream);
     }
 };
+
+// all-gather of device buffers through the host-supplied collective (ShardInfo)
+inline void shard_all_gather(DeviceCtx* ctx, const void* send_dev, void* recv_dev, size_t bytes) {
+    if (!ctx->shard.all_gather) throw OlaError(-1, "sharded proving needs ola_set_shard with an all_gather callback");
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    const int32_t rc = ctx->shard.all_gather(ctx->shard.user, send_dev, recv_dev, bytes);
+    if (rc != 0) throw OlaError(-7, "all_gather callback failed with code " + std::to_string(rc));
+}
 
 // wall-clock of one phase of the prover (the reference's `timed!` scopes, prover.rs), printed when ctx->timing is set
 struct PhaseTimer {

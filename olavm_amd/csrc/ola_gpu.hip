@@ -365,6 +365,21 @@ int32_t ola_prove_with_traces(OlaCtx* ctx, const uint64_t* airset, size_t airset
     OLA_CATCH
 }
 
+int32_t ola_set_shard(OlaCtx* ctx, uint32_t rank, uint32_t world, ola_all_gather_fn all_gather, void* user) {
+    OLA_TRY
+    require(ctx, "ctx");
+    require(world >= 1 && world <= 8 && (world & (world - 1)) == 0 && rank < world, "world must be 1, 2, 4 or 8 and rank < world");
+    require(world == 1 || all_gather, "a sharded context needs an all_gather callback");
+    ShardInfo sh;
+    if (world > 1) {
+        sh.rank = rank; sh.world = world;
+        while ((1u << sh.log_world) < world) sh.log_world++;
+        sh.all_gather = all_gather; sh.user = user;
+    }
+    ctx->dev.shard = sh;
+    OLA_CATCH
+}
+
 int32_t ola_air_kernels_available(const uint64_t* airset, size_t airset_words, uint8_t* has_kernel, size_t ntables) {
     OLA_TRY
     require(airset && has_kernel, "null pointer");

@@ -290,15 +290,17 @@ __global__ __launch_bounds__(QW) void quotient_kernel(QuotParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u64* regs = reinterpret_cast<u64*>(smem_raw);
     const int lane = threadIdx.x;
-    const size_t size = P.n << P.qdb;
+    const size_t size = P.out_plane;   // points this launch evaluates (the rank's cosets of the quotient domain)
     const size_t j = (size_t)blockIdx.x * QW + lane;
     const bool active = j < size;
     const size_t jj = active ? j : 0;
     // leaf j = c*n + r  <->  natural row m = bitrev3(c) + 8*bitrev_n(r); next row m + 8 -> r' = bitrev_n(bitrev_n(r) + 1)
-    const size_t c = jj >> P.log_n, r = jj & (P.n - 1);
+    // (buffers hold cosets from P.coset_first on: `cl` indexes memory, `c` is the coset of the evaluation point)
+    const size_t cl = jj >> P.log_n, r = jj & (P.n - 1);
+    const size_t c = cl + P.coset_first;
     const u32 rr = bitrev32((u32)r, P.log_n);
     const size_t rn = bitrev32((rr + 1) & (u32)(P.n - 1), P.log_n);
-    const size_t jn = (c << P.log_n) + rn;
+    const size_t jn = (cl << P.log_n) + rn;
     const u64 m = ((u64)rr << (P.log_N - P.log_n)) + bitrev32((u32)c, P.log_N - P.log_n);
     const u64 x = gl_mul(GL_GENERATOR, gl_mul(P.gN_lo[m & (((u64)1 << P.gN_h) - 1)], P.gN_hi[m >> P.gN_h]));
     const u64 z_last = gl_sub(x, P.g_inv);
@@ -433,9 +435,44 @@ struct DevTable { u64* vals = nullptr; uint32_t log_n = 0; size_t n() const { re
 
 static void write_cap(ByteWriter& w, const std::vector<u64>& cap) { w.cap(cap.data(), cap.size() / 4); }
 
+// PolynomialBatch::from_values / from_coeffs for the whole table, or -- under the coset partition -- this rank's share of
+// it; either way `cap_full` receives the complete Merkle cap (all-gathered from the ranks' slices when sharded).
+static OlaBatch* commit_shared(DeviceCtx* ctx, NttTables& t, const u64* dev_cols, uint32_t ncols, uint32_t log_n, const OlaGpuConfig& cfg,
+                               bool from_values, bool sharded, const ColumnFeed* feed, std::vector<u64>& cap_full) {
+    const size_t len_cap = (size_t)1 << cfg.cap_height;
+    cap_full.assign(len_cap * 4, 0);
+    if (!sharded) {
+        OlaBatch* b = batch_commit(ctx, t, nullptr, dev_cols, ncols, log_n, cfg.rate_bits, cfg.cap_height, from_values, 0, 0, feed);
+        try { batch_read_cap(ctx, *b, cap_full.data()); } catch (...) { batch_destroy(ctx, b); throw; }
+        return b;
+    }
+    OlaBatch* b = batch_commit(ctx, t, nullptr, dev_cols, ncols, log_n, cfg.rate_bits, cfg.cap_height, from_values, ctx->shard.rank,
+                               ctx->shard.log_world, feed);
+    u64* d_full = nullptr;
+    try {
+        const size_t len_local = len_cap >> ctx->shard.log_world;   // the local tree's cap level (batch_read_cap)
+        d_full = (u64*)ctx->alloc(len_cap * 32);
+        shard_all_gather(ctx, b->heap + 4 * len_local, d_full, len_local * 32);
+        HIP_CHECK(hipMemcpyAsync(cap_full.data(), d_full, len_cap * 32, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        ctx->free(d_full);
+    } catch (...) { if (d_full) ctx->free(d_full); batch_destroy(ctx, b); throw; }
+    return b;
+}
+
+// Which tables run on the coset partition: large ones whose quotient domain is the whole LDE (2^qdb = 2^rate_bits cosets,
+// so every rank evaluates an equal share) -- CPU, memory and Poseidon tables in OlaVM.
+static bool table_is_sharded(const DeviceCtx* ctx, const OlaGpuConfig& cfg, const HTable& air, uint32_t log_n) {
+    if (ctx->shard.world <= 1) return false;
+    int qdb = 0;
+    while ((1 << qdb) < air.quotient_degree_factor()) qdb++;
+    return log_n >= ctx->shard.min_log_n && qdb == (int)cfg.rate_bits && ctx->shard.log_world <= cfg.rate_bits &&
+           ctx->shard.log_world <= cfg.cap_height;
+}
+
 static void prove_single_table(DeviceCtx* ctx, NttTables& tables, const OlaGpuConfig& cfg, const HTable& air, const DevTable& tv,
                                const OlaBatch& trace_c, const std::vector<u64>& trace_cap, const std::vector<CtlJob>& ctl,
-                               const u64* params, OlaChallenger& ch, std::vector<uint8_t>& bytes) {
+                               const u64* params, OlaChallenger& ch, std::vector<uint8_t>& bytes, bool sharded) {
     DevBuf mem(ctx);
     const int nch = (int)cfg.num_challenges;
     if (nch != 2) throw OlaError(OLA_E_INVALID_ARG, "num_challenges must be 2");
@@ -444,6 +481,10 @@ static void prove_single_table(DeviceCtx* ctx, NttTables& tables, const OlaGpuCo
     const int rate_bits = (int)cfg.rate_bits;
     const size_t N = n << rate_bits;
     const size_t len_cap = (size_t)1 << cfg.cap_height;
+    // this rank's part of the LDE domain (everything when not sharded)
+    const uint32_t log_world = sharded ? ctx->shard.log_world : 0;
+    const size_t coset_count = ((size_t)1 << rate_bits) >> log_world, coset_first = sharded ? ctx->shard.rank * coset_count : 0;
+    const size_t N_loc = n * coset_count;
 
     challenger_compact(ch);
     // ---- permutation challenges + Z polys (prover.rs:360-377) ----
@@ -514,9 +555,8 @@ static void prove_single_table(DeviceCtx* ctx, NttTables& tables, const OlaGpuCo
     // ---- Zs commitment ----
     std::unique_ptr<PhaseTimer> ph(new PhaseTimer(ctx, "    compute permutation/CTL Z commitment"));
     BatchHolder zs_c(ctx);
-    zs_c.b = batch_commit(ctx, tables, nullptr, zvals, (uint32_t)nz, (uint32_t)degree_bits, cfg.rate_bits, cfg.cap_height, true);
-    std::vector<u64> zs_cap(len_cap * 4);
-    batch_read_cap(ctx, *zs_c.b, zs_cap.data());
+    std::vector<u64> zs_cap;
+    zs_c.b = commit_shared(ctx, tables, zvals, (uint32_t)nz, (uint32_t)degree_bits, cfg, true, sharded, nullptr, zs_cap);
     challenger_observe(ch, zs_cap.data(), zs_cap.size());
     const u64 alpha0 = challenger_get(ch), alpha1 = challenger_get(ch);
 
@@ -530,12 +570,12 @@ static void prove_single_table(DeviceCtx* ctx, NttTables& tables, const OlaGpuCo
     const size_t size = n << qdb;
     // Lagrange first/last on the LDE domain (leaf order)
     u64* lag_coef = mem.alloc(2 * n);
-    u64* lag_lde = mem.alloc(2 * N);
+    u64* lag_lde = mem.alloc(2 * N_loc);
     {
         TwoLevel gt = get_two(tables, degree_bits, 0);
         const u64 n_inv = gl_inv(((u64)1 << degree_bits) % GL_P);
         hipLaunchKernelGGL(lagrange_coeffs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, lag_coef, n, n_inv, gt.lo, gt.hi, gt.h);
-        ntt_lde_leaf_order(tables, lag_coef, lag_lde, degree_bits, rate_bits, 2);
+        ntt_lde_leaf_order(tables, lag_coef, lag_lde, degree_bits, rate_bits, 2, coset_first, coset_count);
     }
     // descriptor for the kernel
     std::vector<u64> desc(18, 0);
@@ -565,15 +605,19 @@ static void prove_single_table(DeviceCtx* ctx, NttTables& tables, const OlaGpuCo
     u64* d_desc = mem.alloc(desc.size());
     HIP_CHECK(hipMemcpyAsync(d_desc, desc.data(), desc.size() * 8, hipMemcpyHostToDevice, ctx->stream));
     u64* qv = mem.alloc(2 * size);
+    // points this rank evaluates: the whole quotient domain, or (sharded: 2^qdb = 2^rate_bits) its cosets of it
+    const size_t plane = sharded ? N_loc : size;
+    u64* qloc = sharded ? mem.alloc(2 * plane) : qv;
     {
         QuotParams P = {};
         P.trace_lde = trace_c.lde; P.zs_lde = zs_c.b->lde; P.lag_lde = lag_lde;
-        P.N = N; P.n = n; P.log_n = degree_bits; P.log_N = degree_bits + rate_bits; P.qdb = qdb;
+        P.N = N_loc; P.n = n; P.log_n = degree_bits; P.log_N = degree_bits + rate_bits; P.qdb = qdb;
+        P.coset_first = (u32)coset_first; P.out_plane = plane;
         TwoLevel gN = get_two(tables, degree_bits + rate_bits, 0);
         P.gN_lo = gN.lo; P.gN_hi = gN.hi; P.gN_h = gN.h;
         P.desc = d_desc;
         P.g_inv = gl_inv(gl_root_of_unity(degree_bits));
-        P.out = qv;
+        P.out = qloc;
         P.n_regs = air.n_regs;
         // OLA_AIR_KERNELS=interpreter forces the generic kernel, =crosscheck runs both and compares (tests)
         const char* mode = getenv("OLA_AIR_KERNELS");
@@ -588,10 +632,10 @@ static void prove_single_table(DeviceCtx* ctx, NttTables& tables, const OlaGpuCo
             if (lds > 160 * 1024) throw OlaError(OLA_E_INVALID_ARG, "constraint program needs too many registers");
             if (lds > 48 * 1024)
                 HIP_CHECK(hipFuncSetAttribute((const void*)quotient_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(quotient_kernel, dim3((unsigned)((size + QW - 1) / QW)), dim3(QW), lds, ctx->stream, P);
+            hipLaunchKernelGGL(quotient_kernel, dim3((unsigned)((plane + QW - 1) / QW)), dim3(QW), lds, ctx->stream, P);
         };
         if (!spec) {
-            run_interpreter(qv);
+            run_interpreter(qloc);
         } else {
             const int K = spec->n_emits;
             std::vector<u64> sd(8 + 2 * (size_t)K, 0);
@@ -619,19 +663,23 @@ static void prove_single_table(DeviceCtx* ctx, NttTables& tables, const OlaGpuCo
             HIP_CHECK(hipStreamSynchronize(ctx->stream));   // sd is a stack-lifetime staging buffer
             QuotParams S = P;
             S.desc = d_sd;
-            hipLaunchKernelGGL(spec->kernel, dim3((unsigned)((size + AIRQ_THREADS - 1) / AIRQ_THREADS)), dim3(AIRQ_THREADS), 0, ctx->stream, S);
+            hipLaunchKernelGGL(spec->kernel, dim3((unsigned)((plane + AIRQ_THREADS - 1) / AIRQ_THREADS)), dim3(AIRQ_THREADS), 0, ctx->stream, S);
             if (crosscheck) {
-                u64* qv2 = mem.alloc(2 * size);
+                u64* qv2 = mem.alloc(2 * plane);
                 run_interpreter(qv2);
                 unsigned* d_flag = (unsigned*)mem.alloc(1);
                 HIP_CHECK(hipMemsetAsync(d_flag, 0, 8, ctx->stream));
-                hipLaunchKernelGGL(any_diff_kernel, dim3((unsigned)((2 * size + 255) / 256)), dim3(256), 0, ctx->stream, qv, qv2, 2 * size, d_flag);
+                hipLaunchKernelGGL(any_diff_kernel, dim3((unsigned)((2 * plane + 255) / 256)), dim3(256), 0, ctx->stream, qloc, qv2, 2 * plane, d_flag);
                 unsigned flag = 0;
                 HIP_CHECK(hipMemcpyAsync(&flag, d_flag, 4, hipMemcpyDeviceToHost, ctx->stream));
                 HIP_CHECK(hipStreamSynchronize(ctx->stream));
                 if (flag) throw OlaError(OLA_E_INTERNAL, std::string("specialised quotient kernel disagrees with the interpreter: ") + spec->name);
             }
         }
+    }
+    if (sharded) {
+        // every rank needs all cosets for the inverse transform: gather the two planes (8 * size bytes each in total)
+        for (int c = 0; c < 2; c++) shard_all_gather(ctx, qloc + (size_t)c * plane, qv + (size_t)c * size, plane * 8);
     }
     // qv is in bit-reversed order of the size-domain: un-reverse, coset iNTT (prover.rs:700-704)
     const int size_bits = degree_bits + qdb;
@@ -660,9 +708,8 @@ static void prove_single_table(DeviceCtx* ctx, NttTables& tables, const OlaGpuCo
     ph.reset();
     ph.reset(new PhaseTimer(ctx, "    compute quotient commitment"));
     BatchHolder q_c(ctx);
-    q_c.b = batch_commit(ctx, tables, nullptr, chunks, (uint32_t)(2 * q), (uint32_t)degree_bits, cfg.rate_bits, cfg.cap_height, false);
-    std::vector<u64> q_cap(len_cap * 4);
-    batch_read_cap(ctx, *q_c.b, q_cap.data());
+    std::vector<u64> q_cap;
+    q_c.b = commit_shared(ctx, tables, chunks, (uint32_t)(2 * q), (uint32_t)degree_bits, cfg, false, sharded, nullptr, q_cap);
     challenger_observe(ch, q_cap.data(), q_cap.size());
 
     // ---- write_proof (serialization.rs:349-358): caps, then opening set + FRI proof ----
@@ -769,9 +816,8 @@ void prove_with_traces(DeviceCtx* ctx, NttTables& tables, const OlaGpuConfig& cf
             canonicalize(ctx, dev[t].vals + (size_t)c0 * n_t, (size_t)(c1 - c0) * n_t);
         };
         commits.emplace_back(new BatchHolder(ctx));
-        commits[t]->b = batch_commit(ctx, tables, nullptr, dev[t].vals, (uint32_t)set.tables[t].ncols, log_n[t], cfg.rate_bits, cfg.cap_height, true,
-                                     0, 0, &feed);
-        batch_read_cap(ctx, *commits[t]->b, caps[t].data());
+        commits[t]->b = commit_shared(ctx, tables, dev[t].vals, (uint32_t)set.tables[t].ncols, log_n[t], cfg, true,
+                                      table_is_sharded(ctx, cfg, set.tables[t], log_n[t]), &feed, caps[t]);
     }
     up.finish();
     for (size_t t = 0; t < nt; t++) challenger_observe(ch, caps[t].data(), caps[t].size());
@@ -793,7 +839,8 @@ void prove_with_traces(DeviceCtx* ctx, NttTables& tables, const OlaGpuConfig& cf
         if (!params && set.tables[t].n_params > 64) throw OlaError(OLA_E_INVALID_ARG, "params required");
         poff += set.tables[t].n_params;
         PhaseTimer tt(ctx, "  table " + std::to_string(t) + " prove_single_table");
-        prove_single_table(ctx, tables, cfg, set.tables[t], dev[t], *commits[t]->b, caps[t], jobs[t], pr, ch, bytes);
+        prove_single_table(ctx, tables, cfg, set.tables[t], dev[t], *commits[t]->b, caps[t], jobs[t], pr, ch, bytes,
+                           table_is_sharded(ctx, cfg, set.tables[t], log_n[t]));
     }
     // compress_challenges (prover.rs:307-320) -- produced by trace generation, carried through
     w.u32((uint32_t)nt);
