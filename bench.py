@@ -88,7 +88,7 @@ def prove_time(be, log_n, reps=3):
                         "Poseidon config, rate_bits 3, 28 queries, 16 PoW bits; host traces in, proof bytes out"}
 
 
-def sharded_commit_time(be, rank, world, log_n, cols, reps=2):
+def sharded_commit_time(be, rank, world, log_n, cols, coll_dev, reps=2):
     """N > 1 only: PolynomialBatch::from_values of the (replicated) 94 x 2^log_n table under the coset partition -- every
     rank interpolates all columns, extends/hashes its 8/N cosets, the cap slices are all-gathered over RCCL.  Reported
     next to the headline metric; a failure here must not lose the headline line."""
@@ -101,13 +101,37 @@ def sharded_commit_time(be, rank, world, log_n, cols, reps=2):
     for _ in range(reps + 1):
         dist.barrier(); torch.cuda.synchronize()
         t0 = time.perf_counter()
-        b, cap = sharding.commit_sharded(be, rank, world, dev_ptr=vals.data_ptr(), ncols=cols, log_n=log_n, device="cuda")
+        b, cap = sharding.commit_sharded(be, rank, world, dev_ptr=vals.data_ptr(), ncols=cols, log_n=log_n, device=coll_dev)
         torch.cuda.synchronize(); dist.barrier()
         times.append(time.perf_counter() - t0)
         b.free()
-    t = sharding.max_over_ranks([min(times[1:])], device="cuda")[0]
+    t = sharding.max_over_ranks([min(times[1:])], device=coll_dev)[0]
     return {"ms": round(t * 1e3, 3), "workload": f"from_values({cols} x 2^{log_n}), rate_bits 3, coset-sharded over {world} GPUs, "
             "replicated iNTT + caps all-gather (RCCL)", "cap_word0": int(cap[0, 0])}
+
+
+def sharded_prove_time(be, rank, world, log_n, coll_dev, reps=2):
+    """N > 1 only: the end-to-end proof on the coset partition (ola_set_shard): every rank proves the same traces with
+    its 8/N cosets of the CPU, memory and Poseidon tables; exchanges go through RCCL.  Same instance as `prove` at N = 1."""
+    import torch
+    import torch.distributed as dist
+    from olavm_amd import sharding
+    from olavm_amd.air import ola_tables as T
+    from tests import tracegen
+    blob = T.ola_stark().blob()
+    traces, params, compress = tracegen.empty_program_instance(log_n=10, range_bits=16, limb_bits=8, log_n_cpu=log_n, log_n_mem=log_n)
+    be.set_shard(rank, world)
+    times, nbytes = [], 0
+    for _ in range(reps + 1):
+        dist.barrier(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        nbytes = len(be.prove_with_traces(blob, traces, params, compress))
+        torch.cuda.synchronize(); dist.barrier()
+        times.append(time.perf_counter() - t0)
+    be.set_shard(0, 1)
+    t = sharding.max_over_ranks([min(times[1:])], device=coll_dev)[0]
+    return {"seconds": round(t, 4), "proof_bytes": nbytes, "exchanges_per_proof": be.shard_calls // (reps + 1),
+            "workload": f"prove_with_traces on the coset partition over {world} GPUs, 12 tables, CPU/memory 2^{log_n} rows"}
 
 
 def main():
@@ -128,10 +152,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the backend has no CPU fallback")
+    # OLA_BENCH_BACKEND=gloo lets several ranks share one GPU (dry run of the N > 1 path on a single-GPU box); the real
+    # multi-GPU run uses RCCL
+    backend = os.environ.get("OLA_BENCH_BACKEND", "nccl")
+    local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
+    coll_dev = "cuda" if backend == "nccl" else "cpu"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     from olavm_amd.backend import Backend, OLA_NTT_EVALUATE
     stream = torch.cuda.current_stream()
@@ -166,16 +198,21 @@ def main():
     elapsed = time.perf_counter() - t0
     dev_ms = ev0.elapsed_time(ev1)
     from olavm_amd import sharding
-    elapsed, dev_ms = sharding.max_over_ranks([elapsed, dev_ms], device="cuda")
+    elapsed, dev_ms = sharding.max_over_ranks([elapsed, dev_ms], device=coll_dev)
 
-    sharded = None
+    sharded = sharded_prove = None
     if world > 1 and world in (2, 4, 8):
         try:
             del data, out, scratch
             torch.cuda.empty_cache()
-            sharded = sharded_commit_time(be, rank, world, args.log_n, cols)
+            sharded = sharded_commit_time(be, rank, world, args.log_n, cols, coll_dev)
         except Exception as e:                       # noqa: BLE001 -- keep the headline line
             sharded = {"error": repr(e)[:200]}
+        if not args.no_prove:
+            try:
+                sharded_prove = sharded_prove_time(be, rank, world, args.log_n, coll_dev)
+            except Exception as e:                   # noqa: BLE001
+                sharded_prove = {"error": repr(e)[:200]}
 
     if rank == 0:
         bytes_per_step = 16.0 * n * cols            # algorithmic: one read + one write of every element
@@ -203,6 +240,8 @@ def main():
         }
         if sharded is not None:
             res["commit_sharded"] = sharded
+        if sharded_prove is not None:
+            res["prove_sharded"] = sharded_prove
         if world == 1 and not args.no_prove:
             del data, out, scratch
             torch.cuda.empty_cache()

@@ -1,7 +1,8 @@
 """Rank-level plumbing for the multi-GPU runs (one process per GPU, torch.distributed; backend "nccl" = RCCL on the GPU
 box, "gloo" in the CPU tests).  The hot path shards by independent units (columns for the standalone NTT, LDE cosets for
-a full proof -- SURVEY F9); there is no data-path collective, only the barrier/max-reduce used for timing and, for a
-proof, the all-gather of Merkle caps (16 x 4 u64 per tree)."""
+a full proof -- SURVEY F9).  The NTT bench has no data-path collective, only the barrier/max-reduce used for timing; a
+commitment all-gathers its Merkle cap slices (16 x 4 u64 per tree) and a full proof on the coset partition additionally
+exchanges quotient values and opened query rows through Backend.set_shard's callback (olavm_amd/backend.py)."""
 import torch
 import torch.distributed as dist
 
