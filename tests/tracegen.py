@@ -206,7 +206,7 @@ def program_padding_trace(n):
 
 
 def empty_program_instance(log_n=3, range_bits=4, limb_bits=2, bitwise_beta=12345, program_beta=67890, log_n_cpu=None, log_n_mem=None,
-                           live=None):
+                           live=None, log_n_poseidon=None):
     """12 traces in `enum Table` order + per-table params + compress_challenges, for ola_stark(range_bits, limb_bits).
     log_n_cpu / log_n_mem override the height of the two tables that dominate a real execution."""
     n = 1 << log_n
@@ -222,7 +222,8 @@ def empty_program_instance(log_n=3, range_bits=4, limb_bits=2, bitwise_beta=1234
     traces = [
         cpu_padding_trace(1 << (log_n_cpu or log_n)), memory_padding_trace(1 << (log_n_mem or log_n)),
         bitwise_trace(bitwise_beta, limb_bits, bw_ops),
-        generate_cmp_trace(cmp_rows_), generate_rc_trace(rc_rows, range_bits), poseidon_padding_trace(n, pos_live),
+        generate_cmp_trace(cmp_rows_), generate_rc_trace(rc_rows, range_bits),
+        poseidon_padding_trace(1 << log_n_poseidon, 1 << (log_n_poseidon - 1)) if log_n_poseidon else poseidon_padding_trace(n, pos_live),
         flag_padding_trace(T.NUM_POSEIDON_CHUNK_COLS, n, T.COL_POSEIDON_CHUNK_IS_PADDING_LINE),
         flag_padding_trace(T.NUM_COL_ST, n, T.COL_ST_IS_PADDING),
         tape_padding_trace(n),
