@@ -63,6 +63,9 @@ int32_t ola_gpu_init(const OlaGpuConfig* cfg, OlaCtx** out_ctx);
 int32_t ola_gpu_free(OlaCtx* ctx);
 const char* ola_gpu_last_error(void);
 int32_t ola_gpu_sync(OlaCtx* ctx);
+/* Scratch and commitment buffers are recycled through a per-context cache (tens of GB after a 2^22-row proof); this returns
+ * the cached blocks to the driver.  Live OlaBatch objects are not affected. */
+int32_t ola_gpu_trim(OlaCtx* ctx);
 
 /* ---- NTT family: replaces gpu_method and the cfft CPU paths --------------------------------------------
  * op selects the reference function (plonky2/field/src/cfft/mod.rs):

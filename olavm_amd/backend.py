@@ -98,7 +98,7 @@ EXPORTS = [
     "ola_commit_values_dev", "ola_commit_coeffs_dev", "ola_batch_free", "ola_batch_shape", "ola_batch_get_coeffs",
     "ola_batch_get_leaf", "ola_batch_get_lde_row", "ola_challenger_init", "ola_challenger_observe",
     "ola_challenger_get", "ola_challenger_compact", "ola_open_and_prove", "ola_pow", "ola_prove_with_traces",
-    "ola_air_kernels_available", "ola_commit_values_shard", "ola_commit_values_shard_dev", "ola_set_shard",
+    "ola_air_kernels_available", "ola_commit_values_shard", "ola_commit_values_shard_dev", "ola_set_shard", "ola_gpu_trim",
 ]
 
 
@@ -283,6 +283,10 @@ class Backend:
             ptrs = (U64P * ncols)(*[cols[i].ctypes.data_as(U64P) for i in range(ncols)])
             self._chk(self.lib.ola_commit_values_shard(self.ctx, ptrs, ncols, int(n).bit_length() - 1, rank, world, C.byref(h), _p(cap)))
         return Batch(self, h, cap, shard_log_world=lw)
+
+    def trim(self):
+        """Return the context's cached device buffers to the driver (ola_gpu_trim)."""
+        self._chk(self.lib.ola_gpu_trim(self.ctx))
 
     def set_shard(self, rank, world, group=None):
         """Coset-partitioned proving (ola_set_shard): this context is rank `rank` of `world` GPUs.  The all-gather the

@@ -365,6 +365,13 @@ int32_t ola_prove_with_traces(OlaCtx* ctx, const uint64_t* airset, size_t airset
     OLA_CATCH
 }
 
+int32_t ola_gpu_trim(OlaCtx* ctx) {
+    OLA_TRY
+    require(ctx, "ctx");
+    ctx->dev.release_cache();
+    OLA_CATCH
+}
+
 int32_t ola_set_shard(OlaCtx* ctx, uint32_t rank, uint32_t world, ola_all_gather_fn all_gather, void* user) {
     OLA_TRY
     require(ctx, "ctx");
