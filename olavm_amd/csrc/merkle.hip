@@ -97,6 +97,26 @@ __global__ __launch_bounds__(256) void merkle_level_kernel(u64* __restrict__ hea
     o[1] = make_ulonglong2(s[2], s[3]);
 }
 
+// The top of a tree in one launch: levels of `first` nodes and fewer (first <= blockDim.x), down to the level of `last`
+// nodes, one workgroup, a barrier between levels.  Saves a launch per level where a level is a handful of waves anyway.
+__global__ __launch_bounds__(512) void merkle_top_kernel(u64* __restrict__ heap, size_t first, size_t last) {
+    const size_t t = threadIdx.x;
+    for (size_t level = first; level >= last && level >= 1; level >>= 1) {
+        if (t < level) {
+            const size_t i = level + t;
+            const ulonglong2* ch = reinterpret_cast<const ulonglong2*>(heap + 8 * i);
+            const ulonglong2 c0 = ch[0], c1 = ch[1], c2 = ch[2], c3 = ch[3];
+            u64 s[12] = {c0.x, c0.y, c1.x, c1.y, c2.x, c2.y, c3.x, c3.y, 0, 0, 0, 0};
+            poseidon_permute(s);
+            ulonglong2* o = reinterpret_cast<ulonglong2*>(heap + 4 * i);
+            o[0] = make_ulonglong2(s[0], s[1]);
+            o[1] = make_ulonglong2(s[2], s[3]);
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+}
+
 __global__ __launch_bounds__(256) void poseidon_states_kernel(u64* __restrict__ states, size_t n) {
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
@@ -138,10 +158,13 @@ void launch_leaf_hash_ext(DeviceCtx* ctx, const u64* pa, const u64* pb, int arit
 // heap[N..2N) must hold the leaf digests; fills heap[2^cap_height .. N): like the reference (merkle_tree/mod.rs:228-233)
 // nothing above the cap is ever hashed
 void launch_merkle_build(DeviceCtx* ctx, u64* heap, size_t num_leaves, uint32_t cap_height) {
-    for (size_t level = num_leaves / 2; level >= ((size_t)1 << cap_height); level /= 2) {
+    const size_t last = (size_t)1 << cap_height, top = 512;   // levels of <= `top` nodes share one launch
+    size_t level = num_leaves / 2;
+    for (; level >= last && level > top; level /= 2) {
         const unsigned blocks = (unsigned)((level + 255) / 256);
         hipLaunchKernelGGL(merkle_level_kernel, dim3(blocks), dim3(256), 0, ctx->stream, heap, level, level);
     }
+    if (level >= last && level >= 1) hipLaunchKernelGGL(merkle_top_kernel, dim3(1), dim3((unsigned)top), 0, ctx->stream, heap, level, last);
 }
 void launch_poseidon_states(DeviceCtx* ctx, u64* states, size_t n) {
     const unsigned blocks = (unsigned)((n + 255) / 256);

@@ -143,10 +143,14 @@ __device__ __forceinline__ u64 dev_lincol(const u64* __restrict__ d, u32& p, con
 }
 
 // CTL factor column: out[i] = filter(i) ? combine(i) : 1   (cross_table_lookup.rs:284-311)
-__global__ __launch_bounds__(256) void ctl_factor_kernel(const u64* __restrict__ trace, size_t n, const u64* __restrict__ desc,
-                                                         u64* __restrict__ out, unsigned* __restrict__ bad_filter) {
+// One Z column per blockIdx.y: its descriptor starts at desc_all[offs[y]], its output at out_all + y*n.
+__global__ __launch_bounds__(256) void ctl_factor_kernel(const u64* __restrict__ trace, size_t n, const u64* __restrict__ desc_all,
+                                                         const u64* __restrict__ offs, u64* __restrict__ out_all,
+                                                         unsigned* __restrict__ bad_filter) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    const u64* __restrict__ desc = desc_all + offs[blockIdx.y];
+    u64* __restrict__ out = out_all + (size_t)blockIdx.y * n;
     u32 p = 0;
     const u64 beta = desc[p++], gamma = desc[p++];
     const u32 ncol = (u32)desc[p++];
@@ -190,8 +194,11 @@ __global__ __launch_bounds__(256) void perm_factor_kernel(const u64* __restrict_
 
 // multiplicative inclusive prefix scan, 3 phases, blocks of 2048
 #define PSCAN_B 2048
-__global__ __launch_bounds__(256) void pscan_local_kernel(u64* __restrict__ d, size_t n, u64* __restrict__ block_tot) {
+// (the scan kernels take one column per blockIdx.y: data at d + y*n, block totals at block_tot + y*tot_stride)
+__global__ __launch_bounds__(256) void pscan_local_kernel(u64* __restrict__ d_all, size_t n, u64* __restrict__ tot_all, size_t tot_stride) {
     __shared__ u64 sh[256];
+    u64* __restrict__ d = d_all + (size_t)blockIdx.y * n;
+    u64* __restrict__ block_tot = tot_all + (size_t)blockIdx.y * tot_stride;
     const size_t b0 = (size_t)blockIdx.x * PSCAN_B;
     const int t = threadIdx.x;
     u64 v[8];
@@ -222,8 +229,9 @@ __global__ __launch_bounds__(256) void pscan_local_kernel(u64* __restrict__ d, s
 }
 // exclusive running product of the block totals, one workgroup: each thread owns a contiguous chunk, chunk totals
 // are combined with a Hillis-Steele scan in LDS
-__global__ __launch_bounds__(256) void pscan_totals_kernel(u64* __restrict__ tot, size_t nblocks) {
+__global__ __launch_bounds__(256) void pscan_totals_kernel(u64* __restrict__ tot_all, size_t nblocks, size_t tot_stride) {
     __shared__ u64 sh[256];
+    u64* __restrict__ tot = tot_all + (size_t)blockIdx.y * tot_stride;
     const int t = threadIdx.x;
     const size_t per = (nblocks + 255) / 256;
     const size_t lo = (size_t)t * per, hi = lo + per < nblocks ? lo + per : nblocks;
@@ -246,9 +254,11 @@ __global__ __launch_bounds__(256) void pscan_totals_kernel(u64* __restrict__ tot
         acc = gl_mul(acc, v);
     }
 }
-__global__ __launch_bounds__(256) void pscan_apply_kernel(u64* __restrict__ d, size_t n, const u64* __restrict__ tot) {
+__global__ __launch_bounds__(256) void pscan_apply_kernel(u64* __restrict__ d_all, size_t n, const u64* __restrict__ tot_all, size_t tot_stride) {
     const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
+    u64* __restrict__ d = d_all + (size_t)blockIdx.y * n;
+    const u64* __restrict__ tot = tot_all + (size_t)blockIdx.y * tot_stride;
     d[k] = gl_mul(d[k], tot[k / PSCAN_B]);
 }
 // exclusive form: out[0] = 1, out[i] = incl[i-1]
@@ -258,12 +268,15 @@ __global__ __launch_bounds__(256) void shift_right_kernel(const u64* __restrict_
     out[k] = k ? incl[k - 1] : 1;
 }
 
-static void product_scan_inclusive(DeviceCtx* ctx, u64* col, size_t n, u64* tot) {
-    const size_t nblocks = (n + PSCAN_B - 1) / PSCAN_B;
-    hipLaunchKernelGGL(pscan_local_kernel, dim3((unsigned)nblocks), dim3(256), 0, ctx->stream, col, n, tot);
+// running products of `ncols` adjacent columns (n each) in place; tot: scratch of ncols * pscan_tot_stride(n) words
+static size_t pscan_tot_stride(size_t n) { return (n + PSCAN_B - 1) / PSCAN_B + 1; }
+static void product_scan_inclusive(DeviceCtx* ctx, u64* cols, size_t n, u64* tot, size_t ncols = 1) {
+    if (ncols == 0) return;
+    const size_t nblocks = (n + PSCAN_B - 1) / PSCAN_B, ts = pscan_tot_stride(n);
+    hipLaunchKernelGGL(pscan_local_kernel, dim3((unsigned)nblocks, (unsigned)ncols), dim3(256), 0, ctx->stream, cols, n, tot, ts);
     if (nblocks > 1) {
-        hipLaunchKernelGGL(pscan_totals_kernel, dim3(1), dim3(256), 0, ctx->stream, tot, nblocks);
-        hipLaunchKernelGGL(pscan_apply_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, col, n, tot);
+        hipLaunchKernelGGL(pscan_totals_kernel, dim3(1, (unsigned)ncols), dim3(256), 0, ctx->stream, tot, nblocks, ts);
+        hipLaunchKernelGGL(pscan_apply_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)ncols), dim3(256), 0, ctx->stream, cols, n, tot, ts);
     }
 }
 
@@ -496,7 +509,7 @@ static void prove_single_table(DeviceCtx* ctx, NttTables& tables, const OlaGpuCo
     const int nz = nperm + (int)ctl.size();
     if (nz == 0) throw OlaError(OLA_E_INVALID_ARG, "No CTL?");
     u64* zvals = mem.alloc((size_t)nz * n);
-    u64* tot = mem.alloc((n + PSCAN_B - 1) / PSCAN_B + 1);
+    u64* tot = mem.alloc(pscan_tot_stride(n) * std::max<size_t>(1, ctl.size()));
     u64* tmpcol = mem.alloc(n);
     // perm descriptors (also reused by the quotient kernel)
     std::vector<u64> perm_desc;
@@ -540,11 +553,15 @@ static void prove_single_table(DeviceCtx* ctx, NttTables& tables, const OlaGpuCo
     if (!ctl_desc.empty()) HIP_CHECK(hipMemcpyAsync(d_cd, ctl_desc.data(), ctl_desc.size() * 8, hipMemcpyHostToDevice, ctx->stream));
     unsigned* d_bad_filter = (unsigned*)mem.alloc(1);
     HIP_CHECK(hipMemsetAsync(d_bad_filter, 0, 8, ctx->stream));
-    for (size_t i = 0; i < ctl.size(); i++) {
-        u64* zc = zvals + (size_t)(nperm + i) * n;
-        hipLaunchKernelGGL(ctl_factor_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, tv.vals, n, d_cd + ctl_off[i], zc,
-                           d_bad_filter);
-        product_scan_inclusive(ctx, zc, n, tot);
+    if (!ctl.empty()) {   // all CTL Z columns of the table in one launch per step
+        std::vector<u64> offs(ctl_off.begin(), ctl_off.end());
+        u64* d_offs = mem.alloc(offs.size());
+        HIP_CHECK(hipMemcpyAsync(d_offs, offs.data(), offs.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+        u64* zc = zvals + (size_t)nperm * n;
+        hipLaunchKernelGGL(ctl_factor_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)ctl.size()), dim3(256), 0, ctx->stream, tv.vals, n, d_cd,
+                           d_offs, zc, d_bad_filter);
+        product_scan_inclusive(ctx, zc, n, tot, ctl.size());
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));   // offs is a stack-lifetime staging buffer
     }
     if (!ctl.empty()) {
         unsigned bad = 0;
