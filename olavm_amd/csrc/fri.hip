@@ -337,8 +337,17 @@ static void query_leaves(DeviceCtx* ctx, const OlaBatch& b, const size_t* xs, in
 }
 
 // all polynomials of a batch at one or two extension points -> host vectors
-static void eval_batch(DevBuf& mem, const OlaBatch& b, int npoints, ExtPow p0, ExtPow p1, std::vector<Ext2>* out0,
-                       std::vector<Ext2>* out1) {
+// (two phases so that the evaluations of all oracles share one synchronisation: launch + async read-back, then collect)
+struct EvalJob {
+    std::vector<u64> part;
+    unsigned nchunks = 0;
+    uint32_t ncols = 0;
+    int npoints = 0;
+    std::vector<Ext2>* out0 = nullptr;
+    std::vector<Ext2>* out1 = nullptr;
+};
+static void eval_batch_launch(DevBuf& mem, const OlaBatch& b, int npoints, ExtPow p0, ExtPow p1, std::vector<Ext2>* out0,
+                              std::vector<Ext2>* out1, EvalJob& job) {
     DeviceCtx* ctx = mem.ctx;
     const size_t n = b.n();
     const size_t chunk_len = std::max<size_t>(4096, (n + 255) / 256);
@@ -348,15 +357,17 @@ static void eval_batch(DevBuf& mem, const OlaBatch& b, int npoints, ExtPow p0, E
     u64* d_part = mem.alloc(pelems);
     hipLaunchKernelGGL(eval_points_kernel, dim3(nchunks, groups), dim3(256), 0, ctx->stream, b.coeffs, n, (int)b.ncols, p0, p1,
                        npoints, chunk_len, d_part);
-    std::vector<u64> part(pelems);
-    HIP_CHECK(hipMemcpyAsync(part.data(), d_part, pelems * 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    for (int p = 0; p < npoints; p++) {
-        std::vector<Ext2>& o = p == 0 ? *out0 : *out1;
-        o.assign(b.ncols, ext_make(0, 0));
-        for (unsigned ch = 0; ch < nchunks; ch++)
-            for (uint32_t c = 0; c < b.ncols; c++) {
-                const u64* v = &part[(((size_t)p * nchunks + ch) * b.ncols + c) * 2];
+    job.part.resize(pelems);
+    job.nchunks = nchunks; job.ncols = b.ncols; job.npoints = npoints; job.out0 = out0; job.out1 = out1;
+    HIP_CHECK(hipMemcpyAsync(job.part.data(), d_part, pelems * 8, hipMemcpyDeviceToHost, ctx->stream));
+}
+static void eval_batch_collect(const EvalJob& job) {
+    for (int p = 0; p < job.npoints; p++) {
+        std::vector<Ext2>& o = p == 0 ? *job.out0 : *job.out1;
+        o.assign(job.ncols, ext_make(0, 0));
+        for (unsigned ch = 0; ch < job.nchunks; ch++)
+            for (uint32_t c = 0; c < job.ncols; c++) {
+                const u64* v = &job.part[(((size_t)p * job.nchunks + ch) * job.ncols + c) * 2];
                 o[c] = ext_add(o[c], ext_make(v[0], v[1]));
             }
     }
@@ -430,10 +441,15 @@ void open_and_prove(DeviceCtx* ctx, NttTables& tables, const OlaGpuConfig& cfg, 
     ExtPow pz = make_ext_pow(mem, zeta, degree_bits), pzn = make_ext_pow(mem, zeta_next, degree_bits),
            pgi = make_ext_pow(mem, g_inv, degree_bits);
     std::vector<Ext2> local, next, zs_local, zs_next, q_local, zs_last_all, dummy;
-    eval_batch(mem, trace, 2, pz, pzn, &local, &next);
-    eval_batch(mem, zs, 2, pz, pzn, &zs_local, &zs_next);
-    eval_batch(mem, quot, 1, pz, pz, &q_local, &dummy);
-    eval_batch(mem, zs, 1, pgi, pgi, &zs_last_all, &dummy);
+    {
+        EvalJob jobs[4];
+        eval_batch_launch(mem, trace, 2, pz, pzn, &local, &next, jobs[0]);
+        eval_batch_launch(mem, zs, 2, pz, pzn, &zs_local, &zs_next, jobs[1]);
+        eval_batch_launch(mem, quot, 1, pz, pz, &q_local, &dummy, jobs[2]);
+        eval_batch_launch(mem, zs, 1, pgi, pgi, &zs_last_all, &dummy, jobs[3]);
+        HIP_CHECK(hipStreamSynchronize(mem.ctx->stream));
+        for (auto& j : jobs) eval_batch_collect(j);
+    }
     std::vector<u64> ctl_last;
     for (int i = (int)nperm; i < Z; i++) ctl_last.push_back(zs_last_all[i].a);
 
@@ -553,15 +569,17 @@ void open_and_prove(DeviceCtx* ctx, NttTables& tables, const OlaGpuConfig& cfg, 
     std::vector<int> ldepth(layers.size());
     {
         std::vector<size_t> cur = xs;
-        unsigned long long* d_idx = (unsigned long long*)mem.alloc(nq);
+        std::vector<std::vector<unsigned long long>> h_idx_all(layers.size());   // staging buffers live until the one sync below
         for (size_t li = 0; li < layers.size(); li++) {
+            unsigned long long* d_idx = (unsigned long long*)mem.alloc(nq);
             FriLayer& L = layers[li];
             const int arity = 1 << L.arity_bits;
             const size_t nleaves = L.len >> L.arity_bits;
             int lb = 0;
             while (((size_t)1 << lb) < nleaves) lb++;
             ldepth[li] = lb - (int)cfg.cap_height;
-            std::vector<unsigned long long> h_idx(nq);
+            std::vector<unsigned long long>& h_idx = h_idx_all[li];
+            h_idx.resize(nq);
             for (int r = 0; r < nq; r++) { cur[r] >>= L.arity_bits; h_idx[r] = cur[r]; }
             HIP_CHECK(hipMemcpyAsync(d_idx, h_idx.data(), nq * 8, hipMemcpyHostToDevice, ctx->stream));
             u64* d_rows = mem.alloc((size_t)nq * arity * 2);
@@ -575,8 +593,8 @@ void open_and_prove(DeviceCtx* ctx, NttTables& tables, const OlaGpuConfig& cfg, 
                 lpaths[li].resize((size_t)nq * ldepth[li] * 4);
                 HIP_CHECK(hipMemcpyAsync(lpaths[li].data(), d_paths, lpaths[li].size() * 8, hipMemcpyDeviceToHost, ctx->stream));
             }
-            HIP_CHECK(hipStreamSynchronize(ctx->stream));
         }
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
     }
 
     // ---- serialise the FRI proof (serialization.rs:305-317) ----

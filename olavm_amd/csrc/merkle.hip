@@ -11,11 +11,16 @@
 // Leaves are read column-major ([col][leaf]) so consecutive lanes read consecutive addresses.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "device_ctx.h"
 #include "gl.cuh"
 #include "poseidon.cuh"
 
 namespace ola {
+
+// batches up to this many states / nodes / leaves use the quad-cooperative (latency-oriented) kernels
+static const size_t QUAD_MAX = 8192;
 
 // leaf j = (cols[0][j], cols[1][j], ...), column c at base + c*col_stride
 __global__ __launch_bounds__(256) void leaf_hash_colmajor_kernel(const u64* __restrict__ base, size_t col_stride,
@@ -83,6 +88,82 @@ __global__ __launch_bounds__(256) void leaf_hash_ext_kernel(const u64* __restric
     o[1] = make_ulonglong2(s[2], s[3]);
 }
 
+// ---- quad-cooperative variants (4 threads per leaf / node, poseidon.cuh): same digests, used when the batch is too small
+// to fill the chip, where the latency of a permutation is what matters.  Lane q of a quad owns sponge lanes 3q..3q+2.
+#define QUAD_PROLOGUE(count)                                            \
+    const size_t g_ = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   \
+    const size_t j_ = g_ >> 2;                                         \
+    const int q = (int)(g_ & 3);                                       \
+    const bool live = j_ < (count);                                    \
+    const size_t j = live ? j_ : (count) - 1; /* surplus lanes redo the last item so that quads stay converged */
+__device__ __forceinline__ void quad_store_digest(u64* __restrict__ out4, const u64 (&x)[3], int q, bool live) {
+    if (!live) return;
+    if (q == 0) { out4[0] = x[0]; out4[1] = x[1]; out4[2] = x[2]; }
+    if (q == 1) out4[3] = x[0];
+}
+
+__global__ __launch_bounds__(256) void leaf_hash_colmajor_quad_kernel(const u64* __restrict__ base, size_t col_stride, int ncols,
+                                                                       size_t num_leaves, u64* __restrict__ out) {
+    QUAD_PROLOGUE(num_leaves)
+    u64 x[3] = {0, 0, 0};
+    for (int c0 = 0; c0 < ncols; c0 += 8) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const int e = 3 * q + k;   // sponge lane
+            if (e < 8 && c0 + e < ncols) x[k] = gl_canon(base[(size_t)(c0 + e) * col_stride + j]);
+        }
+        poseidon_permute_quad(x, q);
+    }
+    quad_store_digest(out + j * 4, x, q, live);
+}
+
+__global__ __launch_bounds__(256) void leaf_hash_rowmajor_quad_kernel(const u64* __restrict__ rows, size_t row_len, size_t num_leaves,
+                                                                       u64* __restrict__ out) {
+    QUAD_PROLOGUE(num_leaves)
+    const u64* r = rows + j * row_len;
+    u64 x[3] = {0, 0, 0};
+    for (size_t c0 = 0; c0 < row_len; c0 += 8) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const size_t e = 3 * q + k;
+            if (e < 8 && c0 + e < row_len) x[k] = gl_canon(r[c0 + e]);
+        }
+        poseidon_permute_quad(x, q);
+    }
+    quad_store_digest(out + j * 4, x, q, live);
+}
+
+__global__ __launch_bounds__(256) void leaf_hash_ext_quad_kernel(const u64* __restrict__ plane_a, const u64* __restrict__ plane_b, int arity,
+                                                                  size_t num_leaves, u64* __restrict__ out) {
+    QUAD_PROLOGUE(num_leaves)
+    u64 x[3] = {0, 0, 0};
+    for (int k0 = 0; k0 < arity; k0 += 4) {   // sponge lane e = 2*kk (+1): extension element k0 + e/2, plane e & 1
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const int e = 3 * q + k;
+            if (e < 8 && k0 + e / 2 < arity) x[k] = ((e & 1) ? plane_b : plane_a)[j * arity + k0 + e / 2];
+        }
+        poseidon_permute_quad(x, q);
+    }
+    quad_store_digest(out + j * 4, x, q, live);
+}
+
+// node i = H(heap[2i] || heap[2i+1]) for i in [first, first + count)
+__device__ __forceinline__ void quad_hash_node(u64* __restrict__ heap, size_t i, int q, bool live) {
+    u64 x[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const int e = 3 * q + k;
+        x[k] = e < 8 ? heap[8 * i + e] : 0;   // the two child digests are adjacent
+    }
+    poseidon_permute_quad(x, q);
+    quad_store_digest(heap + 4 * i, x, q, live);
+}
+__global__ __launch_bounds__(256) void merkle_level_quad_kernel(u64* __restrict__ heap, size_t first, size_t count) {
+    QUAD_PROLOGUE(count)
+    quad_hash_node(heap, first + j, q, live);
+}
+
 // parents [first, first+count) of a heap-ordered digest array
 __global__ __launch_bounds__(256) void merkle_level_kernel(u64* __restrict__ heap, size_t first, size_t count) {
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -97,23 +178,35 @@ __global__ __launch_bounds__(256) void merkle_level_kernel(u64* __restrict__ hea
     o[1] = make_ulonglong2(s[2], s[3]);
 }
 
-// The top of a tree in one launch: levels of `first` nodes and fewer (first <= blockDim.x), down to the level of `last`
-// nodes, one workgroup, a barrier between levels.  Saves a launch per level where a level is a handful of waves anyway.
-__global__ __launch_bounds__(512) void merkle_top_kernel(u64* __restrict__ heap, size_t first, size_t last) {
-    const size_t t = threadIdx.x;
+// The top of a tree in one launch: levels of `first` nodes and fewer (4 * first <= blockDim.x), down to the level of `last`
+// nodes, one workgroup of quads, a barrier between levels.
+__global__ __launch_bounds__(1024) void merkle_top_kernel(u64* __restrict__ heap, size_t first, size_t last) {
+    const size_t t = threadIdx.x >> 2;
+    const int q = threadIdx.x & 3;
+    const size_t wave_first = (threadIdx.x & ~63u) >> 2;   // first node index of this wavefront's 16 quads
     for (size_t level = first; level >= last && level >= 1; level >>= 1) {
-        if (t < level) {
-            const size_t i = level + t;
-            const ulonglong2* ch = reinterpret_cast<const ulonglong2*>(heap + 8 * i);
-            const ulonglong2 c0 = ch[0], c1 = ch[1], c2 = ch[2], c3 = ch[3];
-            u64 s[12] = {c0.x, c0.y, c1.x, c1.y, c2.x, c2.y, c3.x, c3.y, 0, 0, 0, 0};
-            poseidon_permute(s);
-            ulonglong2* o = reinterpret_cast<ulonglong2*>(heap + 4 * i);
-            o[0] = make_ulonglong2(s[0], s[1]);
-            o[1] = make_ulonglong2(s[2], s[3]);
+        if (wave_first < level) {   // wavefronts without a node of this level only wait at the barrier
+            const bool live = t < level;
+            quad_hash_node(heap, level + (live ? t : level - 1), q, live);
         }
         __threadfence_block();
         __syncthreads();
+    }
+}
+
+// quad-cooperative permutation of whole states (4 threads per state); used for small n
+__global__ __launch_bounds__(256) void poseidon_states_quad_kernel(u64* __restrict__ states, size_t n) {
+    const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t t = g >> 2;
+    const int q = (int)(g & 3);
+    const size_t tt = t < n ? t : n - 1;   // keep whole quads converged; the surplus lanes redo the last state
+    u64 x[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) x[k] = gl_canon(states[tt * 12 + 3 * q + k]);
+    poseidon_permute_quad(x, q);
+    if (t < n) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) states[t * 12 + 3 * q + k] = x[k];
     }
 }
 
@@ -143,30 +236,53 @@ void poseidon_init(DeviceCtx*) { poseidon_upload_constants(); }
 
 void launch_leaf_hash_colmajor(DeviceCtx* ctx, const u64* base, size_t col_stride, int ncols, size_t num_leaves,
                                u64* out) {
+    if (num_leaves <= QUAD_MAX) {
+        hipLaunchKernelGGL(leaf_hash_colmajor_quad_kernel, dim3((unsigned)((4 * num_leaves + 255) / 256)), dim3(256), 0, ctx->stream, base,
+                           col_stride, ncols, num_leaves, out);
+        return;
+    }
     const unsigned blocks = (unsigned)((num_leaves + 255) / 256);
     hipLaunchKernelGGL(leaf_hash_colmajor_kernel, dim3(blocks), dim3(256), 0, ctx->stream, base, col_stride, ncols,
                        num_leaves, out);
 }
 void launch_leaf_hash_rowmajor(DeviceCtx* ctx, const u64* rows, size_t row_len, size_t num_leaves, u64* out) {
+    if (num_leaves <= QUAD_MAX) {
+        hipLaunchKernelGGL(leaf_hash_rowmajor_quad_kernel, dim3((unsigned)((4 * num_leaves + 255) / 256)), dim3(256), 0, ctx->stream, rows,
+                           row_len, num_leaves, out);
+        return;
+    }
     const unsigned blocks = (unsigned)((num_leaves + 255) / 256);
     hipLaunchKernelGGL(leaf_hash_rowmajor_kernel, dim3(blocks), dim3(256), 0, ctx->stream, rows, row_len, num_leaves, out);
 }
 void launch_leaf_hash_ext(DeviceCtx* ctx, const u64* pa, const u64* pb, int arity, size_t num_leaves, u64* out) {
+    if (num_leaves <= QUAD_MAX) {
+        hipLaunchKernelGGL(leaf_hash_ext_quad_kernel, dim3((unsigned)((4 * num_leaves + 255) / 256)), dim3(256), 0, ctx->stream, pa, pb, arity,
+                           num_leaves, out);
+        return;
+    }
     const unsigned blocks = (unsigned)((num_leaves + 255) / 256);
     hipLaunchKernelGGL(leaf_hash_ext_kernel, dim3(blocks), dim3(256), 0, ctx->stream, pa, pb, arity, num_leaves, out);
 }
 // heap[N..2N) must hold the leaf digests; fills heap[2^cap_height .. N): like the reference (merkle_tree/mod.rs:228-233)
 // nothing above the cap is ever hashed
 void launch_merkle_build(DeviceCtx* ctx, u64* heap, size_t num_leaves, uint32_t cap_height) {
-    const size_t last = (size_t)1 << cap_height, top = 512;   // levels of <= `top` nodes share one launch
+    const size_t last = (size_t)1 << cap_height, top = 256;   // levels of <= `top` nodes share one launch (1024 threads)
     size_t level = num_leaves / 2;
     for (; level >= last && level > top; level /= 2) {
-        const unsigned blocks = (unsigned)((level + 255) / 256);
-        hipLaunchKernelGGL(merkle_level_kernel, dim3(blocks), dim3(256), 0, ctx->stream, heap, level, level);
+        if (level <= QUAD_MAX) {
+            hipLaunchKernelGGL(merkle_level_quad_kernel, dim3((unsigned)((4 * level + 255) / 256)), dim3(256), 0, ctx->stream, heap, level, level);
+        } else {
+            hipLaunchKernelGGL(merkle_level_kernel, dim3((unsigned)((level + 255) / 256)), dim3(256), 0, ctx->stream, heap, level, level);
+        }
     }
-    if (level >= last && level >= 1) hipLaunchKernelGGL(merkle_top_kernel, dim3(1), dim3((unsigned)top), 0, ctx->stream, heap, level, last);
+    if (level >= last && level >= 1) hipLaunchKernelGGL(merkle_top_kernel, dim3(1), dim3(1024), 0, ctx->stream, heap, level, last);
 }
 void launch_poseidon_states(DeviceCtx* ctx, u64* states, size_t n) {
+    if (n == 0) return;
+    if (n <= QUAD_MAX) {
+        hipLaunchKernelGGL(poseidon_states_quad_kernel, dim3((unsigned)((4 * n + 255) / 256)), dim3(256), 0, ctx->stream, states, n);
+        return;
+    }
     const unsigned blocks = (unsigned)((n + 255) / 256);
     hipLaunchKernelGGL(poseidon_states_kernel, dim3(blocks), dim3(256), 0, ctx->stream, states, n);
 }
@@ -175,7 +291,8 @@ u64 run_pow(DeviceCtx* ctx, const u64 h[4], u32 bits) {
     unsigned long long* d_best = (unsigned long long*)ctx->alloc(8);
     const unsigned long long none = ~0ull;
     unsigned long long best = none;
-    const u64 batch = 1ull << 20;
+    // expected witness ~2^bits: batches of 4 * 2^bits nonces find it in the first launch 98 % of the time
+    const u64 batch = std::max<u64>((u64)1 << 14, (u64)4 << bits);
     for (u64 start = 0; best == none; start += batch) {
         HIP_CHECK(hipMemcpyAsync(d_best, &none, 8, hipMemcpyHostToDevice, ctx->stream));
         hipLaunchKernelGGL(pow_kernel, dim3((unsigned)(batch / 256)), dim3(256), 0, ctx->stream, h[0], h[1], h[2], h[3],

@@ -151,6 +151,69 @@ __device__ __forceinline__ void poseidon_permute(u64 (&s)[12]) {
 #pragma unroll
     for (int i = 0; i < 12; i++) s[i] = gl_canon(s[i]);
 }
+// ------------------------------------------------------------------------------------------------ quad-cooperative form
+// Latency-oriented variant for small batches (the upper levels of every Merkle tree, the trees of small tables): FOUR
+// lanes of a DPP quad share one state, lane q = lane & 3 holding elements 3q, 3q+1, 3q+2.  The twelve S-boxes of a full
+// round run three per lane, and the MDS layer -- a circulant -- is evaluated on the inputs ROTATED by 3q (fetched from
+// the other lanes with quad_perm DPP moves), which makes the coefficients the same compile-time constants on every lane.
+// One permutation is then a dependent chain of ~8 k instructions instead of ~19 k: a tree level that does not fill the
+// chip anyway finishes in less than half the time.  Same function, same outputs as poseidon_permute.
+template <int ROT>
+__device__ __forceinline__ u32 quad_rot(u32 v) {
+    // lane i of each quad reads lane (i + ROT) & 3
+    constexpr int ctrl = ((0 + ROT) & 3) | (((1 + ROT) & 3) << 2) | (((2 + ROT) & 3) << 4) | (((3 + ROT) & 3) << 6);
+    return (u32)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, 0xF, 0xF, false);
+}
+
+__device__ __forceinline__ void mds_quad(u64 (&x)[3], int q) {
+    constexpr u32 C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+    u32 l[12], h[12];   // y_m = element (m + 3q) mod 12
+#pragma unroll
+    for (int k = 0; k < 3; k++) { l[k] = (u32)x[k]; h[k] = (u32)(x[k] >> 32); }
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        l[3 + k] = quad_rot<1>(l[k]); h[3 + k] = quad_rot<1>(h[k]);
+        l[6 + k] = quad_rot<2>(l[k]); h[6 + k] = quad_rot<2>(h[k]);
+        l[9 + k] = quad_rot<3>(l[k]); h[9 + k] = quad_rot<3>(h[k]);
+    }
+    const u32 diag = (q == 0) ? 8u : 0u;   // + 8 * element 0 in output 0 only
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        // out_{3q+k} = sum_i C[(i - 3q - k) mod 12] * x_i = sum_m C[(m - k) mod 12] * y_m
+        u64 al = 0, ah = 0;
+#pragma unroll
+        for (int m = 0; m < 12; m++) {
+            const u32 c = C[(m - k + 12) % 12];
+            al += (u64)l[m] * c;
+            ah += (u64)h[m] * c;
+        }
+        if (k == 0) { al += (u64)l[0] * diag; ah += (u64)h[0] * diag; }
+        x[k] = fold_halves(al, ah);
+    }
+}
+
+__device__ __forceinline__ void poseidon_permute_quad(u64 (&x)[3], int q) {
+#pragma unroll 1
+    for (int r = 0; r < 4; r++) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) x[k] = sbox7_weak(add_weak(x[k], c_rc[r * 12 + 3 * q + k]));
+        mds_quad(x, q);
+    }
+#pragma unroll 1
+    for (int r = 0; r < 22; r++) {   // dense partial rounds, constants on lane 0 of the state (derive_lane0)
+        const u64 t = sbox7_weak(add_weak(x[0], c_lane0[r]));
+        x[0] = (q == 0) ? t : x[0];
+        mds_quad(x, q);
+    }
+#pragma unroll 1
+    for (int r = 26; r < 30; r++) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) x[k] = sbox7_weak(add_weak(x[k], r == 26 ? c_round26[3 * q + k] : c_rc[r * 12 + 3 * q + k]));
+        mds_quad(x, q);
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++) x[k] = gl_canon(x[k]);
+}
 #endif  // __HIPCC__
 
 }  // namespace ola
