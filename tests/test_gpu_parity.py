@@ -41,6 +41,18 @@ def test_poseidon_random_and_edge_states(be, oracle):
         assert np.array_equal(got[i], oracle.poseidon(st[i])), i
 
 
+def test_poseidon_both_device_forms_agree(be, oracle):
+    """Batches above 8192 states run one state per lane, smaller ones the quad-cooperative form (4 lanes per state): same
+    permutation.  The large batch is checked against the oracle on a sample and against the small-batch form everywhere."""
+    rng = np.random.default_rng(77)
+    st = rand_field(rng, (9001, 12))
+    big = be.poseidon(st)
+    for i in (0, 1, 4500, 9000):
+        assert np.array_equal(big[i], oracle.poseidon(st[i])), i
+    small = np.concatenate([be.poseidon(st[:5000]), be.poseidon(st[5000:])])
+    assert np.array_equal(big, small)
+
+
 @pytest.mark.parametrize("row_len", [1, 3, 4, 7, 8, 9, 16, 17, 29, 94, 134])
 def test_hash_rows(be, oracle, row_len):
     rng = np.random.default_rng(row_len)
