@@ -41,6 +41,15 @@ def test_poseidon_random_and_edge_states(be, oracle):
         assert np.array_equal(got[i], oracle.poseidon(st[i])), i
 
 
+def test_hash_rows_large_batch(be, oracle):
+    rng = np.random.default_rng(5)
+    rows = rand_field(rng, (9000, 11))              # above the quad threshold: one leaf per lane
+    got = be.hash_rows(rows)
+    for i in (0, 17, 4444, 8999):
+        assert np.array_equal(got[i], oracle.hash_no_pad(rows[i])), i
+    assert np.array_equal(got[:100], be.hash_rows(rows[:100]))      # quad form on the same rows
+
+
 def test_poseidon_both_device_forms_agree(be, oracle):
     """Batches above 8192 states run one state per lane, smaller ones the quad-cooperative form (4 lanes per state): same
     permutation.  The large batch is checked against the oracle on a sample and against the small-batch form everywhere."""
