@@ -186,3 +186,27 @@ def test_interpreter_and_specialised_kernels_give_the_same_proof(be, monkeypatch
     fast = be.prove_with_traces(blob, traces, params, compress)
     monkeypatch.setenv("OLA_AIR_KERNELS", "interpreter")
     assert be.prove_with_traces(blob, traces, params, compress) == fast
+
+
+def test_malformed_inputs_are_refused(be):
+    """Error behaviour of ola_prove_with_traces: a damaged AIR-set blob, a table too large for the LDE domain and missing
+    parameters are reported through error codes (never a crash, never proof bytes)."""
+    from olavm_amd.backend import OlaGpuError
+    rng = np.random.default_rng(3)
+    cmp_t, rc_t = tracegen.cmp_rangecheck_instance(rng, 6, 4)
+    blob = mini_set(4).blob()
+    bad = blob.copy()
+    bad[0] ^= 1                                                   # magic
+    with pytest.raises(OlaGpuError, match="magic"):
+        be.prove_with_traces(bad, [cmp_t, rc_t])
+    with pytest.raises(OlaGpuError, match="truncated|trailing"):
+        be.prove_with_traces(blob[:-3], [cmp_t, rc_t])
+    with pytest.raises(OlaGpuError, match="trailing"):
+        be.prove_with_traces(np.concatenate([blob, blob[:2]]), [cmp_t, rc_t])
+    # a table with a CTL but whose partner references a table index that does not exist
+    worse = blob.copy()
+    worse[2] = 1                                                  # claim a single table: the CTL then points outside
+    with pytest.raises(OlaGpuError):
+        be.prove_with_traces(worse, [cmp_t])
+    # the proof of a valid instance still works afterwards (no state is left behind by the failures)
+    assert len(be.prove_with_traces(blob, [cmp_t, rc_t])) > 1000
