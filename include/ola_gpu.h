@@ -179,6 +179,14 @@ int32_t ola_prove_with_traces(OlaCtx* ctx, const uint64_t* airset, size_t airset
                               const uint32_t* log_n, const uint64_t* params, const uint64_t* compress_challenges,
                               uint8_t* out, size_t cap, size_t* out_len);
 
+/* ---- trace generation helper -------------------------------------------------------------------------
+ * The 134-column Poseidon STARK table (circuits/src/builtins/poseidon/columns.rs) from the permutation inputs: what the
+ * reference's executor records per hash (core/src/util/poseidon_utils.rs) and generate_poseidon_trace lays out
+ * (circuits/src/generation/poseidon.rs:5-80).  inputs: 12 x n column-major; filters: 4 x n column-major
+ * (FILTER_LOOKED_NORMAL, _TREEKEY, _STORAGE_LEAF, _STORAGE_BRANCH) or NULL for zeros; out: 134 x n column-major.  Padding
+ * rows are rows with all-zero inputs (the reference's POSEIDON_ZERO_HASH_* constants). */
+int32_t ola_generate_poseidon_trace(OlaCtx* ctx, const uint64_t* inputs, const uint64_t* filters, size_t n, uint64_t* out);
+
 /* ---- coset-partitioned proving over several GPUs ---------------------------------------------------------
  * One process per GPU; every process calls ola_prove_with_traces with the SAME traces.  Because the transcript is a
  * function of the (identical) commitments, all ranks draw the same challenges without talking to each other; only the

@@ -86,6 +86,7 @@ def load_library():
                                           C.POINTER(C.c_void_p), U64P]
     L.ola_commit_values_shard_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                               C.POINTER(C.c_void_p), U64P]
+    L.ola_generate_poseidon_trace.argtypes = [C.c_void_p, U64P, U64P, C.c_size_t, U64P]
     L.ola_set_shard.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, ALL_GATHER_FN, C.c_void_p]
     L.ola_air_kernels_available.argtypes = [U64P, C.c_size_t, C.POINTER(C.c_uint8), C.c_size_t]
     _lib = L
@@ -98,7 +99,7 @@ EXPORTS = [
     "ola_commit_values_dev", "ola_commit_coeffs_dev", "ola_batch_free", "ola_batch_shape", "ola_batch_get_coeffs",
     "ola_batch_get_leaf", "ola_batch_get_lde_row", "ola_challenger_init", "ola_challenger_observe",
     "ola_challenger_get", "ola_challenger_compact", "ola_open_and_prove", "ola_pow", "ola_prove_with_traces",
-    "ola_air_kernels_available", "ola_commit_values_shard", "ola_commit_values_shard_dev", "ola_set_shard", "ola_gpu_trim",
+    "ola_air_kernels_available", "ola_commit_values_shard", "ola_commit_values_shard_dev", "ola_set_shard", "ola_gpu_trim", "ola_generate_poseidon_trace",
 ]
 
 
@@ -283,6 +284,16 @@ class Backend:
             ptrs = (U64P * ncols)(*[cols[i].ctypes.data_as(U64P) for i in range(ncols)])
             self._chk(self.lib.ola_commit_values_shard(self.ctx, ptrs, ncols, int(n).bit_length() - 1, rank, world, C.byref(h), _p(cap)))
         return Batch(self, h, cap, shard_log_world=lw)
+
+    def generate_poseidon_trace(self, inputs, filters=None):
+        """Poseidon STARK table (134 x n) from permutation inputs (12 x n) and optional lookup filters (4 x n)."""
+        inputs = np.ascontiguousarray(inputs, dtype=np.uint64)
+        assert inputs.shape[0] == 12
+        n = inputs.shape[1]
+        f = None if filters is None else np.ascontiguousarray(filters, dtype=np.uint64)
+        out = np.empty((134, n), dtype=np.uint64)
+        self._chk(self.lib.ola_generate_poseidon_trace(self.ctx, _p(inputs), None if f is None else _p(f), n, _p(out)))
+        return out
 
     def trim(self):
         """Return the context's cached device buffers to the driver (ola_gpu_trim)."""

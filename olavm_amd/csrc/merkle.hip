@@ -194,6 +194,48 @@ __global__ __launch_bounds__(1024) void merkle_top_kernel(u64* __restrict__ heap
     }
 }
 
+// Rows of the Poseidon STARK table (builtins/poseidon/columns.rs; layout of generation/poseidon.rs:5-80) from the
+// permutation inputs: the reference's executor records the S-box inputs of every round (core/src/util/poseidon_utils.rs)
+// and generate_poseidon_trace lays them out; here one thread recomputes them for its row.  Columns: 4 lookup filters,
+// input[12], output[12], S-box inputs of full rounds 1..3 [3x12], of the 22 partial rounds (lane 0) [22], of full rounds
+// 26..29 [4x12].  The S-box argument of a round does not depend on how the linear layers are factored, so the dense
+// lane-0 form of poseidon.cuh yields exactly the values the reference's sparse form records.
+__global__ __launch_bounds__(256) void poseidon_trace_kernel(const u64* __restrict__ inputs, const u64* __restrict__ filters, size_t n,
+                                                             u64* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    auto col = [&](int c) -> u64& { return out[(size_t)c * n + i]; };
+    for (int f = 0; f < 4; f++) col(f) = filters ? gl_canon(filters[(size_t)f * n + i]) : 0;
+    u64 s[12];
+    for (int k = 0; k < 12; k++) { s[k] = gl_canon(inputs[(size_t)k * n + i]); col(4 + k) = s[k]; }
+    for (int r = 0; r < 4; r++) {
+        for (int k = 0; k < 12; k++) {
+            s[k] = gl_add(gl_canon(s[k]), c_rc[r * 12 + k]);
+            if (r > 0) col(28 + (r - 1) * 12 + k) = s[k];
+            s[k] = sbox7_weak(s[k]);
+        }
+        mds_weak(s);
+    }
+    for (int r = 0; r < 22; r++) {
+        const u64 a = gl_add(gl_canon(s[0]), c_lane0[r]);
+        col(64 + r) = a;
+        s[0] = sbox7_weak(a);
+        mds_weak(s);
+    }
+    for (int r = 0; r < 4; r++) {
+        for (int k = 0; k < 12; k++) {
+            s[k] = gl_add(gl_canon(s[k]), r == 0 ? c_round26[k] : c_rc[(26 + r) * 12 + k]);
+            col(86 + r * 12 + k) = s[k];
+            s[k] = sbox7_weak(s[k]);
+        }
+        mds_weak(s);
+    }
+    for (int k = 0; k < 12; k++) col(16 + k) = gl_canon(s[k]);
+}
+void launch_poseidon_trace(DeviceCtx* ctx, const u64* inputs, const u64* filters, size_t n, u64* out) {
+    if (n) hipLaunchKernelGGL(poseidon_trace_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, inputs, filters, n, out);
+}
+
 // quad-cooperative permutation of whole states (4 threads per state); used for small n
 __global__ __launch_bounds__(256) void poseidon_states_quad_kernel(u64* __restrict__ states, size_t n) {
     const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -365,6 +365,24 @@ int32_t ola_prove_with_traces(OlaCtx* ctx, const uint64_t* airset, size_t airset
     OLA_CATCH
 }
 
+int32_t ola_generate_poseidon_trace(OlaCtx* ctx, const uint64_t* inputs, const uint64_t* filters, size_t n, uint64_t* out) {
+    OLA_TRY
+    require(ctx && inputs && out, "null pointer");
+    if (n == 0) return OLA_OK;
+    u64* d_in = (u64*)ctx->dev.alloc(12 * n * 8);
+    u64* d_f = filters ? (u64*)ctx->dev.alloc(4 * n * 8) : nullptr;
+    u64* d_out = (u64*)ctx->dev.alloc(134 * n * 8);
+    try {
+        HIP_CHECK(hipMemcpyAsync(d_in, inputs, 12 * n * 8, hipMemcpyHostToDevice, ctx->dev.stream));
+        if (filters) HIP_CHECK(hipMemcpyAsync(d_f, filters, 4 * n * 8, hipMemcpyHostToDevice, ctx->dev.stream));
+        launch_poseidon_trace(&ctx->dev, d_in, d_f, n, d_out);
+        HIP_CHECK(hipMemcpyAsync(out, d_out, 134 * n * 8, hipMemcpyDeviceToHost, ctx->dev.stream));
+        HIP_CHECK(hipStreamSynchronize(ctx->dev.stream));
+    } catch (...) { ctx->dev.free(d_in); ctx->dev.free(d_f); ctx->dev.free(d_out); throw; }
+    ctx->dev.free(d_in); ctx->dev.free(d_f); ctx->dev.free(d_out);
+    OLA_CATCH
+}
+
 int32_t ola_gpu_trim(OlaCtx* ctx) {
     OLA_TRY
     require(ctx, "ctx");

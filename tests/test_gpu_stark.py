@@ -210,3 +210,32 @@ def test_malformed_inputs_are_refused(be):
         be.prove_with_traces(worse, [cmp_t])
     # the proof of a valid instance still works afterwards (no state is left behind by the failures)
     assert len(be.prove_with_traces(blob, [cmp_t, rc_t])) > 1000
+
+
+def test_device_poseidon_trace_generation(be, oracle):
+    """ola_generate_poseidon_trace against the reference's own rows (tests/golden/poseidon_air_rows.json: the ZERO-hash
+    padding row and the row of hashing [1000, 1001, ...], both produced by the reference's executor), and -- for random
+    inputs -- against the Poseidon AIR, under which every generated row must vanish."""
+    import json, os
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "poseidon_air_rows.json")))["rows"]
+    rng = np.random.default_rng(8)
+    n = 64
+    inputs = rng.integers(0, tracegen.P, size=(12, n), dtype=np.uint64)
+    inputs[:, 0] = 0
+    inputs[:, 1] = np.array(g["1000"][4:16], dtype=np.uint64)
+    inputs[9:12, 2:] = 0                     # capacity lanes stay free for the rows that carry a tree-key / storage filter
+    filters = np.zeros((4, n), dtype=np.uint64)
+    filters[0, 2::3] = 1                     # FILTER_LOOKED_NORMAL
+    filters[1, 3::3] = 1                     # FILTER_LOOKED_TREEKEY (needs inputs 9..11 = 0)
+    tr = be.generate_poseidon_trace(inputs, filters)
+    assert [int(x) for x in tr[:, 0]] == g["ZERO"]
+    assert [int(x) for x in tr[:, 1]] == g["1000"]
+    assert np.array_equal(tr[:4], filters) and np.array_equal(tr[4:16], inputs)
+    full = T.ola_stark(range_bits=4, limb_bits=2)
+    assert oracle.check_constraints(full.blob(), 5, tr) == -1
+    bad = tr.copy()
+    bad[70, 5] = (int(bad[70, 5]) + 1) % tracegen.P
+    assert oracle.check_constraints(full.blob(), 5, bad) == 5
+    # and the outputs are the permutation
+    for i in (0, 1, 7, 63):
+        assert np.array_equal(tr[16:28, i], oracle.poseidon(inputs[:, i]))
