@@ -20,6 +20,7 @@
 
 #include <algorithm>
 #include <map>
+#include <tuple>
 #include <vector>
 
 #include "device_ctx.h"
@@ -218,6 +219,7 @@ struct NttTables {
     std::map<std::pair<int, int>, TwoLevel> two;     // (k, inverse) -> two-level powers of w_{2^k}
     std::map<std::pair<int, int>, TwoLevel> coset;   // (log_n, rate_bits) -> per-coset scale tables (blowup cosets)
     std::map<std::pair<int, u64>, TwoLevel> shift;   // (log_n, shift) -> s^k tables (single coset, arbitrary shift)
+    std::map<std::tuple<int, int, int, u64>, const u64*> coset_steps;  // (log_n, rate_bits, e, shift) -> per-coset s^(2^e) (ntt2.hip)
 };
 
 static u64* upload(DeviceCtx* ctx, const std::vector<u64>& v) {

@@ -331,18 +331,6 @@ static const u64* get_coset_steps(NttTables& t, int log_n, int rate_bits, int e,
     return upload(t.ctx, v);  // small; lives in the persistent pool
 }
 
-struct Ntt2StepCacheKey {
-    int log_n, rate_bits, e;
-    u64 shift;
-    bool operator<(const Ntt2StepCacheKey& o) const {
-        if (log_n != o.log_n) return log_n < o.log_n;
-        if (rate_bits != o.rate_bits) return rate_bits < o.rate_bits;
-        if (e != o.e) return e < o.e;
-        return shift < o.shift;
-    }
-};
-static std::map<std::pair<NttTables*, Ntt2StepCacheKey>, const u64*> g_step_cache;
-
 // Same contract as ntt_run (ntt.hip) for L >= 14.  prescale: rate_bits >= 0 selects the LDE coset family
 // (7*g^bitrev(c)) of which cosets [coset_first, coset_first + cosets) are produced, rate_bits = -1 with `shift` a single
 // coset, -2 none.
@@ -383,10 +371,9 @@ void ntt2_run(NttTables& t, const u64* in, size_t in_col_stride, u64* out, size_
                 else sc = get_shift(t, L, sc_shift);
                 // a coset sub-range (one GPU's share of the LDE) starts `coset_first` entries into the per-coset tables
                 p.sc_lo = sc.lo + coset_first * stride; p.sc_hi = sc.hi + coset_first * stride; p.sc_h = sc.h; p.sc_coset_stride = stride;
-                Ntt2StepCacheKey key{L, sc_rate_bits, lo + R - 4, sc_rate_bits >= 0 ? 0 : sc_shift};
-                auto ck = std::make_pair(&t, key);
-                auto it = g_step_cache.find(ck);
-                if (it == g_step_cache.end()) it = g_step_cache.emplace(ck, get_coset_steps(t, L, sc_rate_bits, lo + R - 4, sc_shift)).first;
+                const auto key = std::make_tuple(L, sc_rate_bits, lo + R - 4, sc_rate_bits >= 0 ? (u64)0 : sc_shift);
+                auto it = t.coset_steps.find(key);   // cached per context: the device tables die with it
+                if (it == t.coset_steps.end()) it = t.coset_steps.emplace(key, get_coset_steps(t, L, sc_rate_bits, lo + R - 4, sc_shift)).first;
                 p.sc_step = it->second + coset_first;
             }
             // the strided kernel addresses a workgroup's 2^(8-R) tiles as one uniform base + lane offsets
