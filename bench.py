@@ -71,10 +71,10 @@ def pmc_traffic(log_n, cols):
 def prove_time(be, log_n, reps=3):
     """Second half of BASELINE.json's metric: wall-clock of the whole multi-table proof (ola_prove_with_traces, host
     traces in, AllProof bytes out -- so H2D of the traces is inside the timed region) for the 12-table OlaStark with a
-    2^log_n-row CPU and memory trace.  The traces are an empty-program execution (padding rows, tests/tracegen.py: the
+    2^log_n-row CPU and memory trace.  The traces are an empty-program execution (padding rows, olavm_amd/air/tracegen.py: the
     image has no Rust executor to produce a program trace); prover work does not depend on cell values."""
     from olavm_amd.air import ola_tables as T
-    from tests import tracegen
+    from olavm_amd.air import tracegen
     blob = T.ola_stark().blob()
     traces, params, compress = tracegen.empty_program_instance(log_n=10, range_bits=16, limb_bits=8, log_n_cpu=log_n, log_n_mem=log_n)
     times, nbytes = [], 0
@@ -117,7 +117,7 @@ def sharded_prove_time(be, rank, world, log_n, coll_dev, reps=2):
     import torch.distributed as dist
     from olavm_amd import sharding
     from olavm_amd.air import ola_tables as T
-    from tests import tracegen
+    from olavm_amd.air import tracegen
     blob = T.ola_stark().blob()
     traces, params, compress = tracegen.empty_program_instance(log_n=10, range_bits=16, limb_bits=8, log_n_cpu=log_n, log_n_mem=log_n)
     be.set_shard(rank, world)

@@ -85,7 +85,7 @@ def _per_table_params(airset, params):
 
 def test_all_twelve_tables_vanish_on_the_empty_program_instance(oracle):
     """The reference's AIR test recipe (test_utils.rs:152-195) for every table, on padding rows as its trace generators
-    emit them (tests/tracegen.py); miniature fixed tables (range_bits 4, limb_bits 2) keep it CPU-sized."""
+    emit them (olavm_amd/air/tracegen.py); miniature fixed tables (range_bits 4, limb_bits 2) keep it CPU-sized."""
     s = T.ola_stark(range_bits=4, limb_bits=2)
     blob = s.blob()
     traces, params, _ = tracegen.empty_program_instance()

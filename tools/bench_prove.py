@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from olavm_amd.air import ola_tables as T
 from olavm_amd.backend import Backend
-from tests import tracegen
+from olavm_amd.air import tracegen
 
 L = int(sys.argv[1]) if len(sys.argv) > 1 else 18
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 2
