@@ -86,7 +86,7 @@ def _prove_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_coset_partitioned_proof_equals_the_single_gpu_proof(world, oracle):
     """SURVEY 8e end to end: `world` ranks (sharing the one test GPU, gloo for the exchanges) each prove with their share
     of the cosets; every rank's AllProof bytes equal the single-GPU proof, which the oracle verifier accepts."""
