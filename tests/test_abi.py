@@ -60,3 +60,26 @@ def test_host_challenger_matches_oracle(lib, oracle):
             ch.compact()
             och.compact()
             assert np.array_equal(ch.state(), och.state())
+
+
+def test_specialised_kernels_are_paired_with_the_blob_by_signature(lib):
+    """Host-only entry point: the library hashes each table of the AIR-set blob it is handed (description + the static part of
+    its lookups) and finds the kernel the code generator printed for the same signature -- for the three OlaStark variants
+    of air/codegen.py; any change to a table (here: one more constraint) falls back to the interpreter kernel."""
+    from olavm_amd.air import AirSet, ola_tables as T
+
+    def available(airset):
+        blob = np.ascontiguousarray(airset.blob(), dtype=np.uint64)
+        flags = (C.c_uint8 * len(airset.tables))()
+        rc = lib.ola_air_kernels_available(blob.ctypes.data_as(C.POINTER(C.c_uint64)), blob.size, flags, len(airset.tables))
+        assert rc == 0, lib.ola_gpu_last_error()
+        return [bool(x) for x in flags]
+
+    for variant in (T.ola_stark(), T.ola_stark(range_bits=8, limb_bits=8), T.ola_stark(range_bits=4, limb_bits=2)):
+        assert all(available(variant))
+    s = T.ola_stark(range_bits=4, limb_bits=2)
+    s.tables[8].constraint(s.tables[8].local(0) * s.tables[8].local(1))          # tape table, modified
+    got = available(s)
+    assert got == [i != 8 for i in range(12)]
+    other = T.ola_stark(range_bits=5, limb_bits=2)                                 # a range-check table nobody generated
+    assert available(other) == [i != 4 for i in range(12)]
