@@ -1,0 +1,294 @@
+"""A miniature executor for OlaVM's register instructions (SURVEY f-1): runs a small program and fills the STARK tables it
+touches so that EVERY constraint and EVERY cross-table lookup holds -- a real (if tiny) execution trace without the Rust
+executor.  Supported: MOV, ADD, MUL, EQ, NEQ, JMP, CJMP, RC, AND / OR / XOR, GTE, END with register or immediate second
+operands.  Tables that receive live rows: CPU, program, prog_chunk (program hashing), Poseidon (the chunk hashes),
+range-check (RC and GTE), bitwise, cmp; the rest keep their padding rows (olavm_amd/air/tracegen.py).
+
+Restated from (reference paths): core/src/vm/opcodes.rs (opcode bit masks), circuits/src/cpu/cpu_stark.rs:529-581
+(instruction word = op1_imm * 2^62 + one-hot register selectors at bits 52+r / 42+r / 32+r + opcode mask),
+circuits/src/generation/{cpu,prog,builtin,poseidon}.rs (row layouts and padding), circuits/src/program/*.rs (program /
+prog_chunk tables: 8 instruction words per Poseidon-hashed chunk, capacity chained from the previous chunk's hash).
+The program-hash chain stops short of a result line (prog_chunk_stark.rs never forces one), so no storage-tree proof is
+needed.  Validity is not taken on trust: tests check every table with the oracle's `check_constraints` and the whole
+proof -- including the cross-table products -- with its verifier."""
+import numpy as np
+
+from . import ola_tables as T
+from . import tracegen as TG
+from .dsl import P
+from . import poseidon_params as PP
+
+REG = 10
+
+
+def _inv(x):
+    return pow(x % P, P - 2, P) if x % P else 0
+
+
+# ---- Poseidon with the S-box inputs recorded (the 134-column row of the Poseidon table), plain Python
+def _mds(s):
+    out = []
+    for r in range(12):
+        v = sum(s[(i + r) % 12] * PP.MDS_CIRC[i] for i in range(12)) + s[r] * PP.MDS_DIAG[r]
+        out.append(v % P)
+    return out
+
+
+def _sbox(x):
+    return pow(x, 7, P)
+
+
+def poseidon_row(inp, filters=(0, 0, 0, 0)):
+    row = [0] * T.NUM_POSEIDON_COLS
+    row[0:4] = list(filters)
+    s = [int(x) % P for x in inp]
+    row[4:16] = s
+    for r in range(30):
+        full = r < 4 or r >= 26
+        s = [(x + PP.RC[12 * r + i]) % P for i, x in enumerate(s)]
+        if full:
+            if 1 <= r <= 3:
+                row[28 + 12 * (r - 1):28 + 12 * r] = s
+            elif r >= 26:
+                row[86 + 12 * (r - 26):86 + 12 * (r - 25)] = s
+            s = [_sbox(x) for x in s]
+        else:
+            row[64 + r - 4] = s[0]
+            s[0] = _sbox(s[0])
+        s = _mds(s)
+    row[16:28] = s
+    return row
+
+
+# ---- program
+class Program:
+    """Instructions: (op, dst, op0, op1) with register indices or None; op1 may be ('imm', value)."""
+
+    def __init__(self, code_addr=(11, 22, 33, 44), storage_addr=(55, 66, 77, 88)):
+        self.ins, self.code_addr, self.storage_addr = [], tuple(code_addr), tuple(storage_addr)
+
+    def add(self, op, dst=None, op0=None, op1=None):
+        self.ins.append((op, dst, op0, op1))
+        return self
+
+    def words(self):
+        """-> (list of program words, pc of every instruction)."""
+        words, pcs = [], []
+        for op, dst, op0, op1 in self.ins:
+            imm = isinstance(op1, tuple)
+            w = (1 << 62) if imm else 0
+            if op0 is not None:
+                w += 1 << (52 + op0)
+            if op1 is not None and not imm:
+                w += 1 << (42 + op1)
+            if dst is not None:
+                w += 1 << (32 + dst)
+            w += T.op_mask(op)
+            pcs.append(len(words))
+            words.append(w)
+            if imm:
+                words.append(int(op1[1]) % P)
+        return words, pcs
+
+
+SELECTOR = {"ADD": T.COL_S_SIMPLE_ARITHMATIC_OP, "MUL": T.COL_S_SIMPLE_ARITHMATIC_OP, "EQ": T.COL_S_SIMPLE_ARITHMATIC_OP,
+            "NEQ": T.COL_S_SIMPLE_ARITHMATIC_OP, "MOV": T.COL_S_MOV, "JMP": T.COL_S_JMP, "CJMP": T.COL_S_CJMP, "END": T.COL_S_END,
+            "RC": T.COL_S_RC, "AND": T.COL_S_BITWISE, "OR": T.COL_S_BITWISE, "XOR": T.COL_S_BITWISE, "GTE": T.COL_S_GTE}
+
+
+def execute(prog, max_steps=1 << 16):
+    """-> (cpu rows as dicts of column -> value, side effects {'rc': [...], 'bitwise': [...], 'cmp': [...]}, executed words)."""
+    words, pcs = prog.words()
+    pc_to_idx = {pc: i for i, pc in enumerate(pcs)}
+    regs = [0] * REG
+    pc = clk = 0
+    rows, side, executed = [], {"rc": [], "bitwise": [], "cmp": []}, []
+    while True:
+        assert len(rows) < max_steps, "program does not terminate"
+        op, dst, op0, op1 = prog.ins[pc_to_idx[pc]]
+        imm = isinstance(op1, tuple)
+        r = {c: 0 for c in range(T.NUM_CPU_COLS)}
+        for k, v in zip(T.COL_ADDR_STORAGE_RANGE, prog.storage_addr):
+            r[k] = v
+        for k, v in zip(T.COL_ADDR_CODE_RANGE, prog.code_addr):
+            r[k] = v
+        r[T.COL_CLK], r[T.COL_PC] = clk, pc
+        for i in range(REG):
+            r[T.COL_REGS.start + i] = regs[i]
+        r[T.COL_INST], r[T.COL_OP1_IMM], r[T.COL_OPCODE] = words[pc], int(imm), T.op_mask(op)
+        r[SELECTOR[op]] = 1
+        r[T.COL_IS_ENTRY_SC] = r[T.COL_IS_NEXT_LINE_DIFF_INST] = r[T.COL_IS_NEXT_LINE_SAME_TX] = 1
+        v0 = regs[op0] if op0 is not None else 0
+        v1 = (int(op1[1]) % P) if imm else (regs[op1] if op1 is not None else 0)
+        if op0 is not None:
+            r[T.COL_S_OP0.start + op0], r[T.COL_OP0] = 1, v0
+        if imm:
+            r[T.COL_IMM_VAL] = r[T.COL_OP1] = v1
+            r[T.COL_FILTER_LOOKING_PROG_IMM] = 1
+        elif op1 is not None:
+            r[T.COL_S_OP1.start + op1], r[T.COL_OP1] = 1, v1
+        size = 2 if imm else 1
+        executed.append((pc, words[pc]))
+        if imm:
+            executed.append((pc + 1, v1))
+        next_pc, res = pc + size, None
+        if op == "MOV":
+            res = v1
+        elif op == "ADD":
+            res = (v0 + v1) % P
+        elif op == "MUL":
+            res = v0 * v1 % P
+        elif op in ("EQ", "NEQ"):
+            res = int((v0 == v1) == (op == "EQ"))
+            r[T.COL_AUX0] = _inv(v0 - v1)
+        elif op == "JMP":
+            next_pc = v1
+        elif op == "CJMP":
+            assert v0 in (0, 1)
+            next_pc = v1 if v0 else pc + size
+        elif op == "RC":
+            assert v1 < 1 << 32
+            side["rc"].append(v1)
+        elif op in ("AND", "OR", "XOR"):
+            assert v0 < 1 << 32 and v1 < 1 << 32
+            res = {"AND": v0 & v1, "OR": v0 | v1, "XOR": v0 ^ v1}[op]
+            side["bitwise"].append((op, v0, v1))
+        elif op == "GTE":
+            assert v0 < 1 << 32 and v1 < 1 << 32
+            res = int(v0 >= v1)
+            side["cmp"].append((v0, v1))
+        if dst is not None:
+            assert res is not None
+            r[T.COL_S_DST.start + dst], r[T.COL_DST] = 1, res
+            regs[dst] = res
+        if op == "END":
+            r[T.COL_IS_NEXT_LINE_SAME_TX] = 0
+            rows.append(r)
+            break
+        rows.append(r)
+        pc, clk = next_pc, clk + 1
+    return rows, side, executed
+
+
+def cpu_trace(rows):
+    n = TG.next_pow2(max(len(rows), 8))
+    t = TG.cpu_padding_trace(n)
+    for i, r in enumerate(rows):
+        for c, v in r.items():
+            t[c, i] = v
+    return t
+
+
+def program_trace(prog, executed, beta):
+    """program/columns.rs: the listing side (every word of the program, looked up by prog_chunk) and the executed side
+    (every instruction / immediate word the CPU fetched), each compressed with beta and linked by an in-table lookup."""
+    words, _ = prog.words()
+    words = words + [0] * (-len(words) % 8)              # prog_chunk hashes 8 words at a time
+    n = TG.next_pow2(max(len(words), len(executed), 8))
+    t = np.zeros((T.NUM_PROG_COLS, n), dtype=np.uint64)
+    b = int(beta) % P
+
+    def comp(pc, w):
+        a = prog.code_addr
+        return (a[0] + a[1] * b + a[2] * b ** 2 + a[3] * b ** 3 + pc * b ** 4 + w * b ** 5) % P
+    for pc, w in enumerate(words):
+        for k, v in zip(T.COL_PROG_CODE_ADDR_RANGE, prog.code_addr):
+            t[k, pc] = v
+        t[T.COL_PROG_PC, pc], t[T.COL_PROG_INST, pc], t[T.COL_PROG_COMP_PROG, pc], t[T.COL_PROG_FILTER_PROG_CHUNK, pc] = pc, w, comp(pc, w), 1
+    for i in range(n):
+        pc, w = executed[i] if i < len(executed) else executed[0]     # filler rows repeat a listed word (filter 0)
+        for k, v in zip(T.COL_PROG_EXEC_CODE_ADDR_RANGE, prog.code_addr):
+            t[k, i] = v
+        t[T.COL_PROG_EXEC_PC, i], t[T.COL_PROG_EXEC_INST, i], t[T.COL_PROG_EXEC_COMP_PROG, i] = pc, w, comp(pc, w)
+        t[T.COL_PROG_FILTER_EXEC, i] = int(i < len(executed))
+    pi, pt = TG.permuted_cols([int(x) for x in t[T.COL_PROG_EXEC_COMP_PROG]], [int(x) for x in t[T.COL_PROG_COMP_PROG]])
+    t[T.COL_PROG_EXEC_COMP_PROG_PERM], t[T.COL_PROG_COMP_PROG_PERM] = pi, pt
+    return t, words
+
+
+def prog_chunk_and_poseidon(prog, words, n_poseidon_min=8):
+    """One prog_chunk row per 8 program words, hashed with Poseidon (capacity = last third of the previous chunk's hash);
+    -> (prog_chunk trace, Poseidon-table trace carrying those permutations)."""
+    chunks = [words[i:i + 8] for i in range(0, len(words), 8)]
+    n = TG.next_pow2(max(len(chunks), 8))
+    t = TG.flag_padding_trace(T.NUM_PROG_CHUNK_COLS, n, T.COL_PROG_CHUNK_IS_PADDING_LINE)
+    prow, cap = [], [0, 0, 0, 0]
+    for i, ch in enumerate(chunks):
+        row = poseidon_row(list(ch) + cap, filters=(1, 0, 0, 0))
+        prow.append(row)
+        h = row[16:28]
+        t[T.COL_PROG_CHUNK_IS_PADDING_LINE, i] = 0
+        for k, v in zip(T.COL_PROG_CHUNK_CODE_ADDR_RANGE, prog.code_addr):
+            t[k, i] = v
+        t[T.COL_PROG_CHUNK_START_PC, i] = 8 * i
+        for k, v in zip(T.COL_PROG_CHUNK_INST_RANGE, ch):
+            t[k, i] = v
+        for k, v in zip(T.COL_PROG_CHUNK_CAP_RANGE, cap):
+            t[k, i] = v
+        for k, v in zip(T.COL_PROG_CHUNK_HASH_RANGE, h):
+            t[k, i] = v
+        t[T.COL_PROG_CHUNK_IS_FIRST_LINE, i] = int(i == 0)
+        for k in T.COL_PROG_CHUNK_FILTER_LOOKING_PROG_RANGE:
+            t[k, i] = 1
+        cap = h[8:12]
+    np_ = TG.next_pow2(max(len(prow), n_poseidon_min))
+    pt = TG.poseidon_padding_trace(np_)
+    for i, row in enumerate(prow):
+        pt[:, i] = np.array(row, dtype=np.uint64)
+    return t, pt
+
+
+def instance(prog, range_bits=4, limb_bits=2, bitwise_beta=12345, program_beta=67890):
+    """The 12 traces (enum Table order), params and compress challenges of ola_stark(range_bits, limb_bits) for one run of
+    `prog`.  With miniature fixed tables, RC / GTE operands must stay below 2^(2*range_bits) and bitwise operands below
+    2^(4*limb_bits)."""
+    rows, side, executed = execute(prog)
+    cpu = cpu_trace(rows)
+    program, words = program_trace(prog, executed, program_beta)
+    chunk, poseidon = prog_chunk_and_poseidon(prog, words)
+    cmp_rows = []
+    for a, b in side["cmp"]:
+        d = abs(a - b)
+        cmp_rows.append((a, b, int(a >= b), d, _inv(d), 1))
+    rc_rows = [(v, 1, 0, 0, 0) for v in side["rc"]] + [(r[3], 0, 0, 0, 1) for r in cmp_rows]
+    n = 8
+    traces = [
+        cpu, TG.memory_padding_trace(n), TG.bitwise_trace(bitwise_beta, limb_bits, side["bitwise"], looked_by_cpu=True),
+        TG.generate_cmp_trace(cmp_rows), TG.generate_rc_trace(rc_rows, range_bits), poseidon,
+        TG.flag_padding_trace(T.NUM_POSEIDON_CHUNK_COLS, n, T.COL_POSEIDON_CHUNK_IS_PADDING_LINE),
+        TG.flag_padding_trace(T.NUM_COL_ST, n, T.COL_ST_IS_PADDING),
+        TG.tape_padding_trace(n),
+        TG.flag_padding_trace(T.NUM_COL_SCCALL, n, T.COL_SCCALL_IS_PADDING),
+        program, chunk,
+    ]
+    return traces, [bitwise_beta, program_beta], [0, 0, bitwise_beta, 0, 0, 0, 0, 0, 0, 0, program_beta, 0]
+
+
+def fibonacci(count, a_reg=1, b_reg=2):
+    """r1, r2 <- consecutive Fibonacci numbers, `count` loop iterations driven by a counter, EQ and CJMP."""
+    p = Program()
+    p.add("MOV", dst=a_reg, op1=("imm", 0)).add("MOV", dst=b_reg, op1=("imm", 1)).add("MOV", dst=3, op1=("imm", 0))
+    loop = len(p.words()[0])
+    p.add("ADD", dst=4, op0=a_reg, op1=b_reg).add("MOV", dst=a_reg, op1=b_reg).add("MOV", dst=b_reg, op1=4)
+    p.add("ADD", dst=3, op0=3, op1=("imm", 1)).add("NEQ", dst=5, op0=3, op1=("imm", count)).add("CJMP", op0=5, op1=("imm", loop))
+    p.add("END")
+    return p
+
+
+def mixed_program():
+    """Every supported instruction at least once, with values that fit the miniature fixed tables (< 2^8): arithmetic,
+    comparisons, the three bitwise operations, a range check, a taken and a not-taken conditional jump and a jump."""
+    p = Program()
+    p.add("MOV", dst=0, op1=("imm", 200)).add("MOV", dst=1, op1=("imm", 77))
+    p.add("AND", dst=2, op0=0, op1=1).add("OR", dst=3, op0=0, op1=1).add("XOR", dst=4, op0=0, op1=("imm", 15))
+    p.add("GTE", dst=5, op0=0, op1=1).add("GTE", dst=6, op0=1, op1=0).add("GTE", dst=7, op0=1, op1=("imm", 77))
+    p.add("RC", op1=2).add("RC", op1=("imm", 255))
+    p.add("MUL", dst=8, op0=2, op1=3).add("EQ", dst=8, op0=8, op1=8).add("NEQ", dst=8, op0=5, op1=6)
+    skip = len(p.words()[0]) + 2 + 2          # target: the instruction after the next (2-word) MOV
+    p.add("CJMP", op0=6, op1=("imm", 0))      # r6 = 0: not taken
+    p.add("CJMP", op0=5, op1=("imm", skip + 2))   # r5 = 1: taken, jumps over the MOV below
+    p.add("MOV", dst=8, op1=("imm", 999))
+    end = len(p.words()[0]) + 2
+    p.add("JMP", op1=("imm", end))
+    p.add("END")
+    return p

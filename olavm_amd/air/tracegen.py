@@ -132,11 +132,11 @@ def memory_padding_trace(n):
     return t
 
 
-def bitwise_trace(beta, limb_bits=8, ops=()):
+def bitwise_trace(beta, limb_bits=8, ops=(), looked_by_cpu=False):
     """generation/builtin.rs:35-205 with `limb_bits`-wide limbs: the fixed AND/OR/XOR table, and one row per operation in
     `ops` = [(name, op0, op1)] (operands of 4 limbs) with its limbs, compressed limbs and the permuted lookup columns.
-    The rows carry FILTER = 0: nothing in the CPU table looks them up, but every bitwise constraint and in-table lookup
-    is live on them."""
+    The rows carry FILTER = 0 (nothing in the CPU table looks them up, but every bitwise constraint and in-table lookup
+    is live on them) unless looked_by_cpu, in which case they are the looked-up side of the CPU's AND / OR / XOR rows."""
     size = 1 << limb_bits
     per = size * size
     n = next_pow2(max(size, 3 * per, len(ops)))
@@ -161,6 +161,7 @@ def bitwise_trace(beta, limb_bits=8, ops=()):
         z = fn[name](x, y)
         tag = T.op_mask(name)
         t[T.BW_TAG, r], t[T.BW_OP0, r], t[T.BW_OP1, r], t[T.BW_RES, r] = tag, x, y, z
+        t[T.BW_FILTER, r] = int(looked_by_cpu)
         for i, (lx, ly, lz) in enumerate(zip(limbs(x), limbs(y), limbs(z))):
             t[T.BW_OP0_LIMBS.start + i, r], t[T.BW_OP1_LIMBS.start + i, r], t[T.BW_RES_LIMBS.start + i, r] = lx, ly, lz
             t[T.BW_COMPRESS_LIMBS.start + i, r] = compress(tag, lx, ly, lz)
