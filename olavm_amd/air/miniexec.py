@@ -1,8 +1,9 @@
 """A miniature executor for OlaVM's register instructions (SURVEY f-1): runs a small program and fills the STARK tables it
 touches so that EVERY constraint and EVERY cross-table lookup holds -- a real (if tiny) execution trace without the Rust
-executor.  Supported: MOV, ADD, MUL, EQ, NEQ, JMP, CJMP, RC, AND / OR / XOR, GTE, END with register or immediate second
-operands.  Tables that receive live rows: CPU, program, prog_chunk (program hashing), Poseidon (the chunk hashes),
-range-check (RC and GTE), bitwise, cmp; the rest keep their padding rows (olavm_amd/air/tracegen.py).
+executor.  Supported: MOV, ADD, MUL, EQ, NEQ, JMP, CJMP, RC, AND / OR / XOR, GTE, MSTORE / MLOAD ([reg + imm], stack
+region), END with register or immediate second operands.  Tables that receive live rows: CPU, memory, program, prog_chunk
+(program hashing), Poseidon (the chunk hashes), range-check (RC, GTE and the memory table's sort columns), bitwise, cmp;
+the rest keep their padding rows (olavm_amd/air/tracegen.py).
 
 Restated from (reference paths): core/src/vm/opcodes.rs (opcode bit masks), circuits/src/cpu/cpu_stark.rs:529-581
 (instruction word = op1_imm * 2^62 + one-hot register selectors at bits 52+r / 42+r / 32+r + opcode mask),
@@ -91,7 +92,8 @@ class Program:
         return words, pcs
 
 
-SELECTOR = {"ADD": T.COL_S_SIMPLE_ARITHMATIC_OP, "MUL": T.COL_S_SIMPLE_ARITHMATIC_OP, "EQ": T.COL_S_SIMPLE_ARITHMATIC_OP,
+SELECTOR_MEM = {"MLOAD": T.COL_S_MLOAD, "MSTORE": T.COL_S_MSTORE}
+SELECTOR = {"MLOAD": T.COL_S_MLOAD, "MSTORE": T.COL_S_MSTORE, "ADD": T.COL_S_SIMPLE_ARITHMATIC_OP, "MUL": T.COL_S_SIMPLE_ARITHMATIC_OP, "EQ": T.COL_S_SIMPLE_ARITHMATIC_OP,
             "NEQ": T.COL_S_SIMPLE_ARITHMATIC_OP, "MOV": T.COL_S_MOV, "JMP": T.COL_S_JMP, "CJMP": T.COL_S_CJMP, "END": T.COL_S_END,
             "RC": T.COL_S_RC, "AND": T.COL_S_BITWISE, "OR": T.COL_S_BITWISE, "XOR": T.COL_S_BITWISE, "GTE": T.COL_S_GTE}
 
@@ -102,7 +104,8 @@ def execute(prog, max_steps=1 << 16):
     pc_to_idx = {pc: i for i, pc in enumerate(pcs)}
     regs = [0] * REG
     pc = clk = 0
-    rows, side, executed = [], {"rc": [], "bitwise": [], "cmp": []}, []
+    rows, side, executed = [], {"rc": [], "bitwise": [], "cmp": [], "mem": []}, []
+    memory = {}
     while True:
         assert len(rows) < max_steps, "program does not terminate"
         op, dst, op0, op1 = prog.ins[pc_to_idx[pc]]
@@ -157,6 +160,19 @@ def execute(prog, max_steps=1 << 16):
             assert v0 < 1 << 32 and v1 < 1 << 32
             res = int(v0 >= v1)
             side["cmp"].append((v0, v1))
+        elif op in ("MSTORE", "MLOAD"):
+            # executor/src/lib.rs:868-995: address = op0 + immediate offset (aux1); MSTORE writes the `dst` register, MLOAD
+            # loads into it; both are two-word instructions
+            assert imm, "only the [reg + imm] addressing form is implemented"
+            addr = (v0 + v1) % P
+            r[T.COL_AUX1] = addr
+            if op == "MSTORE":
+                res = regs[dst]
+                memory[addr] = res
+            else:
+                assert addr in memory, "load from an address that was never written"
+                res = memory[addr]
+            side["mem"].append((addr, clk, op, res))
         if dst is not None:
             assert res is not None
             r[T.COL_S_DST.start + dst], r[T.COL_DST] = 1, res
@@ -238,6 +254,49 @@ def prog_chunk_and_poseidon(prog, words, n_poseidon_min=8):
     return t, pt
 
 
+def memory_trace(cells):
+    """Memory table of stack-region accesses (generation/memory.rs:5-95; cell rules of core's memory trace): rows sorted by
+    (address, clk); diff / rw_addr_unchanged / rc_value columns relate each row to its predecessor, rc_value (the clock
+    difference on an unchanged address, else the address difference) is range-checked through the memory<->rangecheck
+    lookup for every row but the first.  The live rows are followed by the prophet-region padding of tracegen.py.
+    -> (trace, range-checked values)"""
+    cells = sorted(cells)
+    n = TG.next_pow2(max(len(cells) + 1, 8))
+    t = np.zeros((T.NUM_MEM_COLS, n), dtype=np.uint64)
+    rc_vals = []
+    prev = None
+    for i, (addr, clk, op, value) in enumerate(cells):
+        t[T.COL_MEM_IS_RW, i] = 1
+        t[T.COL_MEM_ADDR, i], t[T.COL_MEM_CLK, i], t[T.COL_MEM_OP, i], t[T.COL_MEM_VALUE, i] = addr, clk, T.op_mask(op), value
+        t[T.COL_MEM_S_MSTORE if op == "MSTORE" else T.COL_MEM_S_MLOAD, i] = 1
+        t[T.COL_MEM_IS_WRITE, i] = int(op == "MSTORE")
+        if prev is not None:
+            same = int(addr == prev[0])
+            d_addr = addr - prev[0]
+            t[T.COL_MEM_DIFF_ADDR, i], t[T.COL_MEM_DIFF_ADDR_INV, i] = d_addr, _inv(d_addr)
+            t[T.COL_MEM_DIFF_CLK, i] = (clk - prev[1]) if same else 0
+            t[T.COL_MEM_RW_ADDR_UNCHANGED, i] = same
+            rc = (clk - prev[1]) if same else d_addr
+            t[T.COL_MEM_RC_VALUE, i], t[T.COL_MEM_FILTER_LOOKING_RC, i] = rc, 1
+            rc_vals.append(rc)
+        prev = (addr, clk)
+    # prophet-region padding (tracegen.memory_padding_trace), continuing from the last live address
+    span = 2**32 - 1
+    a = (0 - span) % P
+    last_addr = prev[0] if prev else 0
+    start = len(cells) if cells else 1
+    if not cells:
+        t[T.COL_MEM_S_PROPHET, 0] = t[T.COL_MEM_IS_WRITE, 0] = 1
+    for i in range(start, n):
+        t[T.COL_MEM_S_PROPHET, i] = t[T.COL_MEM_IS_WRITE, i] = t[T.COL_MEM_REGION_PROPHET, i] = 1
+        t[T.COL_MEM_ADDR, i] = a
+        d = (a - last_addr) % P if i == start else 1
+        t[T.COL_MEM_DIFF_ADDR, i], t[T.COL_MEM_DIFF_ADDR_INV, i] = d, _inv(d)
+        t[T.COL_MEM_DIFF_ADDR_COND, i] = t[T.COL_MEM_RC_VALUE, i] = (0 - a) % P
+        a = (a + 1) % P
+    return t, rc_vals
+
+
 def instance(prog, range_bits=4, limb_bits=2, bitwise_beta=12345, program_beta=67890):
     """The 12 traces (enum Table order), params and compress challenges of ola_stark(range_bits, limb_bits) for one run of
     `prog`.  With miniature fixed tables, RC / GTE operands must stay below 2^(2*range_bits) and bitwise operands below
@@ -250,10 +309,11 @@ def instance(prog, range_bits=4, limb_bits=2, bitwise_beta=12345, program_beta=6
     for a, b in side["cmp"]:
         d = abs(a - b)
         cmp_rows.append((a, b, int(a >= b), d, _inv(d), 1))
-    rc_rows = [(v, 1, 0, 0, 0) for v in side["rc"]] + [(r[3], 0, 0, 0, 1) for r in cmp_rows]
+    mem, mem_rc = memory_trace(side["mem"])
+    rc_rows = [(v, 1, 0, 0, 0) for v in side["rc"]] + [(r[3], 0, 0, 0, 1) for r in cmp_rows] + [(v, 0, 1, 0, 0) for v in mem_rc]
     n = 8
     traces = [
-        cpu, TG.memory_padding_trace(n), TG.bitwise_trace(bitwise_beta, limb_bits, side["bitwise"], looked_by_cpu=True),
+        cpu, mem, TG.bitwise_trace(bitwise_beta, limb_bits, side["bitwise"], looked_by_cpu=True),
         TG.generate_cmp_trace(cmp_rows), TG.generate_rc_trace(rc_rows, range_bits), poseidon,
         TG.flag_padding_trace(T.NUM_POSEIDON_CHUNK_COLS, n, T.COL_POSEIDON_CHUNK_IS_PADDING_LINE),
         TG.flag_padding_trace(T.NUM_COL_ST, n, T.COL_ST_IS_PADDING),
@@ -290,5 +350,25 @@ def mixed_program():
     p.add("MOV", dst=8, op1=("imm", 999))
     end = len(p.words()[0]) + 2
     p.add("JMP", op1=("imm", end))
+    p.add("END")
+    return p
+
+
+def memory_program(count=6):
+    """Stores the first `count` Fibonacci numbers to memory cells 1..count (stack region), then reads them back in reverse
+    order and sums them: MSTORE / MLOAD rows behind the cpu<->memory lookup, a memory table whose sort columns are
+    range-checked, several accesses per address."""
+    p = Program()
+    p.add("MOV", dst=1, op1=("imm", 0)).add("MOV", dst=2, op1=("imm", 1)).add("MOV", dst=3, op1=("imm", 0))   # r3: address cursor
+    loop = len(p.words()[0])
+    p.add("ADD", dst=3, op0=3, op1=("imm", 1)).add("MSTORE", dst=1, op0=3, op1=("imm", 0))
+    p.add("ADD", dst=4, op0=1, op1=2).add("MOV", dst=1, op1=2).add("MOV", dst=2, op1=4)
+    p.add("NEQ", dst=5, op0=3, op1=("imm", count)).add("CJMP", op0=5, op1=("imm", loop))
+    p.add("MOV", dst=6, op1=("imm", 0))                                                                         # r6: running sum
+    back = len(p.words()[0])
+    p.add("MLOAD", dst=7, op0=3, op1=("imm", 0)).add("ADD", dst=6, op0=6, op1=7)
+    p.add("MSTORE", dst=6, op0=3, op1=("imm", 0))                                                               # overwrite with the partial sum
+    p.add("MLOAD", dst=8, op0=3, op1=("imm", 0))
+    p.add("ADD", dst=3, op0=3, op1=("imm", P - 1)).add("NEQ", dst=5, op0=3, op1=("imm", 0)).add("CJMP", op0=5, op1=("imm", back))
     p.add("END")
     return p
