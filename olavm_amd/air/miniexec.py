@@ -1,8 +1,9 @@
 """A miniature executor for OlaVM's register instructions (SURVEY f-1): runs a small program and fills the STARK tables it
 touches so that EVERY constraint and EVERY cross-table lookup holds -- a real (if tiny) execution trace without the Rust
 executor.  Supported: MOV, ADD, MUL, EQ, NEQ, JMP, CJMP, RC, AND / OR / XOR, GTE, MSTORE / MLOAD ([reg + imm], stack
-region), END with register or immediate second operands.  Tables that receive live rows: CPU, memory, program, prog_chunk
-(program hashing), Poseidon (the chunk hashes), range-check (RC, GTE and the memory table's sort columns), bitwise, cmp;
+region), POSEIDON (whole 8-word blocks), END with register or immediate second operands.  Tables that receive live rows:
+CPU, memory, program, prog_chunk (program hashing), poseidon_chunk (the builtin), Poseidon (chunk and builtin hashes),
+range-check (RC, GTE and the memory table's sort columns), bitwise, cmp;
 the rest keep their padding rows (olavm_amd/air/tracegen.py).
 
 Restated from (reference paths): core/src/vm/opcodes.rs (opcode bit masks), circuits/src/cpu/cpu_stark.rs:529-581
@@ -93,7 +94,7 @@ class Program:
 
 
 SELECTOR_MEM = {"MLOAD": T.COL_S_MLOAD, "MSTORE": T.COL_S_MSTORE}
-SELECTOR = {"MLOAD": T.COL_S_MLOAD, "MSTORE": T.COL_S_MSTORE, "ADD": T.COL_S_SIMPLE_ARITHMATIC_OP, "MUL": T.COL_S_SIMPLE_ARITHMATIC_OP, "EQ": T.COL_S_SIMPLE_ARITHMATIC_OP,
+SELECTOR = {"POSEIDON": T.COL_S_PSDN, "MLOAD": T.COL_S_MLOAD, "MSTORE": T.COL_S_MSTORE, "ADD": T.COL_S_SIMPLE_ARITHMATIC_OP, "MUL": T.COL_S_SIMPLE_ARITHMATIC_OP, "EQ": T.COL_S_SIMPLE_ARITHMATIC_OP,
             "NEQ": T.COL_S_SIMPLE_ARITHMATIC_OP, "MOV": T.COL_S_MOV, "JMP": T.COL_S_JMP, "CJMP": T.COL_S_CJMP, "END": T.COL_S_END,
             "RC": T.COL_S_RC, "AND": T.COL_S_BITWISE, "OR": T.COL_S_BITWISE, "XOR": T.COL_S_BITWISE, "GTE": T.COL_S_GTE}
 
@@ -104,7 +105,7 @@ def execute(prog, max_steps=1 << 16):
     pc_to_idx = {pc: i for i, pc in enumerate(pcs)}
     regs = [0] * REG
     pc = clk = 0
-    rows, side, executed = [], {"rc": [], "bitwise": [], "cmp": [], "mem": []}, []
+    rows, side, executed = [], {"rc": [], "bitwise": [], "cmp": [], "mem": [], "psdn": []}, []
     memory = {}
     while True:
         assert len(rows) < max_steps, "program does not terminate"
@@ -172,7 +173,29 @@ def execute(prog, max_steps=1 << 16):
             else:
                 assert addr in memory, "load from an address that was never written"
                 res = memory[addr]
-            side["mem"].append((addr, clk, op, res))
+            side["mem"].append((addr, clk, op, res, int(op == "MSTORE")))
+        elif op == "POSEIDON":
+            # executor/src/lib.rs:1547-1700: hash `len` (= op1, a multiple of 8 here) words at [op0..] eight at a time, the
+            # capacity chained through the calls, and write the first four words of the last output to [dst..]
+            src, length, dst_addr = v0, v1, regs[dst]
+            assert length and length % 8 == 0, "only whole 8-word blocks are implemented"
+            chunks, cap = [], [0, 0, 0, 0]
+            for k in range(0, length, 8):
+                vals = []
+                for i in range(8):
+                    a = src + k + i
+                    assert a in memory, "hash input was never written"
+                    vals.append(memory[a])
+                    side["mem"].append((a, clk, "POSEIDON", memory[a], 0))
+                row = poseidon_row(vals + cap, filters=(1, 0, 0, 0))
+                chunks.append((src + k, vals, cap, row))
+                cap = row[16:28][8:12]
+            out = chunks[-1][3][16:20]
+            for i in range(4):
+                memory[dst_addr + i] = out[i]
+                side["mem"].append((dst_addr + i, clk, "POSEIDON", out[i], 1))
+            side["psdn"].append({"clk": clk, "src": src, "len": length, "dst": dst_addr, "chunks": chunks})
+            res = dst_addr          # the CPU's dst column carries the destination address; registers do not change
         if dst is not None:
             assert res is not None
             r[T.COL_S_DST.start + dst], r[T.COL_DST] = 1, res
@@ -222,7 +245,7 @@ def program_trace(prog, executed, beta):
     return t, words
 
 
-def prog_chunk_and_poseidon(prog, words, n_poseidon_min=8):
+def prog_chunk_and_poseidon(prog, words, n_poseidon_min=8, extra_rows=()):
     """One prog_chunk row per 8 program words, hashed with Poseidon (capacity = last third of the previous chunk's hash);
     -> (prog_chunk trace, Poseidon-table trace carrying those permutations)."""
     chunks = [words[i:i + 8] for i in range(0, len(words), 8)]
@@ -247,6 +270,7 @@ def prog_chunk_and_poseidon(prog, words, n_poseidon_min=8):
         for k in T.COL_PROG_CHUNK_FILTER_LOOKING_PROG_RANGE:
             t[k, i] = 1
         cap = h[8:12]
+    prow = prow + list(extra_rows)        # permutations of the Poseidon builtin share the table
     np_ = TG.next_pow2(max(len(prow), n_poseidon_min))
     pt = TG.poseidon_padding_trace(np_)
     for i, row in enumerate(prow):
@@ -265,11 +289,12 @@ def memory_trace(cells):
     t = np.zeros((T.NUM_MEM_COLS, n), dtype=np.uint64)
     rc_vals = []
     prev = None
-    for i, (addr, clk, op, value) in enumerate(cells):
+    sel = {"MSTORE": T.COL_MEM_S_MSTORE, "MLOAD": T.COL_MEM_S_MLOAD, "POSEIDON": T.COL_MEM_S_POSEIDON}
+    for i, (addr, clk, op, value, is_write) in enumerate(cells):
         t[T.COL_MEM_IS_RW, i] = 1
         t[T.COL_MEM_ADDR, i], t[T.COL_MEM_CLK, i], t[T.COL_MEM_OP, i], t[T.COL_MEM_VALUE, i] = addr, clk, T.op_mask(op), value
-        t[T.COL_MEM_S_MSTORE if op == "MSTORE" else T.COL_MEM_S_MLOAD, i] = 1
-        t[T.COL_MEM_IS_WRITE, i] = int(op == "MSTORE")
+        t[sel[op], i] = 1
+        t[T.COL_MEM_IS_WRITE, i] = is_write
         if prev is not None:
             same = int(addr == prev[0])
             d_addr = addr - prev[0]
@@ -297,6 +322,45 @@ def memory_trace(cells):
     return t, rc_vals
 
 
+def poseidon_chunk_trace(calls):
+    """Poseidon-builtin table (generation/poseidon_chunk.rs; builtins/poseidon/poseidon_chunk_stark.rs:98-284): per POSEIDON
+    instruction one header row (looked up by the CPU) and one extension row per 8-word block (looking up its 8 source
+    words in memory and its permutation in the Poseidon table); the last one is the result line (its first 4 hash words go
+    to memory).  -> (trace, Poseidon-table rows)"""
+    rows, prow = [], []
+    for c in calls:
+        base = {T.COL_POSEIDON_CHUNK_CLK: c["clk"], T.COL_POSEIDON_CHUNK_OPCODE: T.op_mask("POSEIDON"),
+                T.COL_POSEIDON_CHUNK_OP1: c["len"], T.COL_POSEIDON_CHUNK_DST: c["dst"]}
+        head = dict(base)
+        head[T.COL_POSEIDON_CHUNK_OP0] = c["src"]
+        head[T.COL_POSEIDON_CHUNK_FILTER_LOOKED_CPU] = 1
+        rows.append(head)
+        for j, (addr, vals, cap, prow_j) in enumerate(c["chunks"]):
+            r = dict(base)
+            r[T.COL_POSEIDON_CHUNK_OP0] = addr
+            r[T.COL_POSEIDON_CHUNK_ACC_CNT] = 8 * (j + 1)
+            for k, v in zip(T.COL_POSEIDON_CHUNK_VALUE_RANGE, vals):
+                r[k] = v
+            for k, v in zip(T.COL_POSEIDON_CHUNK_CAP_RANGE, cap):
+                r[k] = v
+            for k, v in zip(T.COL_POSEIDON_CHUNK_HASH_RANGE, prow_j[16:28]):
+                r[k] = v
+            r[T.COL_POSEIDON_CHUNK_IS_EXT_LINE] = 1
+            r[T.COL_POSEIDON_CHUNK_IS_RESULT_LINE] = int(j == len(c["chunks"]) - 1)
+            for k in T.COL_POSEIDON_CHUNK_FILTER_LOOKING_MEM_RANGE:
+                r[k] = 1
+            r[T.COL_POSEIDON_CHUNK_FILTER_LOOKING_POSEIDON] = 1
+            rows.append(r)
+            prow.append(prow_j)
+    n = TG.next_pow2(max(len(rows), 8))
+    t = TG.flag_padding_trace(T.NUM_POSEIDON_CHUNK_COLS, n, T.COL_POSEIDON_CHUNK_IS_PADDING_LINE)
+    for i, r in enumerate(rows):
+        t[T.COL_POSEIDON_CHUNK_IS_PADDING_LINE, i] = 0
+        for k, v in r.items():
+            t[k, i] = v
+    return t, prow
+
+
 def instance(prog, range_bits=4, limb_bits=2, bitwise_beta=12345, program_beta=67890):
     """The 12 traces (enum Table order), params and compress challenges of ola_stark(range_bits, limb_bits) for one run of
     `prog`.  With miniature fixed tables, RC / GTE operands must stay below 2^(2*range_bits) and bitwise operands below
@@ -304,7 +368,8 @@ def instance(prog, range_bits=4, limb_bits=2, bitwise_beta=12345, program_beta=6
     rows, side, executed = execute(prog)
     cpu = cpu_trace(rows)
     program, words = program_trace(prog, executed, program_beta)
-    chunk, poseidon = prog_chunk_and_poseidon(prog, words)
+    pchunk, builtin_rows = poseidon_chunk_trace(side["psdn"])
+    chunk, poseidon = prog_chunk_and_poseidon(prog, words, extra_rows=builtin_rows)
     cmp_rows = []
     for a, b in side["cmp"]:
         d = abs(a - b)
@@ -315,7 +380,7 @@ def instance(prog, range_bits=4, limb_bits=2, bitwise_beta=12345, program_beta=6
     traces = [
         cpu, mem, TG.bitwise_trace(bitwise_beta, limb_bits, side["bitwise"], looked_by_cpu=True),
         TG.generate_cmp_trace(cmp_rows), TG.generate_rc_trace(rc_rows, range_bits), poseidon,
-        TG.flag_padding_trace(T.NUM_POSEIDON_CHUNK_COLS, n, T.COL_POSEIDON_CHUNK_IS_PADDING_LINE),
+        pchunk,
         TG.flag_padding_trace(T.NUM_COL_ST, n, T.COL_ST_IS_PADDING),
         TG.tape_padding_trace(n),
         TG.flag_padding_trace(T.NUM_COL_SCCALL, n, T.COL_SCCALL_IS_PADDING),
@@ -370,5 +435,21 @@ def memory_program(count=6):
     p.add("MSTORE", dst=6, op0=3, op1=("imm", 0))                                                               # overwrite with the partial sum
     p.add("MLOAD", dst=8, op0=3, op1=("imm", 0))
     p.add("ADD", dst=3, op0=3, op1=("imm", P - 1)).add("NEQ", dst=5, op0=3, op1=("imm", 0)).add("CJMP", op0=5, op1=("imm", back))
+    p.add("END")
+    return p
+
+
+def hash_program(blocks=2):
+    """Writes 8*blocks words to memory and hashes them with the POSEIDON builtin, then loads the digest back: the
+    cpu<->poseidon_chunk, poseidon_chunk<->memory (8 source + 4 destination words) and poseidon_chunk<->poseidon lookups."""
+    p = Program()
+    n = 8 * blocks
+    p.add("MOV", dst=1, op1=("imm", 1)).add("MOV", dst=2, op1=("imm", 3))        # r1: address cursor, r2: running value
+    loop = len(p.words()[0])
+    p.add("MSTORE", dst=2, op0=1, op1=("imm", 0)).add("MUL", dst=2, op0=2, op1=("imm", 5)).add("ADD", dst=1, op0=1, op1=("imm", 1))
+    p.add("NEQ", dst=5, op0=1, op1=("imm", n + 1)).add("CJMP", op0=5, op1=("imm", loop))
+    p.add("MOV", dst=3, op1=("imm", 1)).add("MOV", dst=4, op1=("imm", 100))      # r3: source, r4: destination
+    p.add("POSEIDON", dst=4, op0=3, op1=("imm", n))
+    p.add("MLOAD", dst=6, op0=4, op1=("imm", 0)).add("MLOAD", dst=7, op0=4, op1=("imm", 3))
     p.add("END")
     return p

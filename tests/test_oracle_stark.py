@@ -122,23 +122,27 @@ def _check_all_tables(oracle, s, traces, params):
         assert oracle.check_constraints(blob, i, tr, pr) == -1, s.tables[i].name
 
 
-@pytest.mark.parametrize("program", ["fibonacci", "mixed", "memory"])
+@pytest.mark.parametrize("program", ["fibonacci", "mixed", "memory", "hash"])
 def test_mini_executor_traces_are_valid_and_provable(oracle, program):
     """A real execution (olavm_amd/air/miniexec.py): CPU rows with live opcodes, the program table they are fetched
     from, the Poseidon-hashed program chunks, and -- for the mixed program -- bitwise, comparison and range-check rows
     behind the CPU's lookups.  All 251 CPU constraints and the other 11 AIRs vanish, and the proof passes the verifier's
     cross-table product check with 3 (fibonacci) / 7 (mixed) / 5 (memory: cpu<->memory and the memory table's range-checked
-    sort columns) of the 19 lookups carrying rows."""
+    sort columns) / 8 (hash: the Poseidon builtin reading and writing memory) of the 19 lookups carrying rows."""
     from olavm_amd.air import miniexec as M
     s = T.ola_stark(range_bits=4, limb_bits=2)
-    prog = {"fibonacci": lambda: M.fibonacci(5), "mixed": M.mixed_program, "memory": M.memory_program}[program]()
+    prog = {"fibonacci": lambda: M.fibonacci(5), "mixed": M.mixed_program, "memory": M.memory_program, "hash": M.hash_program}[program]()
     rows, side, _ = M.execute(prog)
     if program == "fibonacci":
         assert (rows[-1][T.COL_REGS.start + 1], rows[-1][T.COL_REGS.start + 2]) == (5, 8) and len(rows) == 34
     elif program == "mixed":
         assert len(side["bitwise"]) == 3 and len(side["cmp"]) == 3 and side["rc"] == [200 & 77, 255]
-    else:
+    elif program == "memory":
         assert len(side["mem"]) == 24 and rows[-1][T.COL_REGS.start + 6] == 0 + 1 + 1 + 2 + 3 + 5
+    else:       # the digest the program loads back is the sponge hash of the 16 words it stored
+        words = np.array([3 * pow(5, i, tracegen.P) % tracegen.P for i in range(16)], dtype=np.uint64)
+        digest = oracle.hash_no_pad(words)
+        assert (rows[-1][T.COL_REGS.start + 6], rows[-1][T.COL_REGS.start + 7]) == (int(digest[0]), int(digest[3]))
     traces, params, compress = M.instance(prog)
     _check_all_tables(oracle, s, traces, params)
     # the constraints bite on the live rows: a wrong sum, a wrong fetched instruction
