@@ -1,7 +1,7 @@
 """A miniature executor for OlaVM's register instructions (SURVEY f-1): runs a small program and fills the STARK tables it
 touches so that EVERY constraint and EVERY cross-table lookup holds -- a real (if tiny) execution trace without the Rust
 executor.  Supported: MOV, ADD, MUL, EQ, NEQ, JMP, CJMP, RC, AND / OR / XOR, GTE, MSTORE / MLOAD ([reg + imm], stack
-region), POSEIDON (whole 8-word blocks), END with register or immediate second operands.  Tables that receive live rows:
+region), CALL / RET, POSEIDON (whole 8-word blocks), END with register or immediate second operands.  Tables that receive live rows:
 CPU, memory, program, prog_chunk (program hashing), poseidon_chunk (the builtin), Poseidon (chunk and builtin hashes),
 range-check (RC, GTE and the memory table's sort columns), bitwise, cmp;
 the rest keep their padding rows (olavm_amd/air/tracegen.py).
@@ -94,7 +94,7 @@ class Program:
 
 
 SELECTOR_MEM = {"MLOAD": T.COL_S_MLOAD, "MSTORE": T.COL_S_MSTORE}
-SELECTOR = {"POSEIDON": T.COL_S_PSDN, "MLOAD": T.COL_S_MLOAD, "MSTORE": T.COL_S_MSTORE, "ADD": T.COL_S_SIMPLE_ARITHMATIC_OP, "MUL": T.COL_S_SIMPLE_ARITHMATIC_OP, "EQ": T.COL_S_SIMPLE_ARITHMATIC_OP,
+SELECTOR = {"CALL": T.COL_S_CALL, "RET": T.COL_S_RET, "POSEIDON": T.COL_S_PSDN, "MLOAD": T.COL_S_MLOAD, "MSTORE": T.COL_S_MSTORE, "ADD": T.COL_S_SIMPLE_ARITHMATIC_OP, "MUL": T.COL_S_SIMPLE_ARITHMATIC_OP, "EQ": T.COL_S_SIMPLE_ARITHMATIC_OP,
             "NEQ": T.COL_S_SIMPLE_ARITHMATIC_OP, "MOV": T.COL_S_MOV, "JMP": T.COL_S_JMP, "CJMP": T.COL_S_CJMP, "END": T.COL_S_END,
             "RC": T.COL_S_RC, "AND": T.COL_S_BITWISE, "OR": T.COL_S_BITWISE, "XOR": T.COL_S_BITWISE, "GTE": T.COL_S_GTE}
 
@@ -174,6 +174,25 @@ def execute(prog, max_steps=1 << 16):
                 assert addr in memory, "load from an address that was never written"
                 res = memory[addr]
             side["mem"].append((addr, clk, op, res, int(op == "MSTORE")))
+        elif op == "CALL":
+            # executor/src/lib.rs:816-849: the return address goes to [fp - 1]; [fp - 2] (the caller's saved fp) is read
+            fp = regs[REG - 1]
+            assert imm and (fp - 2) % P in memory, "CALL needs an immediate target and a saved frame pointer at [fp - 2]"
+            ret_pc = pc + size
+            r[T.COL_OP0], r[T.COL_DST], r[T.COL_AUX0], r[T.COL_AUX1] = (fp - 1) % P, ret_pc, (fp - 2) % P, memory[(fp - 2) % P]
+            memory[(fp - 1) % P] = ret_pc
+            side["mem"].append(((fp - 1) % P, clk, "CALL", ret_pc, 1))
+            side["mem"].append(((fp - 2) % P, clk, "CALL", memory[(fp - 2) % P], 0))
+            next_pc = v1
+        elif op == "RET":
+            # executor/src/lib.rs:851-866: pc <- [fp - 1], fp <- [fp - 2]
+            fp = regs[REG - 1]
+            ret_pc, old_fp = memory[(fp - 1) % P], memory[(fp - 2) % P]
+            r[T.COL_OP0], r[T.COL_DST], r[T.COL_AUX0], r[T.COL_AUX1] = (fp - 1) % P, ret_pc, (fp - 2) % P, old_fp
+            side["mem"].append(((fp - 1) % P, clk, "RET", ret_pc, 0))
+            side["mem"].append(((fp - 2) % P, clk, "RET", old_fp, 0))
+            regs[REG - 1] = old_fp
+            next_pc = ret_pc
         elif op == "POSEIDON":
             # executor/src/lib.rs:1547-1700: hash `len` (= op1, a multiple of 8 here) words at [op0..] eight at a time, the
             # capacity chained through the calls, and write the first four words of the last output to [dst..]
@@ -289,7 +308,8 @@ def memory_trace(cells):
     t = np.zeros((T.NUM_MEM_COLS, n), dtype=np.uint64)
     rc_vals = []
     prev = None
-    sel = {"MSTORE": T.COL_MEM_S_MSTORE, "MLOAD": T.COL_MEM_S_MLOAD, "POSEIDON": T.COL_MEM_S_POSEIDON}
+    sel = {"MSTORE": T.COL_MEM_S_MSTORE, "MLOAD": T.COL_MEM_S_MLOAD, "POSEIDON": T.COL_MEM_S_POSEIDON, "CALL": T.COL_MEM_S_CALL,
+           "RET": T.COL_MEM_S_RET}
     for i, (addr, clk, op, value, is_write) in enumerate(cells):
         t[T.COL_MEM_IS_RW, i] = 1
         t[T.COL_MEM_ADDR, i], t[T.COL_MEM_CLK, i], t[T.COL_MEM_OP, i], t[T.COL_MEM_VALUE, i] = addr, clk, T.op_mask(op), value
@@ -451,5 +471,26 @@ def hash_program(blocks=2):
     p.add("MOV", dst=3, op1=("imm", 1)).add("MOV", dst=4, op1=("imm", 100))      # r3: source, r4: destination
     p.add("POSEIDON", dst=4, op0=3, op1=("imm", n))
     p.add("MLOAD", dst=6, op0=4, op1=("imm", 0)).add("MLOAD", dst=7, op0=4, op1=("imm", 3))
+    p.add("END")
+    return p
+
+
+def call_program():
+    """A function call: the caller sets up a frame (fp = r9), saves its frame pointer at [fp - 2], CALLs a routine that
+    doubles r1 three times and RETurns; executed twice."""
+    p = Program()
+    p.add("MOV", dst=9, op1=("imm", 10)).add("MOV", dst=8, op1=("imm", 4))          # fp = 10; the value RET restores into fp
+    p.add("MSTORE", dst=8, op0=9, op1=("imm", P - 2))                                # [fp - 2] <- 4
+    p.add("MOV", dst=1, op1=("imm", 3))
+    words_before = len(p.words()[0])
+    routine = words_before + 2 + 2 + 2 + 2 + 2 + 1                                   # after: CALL, MOV, MSTORE, CALL, END-jump
+    p.add("CALL", op1=("imm", routine))
+    p.add("MOV", dst=9, op1=("imm", 10)).add("MSTORE", dst=8, op0=9, op1=("imm", P - 2))   # same frame again
+    p.add("CALL", op1=("imm", routine))
+    p.add("JMP", op1=("imm", routine + 4))                                           # over the routine to END
+    # pad so that the routine starts exactly at `routine`
+    while len(p.words()[0]) < routine:
+        p.add("ADD", dst=7, op0=7, op1=7)
+    p.add("ADD", dst=1, op0=1, op1=1).add("ADD", dst=1, op0=1, op1=1).add("ADD", dst=1, op0=1, op1=1).add("RET")
     p.add("END")
     return p
