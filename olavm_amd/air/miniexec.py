@@ -1,7 +1,7 @@
 """A miniature executor for OlaVM's register instructions (SURVEY f-1): runs a small program and fills the STARK tables it
 touches so that EVERY constraint and EVERY cross-table lookup holds -- a real (if tiny) execution trace without the Rust
 executor.  Supported: MOV, ADD, MUL, EQ, NEQ, JMP, CJMP, RC, AND / OR / XOR, GTE, MSTORE / MLOAD ([reg + imm], stack
-region), CALL / RET, POSEIDON (whole 8-word blocks), END with register or immediate second operands.  Tables that receive live rows:
+region), CALL / RET, TSTORE / TLOAD (with their CPU extension lines), POSEIDON (whole 8-word blocks), END with register or immediate second operands.  Tables that receive live rows:
 CPU, memory, program, prog_chunk (program hashing), poseidon_chunk (the builtin), Poseidon (chunk and builtin hashes),
 range-check (RC, GTE and the memory table's sort columns), bitwise, cmp;
 the rest keep their padding rows (olavm_amd/air/tracegen.py).
@@ -94,7 +94,7 @@ class Program:
 
 
 SELECTOR_MEM = {"MLOAD": T.COL_S_MLOAD, "MSTORE": T.COL_S_MSTORE}
-SELECTOR = {"CALL": T.COL_S_CALL, "RET": T.COL_S_RET, "POSEIDON": T.COL_S_PSDN, "MLOAD": T.COL_S_MLOAD, "MSTORE": T.COL_S_MSTORE, "ADD": T.COL_S_SIMPLE_ARITHMATIC_OP, "MUL": T.COL_S_SIMPLE_ARITHMATIC_OP, "EQ": T.COL_S_SIMPLE_ARITHMATIC_OP,
+SELECTOR = {"TSTORE": T.COL_S_TSTORE, "TLOAD": T.COL_S_TLOAD, "CALL": T.COL_S_CALL, "RET": T.COL_S_RET, "POSEIDON": T.COL_S_PSDN, "MLOAD": T.COL_S_MLOAD, "MSTORE": T.COL_S_MSTORE, "ADD": T.COL_S_SIMPLE_ARITHMATIC_OP, "MUL": T.COL_S_SIMPLE_ARITHMATIC_OP, "EQ": T.COL_S_SIMPLE_ARITHMATIC_OP,
             "NEQ": T.COL_S_SIMPLE_ARITHMATIC_OP, "MOV": T.COL_S_MOV, "JMP": T.COL_S_JMP, "CJMP": T.COL_S_CJMP, "END": T.COL_S_END,
             "RC": T.COL_S_RC, "AND": T.COL_S_BITWISE, "OR": T.COL_S_BITWISE, "XOR": T.COL_S_BITWISE, "GTE": T.COL_S_GTE}
 
@@ -105,8 +105,9 @@ def execute(prog, max_steps=1 << 16):
     pc_to_idx = {pc: i for i, pc in enumerate(pcs)}
     regs = [0] * REG
     pc = clk = 0
-    rows, side, executed = [], {"rc": [], "bitwise": [], "cmp": [], "mem": [], "psdn": []}, []
+    rows, side, executed = [], {"rc": [], "bitwise": [], "cmp": [], "mem": [], "psdn": [], "tape": []}, []
     memory = {}
+    tape, tp = {}, 0
     while True:
         assert len(rows) < max_steps, "program does not terminate"
         op, dst, op0, op1 = prog.ins[pc_to_idx[pc]]
@@ -116,7 +117,7 @@ def execute(prog, max_steps=1 << 16):
             r[k] = v
         for k, v in zip(T.COL_ADDR_CODE_RANGE, prog.code_addr):
             r[k] = v
-        r[T.COL_CLK], r[T.COL_PC] = clk, pc
+        r[T.COL_CLK], r[T.COL_PC], r[T.COL_TP] = clk, pc, tp
         for i in range(REG):
             r[T.COL_REGS.start + i] = regs[i]
         r[T.COL_INST], r[T.COL_OP1_IMM], r[T.COL_OPCODE] = words[pc], int(imm), T.op_mask(op)
@@ -215,6 +216,8 @@ def execute(prog, max_steps=1 << 16):
                 side["mem"].append((dst_addr + i, clk, "POSEIDON", out[i], 1))
             side["psdn"].append({"clk": clk, "src": src, "len": length, "dst": dst_addr, "chunks": chunks})
             res = dst_addr          # the CPU's dst column carries the destination address; registers do not change
+        if op == "TLOAD":
+            res = regs[dst]         # dst names the register holding the memory base; it does not change
         if dst is not None:
             assert res is not None
             r[T.COL_S_DST.start + dst], r[T.COL_DST] = 1, res
@@ -224,6 +227,40 @@ def execute(prog, max_steps=1 << 16):
             rows.append(r)
             break
         rows.append(r)
+        if op in ("TSTORE", "TLOAD"):
+            # executor/src/lib.rs:1687-1846 + cpu/tape.rs: one extension line per word moved between memory and the tape.
+            # Extension lines repeat the instruction's clk / pc / opcode / selectors / op0 / op1; aux0 walks the memory
+            # addresses, the first register-selector column (COL_S_OP0.start) the tape addresses, aux1 carries the word.
+            if op == "TSTORE":
+                length, mem_base, tape_base = v1, v0, tp
+            else:
+                assert v0 in (0, 1)
+                length, mem_base, tape_base = (v1, regs[dst], tp - v1) if v0 else (1, regs[dst], v1)
+            assert length >= 1
+            r[T.COL_IS_NEXT_LINE_DIFF_INST] = 0
+            for k in range(length):
+                e = dict(r)
+                for c in list(T.COL_S_OP0) + list(T.COL_S_OP1) + list(T.COL_S_DST):
+                    e[c] = 0
+                e[T.COL_INST] = e[T.COL_IMM_VAL] = e[T.COL_FILTER_LOOKING_PROG_IMM] = e[T.COL_DST] = 0
+                e[T.COL_IS_EXT_LINE], e[T.COL_EXT_CNT], e[T.COL_FILTER_TAPE_LOOKING] = 1, k + 1, 1
+                e[T.COL_IS_NEXT_LINE_DIFF_INST] = int(k == length - 1)
+                maddr, taddr = mem_base + k, tape_base + k
+                if op == "TSTORE":
+                    assert maddr in memory, "tstore source was never written"
+                    word = memory[maddr]
+                    tape[taddr] = word
+                    side["mem"].append((maddr, clk, "TSTORE", word, 0))
+                else:
+                    assert taddr in tape, "tload from a tape cell that was never written"
+                    word = tape[taddr]
+                    memory[maddr] = word
+                    side["mem"].append((maddr, clk, "TLOAD", word, 1))
+                side["tape"].append((taddr, len(side["tape"]), op, word))
+                e[T.COL_AUX0], e[T.COL_S_OP0.start], e[T.COL_AUX1] = maddr, taddr, word
+                rows.append(e)
+            if op == "TSTORE":
+                tp += length
         pc, clk = next_pc, clk + 1
     return rows, side, executed
 
@@ -308,7 +345,7 @@ def memory_trace(cells):
     t = np.zeros((T.NUM_MEM_COLS, n), dtype=np.uint64)
     rc_vals = []
     prev = None
-    sel = {"MSTORE": T.COL_MEM_S_MSTORE, "MLOAD": T.COL_MEM_S_MLOAD, "POSEIDON": T.COL_MEM_S_POSEIDON, "CALL": T.COL_MEM_S_CALL,
+    sel = {"TSTORE": T.COL_MEM_S_TSTORE, "TLOAD": T.COL_MEM_S_TLOAD, "MSTORE": T.COL_MEM_S_MSTORE, "MLOAD": T.COL_MEM_S_MLOAD, "POSEIDON": T.COL_MEM_S_POSEIDON, "CALL": T.COL_MEM_S_CALL,
            "RET": T.COL_MEM_S_RET}
     for i, (addr, clk, op, value, is_write) in enumerate(cells):
         t[T.COL_MEM_IS_RW, i] = 1
@@ -381,6 +418,23 @@ def poseidon_chunk_trace(calls):
     return t, prow
 
 
+def tape_trace(cells):
+    """Tape table (builtins/tape/tape_stark.rs:44-143): cells sorted by tape address, the write (TSTORE) of an address
+    first, then its reads (TLOAD); all are looked up by the CPU's extension lines.  Padding repeats the last cell as an
+    unfiltered TLOAD."""
+    cells = sorted(cells, key=lambda c: (c[0], c[1]))
+    n = TG.next_pow2(max(len(cells), 8))
+    if not cells:
+        return TG.tape_padding_trace(n)
+    t = np.zeros((T.NUM_COL_TAPE, n), dtype=np.uint64)
+    for i in range(n):
+        addr, _, op, word = cells[min(i, len(cells) - 1)]
+        live = i < len(cells)
+        t[T.COL_TAPE_OPCODE, i] = T.op_mask(op if live else "TLOAD")
+        t[T.COL_TAPE_ADDR, i], t[T.COL_TAPE_VALUE, i], t[T.COL_TAPE_FILTER_LOOKED, i] = addr, word, int(live)
+    return t
+
+
 def instance(prog, range_bits=4, limb_bits=2, bitwise_beta=12345, program_beta=67890):
     """The 12 traces (enum Table order), params and compress challenges of ola_stark(range_bits, limb_bits) for one run of
     `prog`.  With miniature fixed tables, RC / GTE operands must stay below 2^(2*range_bits) and bitwise operands below
@@ -402,7 +456,7 @@ def instance(prog, range_bits=4, limb_bits=2, bitwise_beta=12345, program_beta=6
         TG.generate_cmp_trace(cmp_rows), TG.generate_rc_trace(rc_rows, range_bits), poseidon,
         pchunk,
         TG.flag_padding_trace(T.NUM_COL_ST, n, T.COL_ST_IS_PADDING),
-        TG.tape_padding_trace(n),
+        tape_trace(side["tape"]),
         TG.flag_padding_trace(T.NUM_COL_SCCALL, n, T.COL_SCCALL_IS_PADDING),
         program, chunk,
     ]
@@ -492,5 +546,23 @@ def call_program():
     while len(p.words()[0]) < routine:
         p.add("ADD", dst=7, op0=7, op1=7)
     p.add("ADD", dst=1, op0=1, op1=1).add("ADD", dst=1, op0=1, op1=1).add("ADD", dst=1, op0=1, op1=1).add("RET")
+    p.add("END")
+    return p
+
+
+def tape_program():
+    """Writes three words to memory, appends them to the tape (TSTORE), reads the last two back to another place (TLOAD,
+    flag 1) and one by absolute tape address (TLOAD, flag 0), then adds what it loaded: multi-line instructions (CPU
+    extension lines), the tape table and the cpu<->tape / cpu<->memory lookups of the extension lines."""
+    p = Program()
+    p.add("MOV", dst=1, op1=("imm", 20)).add("MOV", dst=2, op1=("imm", 7))
+    for k, v in enumerate((7, 11, 13)):
+        p.add("MOV", dst=2, op1=("imm", v)).add("MSTORE", dst=2, op0=1, op1=("imm", k))
+    p.add("TSTORE", op0=1, op1=("imm", 3))                                  # tape[0..3) <- mem[20..23)
+    p.add("MOV", dst=3, op1=("imm", 40)).add("MOV", dst=4, op1=("imm", 1)).add("MOV", dst=5, op1=("imm", 0))
+    p.add("TLOAD", dst=3, op0=4, op1=("imm", 2))                            # mem[40..42) <- tape[tp-2..tp)
+    p.add("MOV", dst=3, op1=("imm", 50)).add("TLOAD", dst=3, op0=5, op1=("imm", 0))   # mem[50] <- tape[0]
+    p.add("MOV", dst=6, op1=("imm", 40)).add("MLOAD", dst=7, op0=6, op1=("imm", 0)).add("MLOAD", dst=8, op0=6, op1=("imm", 1))
+    p.add("MLOAD", dst=6, op0=6, op1=("imm", 10)).add("ADD", dst=7, op0=7, op1=8).add("ADD", dst=7, op0=7, op1=6)
     p.add("END")
     return p

@@ -122,7 +122,7 @@ def _check_all_tables(oracle, s, traces, params):
         assert oracle.check_constraints(blob, i, tr, pr) == -1, s.tables[i].name
 
 
-@pytest.mark.parametrize("program", ["fibonacci", "mixed", "memory", "hash", "call"])
+@pytest.mark.parametrize("program", ["fibonacci", "mixed", "memory", "hash", "call", "tape"])
 def test_mini_executor_traces_are_valid_and_provable(oracle, program):
     """A real execution (olavm_amd/air/miniexec.py): CPU rows with live opcodes, the program table they are fetched
     from, the Poseidon-hashed program chunks, and -- for the mixed program -- bitwise, comparison and range-check rows
@@ -131,7 +131,7 @@ def test_mini_executor_traces_are_valid_and_provable(oracle, program):
     sort columns) / 8 (hash: the Poseidon builtin reading and writing memory) of the 19 lookups carrying rows."""
     from olavm_amd.air import miniexec as M
     s = T.ola_stark(range_bits=4, limb_bits=2)
-    prog = {"fibonacci": lambda: M.fibonacci(5), "mixed": M.mixed_program, "memory": M.memory_program, "hash": M.hash_program, "call": M.call_program}[program]()
+    prog = {"fibonacci": lambda: M.fibonacci(5), "mixed": M.mixed_program, "memory": M.memory_program, "hash": M.hash_program, "call": M.call_program, "tape": M.tape_program}[program]()
     rows, side, _ = M.execute(prog)
     if program == "fibonacci":
         assert (rows[-1][T.COL_REGS.start + 1], rows[-1][T.COL_REGS.start + 2]) == (5, 8) and len(rows) == 34
@@ -139,6 +139,8 @@ def test_mini_executor_traces_are_valid_and_provable(oracle, program):
         assert len(side["bitwise"]) == 3 and len(side["cmp"]) == 3 and side["rc"] == [200 & 77, 255]
     elif program == "memory":
         assert len(side["mem"]) == 24 and rows[-1][T.COL_REGS.start + 6] == 0 + 1 + 1 + 2 + 3 + 5
+    elif program == "tape":
+        assert rows[-1][T.COL_REGS.start + 7] == 11 + 13 + 7 and sum(r[T.COL_IS_EXT_LINE] for r in rows) == 6
     elif program == "call":
         assert rows[-1][T.COL_REGS.start + 1] == 3 * 8 * 8 and sum(1 for c in side["mem"] if c[2] in ("CALL", "RET")) == 8
     else:       # the digest the program loads back is the sponge hash of the 16 words it stored
