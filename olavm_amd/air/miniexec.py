@@ -1,18 +1,20 @@
 """A miniature executor for OlaVM's register instructions (SURVEY f-1): runs a small program and fills the STARK tables it
 touches so that EVERY constraint and EVERY cross-table lookup holds -- a real (if tiny) execution trace without the Rust
-executor.  Supported: MOV, ADD, MUL, EQ, NEQ, JMP, CJMP, RC, AND / OR / XOR, GTE, MSTORE / MLOAD ([reg + imm], stack
-region), CALL / RET, TSTORE / TLOAD (with their CPU extension lines), POSEIDON (whole 8-word blocks), END with register or immediate second operands.  Tables that receive live rows:
-CPU, memory, program, prog_chunk (program hashing), poseidon_chunk (the builtin), Poseidon (chunk and builtin hashes),
-range-check (RC, GTE and the memory table's sort columns), bitwise, cmp;
-the rest keep their padding rows (olavm_amd/air/tracegen.py).
+executor.  Supported: MOV, ADD, MUL, EQ, NEQ, JMP, CJMP, RC, AND / OR / XOR, GTE, MSTORE / MLOAD ([reg + imm], stack and
+heap regions), CALL / RET, TSTORE / TLOAD and SSTORE / SLOAD (with their CPU extension lines), POSEIDON (whole 8-word
+blocks), END, with register or immediate second operands.  Tables that receive live rows: CPU, memory, program,
+prog_chunk (program hashing), poseidon_chunk (the builtin), Poseidon (chunk, builtin, tree-key and state-tree hashes),
+storage_access (256-level proofs), tape, range-check (RC, GTE, the memory table's sort and region columns), bitwise, cmp;
+only the cross-contract-call table keeps its padding rows (olavm_amd/air/tracegen.py).
 
 Restated from (reference paths): core/src/vm/opcodes.rs (opcode bit masks), circuits/src/cpu/cpu_stark.rs:529-581
 (instruction word = op1_imm * 2^62 + one-hot register selectors at bits 52+r / 42+r / 32+r + opcode mask),
-circuits/src/generation/{cpu,prog,builtin,poseidon}.rs (row layouts and padding), circuits/src/program/*.rs (program /
-prog_chunk tables: 8 instruction words per Poseidon-hashed chunk, capacity chained from the previous chunk's hash).
-The program-hash chain stops short of a result line (prog_chunk_stark.rs never forces one), so no storage-tree proof is
-needed.  Validity is not taken on trust: tests check every table with the oracle's `check_constraints` and the whole
-proof -- including the cross-table products -- with its verifier."""
+circuits/src/generation/{cpu,memory,prog,builtin,poseidon,storage}.rs (row layouts and padding), circuits/src/program/*.rs
+(program / prog_chunk tables: 8 instruction words per Poseidon-hashed chunk, capacity chained from the previous chunk's
+hash).  By default the program-hash chain stops short of a result line (prog_chunk_stark.rs never forces one);
+instance(prove_program_hash=True) closes it with the state-tree proof of the code-address leaf.  Validity is not taken on
+trust: tests check every table with the oracle's `check_constraints` and the whole proof -- including the cross-table
+products -- with its verifier."""
 import numpy as np
 
 from . import ola_tables as T
@@ -62,6 +64,87 @@ def poseidon_row(inp, filters=(0, 0, 0, 0)):
     return row
 
 
+# ---- the account-storage tree (a 256-level sparse Merkle tree over Poseidon)
+class StorageTree:
+    """State tree behind SSTORE / SLOAD and the program-hash read (builtins/storage/storage_access_stark.rs:110-334): 256
+    levels below the root, the key's bits (four 64-bit limbs, most significant bit first) choose the child at every level,
+    inner nodes are Poseidon(left || right || [0,0,0,0])[:4] and the lowest level hashes the two 4-word VALUES of a sibling
+    pair with the capacity word set to 1.  Untouched leaves hold [0,0,0,0].  `access` returns the 256 table rows of one
+    proof (root side first) together with the Poseidon-table rows -- old and new hash of every level -- they look up."""
+    DEPTH = 256
+
+    def __init__(self):
+        self.nodes = {}
+        self.default = [None] * (self.DEPTH + 1)
+        self.default[self.DEPTH] = (0, 0, 0, 0)
+        for d in range(self.DEPTH - 1, -1, -1):
+            c = self.default[d + 1]
+            self.default[d] = self.hash(c, c, d == self.DEPTH - 1)[0]
+
+    @staticmethod
+    def hash(left, right, leaf_level):
+        row = poseidon_row(list(left) + list(right) + [int(leaf_level), 0, 0, 0], filters=(0, 0, int(leaf_level), 1 - int(leaf_level)))
+        return tuple(row[16:20]), row
+
+    @staticmethod
+    def key_bits(addr):
+        k = 0
+        for limb in addr:
+            k = (k << 64) | (int(limb) % P)
+        return k
+
+    def node(self, depth, prefix):
+        return self.nodes.get((depth, prefix), self.default[depth])
+
+    def root(self):
+        return self.node(0, 0)
+
+    def _write(self, k, value):
+        """Sets leaf `k`; -> per level (depth DEPTH-1 .. 0) the new hash and its Poseidon row."""
+        self.nodes[(self.DEPTH, k)] = tuple(value)
+        out = []
+        for d in range(self.DEPTH - 1, -1, -1):
+            pre = k >> (self.DEPTH - d)
+            h, row = self.hash(self.node(d + 1, 2 * pre), self.node(d + 1, 2 * pre + 1), d == self.DEPTH - 1)
+            self.nodes[(d, pre)] = h
+            out.append((h, row))
+        return out[::-1]                      # index = depth of the hashed node
+
+    def set(self, addr, value):
+        """State present before the execution starts (no proof rows)."""
+        self._write(self.key_bits(addr), value)
+
+    def get(self, addr):
+        return self.node(self.DEPTH, self.key_bits(addr))
+
+    def access(self, addr, value=None):
+        """Read (value None) or write of leaf `addr` -> (rows, Poseidon rows, value read / written).  rows[l-1] is layer l:
+        dict(bit, sib, pre_path, path, pre_hash, hash); pre_* describe the tree before a write (equal to the others on a
+        read).  Every layer contributes its old-tree and its new-tree hash to the Poseidon table."""
+        k = self.key_bits(addr)
+        pre = []
+        for layer in range(1, self.DEPTH + 1):
+            prefix = k >> (self.DEPTH - layer)
+            pre.append((prefix & 1, self.node(layer, prefix ^ 1), self.node(layer, prefix), self.node(layer - 1, prefix >> 1)))
+        pre_root = self.root()
+        is_write = value is not None
+        if is_write:
+            self._write(k, value)
+        rows, prows = [], []
+        for layer in range(1, self.DEPTH + 1):
+            bit, sib, pre_path, pre_hash = pre[layer - 1]
+            prefix = k >> (self.DEPTH - layer)
+            path, hsh = self.node(layer, prefix), self.node(layer - 1, prefix >> 1)
+            rows.append(dict(layer=layer, bit=bit, sib=sib, pre_path=pre_path, path=path, pre_hash=pre_hash, hash=hsh,
+                             pre_root=pre_root, root=self.root(), is_write=int(is_write), addr=tuple(int(a) % P for a in addr)))
+            for child, expect in ((path, hsh), (pre_path, pre_hash)):
+                pair = (sib, child) if bit else (child, sib)
+                h, prow = self.hash(pair[0], pair[1], layer == self.DEPTH)
+                assert h == expect
+                prows.append(prow)
+        return rows, prows, self.node(self.DEPTH, k)
+
+
 # ---- program
 class Program:
     """Instructions: (op, dst, op0, op1) with register indices or None; op1 may be ('imm', value)."""
@@ -94,20 +177,23 @@ class Program:
 
 
 SELECTOR_MEM = {"MLOAD": T.COL_S_MLOAD, "MSTORE": T.COL_S_MSTORE}
-SELECTOR = {"TSTORE": T.COL_S_TSTORE, "TLOAD": T.COL_S_TLOAD, "CALL": T.COL_S_CALL, "RET": T.COL_S_RET, "POSEIDON": T.COL_S_PSDN, "MLOAD": T.COL_S_MLOAD, "MSTORE": T.COL_S_MSTORE, "ADD": T.COL_S_SIMPLE_ARITHMATIC_OP, "MUL": T.COL_S_SIMPLE_ARITHMATIC_OP, "EQ": T.COL_S_SIMPLE_ARITHMATIC_OP,
+SELECTOR = {"SSTORE": T.COL_S_SSTORE, "SLOAD": T.COL_S_SLOAD, "TSTORE": T.COL_S_TSTORE, "TLOAD": T.COL_S_TLOAD, "CALL": T.COL_S_CALL, "RET": T.COL_S_RET, "POSEIDON": T.COL_S_PSDN, "MLOAD": T.COL_S_MLOAD, "MSTORE": T.COL_S_MSTORE, "ADD": T.COL_S_SIMPLE_ARITHMATIC_OP, "MUL": T.COL_S_SIMPLE_ARITHMATIC_OP, "EQ": T.COL_S_SIMPLE_ARITHMATIC_OP,
             "NEQ": T.COL_S_SIMPLE_ARITHMATIC_OP, "MOV": T.COL_S_MOV, "JMP": T.COL_S_JMP, "CJMP": T.COL_S_CJMP, "END": T.COL_S_END,
             "RC": T.COL_S_RC, "AND": T.COL_S_BITWISE, "OR": T.COL_S_BITWISE, "XOR": T.COL_S_BITWISE, "GTE": T.COL_S_GTE}
 
 
-def execute(prog, max_steps=1 << 16):
-    """-> (cpu rows as dicts of column -> value, side effects {'rc': [...], 'bitwise': [...], 'cmp': [...]}, executed words)."""
+def execute(prog, max_steps=1 << 16, tree=None):
+    """-> (cpu rows as dicts of column -> value, side effects {'rc': [...], 'bitwise': [...], 'cmp': [...], ...}, executed
+    words).  `tree`: the StorageTree SSTORE / SLOAD work on (a fresh empty one by default)."""
     words, pcs = prog.words()
     pc_to_idx = {pc: i for i, pc in enumerate(pcs)}
     regs = [0] * REG
     pc = clk = 0
-    rows, side, executed = [], {"rc": [], "bitwise": [], "cmp": [], "mem": [], "psdn": [], "tape": []}, []
+    rows, side, executed = [], {"rc": [], "bitwise": [], "cmp": [], "mem": [], "psdn": [], "tape": [], "storage": [], "storage_psdn": []}, []
     memory = {}
     tape, tp = {}, 0
+    tree = tree if tree is not None else StorageTree()
+    idx_storage = 0
     while True:
         assert len(rows) < max_steps, "program does not terminate"
         op, dst, op0, op1 = prog.ins[pc_to_idx[pc]]
@@ -117,7 +203,7 @@ def execute(prog, max_steps=1 << 16):
             r[k] = v
         for k, v in zip(T.COL_ADDR_CODE_RANGE, prog.code_addr):
             r[k] = v
-        r[T.COL_CLK], r[T.COL_PC], r[T.COL_TP] = clk, pc, tp
+        r[T.COL_CLK], r[T.COL_PC], r[T.COL_TP], r[T.COL_IDX_STORAGE] = clk, pc, tp, idx_storage
         for i in range(REG):
             r[T.COL_REGS.start + i] = regs[i]
         r[T.COL_INST], r[T.COL_OP1_IMM], r[T.COL_OPCODE] = words[pc], int(imm), T.op_mask(op)
@@ -261,6 +347,46 @@ def execute(prog, max_steps=1 << 16):
                 rows.append(e)
             if op == "TSTORE":
                 tp += length
+        if op in ("SSTORE", "SLOAD"):
+            # executor/src/lib.rs:1301-1545 + cpu/storage.rs: op0 / op1 hold the memory addresses of the 4-word slot key and
+            # the 4-word value.  One extension line carries, in the (otherwise idle) register-selector columns, the eight
+            # memory addresses, the key and value words and the tree key Poseidon(contract storage address || slot key);
+            # it looks up memory (8 cells), the Poseidon table (tree key) and the storage table (leaf row of the proof).
+            assert not imm and op0 is not None and op1 is not None
+            key = []
+            for i in range(4):
+                assert (v0 + i) % P in memory, "storage key was never written"
+                key.append(memory[(v0 + i) % P])
+                side["mem"].append(((v0 + i) % P, clk, op, key[i], 0))
+            krow = poseidon_row(list(prog.storage_addr) + key + [0, 0, 0, 0], filters=(0, 1, 0, 0))
+            tree_key = krow[16:20]
+            if op == "SSTORE":
+                value = []
+                for i in range(4):
+                    assert (v1 + i) % P in memory, "stored value was never written"
+                    value.append(memory[(v1 + i) % P])
+                    side["mem"].append(((v1 + i) % P, clk, op, value[i], 0))
+                srows, prows, _ = tree.access(tree_key, value)
+            else:
+                srows, prows, value = tree.access(tree_key)
+                for i in range(4):
+                    memory[(v1 + i) % P] = value[i]
+                    side["mem"].append(((v1 + i) % P, clk, op, value[i], 1))
+            idx_storage += 1
+            side["storage"].append(srows)
+            side["storage_psdn"] += [krow] + prows
+            r[T.COL_IS_NEXT_LINE_DIFF_INST] = 0
+            e = dict(r)
+            for c in list(T.COL_S_OP0) + list(T.COL_S_OP1) + list(T.COL_S_DST):
+                e[c] = 0
+            e[T.COL_INST] = e[T.COL_IMM_VAL] = e[T.COL_FILTER_LOOKING_PROG_IMM] = e[T.COL_DST] = 0
+            e[T.COL_IS_EXT_LINE] = e[T.COL_EXT_CNT] = e[T.COL_IS_STORAGE_EXT_LINE] = e[T.COL_IS_NEXT_LINE_DIFF_INST] = 1
+            e[T.COL_IDX_STORAGE] = idx_storage
+            for i in range(4):
+                e[T.COL_S_OP0.start + i], e[T.COL_S_OP0.start + 4 + i] = (v0 + i) % P, key[i]
+                e[T.COL_S_OP1.start + i], e[T.COL_S_OP1.start + 4 + i] = (v1 + i) % P, value[i]
+                e[T.COL_S_DST.start + i] = tree_key[i]
+            rows.append(e)
         pc, clk = next_pc, clk + 1
     return rows, side, executed
 
@@ -271,6 +397,7 @@ def cpu_trace(rows):
     for i, r in enumerate(rows):
         for c, v in r.items():
             t[c, i] = v
+    t[T.COL_IDX_STORAGE, len(rows):] = rows[-1][T.COL_IDX_STORAGE]        # generation/cpu.rs:191-202
     return t
 
 
@@ -301,9 +428,20 @@ def program_trace(prog, executed, beta):
     return t, words
 
 
-def prog_chunk_and_poseidon(prog, words, n_poseidon_min=8, extra_rows=()):
+def program_hash(words):
+    """First four words of the chained chunk hash of a (zero-padded) program listing: what the state tree stores at the
+    contract's code address (program/prog_chunk_stark.rs:51-61 ties the result line to that leaf)."""
+    cap = [0, 0, 0, 0]
+    for i in range(0, len(words), 8):
+        h = poseidon_row(list(words[i:i + 8]) + cap)[16:28]
+        cap = h[8:12]
+    return tuple(h[0:4])
+
+
+def prog_chunk_and_poseidon(prog, words, n_poseidon_min=8, extra_rows=(), result_line=False):
     """One prog_chunk row per 8 program words, hashed with Poseidon (capacity = last third of the previous chunk's hash);
-    -> (prog_chunk trace, Poseidon-table trace carrying those permutations)."""
+    with `result_line` the last row is marked as the one carrying the program hash, which the storage table must then
+    prove to be the leaf at the code address.  -> (prog_chunk trace, Poseidon-table trace carrying those permutations)."""
     chunks = [words[i:i + 8] for i in range(0, len(words), 8)]
     n = TG.next_pow2(max(len(chunks), 8))
     t = TG.flag_padding_trace(T.NUM_PROG_CHUNK_COLS, n, T.COL_PROG_CHUNK_IS_PADDING_LINE)
@@ -323,6 +461,7 @@ def prog_chunk_and_poseidon(prog, words, n_poseidon_min=8, extra_rows=()):
         for k, v in zip(T.COL_PROG_CHUNK_HASH_RANGE, h):
             t[k, i] = v
         t[T.COL_PROG_CHUNK_IS_FIRST_LINE, i] = int(i == 0)
+        t[T.COL_PROG_CHUNK_IS_RESULT_LINE, i] = int(result_line and i == len(chunks) - 1)
         for k in T.COL_PROG_CHUNK_FILTER_LOOKING_PROG_RANGE:
             t[k, i] = 1
         cap = h[8:12]
@@ -335,24 +474,35 @@ def prog_chunk_and_poseidon(prog, words, n_poseidon_min=8, extra_rows=()):
 
 
 def memory_trace(cells):
-    """Memory table of stack-region accesses (generation/memory.rs:5-95; cell rules of core's memory trace): rows sorted by
-    (address, clk); diff / rw_addr_unchanged / rc_value columns relate each row to its predecessor, rc_value (the clock
-    difference on an unchanged address, else the address difference) is range-checked through the memory<->rangecheck
-    lookup for every row but the first.  The live rows are followed by the prophet-region padding of tracegen.py.
-    -> (trace, range-checked values)"""
+    """Memory table of stack- and heap-region accesses (generation/memory.rs:5-95; cell rules of core's memory trace): rows
+    sorted by (address, clk); diff / rw_addr_unchanged / rc_value columns relate each row to its predecessor, rc_value
+    (the clock difference on an unchanged address, else the address difference) is range-checked through the
+    memory<->rangecheck lookup for every row but the first and the first heap row.  Heap cells (addresses from
+    ADDR_HEAP_PTR up to p - 2^32) additionally range-check their distance to the top of the region (diff_addr_cond,
+    memory_stark.rs:232,330).  The live rows are followed by the prophet-region padding of tracegen.py.
+    -> (trace, range-checked sort values, range-checked region values)"""
     cells = sorted(cells)
     n = TG.next_pow2(max(len(cells) + 1, 8))
     t = np.zeros((T.NUM_MEM_COLS, n), dtype=np.uint64)
-    rc_vals = []
+    rc_vals, cond_vals = [], []
     prev = None
-    sel = {"TSTORE": T.COL_MEM_S_TSTORE, "TLOAD": T.COL_MEM_S_TLOAD, "MSTORE": T.COL_MEM_S_MSTORE, "MLOAD": T.COL_MEM_S_MLOAD, "POSEIDON": T.COL_MEM_S_POSEIDON, "CALL": T.COL_MEM_S_CALL,
+    span = 2**32 - 1
+    sel = {"SSTORE": T.COL_MEM_S_SSTORE, "SLOAD": T.COL_MEM_S_SLOAD, "TSTORE": T.COL_MEM_S_TSTORE, "TLOAD": T.COL_MEM_S_TLOAD, "MSTORE": T.COL_MEM_S_MSTORE, "MLOAD": T.COL_MEM_S_MLOAD, "POSEIDON": T.COL_MEM_S_POSEIDON, "CALL": T.COL_MEM_S_CALL,
            "RET": T.COL_MEM_S_RET}
     for i, (addr, clk, op, value, is_write) in enumerate(cells):
         t[T.COL_MEM_IS_RW, i] = 1
         t[T.COL_MEM_ADDR, i], t[T.COL_MEM_CLK, i], t[T.COL_MEM_OP, i], t[T.COL_MEM_VALUE, i] = addr, clk, T.op_mask(op), value
         t[sel[op], i] = 1
         t[T.COL_MEM_IS_WRITE, i] = is_write
-        if prev is not None:
+        heap = addr >= T.ADDR_HEAP_PTR
+        if heap:
+            cond = (0 - span - addr) % P
+            t[T.COL_MEM_REGION_HEAP, i], t[T.COL_MEM_DIFF_ADDR_COND, i], t[T.COL_MEM_FILTER_LOOKING_RC_COND, i] = 1, cond, 1
+            cond_vals.append(cond)
+        if prev is not None and heap and not prev[2]:
+            # first heap row: the address gap to the stack region is not range-checked (generation/memory.rs:77-86)
+            t[T.COL_MEM_DIFF_ADDR, i], t[T.COL_MEM_DIFF_ADDR_INV, i] = addr - prev[0], _inv(addr - prev[0])
+        elif prev is not None:
             same = int(addr == prev[0])
             d_addr = addr - prev[0]
             t[T.COL_MEM_DIFF_ADDR, i], t[T.COL_MEM_DIFF_ADDR_INV, i] = d_addr, _inv(d_addr)
@@ -361,9 +511,8 @@ def memory_trace(cells):
             rc = (clk - prev[1]) if same else d_addr
             t[T.COL_MEM_RC_VALUE, i], t[T.COL_MEM_FILTER_LOOKING_RC, i] = rc, 1
             rc_vals.append(rc)
-        prev = (addr, clk)
+        prev = (addr, clk, heap)
     # prophet-region padding (tracegen.memory_padding_trace), continuing from the last live address
-    span = 2**32 - 1
     a = (0 - span) % P
     last_addr = prev[0] if prev else 0
     start = len(cells) if cells else 1
@@ -376,7 +525,7 @@ def memory_trace(cells):
         t[T.COL_MEM_DIFF_ADDR, i], t[T.COL_MEM_DIFF_ADDR_INV, i] = d, _inv(d)
         t[T.COL_MEM_DIFF_ADDR_COND, i] = t[T.COL_MEM_RC_VALUE, i] = (0 - a) % P
         a = (a + 1) % P
-    return t, rc_vals
+    return t, rc_vals, cond_vals
 
 
 def poseidon_chunk_trace(calls):
@@ -418,6 +567,39 @@ def poseidon_chunk_trace(calls):
     return t, prow
 
 
+def storage_trace(accesses, prog_reads=()):
+    """Storage-access table (generation/storage.rs:7-123; builtins/storage/storage_access_stark.rs:110-334): 256 rows per
+    proof, the CPU's accesses in execution order followed by the program-hash reads; the access index counts proofs from
+    1, addr_acc rebuilds each 64-bit limb of the tree key from the layer bits, the layer-256 row is the one the CPU (or
+    the prog_chunk result line) looks up."""
+    flat = [(r, i + 1, False) for i, rows in enumerate(accesses) for r in rows]
+    flat += [(r, len(accesses) + i + 1, True) for i, rows in enumerate(prog_reads) for r in rows]
+    n = TG.next_pow2(max(len(flat), 8))
+    t = TG.flag_padding_trace(T.NUM_COL_ST, n, T.COL_ST_IS_PADDING)
+    acc = 0
+    for i, (r, idx, for_prog) in enumerate(flat):
+        layer = r["layer"]
+        acc = r["bit"] if layer % 64 == 1 else (2 * acc + r["bit"]) % P
+        t[T.COL_ST_IS_PADDING, i] = 0
+        t[T.COL_ST_ACCESS_IDX, i], t[T.COL_ST_IS_WRITE, i], t[T.COL_ST_LAYER, i], t[T.COL_ST_LAYER_BIT, i] = idx, r["is_write"], layer, r["bit"]
+        t[T.COL_ST_ADDR_ACC, i], t[T.COL_ST_HASH_TYPE, i] = acc, int(layer == 256)
+        for rng, key in ((T.COL_ST_PRE_ROOT_RANGE, "pre_root"), (T.COL_ST_ROOT_RANGE, "root"), (T.COL_ST_ADDR_RANGE, "addr"),
+                         (T.COL_ST_PRE_PATH_RANGE, "pre_path"), (T.COL_ST_PATH_RANGE, "path"), (T.COL_ST_SIB_RANGE, "sib"),
+                         (T.COL_ST_PRE_HASH_RANGE, "pre_hash"), (T.COL_ST_HASH_RANGE, "hash")):
+            for c, v in zip(rng, r[key]):
+                t[c, i] = v
+        for c, at in ((T.COL_ST_IS_LAYER_1, 1), (T.COL_ST_IS_LAYER_64, 64), (T.COL_ST_IS_LAYER_128, 128), (T.COL_ST_IS_LAYER_192, 192),
+                      (T.COL_ST_IS_LAYER_256, 256)):
+            t[c, i] = int(layer == at)
+        t[T.COL_ST_ACC_LAYER_MARKER, i] = 1 + layer // 64
+        t[T.COL_ST_FILTER_IS_HASH_BIT_0, i], t[T.COL_ST_FILTER_IS_HASH_BIT_1, i] = 1 - r["bit"], r["bit"]
+        t[T.COL_ST_FILTER_IS_FOR_PROG, i] = int(for_prog and layer == 256)
+    if flat:
+        for c, v in zip(T.COL_ST_ROOT_RANGE, flat[-1][0]["root"]):
+            t[c, len(flat):] = v
+    return t
+
+
 def tape_trace(cells):
     """Tape table (builtins/tape/tape_stark.rs:44-143): cells sorted by tape address, the write (TSTORE) of an address
     first, then its reads (TLOAD); all are looked up by the CPU's extension lines.  Padding repeats the last cell as an
@@ -435,29 +617,40 @@ def tape_trace(cells):
     return t
 
 
-def instance(prog, range_bits=4, limb_bits=2, bitwise_beta=12345, program_beta=67890):
+def instance(prog, range_bits=4, limb_bits=2, bitwise_beta=12345, program_beta=67890, prove_program_hash=False):
     """The 12 traces (enum Table order), params and compress challenges of ola_stark(range_bits, limb_bits) for one run of
     `prog`.  With miniature fixed tables, RC / GTE operands must stay below 2^(2*range_bits) and bitwise operands below
-    2^(4*limb_bits)."""
-    rows, side, executed = execute(prog)
+    2^(4*limb_bits).  `prove_program_hash`: close the program-hash chain with a result line and a state-tree proof that
+    the hash is the leaf at the code address (256 storage rows, 512 Poseidon rows)."""
+    listing = prog.words()[0]
+    listing = listing + [0] * (-len(listing) % 8)
+    tree = StorageTree()
+    if prove_program_hash:
+        tree.set(prog.code_addr, program_hash(listing))
+    rows, side, executed = execute(prog, tree=tree)
     cpu = cpu_trace(rows)
     program, words = program_trace(prog, executed, program_beta)
     pchunk, builtin_rows = poseidon_chunk_trace(side["psdn"])
-    chunk, poseidon = prog_chunk_and_poseidon(prog, words, extra_rows=builtin_rows)
+    prog_reads = []
+    if prove_program_hash:
+        srows, prows, _ = tree.access(prog.code_addr)
+        prog_reads.append(srows)
+        side["storage_psdn"] += prows
+    chunk, poseidon = prog_chunk_and_poseidon(prog, words, extra_rows=builtin_rows + side["storage_psdn"], result_line=prove_program_hash)
     cmp_rows = []
     for a, b in side["cmp"]:
         d = abs(a - b)
         cmp_rows.append((a, b, int(a >= b), d, _inv(d), 1))
-    mem, mem_rc = memory_trace(side["mem"])
-    rc_rows = [(v, 1, 0, 0, 0) for v in side["rc"]] + [(r[3], 0, 0, 0, 1) for r in cmp_rows] + [(v, 0, 1, 0, 0) for v in mem_rc]
-    n = 8
+    mem, mem_rc, mem_cond = memory_trace(side["mem"])
+    rc_rows = ([(v, 1, 0, 0, 0) for v in side["rc"]] + [(r[3], 0, 0, 0, 1) for r in cmp_rows] + [(v, 0, 1, 0, 0) for v in mem_rc]
+               + [(v, 0, 0, 1, 0) for v in mem_cond])
     traces = [
         cpu, mem, TG.bitwise_trace(bitwise_beta, limb_bits, side["bitwise"], looked_by_cpu=True),
         TG.generate_cmp_trace(cmp_rows), TG.generate_rc_trace(rc_rows, range_bits), poseidon,
         pchunk,
-        TG.flag_padding_trace(T.NUM_COL_ST, n, T.COL_ST_IS_PADDING),
+        storage_trace(side["storage"], prog_reads),
         tape_trace(side["tape"]),
-        TG.flag_padding_trace(T.NUM_COL_SCCALL, n, T.COL_SCCALL_IS_PADDING),
+        TG.flag_padding_trace(T.NUM_COL_SCCALL, 8, T.COL_SCCALL_IS_PADDING),
         program, chunk,
     ]
     return traces, [bitwise_beta, program_beta], [0, 0, bitwise_beta, 0, 0, 0, 0, 0, 0, 0, program_beta, 0]
@@ -566,3 +759,41 @@ def tape_program():
     p.add("MLOAD", dst=6, op0=6, op1=("imm", 10)).add("ADD", dst=7, op0=7, op1=8).add("ADD", dst=7, op0=7, op1=6)
     p.add("END")
     return p
+
+
+def storage_program():
+    """Writes a slot key and two values to memory, SSTOREs the first value, SLOADs it back to another place, overwrites the
+    slot with the second value and reads that too: CPU extension lines of the storage instructions, three state-tree
+    updates / reads of 256 levels each (storage table), their 2 x 256 Poseidon rows each, the tree-key hash, and the
+    cpu<->storage, storage<->poseidon, cpu<->poseidon(tree key) and cpu<->memory lookups."""
+    p = Program()
+    p.add("MOV", dst=1, op1=("imm", 10)).add("MOV", dst=2, op1=("imm", 20)).add("MOV", dst=3, op1=("imm", 30)).add("MOV", dst=4, op1=("imm", 40))
+    for k in range(4):
+        p.add("MOV", dst=5, op1=("imm", 1000 + k)).add("MSTORE", dst=5, op0=1, op1=("imm", k))       # slot key at [10..14)
+        p.add("MOV", dst=5, op1=("imm", 7 * k + 1)).add("MSTORE", dst=5, op0=2, op1=("imm", k))      # first value at [20..24)
+        p.add("MOV", dst=5, op1=("imm", P - 1 - k)).add("MSTORE", dst=5, op0=3, op1=("imm", k))      # second value at [30..34)
+    p.add("SSTORE", op0=1, op1=2).add("SLOAD", op0=1, op1=4)
+    p.add("SSTORE", op0=1, op1=3).add("SLOAD", op0=1, op1=4)
+    p.add("MLOAD", dst=6, op0=4, op1=("imm", 0)).add("MLOAD", dst=7, op0=4, op1=("imm", 3)).add("ADD", dst=6, op0=6, op1=7)
+    p.add("END")
+    return p
+
+
+def heap_program():
+    """Stores to and loads from the heap region (the addresses just below p - 2^32 + 1): memory rows whose distance to the
+    top of the region goes through the memory<->rangecheck region lookup, after stack-region rows of the same run."""
+    p = Program()
+    top = P - (2**32 - 1)
+    p.add("MOV", dst=1, op1=("imm", 5)).add("MOV", dst=2, op1=("imm", 42)).add("MSTORE", dst=2, op0=1, op1=("imm", 0))     # stack cell
+    p.add("MOV", dst=3, op1=("imm", top - 9))
+    p.add("MSTORE", dst=2, op0=3, op1=("imm", 0)).add("ADD", dst=2, op0=2, op1=2).add("MSTORE", dst=2, op0=3, op1=("imm", 4))
+    p.add("MLOAD", dst=4, op0=3, op1=("imm", 0)).add("MLOAD", dst=5, op0=3, op1=("imm", 4)).add("MLOAD", dst=6, op0=1, op1=("imm", 0))
+    p.add("ADD", dst=4, op0=4, op1=5).add("MSTORE", dst=4, op0=3, op1=("imm", 0))
+    p.add("END")
+    return p
+
+
+# name -> (program factory, keyword arguments of instance()): the executions the tests prove
+EXAMPLES = {"fibonacci": (lambda: fibonacci(5), {}), "mixed": (mixed_program, {}), "memory": (memory_program, {}), "hash": (hash_program, {}),
+            "call": (call_program, {}), "tape": (tape_program, {}), "storage": (storage_program, {"prove_program_hash": True}),
+            "heap": (heap_program, {})}

@@ -241,14 +241,15 @@ def test_device_poseidon_trace_generation(be, oracle):
         assert np.array_equal(tr[16:28, i], oracle.poseidon(inputs[:, i]))
 
 
-@pytest.mark.parametrize("program", ["fibonacci", "mixed", "memory", "hash", "call", "tape"])
+@pytest.mark.parametrize("program", ["fibonacci", "mixed", "memory", "hash", "call", "tape", "storage", "heap"])
 def test_real_execution_proof_bytes_match_oracle(be, oracle, program):
     """Traces of a real execution (olavm_amd/air/miniexec.py: live CPU opcodes, program fetches, hashed program chunks,
     bitwise / comparison / range-check lookups): AllProof bytes identical to the oracle's, verifier accepts."""
     from olavm_amd.air import miniexec as M
     s = T.ola_stark(range_bits=4, limb_bits=2)
     blob = s.blob()
-    traces, params, compress = M.instance({"fibonacci": lambda: M.fibonacci(5), "mixed": M.mixed_program, "memory": M.memory_program, "hash": M.hash_program, "call": M.call_program, "tape": M.tape_program}[program]())
+    factory, kwargs = M.EXAMPLES[program]
+    traces, params, compress = M.instance(factory(), **kwargs)
     got = be.prove_with_traces(blob, traces, params, compress)
     assert got == oracle.prove_with_traces(blob, traces, params, compress)
     rc, why = oracle.verify_all_proof(blob, got, params)

@@ -122,16 +122,18 @@ def _check_all_tables(oracle, s, traces, params):
         assert oracle.check_constraints(blob, i, tr, pr) == -1, s.tables[i].name
 
 
-@pytest.mark.parametrize("program", ["fibonacci", "mixed", "memory", "hash", "call", "tape"])
+@pytest.mark.parametrize("program", ["fibonacci", "mixed", "memory", "hash", "call", "tape", "storage", "heap"])
 def test_mini_executor_traces_are_valid_and_provable(oracle, program):
     """A real execution (olavm_amd/air/miniexec.py): CPU rows with live opcodes, the program table they are fetched
     from, the Poseidon-hashed program chunks, and -- for the mixed program -- bitwise, comparison and range-check rows
     behind the CPU's lookups.  All 251 CPU constraints and the other 11 AIRs vanish, and the proof passes the verifier's
     cross-table product check with 3 (fibonacci) / 7 (mixed) / 5 (memory: cpu<->memory and the memory table's range-checked
-    sort columns) / 8 (hash: the Poseidon builtin reading and writing memory) of the 19 lookups carrying rows."""
+    sort columns) / 8 (hash: the Poseidon builtin reading and writing memory) / 9 (storage: state-tree proofs, tree keys,
+    the program-hash leaf) of the 19 lookups carrying rows; over all programs 17 of the 19 do."""
     from olavm_amd.air import miniexec as M
     s = T.ola_stark(range_bits=4, limb_bits=2)
-    prog = {"fibonacci": lambda: M.fibonacci(5), "mixed": M.mixed_program, "memory": M.memory_program, "hash": M.hash_program, "call": M.call_program, "tape": M.tape_program}[program]()
+    factory, kwargs = M.EXAMPLES[program]
+    prog = factory()
     rows, side, _ = M.execute(prog)
     if program == "fibonacci":
         assert (rows[-1][T.COL_REGS.start + 1], rows[-1][T.COL_REGS.start + 2]) == (5, 8) and len(rows) == 34
@@ -143,11 +145,23 @@ def test_mini_executor_traces_are_valid_and_provable(oracle, program):
         assert rows[-1][T.COL_REGS.start + 7] == 11 + 13 + 7 and sum(r[T.COL_IS_EXT_LINE] for r in rows) == 6
     elif program == "call":
         assert rows[-1][T.COL_REGS.start + 1] == 3 * 8 * 8 and sum(1 for c in side["mem"] if c[2] in ("CALL", "RET")) == 8
+    elif program == "storage":
+        # the second SLOAD returned the overwriting value; 4 proofs of 256 levels; each SSTORE moved the root, no SLOAD did
+        Pm = tracegen.P
+        assert rows[-1][T.COL_REGS.start + 6] == ((Pm - 1) + (Pm - 4)) % Pm and [len(a) for a in side["storage"]] == [256] * 4
+        roots = [(a[0]["pre_root"], a[0]["root"]) for a in side["storage"]]
+        assert roots[0][0] != roots[0][1] == roots[1][0] == roots[1][1] != roots[2][1] == roots[3][1]
+        leaf = side["storage"][0][255]          # lowest level: hash of the stored value and its (empty) sibling, capacity word 1
+        pair = list(leaf["sib"]) + list(leaf["path"]) if leaf["bit"] else list(leaf["path"]) + list(leaf["sib"])
+        assert tuple(int(x) for x in oracle.poseidon(np.array(pair + [1, 0, 0, 0], dtype=np.uint64))[:4]) == leaf["hash"]
+        assert leaf["path"] == (1, 8, 15, 22) and leaf["pre_path"] == (0, 0, 0, 0)
+    elif program == "heap":
+        assert rows[-1][T.COL_REGS.start + 4] == 42 + 84 and sum(1 for c in side["mem"] if c[0] >= T.ADDR_HEAP_PTR) == 5
     else:       # the digest the program loads back is the sponge hash of the 16 words it stored
         words = np.array([3 * pow(5, i, tracegen.P) % tracegen.P for i in range(16)], dtype=np.uint64)
         digest = oracle.hash_no_pad(words)
         assert (rows[-1][T.COL_REGS.start + 6], rows[-1][T.COL_REGS.start + 7]) == (int(digest[0]), int(digest[3]))
-    traces, params, compress = M.instance(prog)
+    traces, params, compress = M.instance(prog, **kwargs)
     _check_all_tables(oracle, s, traces, params)
     # the constraints bite on the live rows: a wrong sum, a wrong fetched instruction
     bad = traces[0].copy()
