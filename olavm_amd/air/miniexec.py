@@ -5,7 +5,9 @@ heap regions), CALL / RET, TSTORE / TLOAD and SSTORE / SLOAD (with their CPU ext
 blocks), END, with register or immediate second operands.  Tables that receive live rows: CPU, memory, program,
 prog_chunk (program hashing), poseidon_chunk (the builtin), Poseidon (chunk, builtin, tree-key and state-tree hashes),
 storage_access (256-level proofs), tape, range-check (RC, GTE, the memory table's sort and region columns), bitwise, cmp;
-only the cross-contract-call table keeps its padding rows (olavm_amd/air/tracegen.py).
+only the cross-contract-call table keeps its padding rows (olavm_amd/air/tracegen.py) -- SCCALL is not executed because
+the reference constraints contradict each other on it: cpu_stark.rs:432-437 makes the callee's env_idx the caller's
+call_sc_cnt (0 at a transaction's first call), the cpu<->sccall lookup (:238-242) makes it env_idx + 1.
 
 Restated from (reference paths): core/src/vm/opcodes.rs (opcode bit masks), circuits/src/cpu/cpu_stark.rs:529-581
 (instruction word = op1_imm * 2^62 + one-hot register selectors at bits 52+r / 42+r / 32+r + opcode mask),

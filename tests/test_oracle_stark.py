@@ -170,6 +170,8 @@ def test_mini_executor_traces_are_valid_and_provable(oracle, program):
     proof = oracle.prove_with_traces(s.blob(), traces, params, compress)
     rc, why = oracle.verify_all_proof(s.blob(), proof, params)
     assert rc == 0, why
+    if program not in ("fibonacci", "mixed"):
+        return      # one forged proof per kind of run is enough for the CPU suite's time budget
     # a CPU row that fetches a word the program table does not list breaks the cross-table product
     forged = [t.copy() for t in traces]
     forged[10][T.COL_PROG_EXEC_INST, 1] = (int(forged[10][T.COL_PROG_EXEC_INST, 1]) + 1) % tracegen.P
