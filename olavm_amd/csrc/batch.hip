@@ -37,8 +37,38 @@ __global__ __launch_bounds__(256) void bitrev_rows_kernel(const u64* __restrict_
     const size_t col = blockIdx.y;
     out[col * N + i] = in[col * N + bitrev32((u32)i, bits)];
 }
+// Tiled form for bits >= 2T: the index splits as [hi : T | mid | lo : T] and reverses to [rev lo | rev mid | rev hi].  One
+// workgroup moves the 2^T x 2^T tile of one `mid`: rows of 2^T consecutive elements in (fixed hi, running lo), transposed in
+// LDS, rows of 2^T consecutive elements out (fixed rev lo, running rev hi) -- both sides touch whole 2^T * 8 byte segments
+// instead of the 8-byte gathers of the plain kernel.
+template <int T>
+__global__ __launch_bounds__(256) void bitrev_rows_tiled_kernel(const u64* __restrict__ in, u64* __restrict__ out, int bits) {
+    __shared__ u64 tile[1 << T][(1 << T) + 1];
+    const size_t N = (size_t)1 << bits;
+    const int midbits = bits - 2 * T;
+    const u32 mid = blockIdx.x;
+    const u32 rmid = midbits ? bitrev32(mid, midbits) : 0;
+    const u64* src = in + (size_t)blockIdx.y * N + ((size_t)mid << T);
+    u64* dst = out + (size_t)blockIdx.y * N + ((size_t)rmid << T);
+#pragma unroll
+    for (int e = threadIdx.x; e < (1 << (2 * T)); e += 256) {
+        const u32 hi = e >> T, lo = e & ((1 << T) - 1);
+        tile[hi][lo] = src[((size_t)hi << (bits - T)) + lo];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = threadIdx.x; e < (1 << (2 * T)); e += 256) {
+        const u32 a = e >> T, b = e & ((1 << T) - 1);          // a = rev(lo), b = rev(hi)
+        dst[((size_t)a << (bits - T)) + b] = tile[bitrev32(b, T)][bitrev32(a, T)];
+    }
+}
 void launch_bitrev_rows(DeviceCtx* ctx, const u64* in, u64* out, int bits, size_t cols) {
     const size_t N = (size_t)1 << bits;
+    constexpr int T = 5;
+    if (bits >= 2 * T && bits - 2 * T <= 30) {
+        hipLaunchKernelGGL(bitrev_rows_tiled_kernel<T>, dim3(1u << (bits - 2 * T), (unsigned)cols), dim3(256), 0, ctx->stream, in, out, bits);
+        return;
+    }
     hipLaunchKernelGGL(bitrev_rows_kernel, dim3((unsigned)((N + 255) / 256), (unsigned)cols), dim3(256), 0, ctx->stream,
                        in, out, bits);
 }
