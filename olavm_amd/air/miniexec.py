@@ -619,7 +619,7 @@ def tape_trace(cells):
     return t
 
 
-def instance(prog, range_bits=4, limb_bits=2, bitwise_beta=12345, program_beta=67890, prove_program_hash=False):
+def instance(prog, range_bits=4, limb_bits=2, bitwise_beta=12345, program_beta=67890, prove_program_hash=False, max_steps=1 << 16):
     """The 12 traces (enum Table order), params and compress challenges of ola_stark(range_bits, limb_bits) for one run of
     `prog`.  With miniature fixed tables, RC / GTE operands must stay below 2^(2*range_bits) and bitwise operands below
     2^(4*limb_bits).  `prove_program_hash`: close the program-hash chain with a result line and a state-tree proof that
@@ -629,7 +629,7 @@ def instance(prog, range_bits=4, limb_bits=2, bitwise_beta=12345, program_beta=6
     tree = StorageTree()
     if prove_program_hash:
         tree.set(prog.code_addr, program_hash(listing))
-    rows, side, executed = execute(prog, tree=tree)
+    rows, side, executed = execute(prog, max_steps=max_steps, tree=tree)
     cpu = cpu_trace(rows)
     program, words = program_trace(prog, executed, program_beta)
     pchunk, builtin_rows = poseidon_chunk_trace(side["psdn"])

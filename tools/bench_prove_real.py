@@ -1,0 +1,61 @@
+"""ola_prove_with_traces on a REAL execution with a 2^20-row CPU table.
+
+The traces come from the miniature executor (olavm_amd/air/miniexec.py) running its memory program -- a store loop and a
+load / add / store / load loop over `count` cells -- against the full-size fixed tables (range_bits 16, limb_bits 8):
+count = 70000 gives 980 k executed CPU rows (2^20), 280 k memory cells, a 2^21-row program table (every fetched instruction and
+immediate word) and 280 k range-checked sort values.  The proof is checked with the oracle's verifier; with OLA_TIMING=1 the
+library prints its per-phase times (named after the reference's `timed!` scopes) to stderr.
+
+    python tools/bench_prove_real.py [count] [reps] [--json out.json] [--phases]
+"""
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    count = int(args[0]) if args else 70000
+    reps = int(args[1]) if len(args) > 1 else 3
+    out = sys.argv[sys.argv.index("--json") + 1] if "--json" in sys.argv else None
+    from olavm_amd.air import miniexec as M, ola_tables as T
+    from olavm_amd.backend import Backend
+    s = T.ola_stark()
+    blob = s.blob()
+    t0 = time.time()
+    traces, params, compress = M.instance(M.memory_program(count), range_bits=16, limb_bits=8, max_steps=1 << 24)
+    gen_s = time.time() - t0
+    heights = [int(t.shape[1]).bit_length() - 1 for t in traces]
+    print("executed + filled 12 tables in %.1f s; log2 heights %s" % (gen_s, heights), flush=True)
+    be = Backend(device=0)
+    times = []
+    for _ in range(reps):
+        t0 = time.time()
+        proof = be.prove_with_traces(blob, traces, params, compress)
+        times.append(time.time() - t0)
+        print("prove_with_traces: %.3f s, proof %d bytes" % (times[-1], len(proof)), flush=True)
+    if "--phases" in sys.argv:          # one more proof on a context created with OLA_TIMING=1 (phase lines go to stderr)
+        os.environ["OLA_TIMING"] = "1"
+        be2 = Backend(device=0)
+        be2.prove_with_traces(blob, traces, params, compress)          # cold context: tables, twiddles, allocations
+        print("[ola-timing] ---- warm proof ----", file=sys.stderr, flush=True)
+        be2.prove_with_traces(blob, traces, params, compress)
+        be2.close()
+    from tests import oracle_lib
+    rc, why = oracle_lib.load().verify_all_proof(blob, proof, params)
+    print("oracle verifier:", rc, why, flush=True)
+    if out:
+        os.makedirs(os.path.dirname(out) or ".", exist_ok=True)
+        with open(out, "w") as f:
+            json.dump({"workload": "miniexec memory_program(%d), ola_stark(range_bits=16, limb_bits=8)" % count, "log2_heights": heights,
+                       "trace_generation_s": round(gen_s, 1), "prove_s": [round(t, 4) for t in times], "proof_bytes": len(proof),
+                       "oracle_verifier_rc": rc}, f, indent=1)
+    if rc != 0:
+        raise SystemExit(1)
+
+
+if __name__ == "__main__":
+    main()
