@@ -186,6 +186,15 @@ int32_t ola_prove_with_traces(OlaCtx* ctx, const uint64_t* airset, size_t airset
  * (FILTER_LOOKED_NORMAL, _TREEKEY, _STORAGE_LEAF, _STORAGE_BRANCH) or NULL for zeros; out: 134 x n column-major.  Padding
  * rows are rows with all-zero inputs (the reference's POSEIDON_ZERO_HASH_* constants). */
 int32_t ola_generate_poseidon_trace(OlaCtx* ctx, const uint64_t* inputs, const uint64_t* filters, size_t n, uint64_t* out);
+/* The permuted columns of one Halo2-style lookup (circuits/src/stark/lookup.rs:68-132 permuted_cols, called for every
+ * looking column of the range-check, bitwise and program tables: generation/builtin.rs:121-200, generation/prog.rs):
+ * permuted_inputs = the n inputs in canonical form, ascending; permuted_table = the n table values arranged as the
+ * reference's merge loop arranges them (a value next to the first of its inputs, the unused ones in the other slots, in
+ * the reference's stack order).  Inputs need not occur in the table.  Host buffers / buffers resident in HBM. */
+int32_t ola_permuted_cols(OlaCtx* ctx, const uint64_t* inputs, const uint64_t* table, size_t n, uint64_t* permuted_inputs,
+                          uint64_t* permuted_table);
+int32_t ola_permuted_cols_dev(OlaCtx* ctx, const uint64_t* inputs_dev, const uint64_t* table_dev, size_t n,
+                              uint64_t* permuted_inputs_dev, uint64_t* permuted_table_dev);
 
 /* ---- coset-partitioned proving over several GPUs ---------------------------------------------------------
  * One process per GPU; every process calls ola_prove_with_traces with the SAME traces.  Because the transcript is a

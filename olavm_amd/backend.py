@@ -87,6 +87,8 @@ def load_library():
     L.ola_commit_values_shard_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                               C.POINTER(C.c_void_p), U64P]
     L.ola_generate_poseidon_trace.argtypes = [C.c_void_p, U64P, U64P, C.c_size_t, U64P]
+    L.ola_permuted_cols.argtypes = [C.c_void_p, U64P, U64P, C.c_size_t, U64P, U64P]
+    L.ola_permuted_cols_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
     L.ola_set_shard.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, ALL_GATHER_FN, C.c_void_p]
     L.ola_air_kernels_available.argtypes = [U64P, C.c_size_t, C.POINTER(C.c_uint8), C.c_size_t]
     _lib = L
@@ -100,6 +102,7 @@ EXPORTS = [
     "ola_batch_get_leaf", "ola_batch_get_lde_row", "ola_challenger_init", "ola_challenger_observe",
     "ola_challenger_get", "ola_challenger_compact", "ola_open_and_prove", "ola_pow", "ola_prove_with_traces",
     "ola_air_kernels_available", "ola_commit_values_shard", "ola_commit_values_shard_dev", "ola_set_shard", "ola_gpu_trim", "ola_generate_poseidon_trace",
+    "ola_permuted_cols", "ola_permuted_cols_dev",
 ]
 
 
@@ -294,6 +297,18 @@ class Backend:
         out = np.empty((134, n), dtype=np.uint64)
         self._chk(self.lib.ola_generate_poseidon_trace(self.ctx, _p(inputs), None if f is None else _p(f), n, _p(out)))
         return out
+
+    def permuted_cols(self, inputs, table):
+        """lookup.rs permuted_cols on the device: -> (sorted canonical inputs, permuted table), both uint64 arrays."""
+        a = np.ascontiguousarray(inputs, dtype=np.uint64)
+        b = np.ascontiguousarray(table, dtype=np.uint64)
+        assert a.ndim == 1 and a.shape == b.shape
+        pi, pt = np.empty_like(a), np.empty_like(a)
+        self._chk(self.lib.ola_permuted_cols(self.ctx, _p(a), _p(b), a.shape[0], _p(pi), _p(pt)))
+        return pi, pt
+
+    def permuted_cols_dev(self, in_ptr, table_ptr, n, out_in_ptr, out_table_ptr):
+        self._chk(self.lib.ola_permuted_cols_dev(self.ctx, in_ptr, table_ptr, n, out_in_ptr, out_table_ptr))
 
     def trim(self):
         """Return the context's cached device buffers to the driver (ola_gpu_trim)."""

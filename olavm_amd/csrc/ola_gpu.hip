@@ -11,6 +11,7 @@
 #include "device_ctx.h"
 #include "gl.cuh"
 #include "poseidon_host.h"
+#include "lookup.h"
 
 // unity build: device code shares the __constant__ Poseidon tables
 #include "ntt.hip"
@@ -380,6 +381,33 @@ int32_t ola_generate_poseidon_trace(OlaCtx* ctx, const uint64_t* inputs, const u
         HIP_CHECK(hipStreamSynchronize(ctx->dev.stream));
     } catch (...) { ctx->dev.free(d_in); ctx->dev.free(d_f); ctx->dev.free(d_out); throw; }
     ctx->dev.free(d_in); ctx->dev.free(d_f); ctx->dev.free(d_out);
+    OLA_CATCH
+}
+
+int32_t ola_permuted_cols_dev(OlaCtx* ctx, const uint64_t* inputs_dev, const uint64_t* table_dev, size_t n,
+                              uint64_t* permuted_inputs_dev, uint64_t* permuted_table_dev) {
+    OLA_TRY
+    require(ctx && ((inputs_dev && table_dev && permuted_inputs_dev && permuted_table_dev) || n == 0), "null pointer");
+    permuted_cols_dev(&ctx->dev, (const u64*)inputs_dev, (const u64*)table_dev, n, (u64*)permuted_inputs_dev, (u64*)permuted_table_dev);
+    HIP_CHECK(hipStreamSynchronize(ctx->dev.stream));
+    OLA_CATCH
+}
+
+int32_t ola_permuted_cols(OlaCtx* ctx, const uint64_t* inputs, const uint64_t* table, size_t n, uint64_t* permuted_inputs,
+                          uint64_t* permuted_table) {
+    OLA_TRY
+    require(ctx && ((inputs && table && permuted_inputs && permuted_table) || n == 0), "null pointer");
+    if (n == 0) return OLA_OK;
+    u64* d = (u64*)ctx->dev.alloc(4 * n * 8);
+    try {
+        HIP_CHECK(hipMemcpyAsync(d, inputs, n * 8, hipMemcpyHostToDevice, ctx->dev.stream));
+        HIP_CHECK(hipMemcpyAsync(d + n, table, n * 8, hipMemcpyHostToDevice, ctx->dev.stream));
+        permuted_cols_dev(&ctx->dev, d, d + n, n, d + 2 * n, d + 3 * n);
+        HIP_CHECK(hipMemcpyAsync(permuted_inputs, d + 2 * n, n * 8, hipMemcpyDeviceToHost, ctx->dev.stream));
+        HIP_CHECK(hipMemcpyAsync(permuted_table, d + 3 * n, n * 8, hipMemcpyDeviceToHost, ctx->dev.stream));
+        HIP_CHECK(hipStreamSynchronize(ctx->dev.stream));
+    } catch (...) { ctx->dev.free(d); throw; }
+    ctx->dev.free(d);
     OLA_CATCH
 }
 

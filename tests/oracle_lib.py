@@ -40,6 +40,7 @@ class Oracle:
         L.oracle_interpolate_poly_with_offset.argtypes = [U64P, C.c_size_t, C.c_uint64]
         L.oracle_naive_eval.argtypes = [U64P, C.c_size_t, C.c_size_t, C.c_uint64, U64P]
         L.oracle_poseidon.argtypes = [U64P]
+        L.oracle_permuted_cols.argtypes = [U64P, U64P, C.c_size_t, U64P, U64P]
         L.oracle_hash_no_pad.argtypes = [U64P, C.c_size_t, U64P]
         L.oracle_two_to_one.argtypes = [U64P, U64P, U64P]
         L.oracle_merkle.argtypes = [U64P, C.c_size_t, C.c_size_t, C.c_int, U64P, U64P, U64P]
@@ -125,6 +126,15 @@ class Oracle:
         return out
 
     # ---- poseidon ----
+    def permuted_cols(self, inputs, table):
+        """lookup.rs:68-132 -> (sorted canonical inputs, permuted table)."""
+        a = np.ascontiguousarray(inputs, dtype=np.uint64)
+        b = np.ascontiguousarray(table, dtype=np.uint64)
+        assert a.ndim == 1 and a.shape == b.shape
+        pi, pt = np.empty_like(a), np.empty_like(a)
+        self.lib.oracle_permuted_cols(ptr(a), ptr(b), a.shape[0], ptr(pi), ptr(pt))
+        return pi, pt
+
     def poseidon(self, state):
         s = np.array(state, dtype=np.uint64)
         self.lib.oracle_poseidon(ptr(s))
