@@ -795,6 +795,26 @@ def heap_program():
     return p
 
 
+def wide_program():
+    """For the full-size fixed tables (range_bits 16, limb_bits 8) only: 32-bit operands through the bitwise, comparison and
+    range-check instructions (all four 8-bit limbs and both 16-bit limbs of every looked-up value are non-trivial), kept
+    in memory between uses."""
+    p = Program()
+    vals = (0xDEADBEEF, 0x12345678, 0xFFFFFFFF, 0x80000001, 0x0000FFFF, 0xA5A5A5A5)
+    p.add("MOV", dst=1, op1=("imm", 100))
+    for k, v in enumerate(vals):
+        p.add("MOV", dst=2, op1=("imm", v)).add("MSTORE", dst=2, op0=1, op1=("imm", k))
+    for k in range(len(vals) - 1):
+        p.add("MLOAD", dst=2, op0=1, op1=("imm", k)).add("MLOAD", dst=3, op0=1, op1=("imm", k + 1))
+        p.add("AND", dst=4, op0=2, op1=3).add("OR", dst=5, op0=2, op1=3).add("XOR", dst=6, op0=2, op1=3)
+        p.add("GTE", dst=7, op0=2, op1=3).add("GTE", dst=8, op0=6, op1=4)
+        p.add("RC", op1=4).add("RC", op1=5).add("RC", op1=6)
+        p.add("MSTORE", dst=6, op0=1, op1=("imm", 10 + k))
+    p.add("XOR", dst=2, op0=2, op1=("imm", 0xFFFFFFFF)).add("RC", op1=2).add("GTE", dst=7, op0=2, op1=("imm", 0x7FFFFFFF))
+    p.add("END")
+    return p
+
+
 # name -> (program factory, keyword arguments of instance()): the executions the tests prove
 EXAMPLES = {"fibonacci": (lambda: fibonacci(5), {}), "mixed": (mixed_program, {}), "memory": (memory_program, {}), "hash": (hash_program, {}),
             "call": (call_program, {}), "tape": (tape_program, {}), "storage": (storage_program, {"prove_program_hash": True}),

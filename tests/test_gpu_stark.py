@@ -256,6 +256,19 @@ def test_real_execution_proof_bytes_match_oracle(be, oracle, program):
     assert rc == 0, why
 
 
+def test_full_size_tables_proof_bytes_match_oracle(be, oracle):
+    """ola_stark() as the reference instantiates it (2^16-entry range check, 2^18-row bitwise table with its sixteen
+    permuted-column pairs) on the executor's 32-bit-operand program: AllProof bytes identical to the oracle's."""
+    from olavm_amd.air import miniexec as M
+    s = T.ola_stark()
+    blob = s.blob()
+    traces, params, compress = M.instance(M.wide_program(), range_bits=16, limb_bits=8)
+    got = be.prove_with_traces(blob, traces, params, compress)
+    assert got == oracle.prove_with_traces(blob, traces, params, compress)
+    rc, why = oracle.verify_all_proof(blob, got, params)
+    assert rc == 0, why
+
+
 def test_long_fibonacci_execution_verifies(be, oracle, monkeypatch):
     """1300 loop iterations = 7804 executed CPU rows (2^13-row CPU and program tables, specialised kernels, crosschecked
     against the interpreter kernel on this live data); the oracle verifier accepts the GPU proof."""
