@@ -1,6 +1,6 @@
 """A miniature executor for OlaVM's register instructions (SURVEY f-1): runs a small program and fills the STARK tables it
 touches so that EVERY constraint and EVERY cross-table lookup holds -- a real (if tiny) execution trace without the Rust
-executor.  Supported: MOV, ADD, MUL, EQ, NEQ, JMP, CJMP, RC, AND / OR / XOR, GTE, MSTORE / MLOAD ([reg + imm], stack and
+executor.  Supported: MOV, NOT, ADD, MUL, EQ, NEQ, ASSERT, JMP, CJMP, RC, AND / OR / XOR, GTE, MSTORE / MLOAD ([reg + imm], stack and
 heap regions), CALL / RET, TSTORE / TLOAD and SSTORE / SLOAD (with their CPU extension lines), POSEIDON (whole 8-word
 blocks), END, with register or immediate second operands.  Tables that receive live rows: CPU, memory, program,
 prog_chunk (program hashing), poseidon_chunk (the builtin), Poseidon (chunk, builtin, tree-key and state-tree hashes),
@@ -179,7 +179,7 @@ class Program:
 
 
 SELECTOR_MEM = {"MLOAD": T.COL_S_MLOAD, "MSTORE": T.COL_S_MSTORE}
-SELECTOR = {"SSTORE": T.COL_S_SSTORE, "SLOAD": T.COL_S_SLOAD, "TSTORE": T.COL_S_TSTORE, "TLOAD": T.COL_S_TLOAD, "CALL": T.COL_S_CALL, "RET": T.COL_S_RET, "POSEIDON": T.COL_S_PSDN, "MLOAD": T.COL_S_MLOAD, "MSTORE": T.COL_S_MSTORE, "ADD": T.COL_S_SIMPLE_ARITHMATIC_OP, "MUL": T.COL_S_SIMPLE_ARITHMATIC_OP, "EQ": T.COL_S_SIMPLE_ARITHMATIC_OP,
+SELECTOR = {"NOT": T.COL_S_NOT, "ASSERT": T.COL_S_SIMPLE_ARITHMATIC_OP, "SSTORE": T.COL_S_SSTORE, "SLOAD": T.COL_S_SLOAD, "TSTORE": T.COL_S_TSTORE, "TLOAD": T.COL_S_TLOAD, "CALL": T.COL_S_CALL, "RET": T.COL_S_RET, "POSEIDON": T.COL_S_PSDN, "MLOAD": T.COL_S_MLOAD, "MSTORE": T.COL_S_MSTORE, "ADD": T.COL_S_SIMPLE_ARITHMATIC_OP, "MUL": T.COL_S_SIMPLE_ARITHMATIC_OP, "EQ": T.COL_S_SIMPLE_ARITHMATIC_OP,
             "NEQ": T.COL_S_SIMPLE_ARITHMATIC_OP, "MOV": T.COL_S_MOV, "JMP": T.COL_S_JMP, "CJMP": T.COL_S_CJMP, "END": T.COL_S_END,
             "RC": T.COL_S_RC, "AND": T.COL_S_BITWISE, "OR": T.COL_S_BITWISE, "XOR": T.COL_S_BITWISE, "GTE": T.COL_S_GTE}
 
@@ -227,6 +227,10 @@ def execute(prog, max_steps=1 << 16, tree=None):
         next_pc, res = pc + size, None
         if op == "MOV":
             res = v1
+        elif op == "NOT":               # executor/src/lib.rs:602-605: dst = -1 - op1
+            res = (P - 1 - v1) % P
+        elif op == "ASSERT":            # executor/src/lib.rs:673-712: the operand must be 1 (cpu/simple_arithmatic_op.rs:52)
+            assert v1 == 1, "ASSERT on a value other than 1"
         elif op == "ADD":
             res = (v0 + v1) % P
         elif op == "MUL":
@@ -677,7 +681,8 @@ def mixed_program():
     p.add("AND", dst=2, op0=0, op1=1).add("OR", dst=3, op0=0, op1=1).add("XOR", dst=4, op0=0, op1=("imm", 15))
     p.add("GTE", dst=5, op0=0, op1=1).add("GTE", dst=6, op0=1, op1=0).add("GTE", dst=7, op0=1, op1=("imm", 77))
     p.add("RC", op1=2).add("RC", op1=("imm", 255))
-    p.add("MUL", dst=8, op0=2, op1=3).add("EQ", dst=8, op0=8, op1=8).add("NEQ", dst=8, op0=5, op1=6)
+    p.add("MUL", dst=8, op0=2, op1=3).add("EQ", dst=8, op0=8, op1=8).add("ASSERT", op1=8).add("NEQ", dst=8, op0=5, op1=6)
+    p.add("NOT", dst=7, op1=0).add("NOT", dst=7, op1=("imm", 5))
     skip = len(p.words()[0]) + 2 + 2          # target: the instruction after the next (2-word) MOV
     p.add("CJMP", op0=6, op1=("imm", 0))      # r6 = 0: not taken
     p.add("CJMP", op0=5, op1=("imm", skip + 2))   # r5 = 1: taken, jumps over the MOV below
