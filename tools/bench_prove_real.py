@@ -6,7 +6,7 @@ count = 70000 gives 980 k executed CPU rows (2^20), 280 k memory cells, a 2^21-r
 immediate word) and 280 k range-checked sort values.  The proof is checked with the oracle's verifier; with OLA_TIMING=1 the
 library prints its per-phase times (named after the reference's `timed!` scopes) to stderr.
 
-    python tools/bench_prove_real.py [count] [reps] [--json out.json] [--phases]
+    python tools/bench_prove_real.py [count] [reps] [--json out.json] [--phases] [--oracle]
 """
 import json
 import os
@@ -45,14 +45,23 @@ def main():
         be2.prove_with_traces(blob, traces, params, compress)
         be2.close()
     from tests import oracle_lib
-    rc, why = oracle_lib.load().verify_all_proof(blob, proof, params)
+    o = oracle_lib.load()
+    rc, why = o.verify_all_proof(blob, proof, params)
     print("oracle verifier:", rc, why, flush=True)
+    oracle_s = None
+    if "--oracle" in sys.argv:          # the CPU restatement on the same traces (all host cores it uses), byte comparison included
+        t0 = time.time()
+        ref = o.prove_with_traces(blob, traces, params, compress)
+        oracle_s = time.time() - t0
+        print("oracle prove_with_traces (CPU port, %d threads): %.1f s, bytes identical: %s" % (o.lib.oracle_num_threads(), oracle_s, ref == proof), flush=True)
+        if ref != proof:
+            rc = 1
     if out:
         os.makedirs(os.path.dirname(out) or ".", exist_ok=True)
         with open(out, "w") as f:
             json.dump({"workload": "miniexec memory_program(%d), ola_stark(range_bits=16, limb_bits=8)" % count, "log2_heights": heights,
                        "trace_generation_s": round(gen_s, 1), "prove_s": [round(t, 4) for t in times], "proof_bytes": len(proof),
-                       "oracle_verifier_rc": rc}, f, indent=1)
+                       "oracle_verifier_rc": rc, "oracle_cpu_port_prove_s": None if oracle_s is None else round(oracle_s, 1)}, f, indent=1)
     if rc != 0:
         raise SystemExit(1)
 
