@@ -60,7 +60,7 @@ def test_two_ranks_one_gpu_sharded_commit():
     assert (rng0, rng1) == ((0, 4), (4, 8)) and rb0 == rb1 == 2
 
 
-def _prove_worker(rank, world, port, q, log_n=12):
+def _prove_worker(rank, world, port, q, log_n=12, real=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     import torch.distributed as dist
@@ -68,10 +68,16 @@ def _prove_worker(rank, world, port, q, log_n=12):
     from olavm_amd.air import ola_tables as T
     from olavm_amd.backend import Backend
     from tests import tracegen
-    blob = T.ola_stark(range_bits=4, limb_bits=2).blob()
-    # 2^12-row (or 2^15-row: the large-transform kernels) tables: CPU, memory and Poseidon run on the coset partition, the
-    # small / low-degree ones replicated
-    traces, params, compress = tracegen.empty_program_instance(log_n=log_n, live=np.random.default_rng(12))
+    if real:
+        # a real execution against the full-size fixed tables: live cross-table products on sharded and replicated tables
+        from olavm_amd.air import miniexec as M
+        blob = T.ola_stark().blob()
+        traces, params, compress = M.instance(M.memory_program(600), range_bits=16, limb_bits=8, max_steps=1 << 20)
+    else:
+        blob = T.ola_stark(range_bits=4, limb_bits=2).blob()
+        # 2^12-row (or 2^15-row: the large-transform kernels) tables: CPU, memory and Poseidon run on the coset partition,
+        # the small / low-degree ones replicated
+        traces, params, compress = tracegen.empty_program_instance(log_n=log_n, live=np.random.default_rng(12))
     be = Backend(device=0)
     be.set_shard(rank, world)
     sharded = be.prove_with_traces(blob, traces, params, compress)
@@ -111,4 +117,30 @@ def test_coset_partitioned_proof_equals_the_single_gpu_proof(world, log_n, oracl
         assert calls == 3 * 8, calls
     blob = T.ola_stark(range_bits=4, limb_bits=2).blob()
     rc, why = oracle.verify_all_proof(blob, single, [12345, 67890])
+    assert rc == 0, why
+
+
+def test_coset_partitioned_proof_of_a_real_execution(oracle):
+    """Two ranks prove the executor's memory program (2^14 CPU rows) against ola_stark() with its full-size range-check and
+    bitwise tables: bytes equal to the single-GPU proof, verifier accepts -- the lookups between sharded and replicated
+    tables carry live rows here."""
+    import torch.multiprocessing as mp
+    from olavm_amd.air import ola_tables as T
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_prove_worker, args=(r, world, port, q, 0, True)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=600) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    single = res[0][2]
+    assert single is not None and len(single) > 1000
+    for rank, sharded, _, calls in res:
+        assert sharded == single, "rank %d produced different proof bytes" % rank
+        assert calls >= 8 and calls % 8 == 0, calls          # at least one table ran on the coset partition
+    rc, why = oracle.verify_all_proof(T.ola_stark().blob(), single, [12345, 67890])
     assert rc == 0, why
