@@ -54,6 +54,23 @@ def cpu_baseline(log_n, seconds_budget=20.0):
             "sample": f"{cols} columns x 2^{log_n} forward NTT (oracle evaluate_poly, OpenMP over columns) in {dt:.2f}s"}
 
 
+def valu_roofline(log_n, cols, ms_per_transform):
+    """The ceiling that actually binds the NTT (DESIGN.md "NTT roofline accounting"): VALU issue slots.  Instructions per
+    element are the SQ_INSTS_VALU counts of profiles/r01_sq_counters_and_ubench.txt (173 per element in each strided pass,
+    126 in the closing pass, measured on the 94 x 2^22 shape and reported for that size only); the peak is one
+    wave64 instruction per SIMD every 4 cycles (tools/ubench/valu_rates.hip: 4.4-4.8 cycles for the 64-bit / multiply class,
+    2.6 for plain 32-bit VOP2) on 256 CUs x 4 SIMDs at 2.4 GHz."""
+    if log_n != 22:
+        return None
+    insts_per_elem = 173 * 2 + 126
+    wave_insts = insts_per_elem * cols * (1 << log_n) / 64.0
+    peak = 256 * 4 * 2.4e9 / 4.0
+    achieved = wave_insts / (ms_per_transform * 1e-3)
+    return {"insts_per_element": insts_per_elem, "achieved": round(achieved / 1e9, 1), "peak": round(peak / 1e9, 1),
+            "unit": "G wave-instructions/s", "frac": round(achieved / peak, 3),
+            "source": "profiles/r01_sq_counters_and_ubench.txt (rocprofv3 --pmc SQ_INSTS_VALU)"}
+
+
 def pmc_traffic(log_n, cols):
     """HBM bytes per launch of the NTT pass kernel from the committed rocprofv3 PMC summary (tools/pmc.sh; FETCH_SIZE with the
     gfx950 x2 correction + WRITE_SIZE, separate passes).  bench.py cannot run the profiler on itself, so this is the
@@ -250,6 +267,7 @@ def main():
                          "algorithmic_bytes_per_launch": bytes_per_step / passes,
                          "kernel": "ntt2_pass_kernel", "launches_per_step": passes,
                          "avg_launch_ms": round(launch_ms, 4),
+                         "valu": valu_roofline(args.log_n, cols, launch_ms * passes),
                          "note": "every pass streams the whole batch once (traffic = 3 x algorithmic per launch); the kernel is "
                                  "VALU-issue bound (64-bit modular arithmetic on the 32-bit integer pipe), see DESIGN.md"},
         }
