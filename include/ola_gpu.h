@@ -179,6 +179,21 @@ int32_t ola_prove_with_traces(OlaCtx* ctx, const uint64_t* airset, size_t airset
                               const uint32_t* log_n, const uint64_t* params, const uint64_t* compress_challenges,
                               uint8_t* out, size_t cap, size_t* out_len);
 
+/* One table of that proof with the orchestration left to the caller: replaces prove_single_table
+ * (circuits/src/stark/prover.rs:330-513) together with this table's share of cross_table_lookup_data
+ * (cross_table_lookup.rs:224-311), compute_permutation_z_polys (permutation.rs:103-155) and compute_quotient_polys
+ * (prover.rs:571-705).  The caller has committed the traces (ola_commit_values -> trace_commitment, trace_cap), observed
+ * all trace caps and drawn the CTL challenges (get_grand_product_challenge_set, permutation.rs:190-216:
+ * ctl_challenges = num_challenges x (beta, gamma)); `challenger` is the shared transcript at the point where the
+ * reference calls prove_single_table for table `table` and is advanced exactly as the reference advances it.
+ * trace_cols: host pointers to the table's columns (values, 2^log_n each).  out: this table's StarkProof bytes
+ * (serialization.rs:349-358 write_proof); an AllProof is u32 count, the proofs in table order, u32 count, the compress
+ * challenges.  Same error codes as ola_prove_with_traces; on error the challenger is left untouched. */
+int32_t ola_prove_single_table(OlaCtx* ctx, const uint64_t* airset, size_t airset_words, uint32_t table,
+                               const uint64_t* const* trace_cols, const OlaBatch* trace_commitment, const uint64_t* trace_cap,
+                               const uint64_t* ctl_challenges, const uint64_t* params, OlaChallenger* challenger, uint8_t* out,
+                               size_t cap, size_t* out_len);
+
 /* ---- trace generation helper -------------------------------------------------------------------------
  * The 134-column Poseidon STARK table (circuits/src/builtins/poseidon/columns.rs) from the permutation inputs: what the
  * reference's executor records per hash (core/src/util/poseidon_utils.rs) and generate_poseidon_trace lays out

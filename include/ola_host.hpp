@@ -11,6 +11,7 @@
 //   plonky2/plonky2/src/hash/poseidon.rs:593     PoseidonPermutation      ola_host::hash::permute / hash_no_pad / merkle_cap
 //   plonky2/plonky2/src/fri/prover.rs:126        fri_proof_of_work        ola_host::fri_proof_of_work
 //   circuits/src/stark/prover.rs:79              prove_with_traces        ola_host::prove_with_traces
+//   circuits/src/stark/prover.rs:330             prove_single_table       ola_host::prove_single_table
 //   circuits/src/stark/lookup.rs:68              permuted_cols            ola_host::permuted_cols
 //   circuits/src/generation/poseidon.rs:5        generate_poseidon_trace  ola_host::generate_poseidon_trace
 //
@@ -256,6 +257,30 @@ inline std::vector<uint8_t> prove_with_traces(const Gpu& g, const std::vector<F>
         rc = ola_prove_with_traces(g.ctx(), airset.data(), airset.size(), ptrs.data(), log_n.data(), params.empty() ? nullptr : params.data(),
                                    compress_challenges.empty() ? nullptr : compress_challenges.data(), out.data(), out.size(), &len);
     }
+    check(rc);
+    out.resize(len);
+    return out;
+}
+
+// prove_single_table (prover.rs:330-513) for callers that keep the reference's orchestration: `trace` = the table's columns,
+// `commitment` = PolynomialBatch::from_values of them, ctl_challenges = num_challenges x {beta, gamma}; the shared challenger
+// advances as in the reference.  Returns the table's StarkProof bytes (serialization.rs:349-358).
+inline std::vector<uint8_t> prove_single_table(const Gpu& g, const std::vector<F>& airset, uint32_t table, const std::vector<PolynomialValues>& trace,
+                                               const PolynomialBatch& commitment, const std::vector<std::array<F, 2>>& ctl_challenges,
+                                               const std::vector<F>& params, Challenger& challenger) {
+    std::vector<const F*> cols;
+    for (const auto& c : trace) cols.push_back(c.data());
+    std::vector<F> cap, ctl;
+    for (const auto& h : commitment.merkle_cap()) cap.insert(cap.end(), h.begin(), h.end());
+    for (const auto& c : ctl_challenges) { ctl.push_back(c[0]); ctl.push_back(c[1]); }
+    std::vector<uint8_t> out((size_t)4 << 20);
+    size_t len = 0;
+    auto call = [&]() {
+        return ola_prove_single_table(g.ctx(), airset.data(), airset.size(), table, cols.data(), commitment.handle(), cap.data(), ctl.data(),
+                                      params.empty() ? nullptr : params.data(), &challenger.raw(), out.data(), out.size(), &len);
+    };
+    int32_t rc = call();
+    if (rc == OLA_E_INVALID_ARG && len > out.size()) { out.resize(len); rc = call(); }
     check(rc);
     out.resize(len);
     return out;

@@ -87,6 +87,8 @@ def load_library():
     L.ola_commit_values_shard_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                               C.POINTER(C.c_void_p), U64P]
     L.ola_generate_poseidon_trace.argtypes = [C.c_void_p, U64P, U64P, C.c_size_t, U64P]
+    L.ola_prove_single_table.argtypes = [C.c_void_p, U64P, C.c_size_t, C.c_uint32, C.POINTER(U64P), C.c_void_p, U64P, U64P, U64P,
+                                         C.POINTER(OlaChallenger), C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]
     L.ola_permuted_cols.argtypes = [C.c_void_p, U64P, U64P, C.c_size_t, U64P, U64P]
     L.ola_permuted_cols_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
     L.ola_set_shard.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, ALL_GATHER_FN, C.c_void_p]
@@ -102,7 +104,7 @@ EXPORTS = [
     "ola_batch_get_leaf", "ola_batch_get_lde_row", "ola_challenger_init", "ola_challenger_observe",
     "ola_challenger_get", "ola_challenger_compact", "ola_open_and_prove", "ola_pow", "ola_prove_with_traces",
     "ola_air_kernels_available", "ola_commit_values_shard", "ola_commit_values_shard_dev", "ola_set_shard", "ola_gpu_trim", "ola_generate_poseidon_trace",
-    "ola_permuted_cols", "ola_permuted_cols_dev",
+    "ola_permuted_cols", "ola_permuted_cols_dev", "ola_prove_single_table",
 ]
 
 
@@ -363,6 +365,27 @@ class Backend:
             buf = C.create_string_buffer(cap)
             rc = self.lib.ola_prove_with_traces(self.ctx, _p(blob), blob.size, ptrs, logs, None if pr is None else _p(pr),
                                                 None if cc is None else _p(cc), buf, cap, C.byref(need))
+            if rc != 0 and need.value > cap:
+                cap = need.value
+                continue
+            self._chk(rc)
+            return bytes(buf.raw[:need.value])
+
+    def prove_single_table(self, airset_blob, table, trace, batch, ctl_challenges, params, challenger):
+        """StarkProof bytes of one table (ola_prove_single_table): `batch` is the table's trace commitment, `challenger` the
+        shared transcript (a Challenger, advanced in place), ctl_challenges = [(beta, gamma)] * num_challenges."""
+        blob = np.ascontiguousarray(airset_blob, dtype=np.uint64)
+        tr = np.ascontiguousarray(trace, dtype=np.uint64)
+        ptrs = (U64P * tr.shape[0])(*[_p(tr[c]) for c in range(tr.shape[0])])
+        cc = np.ascontiguousarray(np.array(ctl_challenges, dtype=np.uint64).reshape(-1))
+        cap_words = np.ascontiguousarray(batch.cap(), dtype=np.uint64).reshape(-1)
+        pr = None if params is None or len(params) == 0 else np.ascontiguousarray(params, dtype=np.uint64)
+        need = C.c_size_t(0)
+        cap = 1 << 20
+        while True:
+            buf = C.create_string_buffer(cap)
+            rc = self.lib.ola_prove_single_table(self.ctx, _p(blob), blob.size, table, ptrs, batch.h, _p(cap_words), _p(cc),
+                                                 None if pr is None else _p(pr), C.byref(challenger.c), buf, cap, C.byref(need))
             if rc != 0 and need.value > cap:
                 cap = need.value
                 continue

@@ -366,6 +366,23 @@ int32_t ola_prove_with_traces(OlaCtx* ctx, const uint64_t* airset, size_t airset
     OLA_CATCH
 }
 
+int32_t ola_prove_single_table(OlaCtx* ctx, const uint64_t* airset, size_t airset_words, uint32_t table,
+                               const uint64_t* const* trace_cols, const OlaBatch* trace_commitment, const uint64_t* trace_cap,
+                               const uint64_t* ctl_challenges, const uint64_t* params, OlaChallenger* challenger, uint8_t* out,
+                               size_t cap, size_t* out_len) {
+    OLA_TRY
+    require(ctx && airset && trace_cols && trace_commitment && trace_cap && ctl_challenges && challenger && out_len, "null pointer");
+    std::vector<uint8_t> bytes;
+    OlaChallenger ch = *challenger;          // the caller's transcript only advances when the proof was produced
+    prove_single_table_host(&ctx->dev, *ctx->tables, ctx->cfg, (const u64*)airset, airset_words, table, (const u64* const*)trace_cols,
+                            *trace_commitment, (const u64*)trace_cap, (const u64*)ctl_challenges, (const u64*)params, ch, bytes);
+    *out_len = bytes.size();
+    if (bytes.size() > cap || !out) throw OlaError(OLA_E_INVALID_ARG, "output buffer too small");
+    memcpy(out, bytes.data(), bytes.size());
+    *challenger = ch;
+    OLA_CATCH
+}
+
 int32_t ola_generate_poseidon_trace(OlaCtx* ctx, const uint64_t* inputs, const uint64_t* filters, size_t n, uint64_t* out) {
     OLA_TRY
     require(ctx && inputs && out, "null pointer");

@@ -740,6 +740,45 @@ static void prove_single_table(DeviceCtx* ctx, NttTables& tables, const OlaGpuCo
     open_and_prove(ctx, tables, cfg, trace_c, *zs_c.b, *q_c.b, (uint32_t)nperm, ch, bytes, olen);
 }
 
+// Per table, the running products it must carry: one per (lookup it takes part in, challenge), looking sides before the
+// looked side, lookups in declaration order (cross_table_lookup_data, cross_table_lookup.rs:224-311).
+static std::vector<std::vector<CtlJob>> ctl_jobs(const HAirSet& set, const std::vector<GpChallenge>& ctl_ch) {
+    std::vector<std::vector<CtlJob>> jobs(set.tables.size());
+    for (const HCtl& ctl : set.ctls)
+        for (const GpChallenge& c : ctl_ch) {
+            for (const HTwc& twc : ctl.looking) jobs[twc.table].push_back({&twc, c});
+            jobs[ctl.looked.table].push_back({&ctl.looked, c});
+        }
+    return jobs;
+}
+
+// One table's StarkProof with the trace commitment and the transcript supplied by the caller (ola_prove_single_table).
+void prove_single_table_host(DeviceCtx* ctx, NttTables& tables, const OlaGpuConfig& cfg, const u64* airset, size_t airset_words,
+                             uint32_t table, const u64* const* trace_cols, const OlaBatch& trace_c, const u64* trace_cap,
+                             const u64* ctl_challenges, const u64* params, OlaChallenger& ch, std::vector<uint8_t>& bytes) {
+    HAirSet set = parse_airset(airset, airset_words);
+    if (table >= set.tables.size()) throw OlaError(OLA_E_INVALID_ARG, "table index out of range");
+    if (ctx->shard.world != 1) throw OlaError(OLA_E_INVALID_ARG, "per-table proving needs an unsharded context");
+    const HTable& air = set.tables[table];
+    if (trace_c.ncols != (uint32_t)air.ncols || trace_c.is_shard()) throw OlaError(OLA_E_INVALID_ARG, "trace commitment does not match the table");
+    std::vector<GpChallenge> ctl_ch;
+    for (uint32_t c = 0; c < cfg.num_challenges; c++) ctl_ch.push_back({ctl_challenges[2 * c], ctl_challenges[2 * c + 1]});
+    const std::vector<std::vector<CtlJob>> jobs = ctl_jobs(set, ctl_ch);
+    DevBuf mem(ctx);
+    DevTable tv;
+    tv.log_n = trace_c.log_n;
+    const size_t n = tv.n();
+    tv.vals = mem.alloc((size_t)air.ncols * n);
+    for (int c = 0; c < air.ncols; c++)
+        HIP_CHECK(hipMemcpyAsync(tv.vals + (size_t)c * n, trace_cols[c], n * 8, hipMemcpyHostToDevice, ctx->stream));
+    canonicalize(ctx, tv.vals, (size_t)air.ncols * n);
+    const size_t len_cap = (size_t)1 << cfg.cap_height;
+    const std::vector<u64> cap(trace_cap, trace_cap + 4 * len_cap);
+    std::vector<u64> zero_params(64, 0);
+    if (!params && air.n_params > 64) throw OlaError(OLA_E_INVALID_ARG, "params required");
+    prove_single_table(ctx, tables, cfg, air, tv, trace_c, cap, jobs[table], params ? params : zero_params.data(), ch, bytes, false);
+}
+
 // Host -> device transfer of the trace tables on a helper thread and a dedicated stream, in groups of columns of about
 // 64 MB; wait(t, c) blocks until columns [0, c) of table t are on the device.
 class TraceUploader {
@@ -841,12 +880,7 @@ void prove_with_traces(DeviceCtx* ctx, NttTables& tables, const OlaGpuConfig& cf
     // CTL challenges and per-table job lists, in cross_table_lookup_data order
     std::vector<GpChallenge> ctl_ch;
     for (int c = 0; c < nch; c++) ctl_ch.push_back(get_gp(ch));
-    std::vector<std::vector<CtlJob>> jobs(nt);
-    for (const HCtl& ctl : set.ctls)
-        for (const GpChallenge& c : ctl_ch) {
-            for (const HTwc& twc : ctl.looking) jobs[twc.table].push_back({&twc, c});
-            jobs[ctl.looked.table].push_back({&ctl.looked, c});
-        }
+    const std::vector<std::vector<CtlJob>> jobs = ctl_jobs(set, ctl_ch);
     ByteWriter w{bytes};
     w.u32((uint32_t)nt);
     size_t poff = 0;

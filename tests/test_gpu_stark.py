@@ -269,6 +269,44 @@ def test_full_size_tables_proof_bytes_match_oracle(be, oracle):
     assert rc == 0, why
 
 
+def test_per_table_entry_point_reassembles_the_same_all_proof(be, oracle):
+    """The reference's own structure kept on the host: commit every trace (PolynomialBatch::from_values), observe the caps,
+    draw the CTL challenges, then one ola_prove_single_table per table on the shared transcript -- the concatenation is the
+    AllProof of the one-call path, byte for byte."""
+    import struct
+    from olavm_amd.air import miniexec as M
+    from olavm_amd.backend import Challenger
+    s = T.ola_stark(range_bits=4, limb_bits=2)
+    blob = s.blob()
+    traces, params, compress = M.instance(M.mixed_program())
+    whole = be.prove_with_traces(blob, traces, params, compress)
+    batches = [be.commit(t) for t in traces]
+    ch = Challenger()
+    for b in batches:
+        ch.observe(b.cap())
+    ctl = [(ch.get(), ch.get()) for _ in range(2)]                 # (beta, gamma) per challenge, permutation.rs:190-216
+    out, poff = struct.pack("<I", len(traces)), 0
+    for t, tr in enumerate(traces):
+        k = s.tables[t].n_params
+        out += be.prove_single_table(blob, t, tr, batches[t], ctl, params[poff:poff + k], ch)
+        poff += k
+    out += struct.pack("<I", len(traces)) + b"".join(struct.pack("<Q", int(c)) for c in compress)
+    assert out == whole
+    rc, why = oracle.verify_all_proof(blob, out, params)
+    assert rc == 0, why
+    # a failing table leaves the caller's transcript where it was
+    before = ch.state().copy()
+    bad = traces[0].copy()
+    bad[T.COL_DST, 3] = (int(bad[T.COL_DST, 3]) + 1) % tracegen.P          # a wrong sum in the CPU table
+    bad_batch = be.commit(bad)
+    with pytest.raises(Exception, match="not divisible"):
+        be.prove_single_table(blob, 0, bad, bad_batch, ctl, [], ch)
+    assert np.array_equal(before, ch.state())
+    bad_batch.free()
+    for b in batches:
+        b.free()
+
+
 def test_long_fibonacci_execution_verifies(be, oracle, monkeypatch):
     """1300 loop iterations = 7804 executed CPU rows (2^13-row CPU and program tables, specialised kernels, crosschecked
     against the interpreter kernel on this live data); the oracle verifier accepts the GPU proof."""
