@@ -1,7 +1,9 @@
-// C ABI of the backend (include/ola_gpu.h) -- the single translation unit that is compiled into libola_gpu.so.
+// C ABI of the backend (include/ola_gpu.h) -- the main translation unit of libola_gpu.so (lookup.hip and the generated
+// quotient kernels are compiled separately).
 // Everything below the `extern "C"` layer is C++/HIP; errors are caught here and turned into status codes.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -31,8 +33,19 @@ struct OlaCtx {
     OlaGpuConfig cfg;
 };
 
+// Kernel launches report configuration errors (grid / LDS limits, missing code object) only through the sticky "last
+// error"; it is read once per entry point so that such a failure surfaces as OLA_E_HIP instead of a silently wrong result.
+// Only while a context exists: the host-only entry points (challenger, ola_air_kernels_available) also work on machines
+// without a HIP device, where the runtime answers every query with an error.
+static std::atomic<int> g_live_contexts{0};
+static void check_launch_errors() {
+    if (g_live_contexts.load() <= 0) return;
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) throw OlaError(OLA_E_HIP, std::string("kernel launch failed: ") + hipGetErrorString(e));
+}
 #define OLA_TRY try {
 #define OLA_CATCH                                                   \
+        check_launch_errors();                                      \
     }                                                               \
     catch (const OlaError& e) { g_last_error = e.what(); return e.code; } \
     catch (const std::bad_alloc&) { g_last_error = "host out of memory"; return OLA_E_OOM; } \
@@ -66,6 +79,7 @@ int32_t ola_gpu_init(const OlaGpuConfig* cfg, OlaCtx** out_ctx) {
     poseidon_init(&c->dev);
     c->tables = ntt_tables_create(&c->dev);
     *out_ctx = c.release();
+    g_live_contexts.fetch_add(1);
     OLA_CATCH
 }
 
@@ -75,6 +89,7 @@ int32_t ola_gpu_free(OlaCtx* ctx) {
         (void)hipStreamSynchronize(ctx->dev.stream);
         ntt_tables_destroy(ctx->tables);
         delete ctx;
+        g_live_contexts.fetch_sub(1);
     }
     OLA_CATCH
 }
