@@ -302,7 +302,7 @@ int32_t ola_batch_get_coeffs(OlaCtx* ctx, const OlaBatch* b, uint64_t* out) {
 }
 int32_t ola_batch_get_leaf(OlaCtx* ctx, const OlaBatch* b, size_t leaf_index, uint64_t* row_out, uint64_t* siblings_out) {
     OLA_TRY
-    require(ctx && b, "null pointer");
+    require(ctx && b && row_out, "null pointer");
     require(leaf_index < b->num_leaves(), "leaf index out of range");
     batch_get_leaf(&ctx->dev, *b, leaf_index, (u64*)row_out, (u64*)siblings_out);
     OLA_CATCH
@@ -315,6 +315,7 @@ int32_t ola_batch_get_lde_row(OlaCtx* ctx, const OlaBatch* b, size_t index, size
     OLA_TRY
     require(ctx && b && row_out, "null pointer");
     require_full(b);   // natural-order LDE rows interleave the cosets of all shards
+    require(step == 0 || index <= b->num_leaves() / step, "row index out of range");
     const size_t nat = index * step;
     require(nat < b->num_leaves(), "row index out of range");
     batch_get_leaf(&ctx->dev, *b, bitrev32((u32)nat, b->log_n + b->rate_bits), (u64*)row_out, nullptr);
