@@ -1,0 +1,668 @@
+// Native trace generator behind include/ola_tracegen.h (host only, no HIP): the register-instruction subset of the miniature
+// executor olavm_amd/air/miniexec.py, word for word -- tests/test_tracegen_native.py compares all twelve tables of both on
+// the same programs.  Reference rules restated here are cited where they apply; the column indices come from the Python
+// table descriptions through the generated header gen/ola_columns.h.
+#include <algorithm>
+#include <array>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../../include/ola_poseidon_constants.h"
+#include "../../../include/ola_tracegen.h"
+#include "../gen/ola_columns.h"
+
+namespace {
+
+using namespace olacols;
+typedef uint64_t u64;
+typedef unsigned __int128 u128;
+
+const u64 P = 0xFFFFFFFF00000001ULL;
+// arguments may be any u64, results are canonical; the 128-bit reduction uses 2^64 = 2^32 - 1 and 2^96 = -1 (mod p)
+inline u64 canon(u64 x) { return x >= P ? x - P : x; }
+inline u64 addm(u64 a, u64 b) { a = canon(a); b = canon(b); const u64 s = a + b; return (s < a || s >= P) ? s - P : s; }
+inline u64 subm(u64 a, u64 b) { a = canon(a); b = canon(b); return a >= b ? a - b : a + (P - b); }
+inline u64 mulm(u64 a, u64 b) {
+    const u128 x = (u128)a * b;
+    const u64 lo = (u64)x, hi = (u64)(x >> 64), hh = hi >> 32, hl = hi & 0xFFFFFFFFULL;
+    u64 t0 = lo - hh;
+    if (lo < hh) t0 -= 0xFFFFFFFFULL;                 // borrowed 2^64 = p + (2^32 - 1): take the extra back
+    const u64 t1 = hl * 0xFFFFFFFFULL;
+    u64 t2 = t0 + t1;
+    if (t2 < t1) t2 += 0xFFFFFFFFULL;                 // carried 2^64 = 2^32 - 1 (mod p)
+    return canon(t2);
+}
+u64 powm(u64 b, u64 e) { u64 r = 1; b %= P; while (e) { if (e & 1) r = mulm(r, b); b = mulm(b, b); e >>= 1; } return r; }
+inline u64 invm(u64 x) { return x % P ? powm(x % P, P - 2) : 0; }
+inline size_t next_pow2(size_t n) { size_t k = 2; while (k < n) k <<= 1; return k; }
+
+struct Err : std::runtime_error { using std::runtime_error::runtime_error; };
+void need(bool ok, const char* what) { if (!ok) throw Err(what); }
+
+// A table: ncols columns of n words, column-major (what ola_prove_with_traces takes).
+struct Table {
+    size_t ncols = 0, n = 0;
+    std::vector<u64> d;
+    void init(size_t c, size_t rows) { ncols = c; n = rows; d.assign(c * rows, 0); }
+    u64& at(size_t col, size_t row) { return d[col * n + row]; }
+    void fill(size_t col, u64 v) { std::fill(d.begin() + col * n, d.begin() + (col + 1) * n, v); }
+    std::vector<u64> column(size_t col) const { return std::vector<u64>(d.begin() + col * n, d.begin() + (col + 1) * n); }
+    void set_column(size_t col, const std::vector<u64>& v) { std::copy(v.begin(), v.end(), d.begin() + col * n); }
+};
+
+// ---- Poseidon with the S-box inputs recorded: one row of the Poseidon table (generation/poseidon.rs:5-80; the
+// permutation is the plain round structure of plonky2/src/hash/poseidon.rs:617-627)
+std::vector<u64> poseidon_row(const u64* in12, const u64 filters[4]) {
+    std::vector<u64> row(NUM_POSEIDON_COLS, 0);
+    for (int i = 0; i < 4; i++) row[i] = filters[i];
+    u64 s[12];
+    for (int i = 0; i < 12; i++) { s[i] = in12[i] % P; row[COL_POSEIDON_INPUT_RANGE_START + i] = s[i]; }
+    auto sbox = [](u64 x) { u64 x2 = mulm(x, x), x4 = mulm(x2, x2), x3 = mulm(x2, x); return mulm(x3, x4); };
+    for (int r = 0; r < 30; r++) {
+        const bool full = r < 4 || r >= 26;
+        for (int i = 0; i < 12; i++) s[i] = addm(s[i], OLA_POSEIDON_RC[12 * r + i]);
+        if (full) {
+            if (r >= 1 && r <= 3) for (int i = 0; i < 12; i++) row[COL_POSEIDON_FULL_ROUND_0_1_STATE_RANGE_START + 12 * (r - 1) + i] = s[i];
+            else if (r >= 26) for (int i = 0; i < 12; i++) row[COL_POSEIDON_FULL_ROUND_1_0_STATE_RANGE_START + 12 * (r - 26) + i] = s[i];
+            for (int i = 0; i < 12; i++) s[i] = sbox(s[i]);
+        } else {
+            row[COL_POSEIDON_PARTIAL_ROUND_ELEMENT_RANGE_START + (r - 4)] = s[0];
+            s[0] = sbox(s[0]);
+        }
+        u64 o[12];
+        for (int k = 0; k < 12; k++) {
+            u128 acc = 0;
+            for (int i = 0; i < 12; i++) acc += (u128)s[(i + k) % 12] * OLA_POSEIDON_MDS_CIRC[i];
+            acc += (u128)s[k] * OLA_POSEIDON_MDS_DIAG[k];
+            o[k] = addm(mulm((u64)(acc >> 64), 0xFFFFFFFFULL), canon((u64)acc));      // acc = hi * 2^64 + lo, 2^64 = 2^32 - 1
+        }
+        memcpy(s, o, sizeof(s));
+    }
+    for (int i = 0; i < 12; i++) row[COL_POSEIDON_OUTPUT_RANGE_START + i] = s[i];
+    return row;
+}
+
+// ---- lookup.rs:68-132
+void permuted_cols(const std::vector<u64>& inputs, const std::vector<u64>& table, std::vector<u64>& pi, std::vector<u64>& pt) {
+    const size_t n = inputs.size();
+    pi = inputs;
+    std::vector<u64> st = table;
+    for (auto& x : pi) x %= P;
+    for (auto& x : st) x %= P;
+    std::sort(pi.begin(), pi.end());
+    std::sort(st.begin(), st.end());
+    pt.assign(n, 0);
+    std::vector<size_t> unused_inds;
+    std::vector<u64> unused_vals;
+    size_t i = 0, j = 0;
+    while (j < n && i < n) {
+        const u64 a = pi[i], b = st[j];
+        if (a > b) { unused_vals.push_back(b); j++; }
+        else if (a < b) {
+            if (!unused_vals.empty()) { pt[i] = unused_vals.back(); unused_vals.pop_back(); } else unused_inds.push_back(i);
+            i++;
+        } else { pt[i] = b; i++; j++; }
+    }
+    for (; j < n; j++) unused_vals.push_back(st[j]);
+    for (; i < n; i++) unused_inds.push_back(i);
+    need(unused_inds.size() == unused_vals.size(), "permuted_cols: unused slots and values differ in number");
+    for (size_t k = 0; k < unused_inds.size(); k++) pt[unused_inds[k]] = unused_vals[k];
+}
+
+// ---- execution -----------------------------------------------------------------------------------------------------------------
+enum MemOp { M_CALL, M_MLOAD, M_MSTORE, M_POSEIDON, M_RET };     // alphabetical: ties of (address, clock) sort by name, as in Python
+struct MemCell { u64 addr, clk; MemOp op; u64 value; int is_write; };
+struct PsdnChunk { u64 addr; u64 vals[8]; u64 cap[4]; std::vector<u64> row; };
+struct PsdnCall { u64 clk, src, len, dst; std::vector<PsdnChunk> chunks; };
+struct BwOp { uint32_t op; u64 a, b; };
+
+struct Run {
+    // executed CPU rows, row-major (NUM_CPU_COLS words each), in chunks so that a long run never re-copies what it has
+    static constexpr size_t CHUNK_ROWS = 1 << 14;
+    std::vector<std::unique_ptr<u64[]>> row_chunks;
+    size_t n_rows = 0;
+    size_t nrows() const { return n_rows; }
+    const u64* row(size_t i) const { return row_chunks[i / CHUNK_ROWS].get() + (i % CHUNK_ROWS) * NUM_CPU_COLS; }
+    void push_row(const std::vector<u64>& r) {
+        if (n_rows % CHUNK_ROWS == 0) row_chunks.emplace_back(new u64[CHUNK_ROWS * NUM_CPU_COLS]);
+        std::copy(r.begin(), r.end(), row_chunks.back().get() + (n_rows % CHUNK_ROWS) * NUM_CPU_COLS);
+        n_rows++;
+    }
+    std::vector<std::pair<u64, u64>> executed;           // fetched (pc, word)
+    std::vector<u64> rc;
+    std::vector<BwOp> bitwise;
+    std::vector<std::pair<u64, u64>> cmp;
+    std::vector<MemCell> mem;
+    std::vector<PsdnCall> psdn;
+    std::vector<u64> words;
+};
+
+const int REG = 10;
+
+void program_words(const OlaInstr* ins, size_t n, std::vector<u64>& words, std::vector<size_t>& pcs) {
+    for (size_t k = 0; k < n; k++) {
+        const OlaInstr& I = ins[k];
+        need(I.op < 32 && I.dst < REG && I.op0 < REG && I.op1 < REG, "instruction field out of range");
+        u64 w = I.op1_is_imm ? (1ULL << 62) : 0;
+        if (I.op0 >= 0) w += 1ULL << (52 + I.op0);
+        if (I.op1 >= 0 && !I.op1_is_imm) w += 1ULL << (42 + I.op1);
+        if (I.dst >= 0) w += 1ULL << (32 + I.dst);
+        w += 1ULL << I.op;
+        pcs.push_back(words.size());
+        words.push_back(w);
+        if (I.op1_is_imm) words.push_back(I.imm % P);
+    }
+}
+
+u64 selector_of(uint32_t op) {
+    switch (op) {
+        case OP_ADD: case OP_MUL: case OP_EQ: case OP_NEQ: case OP_ASSERT: return COL_S_SIMPLE_ARITHMATIC_OP;
+        case OP_MOV: return COL_S_MOV;
+        case OP_NOT: return COL_S_NOT;
+        case OP_JMP: return COL_S_JMP;
+        case OP_CJMP: return COL_S_CJMP;
+        case OP_CALL: return COL_S_CALL;
+        case OP_RET: return COL_S_RET;
+        case OP_MLOAD: return COL_S_MLOAD;
+        case OP_MSTORE: return COL_S_MSTORE;
+        case OP_END: return COL_S_END;
+        case OP_RC: return COL_S_RC;
+        case OP_AND: case OP_OR: case OP_XOR: return COL_S_BITWISE;
+        case OP_GTE: return COL_S_GTE;
+        case OP_POSEIDON: return COL_S_PSDN;
+        default: throw Err("instruction not supported by the native generator");
+    }
+}
+
+void execute(const OlaInstr* ins, size_t n_ins, const u64 code_addr[4], const u64 storage_addr[4], u64 max_steps, Run& R) {
+    std::vector<size_t> pcs;
+    program_words(ins, n_ins, R.words, pcs);
+    std::map<u64, size_t> pc_to_idx;
+    for (size_t k = 0; k < pcs.size(); k++) pc_to_idx[pcs[k]] = k;
+    u64 regs[REG] = {0};
+    u64 pc = 0, clk = 0;
+    std::map<u64, u64> memory;
+    std::vector<u64> r(NUM_CPU_COLS);
+    auto mem_at = [&](u64 a, const char* what) -> u64 { auto it = memory.find(a); need(it != memory.end(), what); return it->second; };
+    for (;;) {
+        need(R.nrows() < max_steps, "program does not terminate");
+        auto it = pc_to_idx.find(pc);
+        need(it != pc_to_idx.end(), "jump into the middle of an instruction");
+        const OlaInstr& I = ins[it->second];
+        const bool imm = I.op1_is_imm != 0;
+        std::fill(r.begin(), r.end(), 0);
+        for (int i = 0; i < 4; i++) { r[COL_ADDR_STORAGE_RANGE_START + i] = storage_addr[i]; r[COL_ADDR_CODE_RANGE_START + i] = code_addr[i]; }
+        r[COL_CLK] = clk; r[COL_PC] = pc;
+        for (int i = 0; i < REG; i++) r[COL_REGS_START + i] = regs[i];
+        r[COL_INST] = R.words[pc]; r[COL_OP1_IMM] = imm; r[COL_OPCODE] = 1ULL << I.op;
+        r[selector_of(I.op)] = 1;
+        r[COL_IS_ENTRY_SC] = r[COL_IS_NEXT_LINE_DIFF_INST] = r[COL_IS_NEXT_LINE_SAME_TX] = 1;
+        const u64 v0 = I.op0 >= 0 ? regs[I.op0] : 0;
+        const u64 v1 = imm ? I.imm % P : (I.op1 >= 0 ? regs[I.op1] : 0);
+        if (I.op0 >= 0) { r[COL_S_OP0_START + I.op0] = 1; r[COL_OP0] = v0; }
+        if (imm) { r[COL_IMM_VAL] = r[COL_OP1] = v1; r[COL_FILTER_LOOKING_PROG_IMM] = 1; }
+        else if (I.op1 >= 0) { r[COL_S_OP1_START + I.op1] = 1; r[COL_OP1] = v1; }
+        const u64 size = imm ? 2 : 1;
+        R.executed.push_back({pc, R.words[pc]});
+        if (imm) R.executed.push_back({pc + 1, v1});
+        u64 next_pc = pc + size, res = 0;
+        bool has_res = false;
+        switch (I.op) {
+            case OP_MOV: res = v1; has_res = true; break;
+            case OP_NOT: res = subm(P - 1, v1); has_res = true; break;                          // executor/src/lib.rs:602-605
+            case OP_ASSERT: need(v1 == 1, "ASSERT on a value other than 1"); break;               // :673-712
+            case OP_ADD: res = addm(v0, v1); has_res = true; break;
+            case OP_MUL: res = mulm(v0, v1); has_res = true; break;
+            case OP_EQ: case OP_NEQ:
+                res = ((v0 == v1) == (I.op == OP_EQ)) ? 1 : 0; has_res = true;
+                r[COL_AUX0] = invm(subm(v0, v1));
+                break;
+            case OP_JMP: next_pc = v1; break;
+            case OP_CJMP: need(v0 <= 1, "CJMP on a non-boolean"); next_pc = v0 ? v1 : pc + size; break;
+            case OP_RC: need(v1 < (1ULL << 32), "RC operand too wide"); R.rc.push_back(v1); break;
+            case OP_AND: case OP_OR: case OP_XOR:
+                need(v0 < (1ULL << 32) && v1 < (1ULL << 32), "bitwise operand too wide");
+                res = I.op == OP_AND ? (v0 & v1) : I.op == OP_OR ? (v0 | v1) : (v0 ^ v1); has_res = true;
+                R.bitwise.push_back({I.op, v0, v1});
+                break;
+            case OP_GTE:
+                need(v0 < (1ULL << 32) && v1 < (1ULL << 32), "GTE operand too wide");
+                res = v0 >= v1; has_res = true;
+                R.cmp.push_back({v0, v1});
+                break;
+            case OP_MSTORE: case OP_MLOAD: {
+                // executor/src/lib.rs:868-995: address = op0 + immediate offset (aux1)
+                need(imm && I.dst >= 0, "only the [reg + imm] addressing form is implemented");
+                const u64 addr = addm(v0, v1);
+                r[COL_AUX1] = addr;
+                if (I.op == OP_MSTORE) { res = regs[I.dst]; memory[addr] = res; }
+                else res = mem_at(addr, "load from an address that was never written");
+                has_res = true;
+                R.mem.push_back({addr, clk, I.op == OP_MSTORE ? M_MSTORE : M_MLOAD, res, I.op == OP_MSTORE});
+                break;
+            }
+            case OP_CALL: {
+                // executor/src/lib.rs:816-849: the return address goes to [fp - 1]; [fp - 2] (the caller's saved fp) is read
+                const u64 fp = regs[REG - 1], a1 = subm(fp, 1), a2 = subm(fp, 2);
+                need(imm, "CALL needs an immediate target");
+                const u64 saved = mem_at(a2, "CALL needs a saved frame pointer at [fp - 2]");
+                const u64 ret_pc = pc + size;
+                r[COL_OP0] = a1; r[COL_DST] = ret_pc; r[COL_AUX0] = a2; r[COL_AUX1] = saved;
+                memory[a1] = ret_pc;
+                R.mem.push_back({a1, clk, M_CALL, ret_pc, 1});
+                R.mem.push_back({a2, clk, M_CALL, saved, 0});
+                next_pc = v1;
+                break;
+            }
+            case OP_RET: {
+                // executor/src/lib.rs:851-866: pc <- [fp - 1], fp <- [fp - 2]
+                const u64 fp = regs[REG - 1], a1 = subm(fp, 1), a2 = subm(fp, 2);
+                const u64 ret_pc = mem_at(a1, "RET without a return address"), old_fp = mem_at(a2, "RET without a saved frame pointer");
+                r[COL_OP0] = a1; r[COL_DST] = ret_pc; r[COL_AUX0] = a2; r[COL_AUX1] = old_fp;
+                R.mem.push_back({a1, clk, M_RET, ret_pc, 0});
+                R.mem.push_back({a2, clk, M_RET, old_fp, 0});
+                regs[REG - 1] = old_fp;
+                next_pc = ret_pc;
+                break;
+            }
+            case OP_POSEIDON: {
+                // executor/src/lib.rs:1547-1700: hash `len` words at [op0..] eight at a time, capacity chained, digest to [dst..]
+                need(I.dst >= 0, "POSEIDON needs a destination register");
+                const u64 src = v0, length = v1, dst_addr = regs[I.dst];
+                need(length && length % 8 == 0, "only whole 8-word blocks are implemented");
+                PsdnCall call{clk, src, length, dst_addr, {}};
+                u64 cap[4] = {0, 0, 0, 0};
+                const u64 filt[4] = {1, 0, 0, 0};
+                for (u64 k = 0; k < length; k += 8) {
+                    PsdnChunk ch;
+                    ch.addr = src + k;
+                    u64 in[12];
+                    for (int i = 0; i < 8; i++) {
+                        ch.vals[i] = in[i] = mem_at(src + k + i, "hash input was never written");
+                        R.mem.push_back({src + k + i, clk, M_POSEIDON, in[i], 0});
+                    }
+                    for (int i = 0; i < 4; i++) ch.cap[i] = in[8 + i] = cap[i];
+                    ch.row = poseidon_row(in, filt);
+                    for (int i = 0; i < 4; i++) cap[i] = ch.row[COL_POSEIDON_OUTPUT_RANGE_START + 8 + i];
+                    call.chunks.push_back(std::move(ch));
+                }
+                for (int i = 0; i < 4; i++) {
+                    const u64 o = call.chunks.back().row[COL_POSEIDON_OUTPUT_RANGE_START + i];
+                    memory[dst_addr + i] = o;
+                    R.mem.push_back({dst_addr + i, clk, M_POSEIDON, o, 1});
+                }
+                R.psdn.push_back(std::move(call));
+                res = dst_addr; has_res = true;       // the CPU's dst column carries the destination address
+                break;
+            }
+            case OP_END: break;
+            default: throw Err("instruction not supported by the native generator");
+        }
+        if (I.dst >= 0) {
+            need(has_res, "instruction has a destination but no result");
+            r[COL_S_DST_START + I.dst] = 1; r[COL_DST] = res;
+            regs[I.dst] = res;
+        }
+        if (I.op == OP_END) r[COL_IS_NEXT_LINE_SAME_TX] = 0;
+        R.push_row(r);
+        if (I.op == OP_END) break;
+        pc = next_pc;
+        clk += 1;
+    }
+}
+
+// ---- tables ----------------------------------------------------------------------------------------------------------------------
+void cpu_table(const Run& R, Table& t) {                                           // generation/cpu.rs:180-208 padding
+    const size_t live = R.nrows();
+    const size_t n = next_pow2(std::max<size_t>(live, 8));
+    t.init(NUM_CPU_COLS, n);
+    // row-major rows -> column-major table, a block of rows at a time so that both sides stay in cache
+    const size_t B = 256;
+    for (size_t i0 = 0; i0 < live; i0 += B) {
+        const size_t i1 = std::min(live, i0 + B);
+        for (size_t c = 0; c < NUM_CPU_COLS; c++) {
+            u64* dst = &t.d[c * n];
+            for (size_t i = i0; i < i1; i++) dst[i] = R.row(i)[c];
+        }
+    }
+    const u64 pad_vals[][2] = {{COL_INST, 1048576}, {COL_OPCODE, 1ULL << OP_END}, {COL_S_END, 1}, {COL_IS_ENTRY_SC, 1}, {COL_IS_NEXT_LINE_DIFF_INST, 1},
+                               {COL_IS_PADDING, 1}, {COL_IDX_STORAGE, R.row(live - 1)[COL_IDX_STORAGE]}};
+    for (const auto& pv : pad_vals) std::fill(t.d.begin() + pv[0] * n + live, t.d.begin() + (pv[0] + 1) * n, pv[1]);
+}
+
+void program_table(const Run& R, const u64 code_addr[4], u64 beta, Table& t, std::vector<u64>& words) {
+    words = R.words;
+    while (words.size() % 8) words.push_back(0);                                   // prog_chunk hashes 8 words at a time
+    const size_t n = next_pow2(std::max<size_t>(std::max(words.size(), R.executed.size()), 8));
+    t.init(NUM_PROG_COLS, n);
+    const u64 b = beta % P, b2 = mulm(b, b), b3 = mulm(b2, b), b4 = mulm(b3, b), b5 = mulm(b4, b);
+    auto comp = [&](u64 pc, u64 w) {
+        u64 acc = code_addr[0] % P;
+        acc = addm(acc, mulm(code_addr[1], b)); acc = addm(acc, mulm(code_addr[2], b2)); acc = addm(acc, mulm(code_addr[3], b3));
+        acc = addm(acc, mulm(pc % P, b4)); acc = addm(acc, mulm(w % P, b5));
+        return acc;
+    };
+    for (size_t pc = 0; pc < words.size(); pc++) {
+        for (int k = 0; k < 4; k++) t.at(COL_PROG_CODE_ADDR_RANGE_START + k, pc) = code_addr[k];
+        t.at(COL_PROG_PC, pc) = pc; t.at(COL_PROG_INST, pc) = words[pc]; t.at(COL_PROG_COMP_PROG, pc) = comp(pc, words[pc]);
+        t.at(COL_PROG_FILTER_PROG_CHUNK, pc) = 1;
+    }
+    for (size_t i = 0; i < n; i++) {
+        const auto& e = i < R.executed.size() ? R.executed[i] : R.executed[0];      // filler rows repeat a listed word (filter 0)
+        for (int k = 0; k < 4; k++) t.at(COL_PROG_EXEC_CODE_ADDR_RANGE_START + k, i) = code_addr[k];
+        t.at(COL_PROG_EXEC_PC, i) = e.first; t.at(COL_PROG_EXEC_INST, i) = e.second; t.at(COL_PROG_EXEC_COMP_PROG, i) = comp(e.first, e.second);
+        t.at(COL_PROG_FILTER_EXEC, i) = i < R.executed.size();
+    }
+    std::vector<u64> pi, pt;
+    permuted_cols(t.column(COL_PROG_EXEC_COMP_PROG), t.column(COL_PROG_COMP_PROG), pi, pt);
+    t.set_column(COL_PROG_EXEC_COMP_PROG_PERM, pi);
+    t.set_column(COL_PROG_COMP_PROG_PERM, pt);
+}
+
+// program/prog_chunk_stark.rs + generation/prog.rs: one row per 8 program words, capacity chained; Poseidon rows of the
+// chunk hashes followed by the builtin's rows, padded with the zero-input permutation
+void prog_chunk_and_poseidon(const u64 code_addr[4], const std::vector<u64>& words, const std::vector<std::vector<u64>>& extra_rows,
+                             Table& chunk, Table& poseidon) {
+    const size_t nchunks = words.size() / 8;
+    const size_t n = next_pow2(std::max<size_t>(nchunks, 8));
+    chunk.init(NUM_PROG_CHUNK_COLS, n);
+    chunk.fill(COL_PROG_CHUNK_IS_PADDING_LINE, 1);
+    std::vector<std::vector<u64>> prow;
+    u64 cap[4] = {0, 0, 0, 0};
+    const u64 filt[4] = {1, 0, 0, 0};
+    for (size_t i = 0; i < nchunks; i++) {
+        u64 in[12];
+        for (int k = 0; k < 8; k++) in[k] = words[8 * i + k];
+        for (int k = 0; k < 4; k++) in[8 + k] = cap[k];
+        std::vector<u64> row = poseidon_row(in, filt);
+        chunk.at(COL_PROG_CHUNK_IS_PADDING_LINE, i) = 0;
+        for (int k = 0; k < 4; k++) chunk.at(COL_PROG_CHUNK_CODE_ADDR_RANGE_START + k, i) = code_addr[k];
+        chunk.at(COL_PROG_CHUNK_START_PC, i) = 8 * i;
+        for (int k = 0; k < 8; k++) chunk.at(COL_PROG_CHUNK_INST_RANGE_START + k, i) = words[8 * i + k];
+        for (int k = 0; k < 4; k++) chunk.at(COL_PROG_CHUNK_CAP_RANGE_START + k, i) = cap[k];
+        for (int k = 0; k < 12; k++) chunk.at(COL_PROG_CHUNK_HASH_RANGE_START + k, i) = row[COL_POSEIDON_OUTPUT_RANGE_START + k];
+        chunk.at(COL_PROG_CHUNK_IS_FIRST_LINE, i) = i == 0;
+        for (u64 k = COL_PROG_CHUNK_FILTER_LOOKING_PROG_RANGE_START; k < COL_PROG_CHUNK_FILTER_LOOKING_PROG_RANGE_END; k++) chunk.at(k, i) = 1;
+        for (int k = 0; k < 4; k++) cap[k] = row[COL_POSEIDON_OUTPUT_RANGE_START + 8 + k];
+        prow.push_back(std::move(row));
+    }
+    for (const auto& r : extra_rows) prow.push_back(r);
+    const size_t np = next_pow2(std::max<size_t>(prow.size(), 8));
+    poseidon.init(NUM_POSEIDON_COLS, np);
+    const u64 zero_in[12] = {0}, zero_f[4] = {0, 0, 0, 0};
+    const std::vector<u64> zero_row = poseidon_row(zero_in, zero_f);               // generation/poseidon.rs: ZERO-hash padding rows
+    for (size_t i = 0; i < np; i++) {
+        const std::vector<u64>& r = i < prow.size() ? prow[i] : zero_row;
+        for (size_t c = 0; c < NUM_POSEIDON_COLS; c++) poseidon.at(c, i) = r[c];
+    }
+}
+
+u64 mem_selector(MemOp op) {
+    switch (op) {
+        case M_CALL: return COL_MEM_S_CALL;
+        case M_MLOAD: return COL_MEM_S_MLOAD;
+        case M_MSTORE: return COL_MEM_S_MSTORE;
+        case M_POSEIDON: return COL_MEM_S_POSEIDON;
+        default: return COL_MEM_S_RET;
+    }
+}
+uint32_t mem_opcode(MemOp op) {
+    switch (op) {
+        case M_CALL: return OP_CALL;
+        case M_MLOAD: return OP_MLOAD;
+        case M_MSTORE: return OP_MSTORE;
+        case M_POSEIDON: return OP_POSEIDON;
+        default: return OP_RET;
+    }
+}
+
+// generation/memory.rs:5-95: cells sorted by (address, clock); stack and heap regions live, prophet-region padding after them
+void memory_table(std::vector<MemCell> cells, Table& t, std::vector<u64>& rc_vals, std::vector<u64>& cond_vals) {
+    std::sort(cells.begin(), cells.end(), [](const MemCell& a, const MemCell& b) {
+        if (a.addr != b.addr) return a.addr < b.addr;
+        if (a.clk != b.clk) return a.clk < b.clk;
+        if (a.op != b.op) return a.op < b.op;
+        if (a.value != b.value) return a.value < b.value;
+        return a.is_write < b.is_write;
+    });
+    const size_t n = next_pow2(std::max<size_t>(cells.size() + 1, 8));
+    t.init(NUM_MEM_COLS, n);
+    const u64 span = 0xFFFFFFFFULL;
+    bool have_prev = false, prev_heap = false;
+    u64 prev_addr = 0, prev_clk = 0;
+    for (size_t i = 0; i < cells.size(); i++) {
+        const MemCell& c = cells[i];
+        t.at(COL_MEM_IS_RW, i) = 1;
+        t.at(COL_MEM_ADDR, i) = c.addr; t.at(COL_MEM_CLK, i) = c.clk; t.at(COL_MEM_OP, i) = 1ULL << mem_opcode(c.op); t.at(COL_MEM_VALUE, i) = c.value;
+        t.at(mem_selector(c.op), i) = 1;
+        t.at(COL_MEM_IS_WRITE, i) = c.is_write;
+        const bool heap = c.addr >= ADDR_HEAP_PTR;
+        if (heap) {
+            const u64 cond = subm(subm(0, span), c.addr);
+            t.at(COL_MEM_REGION_HEAP, i) = 1; t.at(COL_MEM_DIFF_ADDR_COND, i) = cond; t.at(COL_MEM_FILTER_LOOKING_RC_COND, i) = 1;
+            cond_vals.push_back(cond);
+        }
+        if (have_prev && heap && !prev_heap) {
+            // first heap row: the address gap to the stack region is not range-checked (generation/memory.rs:77-86)
+            t.at(COL_MEM_DIFF_ADDR, i) = c.addr - prev_addr; t.at(COL_MEM_DIFF_ADDR_INV, i) = invm(c.addr - prev_addr);
+        } else if (have_prev) {
+            const bool same = c.addr == prev_addr;
+            const u64 d_addr = c.addr - prev_addr;
+            t.at(COL_MEM_DIFF_ADDR, i) = d_addr; t.at(COL_MEM_DIFF_ADDR_INV, i) = invm(d_addr);
+            t.at(COL_MEM_DIFF_CLK, i) = same ? c.clk - prev_clk : 0;
+            t.at(COL_MEM_RW_ADDR_UNCHANGED, i) = same;
+            const u64 rc = same ? c.clk - prev_clk : d_addr;
+            t.at(COL_MEM_RC_VALUE, i) = rc; t.at(COL_MEM_FILTER_LOOKING_RC, i) = 1;
+            rc_vals.push_back(rc);
+        }
+        have_prev = true; prev_addr = c.addr; prev_clk = c.clk; prev_heap = heap;
+    }
+    u64 a = subm(0, span);
+    const u64 last_addr = have_prev ? prev_addr : 0;
+    const size_t start = cells.empty() ? 1 : cells.size();
+    if (cells.empty()) { t.at(COL_MEM_S_PROPHET, 0) = 1; t.at(COL_MEM_IS_WRITE, 0) = 1; }
+    for (size_t i = start; i < n; i++) {
+        t.at(COL_MEM_S_PROPHET, i) = t.at(COL_MEM_IS_WRITE, i) = t.at(COL_MEM_REGION_PROPHET, i) = 1;
+        t.at(COL_MEM_ADDR, i) = a;
+        const u64 d = i == start ? subm(a, last_addr) : 1;
+        t.at(COL_MEM_DIFF_ADDR, i) = d; t.at(COL_MEM_DIFF_ADDR_INV, i) = invm(d);
+        t.at(COL_MEM_DIFF_ADDR_COND, i) = t.at(COL_MEM_RC_VALUE, i) = subm(0, a);
+        a = addm(a, 1);
+    }
+}
+
+// generation/poseidon_chunk.rs; builtins/poseidon/poseidon_chunk_stark.rs:98-284
+void poseidon_chunk_table(const std::vector<PsdnCall>& calls, Table& t, std::vector<std::vector<u64>>& prow) {
+    std::vector<std::map<u64, u64>> rows;
+    for (const PsdnCall& c : calls) {
+        std::map<u64, u64> base{{COL_POSEIDON_CHUNK_CLK, c.clk}, {COL_POSEIDON_CHUNK_OPCODE, 1ULL << OP_POSEIDON}, {COL_POSEIDON_CHUNK_OP1, c.len},
+                                {COL_POSEIDON_CHUNK_DST, c.dst}};
+        std::map<u64, u64> head = base;
+        head[COL_POSEIDON_CHUNK_OP0] = c.src;
+        head[COL_POSEIDON_CHUNK_FILTER_LOOKED_CPU] = 1;
+        rows.push_back(head);
+        for (size_t j = 0; j < c.chunks.size(); j++) {
+            const PsdnChunk& ch = c.chunks[j];
+            std::map<u64, u64> r = base;
+            r[COL_POSEIDON_CHUNK_OP0] = ch.addr;
+            r[COL_POSEIDON_CHUNK_ACC_CNT] = 8 * (j + 1);
+            for (int k = 0; k < 8; k++) r[COL_POSEIDON_CHUNK_VALUE_RANGE_START + k] = ch.vals[k];
+            for (int k = 0; k < 4; k++) r[COL_POSEIDON_CHUNK_CAP_RANGE_START + k] = ch.cap[k];
+            for (int k = 0; k < 12; k++) r[COL_POSEIDON_CHUNK_HASH_RANGE_START + k] = ch.row[COL_POSEIDON_OUTPUT_RANGE_START + k];
+            r[COL_POSEIDON_CHUNK_IS_EXT_LINE] = 1;
+            r[COL_POSEIDON_CHUNK_IS_RESULT_LINE] = j + 1 == c.chunks.size();
+            for (u64 k = COL_POSEIDON_CHUNK_FILTER_LOOKING_MEM_RANGE_START; k < COL_POSEIDON_CHUNK_FILTER_LOOKING_MEM_RANGE_END; k++) r[k] = 1;
+            r[COL_POSEIDON_CHUNK_FILTER_LOOKING_POSEIDON] = 1;
+            rows.push_back(r);
+            prow.push_back(ch.row);
+        }
+    }
+    const size_t n = next_pow2(std::max<size_t>(rows.size(), 8));
+    t.init(NUM_POSEIDON_CHUNK_COLS, n);
+    t.fill(COL_POSEIDON_CHUNK_IS_PADDING_LINE, 1);
+    for (size_t i = 0; i < rows.size(); i++) {
+        t.at(COL_POSEIDON_CHUNK_IS_PADDING_LINE, i) = 0;
+        for (const auto& kv : rows[i]) t.at(kv.first, i) = kv.second;
+    }
+}
+
+// generation/builtin.rs:208-247
+void cmp_table(const std::vector<std::pair<u64, u64>>& ops, Table& t, std::vector<u64>& abs_diffs) {
+    const size_t n = next_pow2(ops.size());
+    t.init(COL_NUM_CMP, n);
+    for (size_t i = 0; i < ops.size(); i++) {
+        const u64 a = ops[i].first, b = ops[i].second, d = a >= b ? a - b : b - a;
+        t.at(COL_CMP_OP0, i) = a; t.at(COL_CMP_OP1, i) = b; t.at(COL_CMP_GTE, i) = a >= b; t.at(COL_CMP_ABS_DIFF, i) = d;
+        t.at(COL_CMP_ABS_DIFF_INV, i) = invm(d); t.at(COL_CMP_FILTER_LOOKING_RC, i) = 1;
+        abs_diffs.push_back(d);
+    }
+    for (size_t i = ops.size(); i < n; i++)
+        t.at(COL_CMP_OP0, i) = t.at(COL_CMP_GTE, i) = t.at(COL_CMP_ABS_DIFF, i) = t.at(COL_CMP_ABS_DIFF_INV, i) = 1;
+}
+
+// generation/builtin.rs:249-316: value, filters (cpu, memory sort, memory region, cmp), 16-bit limbs, fixed table, permuted columns
+struct RcRow { u64 v; int f[4]; };
+void rc_table(const std::vector<RcRow>& rows, uint32_t range_bits, Table& t) {
+    const size_t size = (size_t)1 << range_bits;
+    const size_t n = next_pow2(std::max(rows.size(), size));
+    t.init(COL_NUM_RC, n);
+    for (size_t i = 0; i < rows.size(); i++) {
+        need(rows[i].v < (u64)size * size, "range-checked value does not fit two limbs");
+        t.at(RC_CPU_FILTER, i) = rows[i].f[0]; t.at(RC_MEMORY_SORT_FILTER, i) = rows[i].f[1]; t.at(RC_MEMORY_REGION_FILTER, i) = rows[i].f[2];
+        t.at(RC_CMP_FILTER, i) = rows[i].f[3];
+        t.at(RC_VAL, i) = rows[i].v; t.at(RC_LIMB_LO, i) = rows[i].v % size; t.at(RC_LIMB_HI, i) = rows[i].v / size;
+    }
+    std::vector<u64> fix(n);
+    for (size_t i = 0; i < n; i++) fix[i] = i < size ? i : size - 1;
+    t.set_column(RC_FIX_RANGE_CHECK_U16, fix);
+    std::vector<u64> pi, pt;
+    permuted_cols(t.column(RC_LIMB_LO), fix, pi, pt);
+    t.set_column(RC_LIMB_LO_PERMUTED, pi); t.set_column(RC_FIX_RANGE_CHECK_U16_PERMUTED_LO, pt);
+    permuted_cols(t.column(RC_LIMB_HI), fix, pi, pt);
+    t.set_column(RC_LIMB_HI_PERMUTED, pi); t.set_column(RC_FIX_RANGE_CHECK_U16_PERMUTED_HI, pt);
+}
+
+// generation/builtin.rs:35-205 with limb_bits-wide limbs
+void bitwise_table(u64 beta, uint32_t limb_bits, const std::vector<BwOp>& ops, Table& t) {
+    const size_t size = (size_t)1 << limb_bits, per = size * size;
+    const size_t n = next_pow2(std::max(std::max(size, 3 * per), ops.size()));
+    t.init(COL_NUM_BITWISE, n);
+    size_t index = 0;
+    for (size_t a = 0; a < size; a++) {
+        t.at(BW_FIX_RANGE_CHECK_U8, a) = a;
+        for (size_t b = 0; b < size; b++) {
+            const u64 res[3] = {a & b, a | b, a ^ b};
+            const uint32_t tag[3] = {OP_AND, OP_OR, OP_XOR};
+            for (int k = 0; k < 3; k++) {
+                const size_t r = k * per + index;
+                t.at(BW_FIX_BITWSIE_OP0, r) = a; t.at(BW_FIX_BITWSIE_OP1, r) = b; t.at(BW_FIX_BITWSIE_RES, r) = res[k]; t.at(BW_FIX_TAG, r) = 1ULL << tag[k];
+            }
+            index++;
+        }
+    }
+    const u64 b1 = beta % P, b2 = mulm(b1, b1), b3 = mulm(b2, b1);
+    auto compress = [&](u64 tag, u64 x, u64 y, u64 z) { return addm(addm(tag % P, mulm(x, b1)), addm(mulm(y, b2), mulm(z, b3))); };
+    std::vector<u64> fix(n);
+    for (size_t i = 0; i < n; i++) fix[i] = compress(t.at(BW_FIX_TAG, i), t.at(BW_FIX_BITWSIE_OP0, i), t.at(BW_FIX_BITWSIE_OP1, i), t.at(BW_FIX_BITWSIE_RES, i));
+    t.set_column(BW_FIX_COMPRESS, fix);
+    for (size_t r = 0; r < ops.size(); r++) {
+        const u64 x = ops[r].a, y = ops[r].b;
+        need(limb_bits >= 16 || (x < ((u64)1 << (4 * limb_bits)) && y < ((u64)1 << (4 * limb_bits))), "bitwise operand does not fit four limbs");
+        const u64 z = ops[r].op == OP_AND ? (x & y) : ops[r].op == OP_OR ? (x | y) : (x ^ y);
+        const u64 tag = 1ULL << ops[r].op;
+        t.at(BW_TAG, r) = tag; t.at(BW_OP0, r) = x; t.at(BW_OP1, r) = y; t.at(BW_RES, r) = z;
+        t.at(BW_FILTER, r) = 1;                                                     // looked up by the CPU's AND / OR / XOR rows
+        for (int i = 0; i < 4; i++) {
+            const u64 lx = (x >> (limb_bits * i)) & (size - 1), ly = (y >> (limb_bits * i)) & (size - 1), lz = (z >> (limb_bits * i)) & (size - 1);
+            t.at(BW_OP0_LIMBS_START + i, r) = lx; t.at(BW_OP1_LIMBS_START + i, r) = ly; t.at(BW_RES_LIMBS_START + i, r) = lz;
+            t.at(BW_COMPRESS_LIMBS_START + i, r) = compress(tag, lx, ly, lz);
+        }
+    }
+    const std::vector<u64> rc8 = t.column(BW_FIX_RANGE_CHECK_U8);
+    std::vector<u64> pi, pt;
+    for (int i = 0; i < 4; i++) {
+        const u64 src[3] = {BW_OP0_LIMBS_START, BW_OP1_LIMBS_START, BW_RES_LIMBS_START};
+        const u64 dst[3] = {BW_OP0_LIMBS_PERMUTED_START, BW_OP1_LIMBS_PERMUTED_START, BW_RES_LIMBS_PERMUTED_START};
+        for (int k = 0; k < 3; k++) {
+            permuted_cols(t.column(src[k] + i), rc8, pi, pt);
+            t.set_column(dst[k] + i, pi);
+            t.set_column(BW_FIX_RANGE_CHECK_U8_PERMUTED_START + 4 * k + i, pt);
+        }
+        permuted_cols(t.column(BW_COMPRESS_LIMBS_START + i), fix, pi, pt);
+        t.set_column(BW_COMPRESS_PERMUTED_START + i, pi);
+        t.set_column(BW_FIX_COMPRESS_PERMUTED_START + i, pt);
+    }
+}
+
+void flag_padding(Table& t, size_t ncols, size_t n, size_t flag_col) { t.init(ncols, n); t.fill(flag_col, 1); }
+
+thread_local std::string g_err;
+
+}  // namespace
+
+struct OlaTraceSet {
+    std::array<Table, 12> tables;
+    uint64_t cpu_rows = 0;
+};
+
+extern "C" {
+
+const char* ola_tracegen_last_error(void) { return g_err.c_str(); }
+
+int32_t ola_tracegen_run(const OlaInstr* program, size_t n_instr, const uint64_t code_addr[4], const uint64_t storage_addr[4],
+                         uint32_t range_bits, uint32_t limb_bits, uint64_t bitwise_beta, uint64_t program_beta, uint64_t max_steps,
+                         OlaTraceSet** out) {
+    try {
+        need(program && n_instr && code_addr && storage_addr && out, "null argument");
+        need(range_bits >= 1 && range_bits <= 16 && limb_bits >= 1 && limb_bits <= 8, "range_bits / limb_bits out of range");
+        std::unique_ptr<OlaTraceSet> set(new OlaTraceSet());
+        Run R;
+        execute(program, n_instr, code_addr, storage_addr, max_steps, R);
+        set->cpu_rows = R.nrows();
+        auto& T = set->tables;
+        cpu_table(R, T[CPU]);
+        std::vector<u64> words;
+        program_table(R, code_addr, program_beta, T[PROGRAM], words);
+        std::vector<std::vector<u64>> builtin_rows;
+        poseidon_chunk_table(R.psdn, T[POSEIDON_CHUNK], builtin_rows);
+        prog_chunk_and_poseidon(code_addr, words, builtin_rows, T[PROG_CHUNK], T[POSEIDON]);
+        std::vector<u64> abs_diffs, mem_rc, mem_cond;
+        cmp_table(R.cmp, T[CMP], abs_diffs);
+        memory_table(R.mem, T[MEMORY], mem_rc, mem_cond);
+        std::vector<RcRow> rc;
+        for (u64 v : R.rc) rc.push_back({v, {1, 0, 0, 0}});
+        for (u64 v : abs_diffs) rc.push_back({v, {0, 0, 0, 1}});
+        for (u64 v : mem_rc) rc.push_back({v, {0, 1, 0, 0}});
+        for (u64 v : mem_cond) rc.push_back({v, {0, 0, 1, 0}});
+        rc_table(rc, range_bits, T[RANGECHECK]);
+        bitwise_table(bitwise_beta, limb_bits, R.bitwise, T[BITWISE]);
+        flag_padding(T[STORAGE_ACCESS], NUM_COL_ST, 8, COL_ST_IS_PADDING);
+        T[TAPE].init(NUM_COL_TAPE, 8);
+        T[TAPE].fill(COL_TAPE_OPCODE, 1ULL << OP_TLOAD);
+        flag_padding(T[SCCALL], NUM_COL_SCCALL, 8, COL_SCCALL_IS_PADDING);
+        *out = set.release();
+        return 0;
+    } catch (const std::exception& e) {
+        g_err = e.what();
+        return -1;
+    }
+}
+
+int32_t ola_tracegen_table(const OlaTraceSet* set, uint32_t table, uint32_t* ncols, uint32_t* log_n, const uint64_t** data) {
+    if (!set || table >= 12 || !ncols || !log_n || !data) { g_err = "invalid argument"; return -1; }
+    const Table& t = set->tables[table];
+    uint32_t l = 0;
+    while (((size_t)1 << l) < t.n) l++;
+    *ncols = (uint32_t)t.ncols; *log_n = l; *data = t.d.data();
+    return 0;
+}
+
+uint64_t ola_tracegen_cpu_rows(const OlaTraceSet* set) { return set ? set->cpu_rows : 0; }
+
+void ola_tracegen_free(OlaTraceSet* set) { delete set; }
+
+}  // extern "C"
