@@ -1,12 +1,13 @@
 """ola_prove_with_traces on a REAL execution with a 2^20-row CPU table.
 
-The traces come from the miniature executor (olavm_amd/air/miniexec.py) running its memory program -- a store loop and a
+The traces come from the executor (native generator include/ola_tracegen.h, or olavm_amd/air/miniexec.py with --python)
+running the memory program -- a store loop and a
 load / add / store / load loop over `count` cells -- against the full-size fixed tables (range_bits 16, limb_bits 8):
 count = 70000 gives 980 k executed CPU rows (2^20), 280 k memory cells, a 2^21-row program table (every fetched instruction and
 immediate word) and 280 k range-checked sort values.  The proof is checked with the oracle's verifier; with OLA_TIMING=1 the
 library prints its per-phase times (named after the reference's `timed!` scopes) to stderr.
 
-    python tools/bench_prove_real.py [count] [reps] [--json out.json] [--phases] [--oracle]
+    python tools/bench_prove_real.py [count] [reps] [--json out.json] [--phases] [--oracle] [--python]
 """
 import json
 import os
@@ -21,12 +22,13 @@ def main():
     count = int(args[0]) if args else 70000
     reps = int(args[1]) if len(args) > 1 else 3
     out = sys.argv[sys.argv.index("--json") + 1] if "--json" in sys.argv else None
-    from olavm_amd.air import miniexec as M, ola_tables as T
+    from olavm_amd.air import fastexec, miniexec as M, ola_tables as T
     from olavm_amd.backend import Backend
     s = T.ola_stark()
     blob = s.blob()
     t0 = time.time()
-    traces, params, compress = M.instance(M.memory_program(count), range_bits=16, limb_bits=8, max_steps=1 << 24)
+    gen = M if "--python" in sys.argv else fastexec          # the native generator reproduces the Python executor word for word
+    traces, params, compress = gen.instance(M.memory_program(count), range_bits=16, limb_bits=8, max_steps=1 << 24)
     gen_s = time.time() - t0
     heights = [int(t.shape[1]).bit_length() - 1 for t in traces]
     print("executed + filled 12 tables in %.1f s; log2 heights %s" % (gen_s, heights), flush=True)
