@@ -30,7 +30,7 @@ def load_library():
             raise RuntimeError("libola_tracegen.so is missing: run `python __graft_entry__.py` (build) first")
         L = C.CDLL(lib_path())
         L.ola_tracegen_run.argtypes = [C.POINTER(OlaInstr), C.c_size_t, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_uint32, C.c_uint32,
-                                       C.c_uint64, C.c_uint64, C.c_uint64, C.POINTER(C.c_void_p)]
+                                       C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.POINTER(C.c_void_p)]
         L.ola_tracegen_table.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.POINTER(C.c_uint64))]
         L.ola_tracegen_cpu_rows.argtypes = [C.c_void_p]
         L.ola_tracegen_cpu_rows.restype = C.c_uint64
@@ -50,14 +50,14 @@ def encode(prog):
     return arr
 
 
-def instance(prog, range_bits=4, limb_bits=2, bitwise_beta=12345, program_beta=67890, max_steps=1 << 16):
-    """Same contract as miniexec.instance(prog, ...) without the storage / tape options.  -> (traces, params, compress)."""
+def instance(prog, range_bits=4, limb_bits=2, bitwise_beta=12345, program_beta=67890, prove_program_hash=False, max_steps=1 << 16):
+    """Same contract as miniexec.instance(prog, ...).  -> (traces, params, compress)."""
     L = load_library()
     ins = encode(prog)
     code = (C.c_uint64 * 4)(*prog.code_addr)
     stor = (C.c_uint64 * 4)(*prog.storage_addr)
     handle = C.c_void_p()
-    rc = L.ola_tracegen_run(ins, len(prog.ins), code, stor, range_bits, limb_bits, bitwise_beta, program_beta, max_steps, C.byref(handle))
+    rc = L.ola_tracegen_run(ins, len(prog.ins), code, stor, range_bits, limb_bits, bitwise_beta, program_beta, max_steps, int(bool(prove_program_hash)), C.byref(handle))
     if rc != 0:
         raise RuntimeError("ola_tracegen_run: " + L.ola_tracegen_last_error().decode())
     try:

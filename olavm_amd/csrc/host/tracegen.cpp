@@ -114,11 +114,84 @@ void permuted_cols(const std::vector<u64>& inputs, const std::vector<u64>& table
 }
 
 // ---- execution -----------------------------------------------------------------------------------------------------------------
-enum MemOp { M_CALL, M_MLOAD, M_MSTORE, M_POSEIDON, M_RET };     // alphabetical: ties of (address, clock) sort by name, as in Python
+enum MemOp { M_CALL, M_MLOAD, M_MSTORE, M_POSEIDON, M_RET, M_SLOAD, M_SSTORE, M_TLOAD, M_TSTORE };   // alphabetical: ties of (address, clock) sort by name, as in Python
 struct MemCell { u64 addr, clk; MemOp op; u64 value; int is_write; };
 struct PsdnChunk { u64 addr; u64 vals[8]; u64 cap[4]; std::vector<u64> row; };
 struct PsdnCall { u64 clk, src, len, dst; std::vector<PsdnChunk> chunks; };
 struct BwOp { uint32_t op; u64 a, b; };
+struct TapeCell { u64 addr, seq; uint32_t op; u64 word; };
+typedef std::array<u64, 4> Hash4;
+
+// ---- the account-storage tree: 256 levels, key bits (four limbs, most significant first) choose the child, inner nodes
+// Poseidon(left || right || [0,0,0,0])[:4], the lowest level hashes the two 4-word VALUES of a sibling pair with the
+// capacity word 1, untouched leaves are [0,0,0,0] (builtins/storage/storage_access_stark.rs:110-334)
+struct StorageRow { int layer, bit; Hash4 sib, pre_path, path, pre_hash, hash, pre_root, root, addr; int is_write; };
+struct StorageTree {
+    typedef std::array<u64, 5> NodeKey;                       // depth, prefix (bits below the depth cleared)
+    std::map<NodeKey, Hash4> nodes;
+    std::vector<Hash4> dflt;
+    static Hash4 hash(const Hash4& l, const Hash4& r, bool leaf_level, std::vector<u64>* row_out = nullptr) {
+        const u64 in[12] = {l[0], l[1], l[2], l[3], r[0], r[1], r[2], r[3], (u64)leaf_level, 0, 0, 0};
+        const u64 f[4] = {0, 0, (u64)leaf_level, (u64)!leaf_level};
+        std::vector<u64> row = poseidon_row(in, f);
+        Hash4 h{row[COL_POSEIDON_OUTPUT_RANGE_START], row[COL_POSEIDON_OUTPUT_RANGE_START + 1], row[COL_POSEIDON_OUTPUT_RANGE_START + 2],
+                row[COL_POSEIDON_OUTPUT_RANGE_START + 3]};
+        if (row_out) *row_out = std::move(row);
+        return h;
+    }
+    StorageTree() : dflt(257) {
+        dflt[256] = Hash4{0, 0, 0, 0};
+        for (int d = 255; d >= 0; d--) dflt[d] = hash(dflt[d + 1], dflt[d + 1], d == 255);
+    }
+    static Hash4 key_of(const Hash4& addr) { return Hash4{addr[0] % P, addr[1] % P, addr[2] % P, addr[3] % P}; }
+    static int bit_at(const Hash4& k, int layer) { return (int)((k[(layer - 1) / 64] >> (63 - (layer - 1) % 64)) & 1); }   // layer-th bit from the top
+    static NodeKey node_key(const Hash4& k, int depth) {
+        NodeKey nk{(u64)depth, 0, 0, 0, 0};
+        for (int w = 0; w < 4; w++) {
+            const int keep = std::min(64, std::max(0, depth - 64 * w));
+            nk[1 + w] = keep == 0 ? 0 : keep == 64 ? k[w] : (k[w] & ~((1ULL << (64 - keep)) - 1));
+        }
+        return nk;
+    }
+    static Hash4 flip(Hash4 k, int layer) { k[(layer - 1) / 64] ^= 1ULL << (63 - (layer - 1) % 64); return k; }
+    Hash4 node(const Hash4& k, int depth) const { auto it = nodes.find(node_key(k, depth)); return it == nodes.end() ? dflt[depth] : it->second; }
+    Hash4 root() const { return node(Hash4{0, 0, 0, 0}, 0); }
+    void write(const Hash4& k, const Hash4& value) {
+        nodes[node_key(k, 256)] = value;
+        for (int d = 255; d >= 0; d--) {
+            // children of the depth-d node on k's path: bit (d+1) cleared / set
+            Hash4 l = k, r = k;
+            if (bit_at(k, d + 1)) l = flip(k, d + 1); else r = flip(k, d + 1);
+            nodes[node_key(k, d)] = hash(node(l, d + 1), node(r, d + 1), d == 255);
+        }
+    }
+    // read (value == nullptr) or write of a leaf: 256 table rows (root side first) and, per layer, the Poseidon rows of the
+    // new-tree and of the old-tree hash
+    Hash4 access(const Hash4& addr, const Hash4* value, std::vector<StorageRow>& rows, std::vector<std::vector<u64>>& prows) {
+        const Hash4 k = key_of(addr);
+        struct Pre { int bit; Hash4 sib, path, hash; };
+        std::vector<Pre> pre;
+        for (int layer = 1; layer <= 256; layer++) pre.push_back({bit_at(k, layer), node(flip(k, layer), layer), node(k, layer), node(k, layer - 1)});
+        const Hash4 pre_root = root();
+        if (value) write(k, *value);
+        for (int layer = 1; layer <= 256; layer++) {
+            const Pre& p = pre[layer - 1];
+            StorageRow r;
+            r.layer = layer; r.bit = p.bit; r.sib = p.sib; r.pre_path = p.path; r.pre_hash = p.hash;
+            r.path = node(k, layer); r.hash = node(k, layer - 1); r.pre_root = pre_root; r.root = root(); r.is_write = value != nullptr; r.addr = k;
+            rows.push_back(r);
+            const Hash4* child[2] = {&r.path, &r.pre_path};
+            const Hash4* expect[2] = {&r.hash, &r.pre_hash};
+            for (int v = 0; v < 2; v++) {
+                std::vector<u64> prow;
+                const Hash4 h = p.bit ? hash(p.sib, *child[v], layer == 256, &prow) : hash(*child[v], p.sib, layer == 256, &prow);
+                need(h == *expect[v], "storage tree: inconsistent node hash");
+                prows.push_back(std::move(prow));
+            }
+        }
+        return node(k, 256);
+    }
+};
 
 struct Run {
     // executed CPU rows, row-major (NUM_CPU_COLS words each), in chunks so that a long run never re-copies what it has
@@ -138,6 +211,9 @@ struct Run {
     std::vector<std::pair<u64, u64>> cmp;
     std::vector<MemCell> mem;
     std::vector<PsdnCall> psdn;
+    std::vector<TapeCell> tape;
+    std::vector<std::vector<StorageRow>> storage;        // one 256-row proof per SSTORE / SLOAD
+    std::vector<std::vector<u64>> storage_psdn;          // tree-key and state-tree rows of the Poseidon table
     std::vector<u64> words;
 };
 
@@ -174,18 +250,22 @@ u64 selector_of(uint32_t op) {
         case OP_AND: case OP_OR: case OP_XOR: return COL_S_BITWISE;
         case OP_GTE: return COL_S_GTE;
         case OP_POSEIDON: return COL_S_PSDN;
+        case OP_SSTORE: return COL_S_SSTORE;
+        case OP_SLOAD: return COL_S_SLOAD;
+        case OP_TSTORE: return COL_S_TSTORE;
+        case OP_TLOAD: return COL_S_TLOAD;
         default: throw Err("instruction not supported by the native generator");
     }
 }
 
-void execute(const OlaInstr* ins, size_t n_ins, const u64 code_addr[4], const u64 storage_addr[4], u64 max_steps, Run& R) {
+void execute(const OlaInstr* ins, size_t n_ins, const u64 code_addr[4], const u64 storage_addr[4], u64 max_steps, StorageTree& tree, Run& R) {
     std::vector<size_t> pcs;
     program_words(ins, n_ins, R.words, pcs);
     std::map<u64, size_t> pc_to_idx;
     for (size_t k = 0; k < pcs.size(); k++) pc_to_idx[pcs[k]] = k;
     u64 regs[REG] = {0};
-    u64 pc = 0, clk = 0;
-    std::map<u64, u64> memory;
+    u64 pc = 0, clk = 0, tp = 0, idx_storage = 0;
+    std::map<u64, u64> memory, tape;
     std::vector<u64> r(NUM_CPU_COLS);
     auto mem_at = [&](u64 a, const char* what) -> u64 { auto it = memory.find(a); need(it != memory.end(), what); return it->second; };
     for (;;) {
@@ -196,7 +276,7 @@ void execute(const OlaInstr* ins, size_t n_ins, const u64 code_addr[4], const u6
         const bool imm = I.op1_is_imm != 0;
         std::fill(r.begin(), r.end(), 0);
         for (int i = 0; i < 4; i++) { r[COL_ADDR_STORAGE_RANGE_START + i] = storage_addr[i]; r[COL_ADDR_CODE_RANGE_START + i] = code_addr[i]; }
-        r[COL_CLK] = clk; r[COL_PC] = pc;
+        r[COL_CLK] = clk; r[COL_PC] = pc; r[COL_TP] = tp; r[COL_IDX_STORAGE] = idx_storage;
         for (int i = 0; i < REG; i++) r[COL_REGS_START + i] = regs[i];
         r[COL_INST] = R.words[pc]; r[COL_OP1_IMM] = imm; r[COL_OPCODE] = 1ULL << I.op;
         r[selector_of(I.op)] = 1;
@@ -299,7 +379,8 @@ void execute(const OlaInstr* ins, size_t n_ins, const u64 code_addr[4], const u6
                 res = dst_addr; has_res = true;       // the CPU's dst column carries the destination address
                 break;
             }
-            case OP_END: break;
+            case OP_END: case OP_TSTORE: case OP_SSTORE: case OP_SLOAD: break;
+            case OP_TLOAD: need(I.dst >= 0, "TLOAD needs the register holding the memory base"); res = regs[I.dst]; has_res = true; break;
             default: throw Err("instruction not supported by the native generator");
         }
         if (I.dst >= 0) {
@@ -308,8 +389,91 @@ void execute(const OlaInstr* ins, size_t n_ins, const u64 code_addr[4], const u6
             regs[I.dst] = res;
         }
         if (I.op == OP_END) r[COL_IS_NEXT_LINE_SAME_TX] = 0;
+        const bool multi_line = I.op == OP_TSTORE || I.op == OP_TLOAD || I.op == OP_SSTORE || I.op == OP_SLOAD;
+        if (multi_line) r[COL_IS_NEXT_LINE_DIFF_INST] = 0;
         R.push_row(r);
         if (I.op == OP_END) break;
+        if (multi_line) {
+            // extension lines repeat the instruction's clk / pc / opcode / selectors / op0 / op1 and use the register-selector
+            // columns as data carriers (cpu/tape.rs, cpu/storage.rs)
+            std::vector<u64> e = r;
+            for (u64 c = COL_S_OP0_START; c < COL_S_OP0_END; c++) e[c] = 0;
+            for (u64 c = COL_S_OP1_START; c < COL_S_OP1_END; c++) e[c] = 0;
+            for (u64 c = COL_S_DST_START; c < COL_S_DST_END; c++) e[c] = 0;
+            e[COL_INST] = e[COL_IMM_VAL] = e[COL_FILTER_LOOKING_PROG_IMM] = e[COL_DST] = 0;
+            e[COL_IS_EXT_LINE] = 1;
+            if (I.op == OP_TSTORE || I.op == OP_TLOAD) {
+                // executor/src/lib.rs:1687-1846: one extension line per word moved between memory and the tape
+                u64 length, mem_base, tape_base;
+                if (I.op == OP_TSTORE) { length = v1; mem_base = v0; tape_base = tp; }
+                else {
+                    need(v0 <= 1, "TLOAD flag must be 0 or 1");
+                    if (v0) { length = v1; mem_base = regs[I.dst]; tape_base = tp - v1; } else { length = 1; mem_base = regs[I.dst]; tape_base = v1; }
+                }
+                need(length >= 1, "tape transfer of zero words");
+                e[COL_FILTER_TAPE_LOOKING] = 1;
+                for (u64 k = 0; k < length; k++) {
+                    need(R.nrows() < max_steps, "program does not terminate");
+                    const u64 maddr = mem_base + k, taddr = tape_base + k;
+                    u64 word;
+                    if (I.op == OP_TSTORE) {
+                        word = mem_at(maddr, "tstore source was never written");
+                        tape[taddr] = word;
+                        R.mem.push_back({maddr, clk, M_TSTORE, word, 0});
+                    } else {
+                        auto tit = tape.find(taddr);
+                        need(tit != tape.end(), "tload from a tape cell that was never written");
+                        word = tit->second;
+                        memory[maddr] = word;
+                        R.mem.push_back({maddr, clk, M_TLOAD, word, 1});
+                    }
+                    R.tape.push_back({taddr, (u64)R.tape.size(), I.op, word});
+                    e[COL_EXT_CNT] = k + 1;
+                    e[COL_IS_NEXT_LINE_DIFF_INST] = k + 1 == length;
+                    e[COL_AUX0] = maddr; e[COL_S_OP0_START] = taddr; e[COL_AUX1] = word;
+                    R.push_row(e);
+                }
+                if (I.op == OP_TSTORE) tp += length;
+            } else {
+                // executor/src/lib.rs:1301-1545 + cpu/storage.rs: op0 / op1 = memory addresses of the 4-word slot key and value
+                need(!imm && I.op0 >= 0 && I.op1 >= 0, "storage instructions take two registers");
+                const MemOp mop = I.op == OP_SSTORE ? M_SSTORE : M_SLOAD;
+                Hash4 key, value;
+                for (int i = 0; i < 4; i++) {
+                    key[i] = mem_at(addm(v0, i), "storage key was never written");
+                    R.mem.push_back({addm(v0, i), clk, mop, key[i], 0});
+                }
+                const u64 kin[12] = {storage_addr[0], storage_addr[1], storage_addr[2], storage_addr[3], key[0], key[1], key[2], key[3], 0, 0, 0, 0};
+                const u64 kf[4] = {0, 1, 0, 0};
+                std::vector<u64> krow = poseidon_row(kin, kf);
+                const Hash4 tree_key{krow[COL_POSEIDON_OUTPUT_RANGE_START], krow[COL_POSEIDON_OUTPUT_RANGE_START + 1],
+                                     krow[COL_POSEIDON_OUTPUT_RANGE_START + 2], krow[COL_POSEIDON_OUTPUT_RANGE_START + 3]};
+                std::vector<StorageRow> srows;
+                std::vector<std::vector<u64>> prows;
+                if (I.op == OP_SSTORE) {
+                    for (int i = 0; i < 4; i++) {
+                        value[i] = mem_at(addm(v1, i), "stored value was never written");
+                        R.mem.push_back({addm(v1, i), clk, mop, value[i], 0});
+                    }
+                    tree.access(tree_key, &value, srows, prows);
+                } else {
+                    value = tree.access(tree_key, nullptr, srows, prows);
+                    for (int i = 0; i < 4; i++) { memory[addm(v1, i)] = value[i]; R.mem.push_back({addm(v1, i), clk, mop, value[i], 1}); }
+                }
+                idx_storage += 1;
+                R.storage.push_back(std::move(srows));
+                R.storage_psdn.push_back(std::move(krow));
+                for (auto& pr : prows) R.storage_psdn.push_back(std::move(pr));
+                e[COL_EXT_CNT] = e[COL_IS_STORAGE_EXT_LINE] = e[COL_IS_NEXT_LINE_DIFF_INST] = 1;
+                e[COL_IDX_STORAGE] = idx_storage;
+                for (int i = 0; i < 4; i++) {
+                    e[COL_S_OP0_START + i] = addm(v0, i); e[COL_S_OP0_START + 4 + i] = key[i];
+                    e[COL_S_OP1_START + i] = addm(v1, i); e[COL_S_OP1_START + 4 + i] = value[i];
+                    e[COL_S_DST_START + i] = tree_key[i];
+                }
+                R.push_row(e);
+            }
+        }
         pc = next_pc;
         clk += 1;
     }
@@ -365,8 +529,23 @@ void program_table(const Run& R, const u64 code_addr[4], u64 beta, Table& t, std
 
 // program/prog_chunk_stark.rs + generation/prog.rs: one row per 8 program words, capacity chained; Poseidon rows of the
 // chunk hashes followed by the builtin's rows, padded with the zero-input permutation
+Hash4 program_hash(const std::vector<u64>& words) {
+    // first four words of the chained chunk hash: what the state tree stores at the code address (prog_chunk_stark.rs:51-61)
+    u64 cap[4] = {0, 0, 0, 0};
+    const u64 f[4] = {0, 0, 0, 0};
+    Hash4 h{0, 0, 0, 0};
+    for (size_t i = 0; i + 8 <= words.size(); i += 8) {
+        u64 in[12];
+        for (int k = 0; k < 8; k++) in[k] = words[i + k];
+        for (int k = 0; k < 4; k++) in[8 + k] = cap[k];
+        const std::vector<u64> row = poseidon_row(in, f);
+        for (int k = 0; k < 4; k++) { h[k] = row[COL_POSEIDON_OUTPUT_RANGE_START + k]; cap[k] = row[COL_POSEIDON_OUTPUT_RANGE_START + 8 + k]; }
+    }
+    return h;
+}
+
 void prog_chunk_and_poseidon(const u64 code_addr[4], const std::vector<u64>& words, const std::vector<std::vector<u64>>& extra_rows,
-                             Table& chunk, Table& poseidon) {
+                             bool result_line, Table& chunk, Table& poseidon) {
     const size_t nchunks = words.size() / 8;
     const size_t n = next_pow2(std::max<size_t>(nchunks, 8));
     chunk.init(NUM_PROG_CHUNK_COLS, n);
@@ -386,6 +565,7 @@ void prog_chunk_and_poseidon(const u64 code_addr[4], const std::vector<u64>& wor
         for (int k = 0; k < 4; k++) chunk.at(COL_PROG_CHUNK_CAP_RANGE_START + k, i) = cap[k];
         for (int k = 0; k < 12; k++) chunk.at(COL_PROG_CHUNK_HASH_RANGE_START + k, i) = row[COL_POSEIDON_OUTPUT_RANGE_START + k];
         chunk.at(COL_PROG_CHUNK_IS_FIRST_LINE, i) = i == 0;
+        chunk.at(COL_PROG_CHUNK_IS_RESULT_LINE, i) = result_line && i + 1 == nchunks;
         for (u64 k = COL_PROG_CHUNK_FILTER_LOOKING_PROG_RANGE_START; k < COL_PROG_CHUNK_FILTER_LOOKING_PROG_RANGE_END; k++) chunk.at(k, i) = 1;
         for (int k = 0; k < 4; k++) cap[k] = row[COL_POSEIDON_OUTPUT_RANGE_START + 8 + k];
         prow.push_back(std::move(row));
@@ -407,6 +587,10 @@ u64 mem_selector(MemOp op) {
         case M_MLOAD: return COL_MEM_S_MLOAD;
         case M_MSTORE: return COL_MEM_S_MSTORE;
         case M_POSEIDON: return COL_MEM_S_POSEIDON;
+        case M_SLOAD: return COL_MEM_S_SLOAD;
+        case M_SSTORE: return COL_MEM_S_SSTORE;
+        case M_TLOAD: return COL_MEM_S_TLOAD;
+        case M_TSTORE: return COL_MEM_S_TSTORE;
         default: return COL_MEM_S_RET;
     }
 }
@@ -416,6 +600,10 @@ uint32_t mem_opcode(MemOp op) {
         case M_MLOAD: return OP_MLOAD;
         case M_MSTORE: return OP_MSTORE;
         case M_POSEIDON: return OP_POSEIDON;
+        case M_SLOAD: return OP_SLOAD;
+        case M_SSTORE: return OP_SSTORE;
+        case M_TLOAD: return OP_TLOAD;
+        case M_TSTORE: return OP_TSTORE;
         default: return OP_RET;
     }
 }
@@ -507,6 +695,57 @@ void poseidon_chunk_table(const std::vector<PsdnCall>& calls, Table& t, std::vec
     for (size_t i = 0; i < rows.size(); i++) {
         t.at(COL_POSEIDON_CHUNK_IS_PADDING_LINE, i) = 0;
         for (const auto& kv : rows[i]) t.at(kv.first, i) = kv.second;
+    }
+}
+
+// generation/storage.rs:7-123: 256 rows per proof, the CPU's accesses in execution order, then the program-hash reads
+void storage_table(const std::vector<std::vector<StorageRow>>& accesses, const std::vector<std::vector<StorageRow>>& prog_reads, Table& t) {
+    size_t total = 0;
+    for (const auto& a : accesses) total += a.size();
+    for (const auto& a : prog_reads) total += a.size();
+    const size_t n = next_pow2(std::max<size_t>(total, 8));
+    t.init(NUM_COL_ST, n);
+    t.fill(COL_ST_IS_PADDING, 1);
+    size_t i = 0;
+    u64 acc = 0;
+    const Hash4* last_root = nullptr;
+    auto emit = [&](const std::vector<StorageRow>& rows, u64 idx, bool for_prog) {
+        for (const StorageRow& r : rows) {
+            acc = r.layer % 64 == 1 ? (u64)r.bit : addm(addm(acc, acc), (u64)r.bit);
+            t.at(COL_ST_IS_PADDING, i) = 0;
+            t.at(COL_ST_ACCESS_IDX, i) = idx; t.at(COL_ST_IS_WRITE, i) = r.is_write; t.at(COL_ST_LAYER, i) = r.layer; t.at(COL_ST_LAYER_BIT, i) = r.bit;
+            t.at(COL_ST_ADDR_ACC, i) = acc; t.at(COL_ST_HASH_TYPE, i) = r.layer == 256;
+            const Hash4* src[8] = {&r.pre_root, &r.root, &r.addr, &r.pre_path, &r.path, &r.sib, &r.pre_hash, &r.hash};
+            const u64 dst[8] = {COL_ST_PRE_ROOT_RANGE_START, COL_ST_ROOT_RANGE_START, COL_ST_ADDR_RANGE_START, COL_ST_PRE_PATH_RANGE_START,
+                                COL_ST_PATH_RANGE_START, COL_ST_SIB_RANGE_START, COL_ST_PRE_HASH_RANGE_START, COL_ST_HASH_RANGE_START};
+            for (int g = 0; g < 8; g++) for (int k = 0; k < 4; k++) t.at(dst[g] + k, i) = (*src[g])[k];
+            t.at(COL_ST_IS_LAYER_1, i) = r.layer == 1; t.at(COL_ST_IS_LAYER_64, i) = r.layer == 64; t.at(COL_ST_IS_LAYER_128, i) = r.layer == 128;
+            t.at(COL_ST_IS_LAYER_192, i) = r.layer == 192; t.at(COL_ST_IS_LAYER_256, i) = r.layer == 256;
+            t.at(COL_ST_ACC_LAYER_MARKER, i) = 1 + r.layer / 64;
+            t.at(COL_ST_FILTER_IS_HASH_BIT_0, i) = 1 - r.bit; t.at(COL_ST_FILTER_IS_HASH_BIT_1, i) = r.bit;
+            t.at(COL_ST_FILTER_IS_FOR_PROG, i) = for_prog && r.layer == 256;
+            last_root = &r.root;
+            i++;
+        }
+    };
+    for (size_t a = 0; a < accesses.size(); a++) emit(accesses[a], a + 1, false);
+    for (size_t a = 0; a < prog_reads.size(); a++) emit(prog_reads[a], accesses.size() + a + 1, true);
+    if (last_root)
+        for (int k = 0; k < 4; k++) std::fill(t.d.begin() + (COL_ST_ROOT_RANGE_START + k) * n + i, t.d.begin() + (COL_ST_ROOT_RANGE_START + k + 1) * n, (*last_root)[k]);
+}
+
+// builtins/tape/tape_stark.rs:44-143: cells sorted by tape address, the write first, then its reads; padding repeats the last
+// cell as an unfiltered TLOAD
+void tape_table(std::vector<TapeCell> cells, Table& t) {
+    std::sort(cells.begin(), cells.end(), [](const TapeCell& a, const TapeCell& b) { return a.addr != b.addr ? a.addr < b.addr : a.seq < b.seq; });
+    const size_t n = next_pow2(std::max<size_t>(cells.size(), 8));
+    t.init(NUM_COL_TAPE, n);
+    if (cells.empty()) { t.fill(COL_TAPE_OPCODE, 1ULL << OP_TLOAD); return; }
+    for (size_t i = 0; i < n; i++) {
+        const TapeCell& c = cells[std::min(i, cells.size() - 1)];
+        const bool live = i < cells.size();
+        t.at(COL_TAPE_OPCODE, i) = 1ULL << (live ? c.op : OP_TLOAD);
+        t.at(COL_TAPE_ADDR, i) = c.addr; t.at(COL_TAPE_VALUE, i) = c.word; t.at(COL_TAPE_FILTER_LOOKED, i) = live;
     }
 }
 
@@ -615,13 +854,23 @@ const char* ola_tracegen_last_error(void) { return g_err.c_str(); }
 
 int32_t ola_tracegen_run(const OlaInstr* program, size_t n_instr, const uint64_t code_addr[4], const uint64_t storage_addr[4],
                          uint32_t range_bits, uint32_t limb_bits, uint64_t bitwise_beta, uint64_t program_beta, uint64_t max_steps,
-                         OlaTraceSet** out) {
+                         uint32_t flags, OlaTraceSet** out) {
     try {
         need(program && n_instr && code_addr && storage_addr && out, "null argument");
         need(range_bits >= 1 && range_bits <= 16 && limb_bits >= 1 && limb_bits <= 8, "range_bits / limb_bits out of range");
         std::unique_ptr<OlaTraceSet> set(new OlaTraceSet());
+        const bool prove_program_hash = flags & OLA_TRACEGEN_PROVE_PROGRAM_HASH;
         Run R;
-        execute(program, n_instr, code_addr, storage_addr, max_steps, R);
+        StorageTree tree;
+        const Hash4 code_key{code_addr[0], code_addr[1], code_addr[2], code_addr[3]};
+        if (prove_program_hash) {
+            std::vector<u64> listing;
+            std::vector<size_t> pcs;
+            program_words(program, n_instr, listing, pcs);
+            while (listing.size() % 8) listing.push_back(0);
+            tree.write(StorageTree::key_of(code_key), program_hash(listing));
+        }
+        execute(program, n_instr, code_addr, storage_addr, max_steps, tree, R);
         set->cpu_rows = R.nrows();
         auto& T = set->tables;
         cpu_table(R, T[CPU]);
@@ -629,7 +878,15 @@ int32_t ola_tracegen_run(const OlaInstr* program, size_t n_instr, const uint64_t
         program_table(R, code_addr, program_beta, T[PROGRAM], words);
         std::vector<std::vector<u64>> builtin_rows;
         poseidon_chunk_table(R.psdn, T[POSEIDON_CHUNK], builtin_rows);
-        prog_chunk_and_poseidon(code_addr, words, builtin_rows, T[PROG_CHUNK], T[POSEIDON]);
+        std::vector<std::vector<StorageRow>> prog_reads;
+        if (prove_program_hash) {
+            prog_reads.emplace_back();
+            std::vector<std::vector<u64>> prows;
+            tree.access(code_key, nullptr, prog_reads.back(), prows);
+            for (auto& pr : prows) R.storage_psdn.push_back(std::move(pr));
+        }
+        for (auto& pr : R.storage_psdn) builtin_rows.push_back(std::move(pr));
+        prog_chunk_and_poseidon(code_addr, words, builtin_rows, prove_program_hash, T[PROG_CHUNK], T[POSEIDON]);
         std::vector<u64> abs_diffs, mem_rc, mem_cond;
         cmp_table(R.cmp, T[CMP], abs_diffs);
         memory_table(R.mem, T[MEMORY], mem_rc, mem_cond);
@@ -640,9 +897,8 @@ int32_t ola_tracegen_run(const OlaInstr* program, size_t n_instr, const uint64_t
         for (u64 v : mem_cond) rc.push_back({v, {0, 0, 1, 0}});
         rc_table(rc, range_bits, T[RANGECHECK]);
         bitwise_table(bitwise_beta, limb_bits, R.bitwise, T[BITWISE]);
-        flag_padding(T[STORAGE_ACCESS], NUM_COL_ST, 8, COL_ST_IS_PADDING);
-        T[TAPE].init(NUM_COL_TAPE, 8);
-        T[TAPE].fill(COL_TAPE_OPCODE, 1ULL << OP_TLOAD);
+        storage_table(R.storage, prog_reads, T[STORAGE_ACCESS]);
+        tape_table(R.tape, T[TAPE]);
         flag_padding(T[SCCALL], NUM_COL_SCCALL, 8, COL_SCCALL_IS_PADDING);
         *out = set.release();
         return 0;

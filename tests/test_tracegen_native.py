@@ -27,12 +27,11 @@ def test_library_exports_what_the_header_declares():
         assert hasattr(lib, name), name
 
 
-@pytest.mark.parametrize("program", ["fibonacci", "mixed", "memory", "hash", "call", "heap"])
+@pytest.mark.parametrize("program", ["fibonacci", "mixed", "memory", "hash", "call", "heap", "tape", "storage"])
 def test_native_generator_reproduces_the_python_executor(program):
     factory, kwargs = M.EXAMPLES[program]
-    assert not kwargs
-    want, params, compress = M.instance(factory())
-    got, gparams, gcompress = fastexec.instance(factory())
+    want, params, compress = M.instance(factory(), **kwargs)
+    got, gparams, gcompress = fastexec.instance(factory(), **kwargs)
     assert (params, compress) == (gparams, gcompress)
     for t, (a, b) in enumerate(zip(want, got)):
         assert a.shape == b.shape, (program, t, a.shape, b.shape)
@@ -56,8 +55,8 @@ def test_native_generator_with_full_size_tables_and_a_long_run(oracle):
 
 def test_unsupported_and_faulty_programs_are_reported():
     p = M.Program()
-    p.add("TSTORE", op0=1, op1=("imm", 1)).add("END")
-    with pytest.raises(RuntimeError, match="not supported"):
+    p.add("TSTORE", op0=1, op1=("imm", 1)).add("END")            # memory cell 0 was never written
+    with pytest.raises(RuntimeError, match="never written"):
         fastexec.instance(p)
     q = M.Program()
     q.add("JMP", op1=("imm", 0))                   # never reaches END
