@@ -820,7 +820,37 @@ def wide_program():
     return p
 
 
+def storage_heavy_program(slots, cells=0):
+    """BASELINE config 4 as an execution: `slots` iterations that each SSTORE a fresh slot and SLOAD it back -- two 256-level
+    state-tree proofs, 1026 Poseidon-table rows and 512 storage-table rows per iteration -- followed, when cells > 0, by the
+    store / load loops of memory_program(cells) to fill the CPU and memory tables.  slots = 4085 makes a 2^22-row Poseidon
+    table and a 2^21-row storage table."""
+    p = Program()
+    p.add("MOV", dst=1, op1=("imm", 10)).add("MOV", dst=2, op1=("imm", 20)).add("MOV", dst=4, op1=("imm", 40)).add("MOV", dst=3, op1=("imm", 0))
+    for k in range(1, 4):
+        p.add("MOV", dst=5, op1=("imm", 1000 + k)).add("MSTORE", dst=5, op0=1, op1=("imm", k))        # key words 1..3
+        p.add("MOV", dst=5, op1=("imm", 7 * k + 1)).add("MSTORE", dst=5, op0=2, op1=("imm", k))       # value words 1..3
+    loop = len(p.words()[0])
+    p.add("ADD", dst=3, op0=3, op1=("imm", 1)).add("MSTORE", dst=3, op0=1, op1=("imm", 0)).add("MUL", dst=6, op0=3, op1=("imm", 3))
+    p.add("MSTORE", dst=6, op0=2, op1=("imm", 0)).add("SSTORE", op0=1, op1=2).add("SLOAD", op0=1, op1=4)
+    p.add("NEQ", dst=5, op0=3, op1=("imm", slots)).add("CJMP", op0=5, op1=("imm", loop))
+    if cells:
+        # memory_program's two loops, on addresses above everything used so far
+        p.add("MOV", dst=1, op1=("imm", 0)).add("MOV", dst=2, op1=("imm", 1)).add("MOV", dst=3, op1=("imm", 100))
+        first = len(p.words()[0])
+        p.add("ADD", dst=3, op0=3, op1=("imm", 1)).add("MSTORE", dst=1, op0=3, op1=("imm", 0))
+        p.add("ADD", dst=4, op0=1, op1=2).add("MOV", dst=1, op1=2).add("MOV", dst=2, op1=4)
+        p.add("NEQ", dst=5, op0=3, op1=("imm", 100 + cells)).add("CJMP", op0=5, op1=("imm", first))
+        p.add("MOV", dst=6, op1=("imm", 0))
+        back = len(p.words()[0])
+        p.add("MLOAD", dst=7, op0=3, op1=("imm", 0)).add("ADD", dst=6, op0=6, op1=7).add("MSTORE", dst=6, op0=3, op1=("imm", 0))
+        p.add("MLOAD", dst=8, op0=3, op1=("imm", 0))
+        p.add("ADD", dst=3, op0=3, op1=("imm", P - 1)).add("NEQ", dst=5, op0=3, op1=("imm", 100)).add("CJMP", op0=5, op1=("imm", back))
+    p.add("END")
+    return p
+
+
 # name -> (program factory, keyword arguments of instance()): the executions the tests prove
 EXAMPLES = {"fibonacci": (lambda: fibonacci(5), {}), "mixed": (mixed_program, {}), "memory": (memory_program, {}), "hash": (hash_program, {}),
             "call": (call_program, {}), "tape": (tape_program, {}), "storage": (storage_program, {"prove_program_hash": True}),
-            "heap": (heap_program, {})}
+            "heap": (heap_program, {}), "storage_heavy": (lambda: storage_heavy_program(3, 5), {"prove_program_hash": True})}

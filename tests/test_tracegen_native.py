@@ -27,7 +27,7 @@ def test_library_exports_what_the_header_declares():
         assert hasattr(lib, name), name
 
 
-@pytest.mark.parametrize("program", ["fibonacci", "mixed", "memory", "hash", "call", "heap", "tape", "storage"])
+@pytest.mark.parametrize("program", ["fibonacci", "mixed", "memory", "hash", "call", "heap", "tape", "storage", "storage_heavy"])
 def test_native_generator_reproduces_the_python_executor(program):
     factory, kwargs = M.EXAMPLES[program]
     want, params, compress = M.instance(factory(), **kwargs)

@@ -7,7 +7,7 @@ count = 70000 gives 980 k executed CPU rows (2^20), 280 k memory cells, a 2^21-r
 immediate word) and 280 k range-checked sort values.  The proof is checked with the oracle's verifier; with OLA_TIMING=1 the
 library prints its per-phase times (named after the reference's `timed!` scopes) to stderr.
 
-    python tools/bench_prove_real.py [count] [reps] [--json out.json] [--phases] [--oracle] [--python]
+    python tools/bench_prove_real.py [count] [reps] [--json out.json] [--phases] [--oracle] [--python] [--storage-slots N]
 """
 import json
 import os
@@ -28,7 +28,12 @@ def main():
     blob = s.blob()
     t0 = time.time()
     gen = M if "--python" in sys.argv else fastexec          # the native generator reproduces the Python executor word for word
-    traces, params, compress = gen.instance(M.memory_program(count), range_bits=16, limb_bits=8, max_steps=1 << 24)
+    slots = int(sys.argv[sys.argv.index("--storage-slots") + 1]) if "--storage-slots" in sys.argv else 0
+    if slots:       # BASELINE config 4: a Poseidon table of 1026 * slots live rows next to the CPU / memory tables
+        prog, kw = M.storage_heavy_program(slots, count), {"prove_program_hash": True}
+    else:
+        prog, kw = M.memory_program(count), {}
+    traces, params, compress = gen.instance(prog, range_bits=16, limb_bits=8, max_steps=1 << 24, **kw)
     gen_s = time.time() - t0
     heights = [int(t.shape[1]).bit_length() - 1 for t in traces]
     print("executed + filled 12 tables in %.1f s; log2 heights %s" % (gen_s, heights), flush=True)
@@ -61,7 +66,7 @@ def main():
     if out:
         os.makedirs(os.path.dirname(out) or ".", exist_ok=True)
         with open(out, "w") as f:
-            json.dump({"workload": "miniexec memory_program(%d), ola_stark(range_bits=16, limb_bits=8)" % count, "log2_heights": heights,
+            json.dump({"workload": ("storage_heavy_program(%d, %d)" % (slots, count) if slots else "memory_program(%d)" % count) + ", ola_stark(range_bits=16, limb_bits=8)", "log2_heights": heights,
                        "trace_generation_s": round(gen_s, 1), "prove_s": [round(t, 4) for t in times], "proof_bytes": len(proof),
                        "oracle_verifier_rc": rc, "oracle_cpu_port_prove_s": None if oracle_s is None else round(oracle_s, 1)}, f, indent=1)
     if rc != 0:
