@@ -1,6 +1,5 @@
 """ctypes binding of the native trace generator (include/ola_tracegen.h, olavm_amd/csrc/host/tracegen.cpp): the same
-instance() as olavm_amd/air/miniexec.py -- 12 traces, params, compress challenges -- for programs made of the register
-instructions it supports, at native speed (a 2^22-row execution in seconds instead of minutes)."""
+instance() as olavm_amd/air/miniexec.py -- 12 traces, params, compress challenges -- at native speed (a 2^22-row execution in seconds instead of minutes)."""
 import ctypes as C
 import os
 

@@ -1,5 +1,5 @@
-// Native trace generator behind include/ola_tracegen.h (host only, no HIP): the register-instruction subset of the miniature
-// executor olavm_amd/air/miniexec.py, word for word -- tests/test_tracegen_native.py compares all twelve tables of both on
+// Native trace generator behind include/ola_tracegen.h (host only, no HIP): the miniature executor
+// olavm_amd/air/miniexec.py in C++, word for word -- tests/test_tracegen_native.py compares all twelve tables of both on
 // the same programs.  Reference rules restated here are cited where they apply; the column indices come from the Python
 // table descriptions through the generated header gen/ola_columns.h.
 #include <algorithm>

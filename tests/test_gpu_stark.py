@@ -241,7 +241,7 @@ def test_device_poseidon_trace_generation(be, oracle):
         assert np.array_equal(tr[16:28, i], oracle.poseidon(inputs[:, i]))
 
 
-@pytest.mark.parametrize("program", ["fibonacci", "mixed", "memory", "hash", "call", "tape", "storage", "heap"])
+@pytest.mark.parametrize("program", ["fibonacci", "mixed", "memory", "hash", "call", "tape", "storage", "heap", "storage_heavy"])
 def test_real_execution_proof_bytes_match_oracle(be, oracle, program):
     """Traces of a real execution (olavm_amd/air/miniexec.py: live CPU opcodes, program fetches, hashed program chunks,
     bitwise / comparison / range-check lookups): AllProof bytes identical to the oracle's, verifier accepts."""
