@@ -62,3 +62,77 @@ def test_unsupported_and_faulty_programs_are_reported():
     q.add("JMP", op1=("imm", 0))                   # never reaches END
     with pytest.raises(RuntimeError, match="does not terminate"):
         fastexec.instance(q, max_steps=100)
+
+
+def random_program(rng, length=60):
+    """A random straight-line program (with a few forward jumps) over the instructions whose operands need no set-up, kept
+    valid by shadowing the register file: bitwise / comparison / range-check operands stay below 2^8 (miniature tables),
+    loads only touch written cells."""
+    Pm = 0xFFFFFFFF00000001
+    p = M.Program()
+    regs = [0] * 10
+    written = {}
+    small = lambda r: regs[r] < 256
+
+    def emit(op, dst=None, op0=None, op1=None, val=None):
+        p.add(op, dst=dst, op0=op0, op1=op1)
+        if dst is not None and val is not None:
+            regs[dst] = val % Pm
+    for _ in range(length):
+        kind = rng.choice(["mov", "add", "mul", "not", "eq", "bit", "gte", "rc", "store", "load", "assert", "skip"])
+        d, a, b = (int(x) for x in rng.integers(0, 9, 3))          # r9 (fp) stays 0
+        if kind == "mov":
+            v = int(rng.integers(0, 256)) if rng.integers(0, 2) else int(rng.integers(0, 2**63)) % Pm
+            emit("MOV", d, None, ("imm", v), v)
+        elif kind == "add":
+            if rng.integers(0, 2):
+                v = int(rng.integers(0, 2**62))
+                emit("ADD", d, a, ("imm", v), regs[a] + v)
+            else:
+                emit("ADD", d, a, b, regs[a] + regs[b])
+        elif kind == "mul":
+            emit("MUL", d, a, b, regs[a] * regs[b])
+        elif kind == "not":
+            emit("NOT", d, None, b, Pm - 1 - regs[b])
+        elif kind == "eq":
+            op = "EQ" if rng.integers(0, 2) else "NEQ"
+            emit(op, d, a, b, int((regs[a] == regs[b]) == (op == "EQ")))
+        elif kind == "bit" and small(a) and small(b):
+            op = str(rng.choice(["AND", "OR", "XOR"]))
+            emit(op, d, a, b, {"AND": regs[a] & regs[b], "OR": regs[a] | regs[b], "XOR": regs[a] ^ regs[b]}[op])
+        elif kind == "gte" and small(a) and small(b):
+            emit("GTE", d, a, b, int(regs[a] >= regs[b]))
+        elif kind == "rc" and small(b):
+            emit("RC", None, None, b)
+        elif kind == "store" and small(a):
+            off = int(rng.integers(1, 40))
+            emit("MSTORE", d, a, ("imm", off), regs[d])
+            written[regs[a] + off] = regs[d]
+        elif kind == "load" and written:
+            addr = int(rng.choice(sorted(written)))
+            emit("MOV", a, None, ("imm", 0), 0)
+            emit("MLOAD", d, a, ("imm", addr), written[addr])
+        elif kind == "assert":
+            emit("EQ", d, a, a, 1)
+            emit("ASSERT", None, None, d)
+        elif kind == "skip":                                              # a taken conditional jump over one instruction
+            emit("EQ", d, a, a, 1)
+            here = len(p.words()[0])
+            emit("CJMP", None, d, ("imm", here + 2 + 2))
+            p.add("MOV", dst=b, op1=("imm", 12345))                       # skipped: the shadow register keeps its value
+    p.add("END")
+    return p
+
+
+def test_random_programs_native_equals_python_and_all_airs_vanish(oracle):
+    from tests.test_oracle_stark import _per_table_params
+    s = T.ola_stark(range_bits=4, limb_bits=2)
+    rng = np.random.default_rng(4242)
+    for trial in range(8):
+        prog = random_program(rng)
+        want, params, _ = M.instance(prog)
+        got, _, _ = fastexec.instance(prog)
+        for t, (a, b) in enumerate(zip(want, got)):
+            assert np.array_equal(a, b), (trial, t)
+        for i, (tr, pr) in enumerate(zip(got, _per_table_params(s, params))):
+            assert oracle.check_constraints(s.blob(), i, tr, pr) == -1, (trial, s.tables[i].name)
