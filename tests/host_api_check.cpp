@@ -163,14 +163,44 @@ int main(int argc, char** argv) {
     {
         const auto& airset = sec[1];
         std::vector<uint32_t> log_n(sec[2].begin(), sec[2].end());
-        std::vector<std::vector<F>> traces(sec.begin() + 5, sec.end());
-        EXPECT(traces.size() == log_n.size());
+        const auto& n_params = sec[5];
+        std::vector<std::vector<F>> traces(sec.begin() + 6, sec.end());
+        EXPECT(traces.size() == log_n.size() && n_params.size() == log_n.size());
         const auto proof = prove_with_traces(gpu, airset, traces, log_n, sec[3], sec[4]);
         EXPECT(proof.size() > 1000 && proof == prove_with_traces(gpu, airset, traces, log_n, sec[3], sec[4]));
         std::ofstream(argv[2], std::ios::binary).write(reinterpret_cast<const char*>(proof.data()), (std::streamsize)proof.size());
         bool threw = false;
         try { auto bad = airset; bad[0] ^= 1; (void)prove_with_traces(gpu, bad, traces, log_n, sec[3], sec[4]); } catch (const Error&) { threw = true; }
         EXPECT(threw);
+
+        // the same proof with the reference's own orchestration (prover.rs:79-327): commit every trace, observe the caps, draw
+        // the CTL challenges, prove table by table on the shared challenger, concatenate
+        std::vector<PolynomialBatch> commitments;
+        std::vector<std::vector<PolynomialValues>> columns;
+        for (size_t t = 0; t < traces.size(); t++) {
+            const size_t n = (size_t)1 << log_n[t], ncols = traces[t].size() / n;
+            std::vector<PolynomialValues> cols(ncols);
+            for (size_t c = 0; c < ncols; c++) cols[c].assign(traces[t].begin() + c * n, traces[t].begin() + (c + 1) * n);
+            commitments.push_back(PolynomialBatch::from_values(gpu, cols));
+            columns.push_back(std::move(cols));
+        }
+        Challenger challenger;
+        for (const auto& c : commitments) challenger.observe_cap(c.merkle_cap());
+        std::vector<std::array<F, 2>> ctl_challenges;
+        for (int c = 0; c < 2; c++) { const F beta = challenger.get_challenge(), gamma = challenger.get_challenge(); ctl_challenges.push_back({beta, gamma}); }
+        auto put_u32 = [](std::vector<uint8_t>& v, uint32_t x) { for (int i = 0; i < 4; i++) v.push_back((uint8_t)(x >> (8 * i))); };
+        std::vector<uint8_t> assembled;
+        put_u32(assembled, (uint32_t)traces.size());
+        size_t poff = 0;
+        for (size_t t = 0; t < traces.size(); t++) {
+            const std::vector<F> params(sec[3].begin() + poff, sec[3].begin() + poff + n_params[t]);
+            poff += n_params[t];
+            const auto part = prove_single_table(gpu, airset, (uint32_t)t, columns[t], commitments[t], ctl_challenges, params, challenger);
+            assembled.insert(assembled.end(), part.begin(), part.end());
+        }
+        put_u32(assembled, (uint32_t)traces.size());
+        for (size_t t = 0; t < traces.size(); t++) for (int i = 0; i < 8; i++) assembled.push_back((uint8_t)(sec[4][t] >> (8 * i)));
+        EXPECT(assembled == proof);
     }
 
     std::printf(failures ? "host_api_check: %d FAILURES\n" : "host_api_check: all checks passed\n", failures);

@@ -33,7 +33,8 @@ def test_cpp_host_layer_passes_the_reference_style_checks_and_proves_the_same_by
     traces, params, compress = M.instance(M.mixed_program())
     logs = [int(t.shape[1]).bit_length() - 1 for t in traces]
     fixture, proof_path = tmp_path / "fixture.bin", tmp_path / "proof.bin"
-    write_fixture(fixture, [kat_words, blob, logs, params, compress] + list(traces))
+    n_params = [t.n_params for t in s.tables]
+    write_fixture(fixture, [kat_words, blob, logs, params, compress, n_params] + list(traces))
     exe = host_api_build.build(tmp_path)
     r = subprocess.run([exe, str(fixture), str(proof_path)], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "all checks passed" in r.stdout, r.stdout + r.stderr
