@@ -67,6 +67,7 @@ struct DeviceCtx {
     }
     void release_cache() {
         if (cache.empty()) return;
+        if (timing) fprintf(stderr, "[ola-timing] device allocator: out of memory, releasing %.1f GB of cached blocks\n", cached_bytes / 1e9);
         (void)hipStreamSynchronize(stream);
         for (auto& kv : cache) (void)hipFree(kv.second);
         cache.clear();
