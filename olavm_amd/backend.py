@@ -360,7 +360,7 @@ class Backend:
         pr = None if params is None else np.ascontiguousarray(params, dtype=np.uint64)
         cc = None if compress is None else np.ascontiguousarray(compress, dtype=np.uint64)
         need = C.c_size_t(0)
-        cap = 1 << 20
+        cap = 8 << 20          # larger than any proof of the supported sizes: a too-small buffer costs a second full proof
         while True:
             buf = C.create_string_buffer(cap)
             rc = self.lib.ola_prove_with_traces(self.ctx, _p(blob), blob.size, ptrs, logs, None if pr is None else _p(pr),
@@ -381,7 +381,7 @@ class Backend:
         cap_words = np.ascontiguousarray(batch.cap(), dtype=np.uint64).reshape(-1)
         pr = None if params is None or len(params) == 0 else np.ascontiguousarray(params, dtype=np.uint64)
         need = C.c_size_t(0)
-        cap = 1 << 20
+        cap = 8 << 20          # larger than any proof of the supported sizes: a too-small buffer costs a second full proof
         while True:
             buf = C.create_string_buffer(cap)
             rc = self.lib.ola_prove_single_table(self.ctx, _p(blob), blob.size, table, ptrs, batch.h, _p(cap_words), _p(cc),
