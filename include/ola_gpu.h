@@ -173,11 +173,15 @@ int32_t ola_pow(OlaCtx* ctx, const uint64_t h[4], uint32_t bits, uint64_t* witne
  *   the AIR), may be NULL when no table has any; compress_challenges: one per table as carried in AllProof
  *   (prover.rs:307-320), may be NULL (zeros).
  * out: AllProof in the reference wire format (serialization.rs:377-393 write_all_proof).  Returns
- * OLA_E_INVALID_ARG with *out_len = required size when `cap` is too small, OLA_E_QUOTIENT_DEGREE when the trace
- * does not satisfy the constraints (prover.rs:469-473). */
+ * OLA_E_INVALID_ARG with *out_len = required size when `cap` is too small -- the finished proof then stays in the context
+ * and ola_take_pending_proof copies it out without proving again -- and OLA_E_QUOTIENT_DEGREE when the trace does not
+ * satisfy the constraints (prover.rs:469-473).  A 12-table proof is 0.8 - 1.2 MB. */
 int32_t ola_prove_with_traces(OlaCtx* ctx, const uint64_t* airset, size_t airset_words, const uint64_t* const* traces,
                               const uint32_t* log_n, const uint64_t* params, const uint64_t* compress_challenges,
                               uint8_t* out, size_t cap, size_t* out_len);
+
+/* Copies out (and forgets) the proof a preceding ola_prove_with_traces could not return because its buffer was too small. */
+int32_t ola_take_pending_proof(OlaCtx* ctx, uint8_t* out, size_t cap, size_t* out_len);
 
 /* One table of that proof with the orchestration left to the caller: replaces prove_single_table
  * (circuits/src/stark/prover.rs:330-513) together with this table's share of cross_table_lookup_data

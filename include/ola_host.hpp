@@ -252,10 +252,9 @@ inline std::vector<uint8_t> prove_with_traces(const Gpu& g, const std::vector<F>
     size_t len = 0;
     int32_t rc = ola_prove_with_traces(g.ctx(), airset.data(), airset.size(), ptrs.data(), log_n.data(), params.empty() ? nullptr : params.data(),
                                        compress_challenges.empty() ? nullptr : compress_challenges.data(), out.data(), out.size(), &len);
-    if (rc == OLA_E_INVALID_ARG && len > out.size()) {      // buffer too small: the needed size came back
+    if (rc == OLA_E_INVALID_ARG && len > out.size()) {      // buffer too small: the finished proof waits in the context
         out.resize(len);
-        rc = ola_prove_with_traces(g.ctx(), airset.data(), airset.size(), ptrs.data(), log_n.data(), params.empty() ? nullptr : params.data(),
-                                   compress_challenges.empty() ? nullptr : compress_challenges.data(), out.data(), out.size(), &len);
+        rc = ola_take_pending_proof(g.ctx(), out.data(), out.size(), &len);
     }
     check(rc);
     out.resize(len);

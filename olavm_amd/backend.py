@@ -89,6 +89,7 @@ def load_library():
     L.ola_generate_poseidon_trace.argtypes = [C.c_void_p, U64P, U64P, C.c_size_t, U64P]
     L.ola_prove_single_table.argtypes = [C.c_void_p, U64P, C.c_size_t, C.c_uint32, C.POINTER(U64P), C.c_void_p, U64P, U64P, U64P,
                                          C.POINTER(OlaChallenger), C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.ola_take_pending_proof.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]
     L.ola_permuted_cols.argtypes = [C.c_void_p, U64P, U64P, C.c_size_t, U64P, U64P]
     L.ola_permuted_cols_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
     L.ola_set_shard.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, ALL_GATHER_FN, C.c_void_p]
@@ -104,7 +105,7 @@ EXPORTS = [
     "ola_batch_get_leaf", "ola_batch_get_lde_row", "ola_challenger_init", "ola_challenger_observe",
     "ola_challenger_get", "ola_challenger_compact", "ola_open_and_prove", "ola_pow", "ola_prove_with_traces",
     "ola_air_kernels_available", "ola_commit_values_shard", "ola_commit_values_shard_dev", "ola_set_shard", "ola_gpu_trim", "ola_generate_poseidon_trace",
-    "ola_permuted_cols", "ola_permuted_cols_dev", "ola_prove_single_table",
+    "ola_permuted_cols", "ola_permuted_cols_dev", "ola_prove_single_table", "ola_take_pending_proof",
 ]
 
 
@@ -351,7 +352,7 @@ class Backend:
         self._shard_cb = ALL_GATHER_FN(all_gather)      # keep the trampoline alive as long as the context uses it
         self._chk(self.lib.ola_set_shard(self.ctx, rank, world, self._shard_cb, None))
 
-    def prove_with_traces(self, airset_blob, traces, params=None, compress=None):
+    def prove_with_traces(self, airset_blob, traces, params=None, compress=None, cap=8 << 20):
         """AllProof bytes for the multi-table STARK described by `airset_blob` (olavm_amd.air.AirSet.blob())."""
         blob = np.ascontiguousarray(airset_blob, dtype=np.uint64)
         tr = [np.ascontiguousarray(t, dtype=np.uint64) for t in traces]
@@ -360,16 +361,14 @@ class Backend:
         pr = None if params is None else np.ascontiguousarray(params, dtype=np.uint64)
         cc = None if compress is None else np.ascontiguousarray(compress, dtype=np.uint64)
         need = C.c_size_t(0)
-        cap = 8 << 20          # larger than any proof of the supported sizes: a too-small buffer costs a second full proof
-        while True:
-            buf = C.create_string_buffer(cap)
-            rc = self.lib.ola_prove_with_traces(self.ctx, _p(blob), blob.size, ptrs, logs, None if pr is None else _p(pr),
-                                                None if cc is None else _p(cc), buf, cap, C.byref(need))
-            if rc != 0 and need.value > cap:
-                cap = need.value
-                continue
-            self._chk(rc)
-            return bytes(buf.raw[:need.value])
+        buf = C.create_string_buffer(cap)
+        rc = self.lib.ola_prove_with_traces(self.ctx, _p(blob), blob.size, ptrs, logs, None if pr is None else _p(pr),
+                                            None if cc is None else _p(cc), buf, cap, C.byref(need))
+        if rc != 0 and need.value > cap:            # the proof is kept in the context: fetch it, do not prove again
+            buf = C.create_string_buffer(need.value)
+            rc = self.lib.ola_take_pending_proof(self.ctx, buf, need.value, C.byref(need))
+        self._chk(rc)
+        return bytes(buf.raw[:need.value])
 
     def prove_single_table(self, airset_blob, table, trace, batch, ctl_challenges, params, challenger):
         """StarkProof bytes of one table (ola_prove_single_table): `batch` is the table's trace commitment, `challenger` the

@@ -31,6 +31,7 @@ struct OlaCtx {
     DeviceCtx dev;
     NttTables* tables = nullptr;
     OlaGpuConfig cfg;
+    std::vector<uint8_t> pending_proof;   // an AllProof that did not fit the caller's buffer (ola_take_pending_proof)
 };
 
 // Kernel launches report configuration errors (grid / LDS limits, missing code object) only through the sticky "last
@@ -377,8 +378,24 @@ int32_t ola_prove_with_traces(OlaCtx* ctx, const uint64_t* airset, size_t airset
     prove_with_traces(&ctx->dev, *ctx->tables, ctx->cfg, (const u64*)airset, airset_words, (const u64* const*)traces, log_n,
                       (const u64*)params, (const u64*)compress_challenges, bytes);
     *out_len = bytes.size();
-    if (bytes.size() > cap || !out) throw OlaError(OLA_E_INVALID_ARG, "output buffer too small");
+    if (bytes.size() > cap || !out) {
+        ctx->pending_proof = std::move(bytes);          // the work is not lost: ola_take_pending_proof hands it over
+        throw OlaError(OLA_E_INVALID_ARG, "output buffer too small");
+    }
+    ctx->pending_proof.clear();
     memcpy(out, bytes.data(), bytes.size());
+    OLA_CATCH
+}
+
+int32_t ola_take_pending_proof(OlaCtx* ctx, uint8_t* out, size_t cap, size_t* out_len) {
+    OLA_TRY
+    require(ctx && out_len, "null pointer");
+    require(!ctx->pending_proof.empty(), "no proof is pending");
+    *out_len = ctx->pending_proof.size();
+    if (ctx->pending_proof.size() > cap || !out) throw OlaError(OLA_E_INVALID_ARG, "output buffer too small");
+    memcpy(out, ctx->pending_proof.data(), ctx->pending_proof.size());
+    ctx->pending_proof.clear();
+    ctx->pending_proof.shrink_to_fit();
     OLA_CATCH
 }
 

@@ -269,6 +269,19 @@ def test_full_size_tables_proof_bytes_match_oracle(be, oracle):
     assert rc == 0, why
 
 
+def test_too_small_proof_buffer_does_not_cost_a_second_proof(be):
+    """A caller that under-sizes the output buffer gets OLA_E_INVALID_ARG with the needed size, and the finished proof from
+    ola_take_pending_proof -- identical to what a large buffer returns."""
+    import ctypes as C
+    from olavm_amd.air import miniexec as M
+    s = T.ola_stark(range_bits=4, limb_bits=2)
+    traces, params, compress = M.instance(M.fibonacci(5))
+    whole = be.prove_with_traces(s.blob(), traces, params, compress)
+    assert be.prove_with_traces(s.blob(), traces, params, compress, cap=1000) == whole      # goes through ola_take_pending_proof
+    need = C.c_size_t(0)
+    assert be.lib.ola_take_pending_proof(be.ctx, C.create_string_buffer(16), 16, C.byref(need)) == -1    # nothing pending any more
+
+
 def test_per_table_entry_point_reassembles_the_same_all_proof(be, oracle):
     """The reference's own structure kept on the host: commit every trace (PolynomialBatch::from_values), observe the caps,
     draw the CTL challenges, then one ola_prove_single_table per table on the shared transcript -- the concatenation is the
