@@ -56,21 +56,20 @@ struct Table {
 
 // ---- Poseidon with the S-box inputs recorded: one row of the Poseidon table (generation/poseidon.rs:5-80; the
 // permutation is the plain round structure of plonky2/src/hash/poseidon.rs:617-627)
-std::vector<u64> poseidon_row(const u64* in12, const u64 filters[4]) {
-    std::vector<u64> row(NUM_POSEIDON_COLS, 0);
-    for (int i = 0; i < 4; i++) row[i] = filters[i];
-    u64 s[12];
-    for (int i = 0; i < 12; i++) { s[i] = in12[i] % P; row[COL_POSEIDON_INPUT_RANGE_START + i] = s[i]; }
+template <bool RECORD>
+void poseidon_core(u64 s[12], u64* row) {
     auto sbox = [](u64 x) { u64 x2 = mulm(x, x), x4 = mulm(x2, x2), x3 = mulm(x2, x); return mulm(x3, x4); };
     for (int r = 0; r < 30; r++) {
         const bool full = r < 4 || r >= 26;
         for (int i = 0; i < 12; i++) s[i] = addm(s[i], OLA_POSEIDON_RC[12 * r + i]);
         if (full) {
-            if (r >= 1 && r <= 3) for (int i = 0; i < 12; i++) row[COL_POSEIDON_FULL_ROUND_0_1_STATE_RANGE_START + 12 * (r - 1) + i] = s[i];
-            else if (r >= 26) for (int i = 0; i < 12; i++) row[COL_POSEIDON_FULL_ROUND_1_0_STATE_RANGE_START + 12 * (r - 26) + i] = s[i];
+            if (RECORD) {
+                if (r >= 1 && r <= 3) for (int i = 0; i < 12; i++) row[COL_POSEIDON_FULL_ROUND_0_1_STATE_RANGE_START + 12 * (r - 1) + i] = s[i];
+                else if (r >= 26) for (int i = 0; i < 12; i++) row[COL_POSEIDON_FULL_ROUND_1_0_STATE_RANGE_START + 12 * (r - 26) + i] = s[i];
+            }
             for (int i = 0; i < 12; i++) s[i] = sbox(s[i]);
         } else {
-            row[COL_POSEIDON_PARTIAL_ROUND_ELEMENT_RANGE_START + (r - 4)] = s[0];
+            if (RECORD) row[COL_POSEIDON_PARTIAL_ROUND_ELEMENT_RANGE_START + (r - 4)] = s[0];
             s[0] = sbox(s[0]);
         }
         u64 o[12];
@@ -80,10 +79,24 @@ std::vector<u64> poseidon_row(const u64* in12, const u64 filters[4]) {
             acc += (u128)s[k] * OLA_POSEIDON_MDS_DIAG[k];
             o[k] = addm(mulm((u64)(acc >> 64), 0xFFFFFFFFULL), canon((u64)acc));      // acc = hi * 2^64 + lo, 2^64 = 2^32 - 1
         }
-        memcpy(s, o, sizeof(s));
+        memcpy(s, o, sizeof(o));
     }
+}
+
+std::vector<u64> poseidon_row(const u64* in12, const u64 filters[4]) {
+    std::vector<u64> row(NUM_POSEIDON_COLS, 0);
+    for (int i = 0; i < 4; i++) row[i] = filters[i];
+    u64 s[12];
+    for (int i = 0; i < 12; i++) { s[i] = in12[i] % P; row[COL_POSEIDON_INPUT_RANGE_START + i] = s[i]; }
+    poseidon_core<true>(s, row.data());
     for (int i = 0; i < 12; i++) row[COL_POSEIDON_OUTPUT_RANGE_START + i] = s[i];
     return row;
+}
+
+// the permutation alone (state in, state out)
+void poseidon_permute(u64 s[12]) {
+    for (int i = 0; i < 12; i++) s[i] %= P;
+    poseidon_core<false>(s, nullptr);
 }
 
 // ---- lookup.rs:68-132
@@ -131,13 +144,13 @@ struct StorageTree {
     std::map<NodeKey, Hash4> nodes;
     std::vector<Hash4> dflt;
     static Hash4 hash(const Hash4& l, const Hash4& r, bool leaf_level, std::vector<u64>* row_out = nullptr) {
-        const u64 in[12] = {l[0], l[1], l[2], l[3], r[0], r[1], r[2], r[3], (u64)leaf_level, 0, 0, 0};
+        u64 in[12] = {l[0], l[1], l[2], l[3], r[0], r[1], r[2], r[3], (u64)leaf_level, 0, 0, 0};
+        if (!row_out) { poseidon_permute(in); return Hash4{in[0], in[1], in[2], in[3]}; }
         const u64 f[4] = {0, 0, (u64)leaf_level, (u64)!leaf_level};
-        std::vector<u64> row = poseidon_row(in, f);
-        Hash4 h{row[COL_POSEIDON_OUTPUT_RANGE_START], row[COL_POSEIDON_OUTPUT_RANGE_START + 1], row[COL_POSEIDON_OUTPUT_RANGE_START + 2],
-                row[COL_POSEIDON_OUTPUT_RANGE_START + 3]};
-        if (row_out) *row_out = std::move(row);
-        return h;
+        *row_out = poseidon_row(in, f);
+        const std::vector<u64>& row = *row_out;
+        return Hash4{row[COL_POSEIDON_OUTPUT_RANGE_START], row[COL_POSEIDON_OUTPUT_RANGE_START + 1], row[COL_POSEIDON_OUTPUT_RANGE_START + 2],
+                     row[COL_POSEIDON_OUTPUT_RANGE_START + 3]};
     }
     StorageTree() : dflt(257) {
         dflt[256] = Hash4{0, 0, 0, 0};
