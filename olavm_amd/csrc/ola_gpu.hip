@@ -42,9 +42,15 @@ static std::atomic<int> g_live_contexts{0};
 static void check_launch_errors() {
     if (g_live_contexts.load() <= 0) return;
     const hipError_t e = hipGetLastError();
-    if (e != hipSuccess) throw OlaError(OLA_E_HIP, std::string("kernel launch failed: ") + hipGetErrorString(e));
+    // hipErrorNotReady is what event / stream queries answer while work is in flight, not a failure
+    if (e != hipSuccess && e != hipErrorNotReady) throw OlaError(OLA_E_HIP, std::string("kernel launch failed: ") + hipGetErrorString(e));
 }
-#define OLA_TRY try {
+// The error slot is per host thread and shared with whatever else uses HIP in the process (the caller's framework polls
+// events, for instance): forget what was there before this call so that only this call's launches are judged.
+static void clear_stale_errors() {
+    if (g_live_contexts.load() > 0) (void)hipGetLastError();
+}
+#define OLA_TRY try { clear_stale_errors();
 #define OLA_CATCH                                                   \
         check_launch_errors();                                      \
     }                                                               \
