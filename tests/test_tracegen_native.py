@@ -66,12 +66,13 @@ def test_unsupported_and_faulty_programs_are_reported():
 
 def random_program(rng, length=60):
     """A random straight-line program (with a few forward jumps) over the instructions whose operands need no set-up, kept
-    valid by shadowing the register file: bitwise / comparison / range-check operands stay below 2^8 (miniature tables),
+    valid by shadowing the register file: bitwise / comparison / range-check operands stay below 2^8 (miniature bitwise table),
     loads only touch written cells."""
     Pm = 0xFFFFFFFF00000001
     p = M.Program()
     regs = [0] * 10
     written = {}
+    blocks, unknown = [0], [2**50]
     small = lambda r: regs[r] < 256
 
     def emit(op, dst=None, op0=None, op1=None, val=None):
@@ -79,7 +80,7 @@ def random_program(rng, length=60):
         if dst is not None and val is not None:
             regs[dst] = val % Pm
     for _ in range(length):
-        kind = rng.choice(["mov", "add", "mul", "not", "eq", "bit", "gte", "rc", "store", "load", "assert", "skip"])
+        kind = rng.choice(["mov", "add", "mul", "not", "eq", "bit", "gte", "rc", "store", "load", "assert", "skip", "block"])
         d, a, b = (int(x) for x in rng.integers(0, 9, 3))          # r9 (fp) stays 0
         if kind == "mov":
             v = int(rng.integers(0, 256)) if rng.integers(0, 2) else int(rng.integers(0, 2**63)) % Pm
@@ -115,6 +116,26 @@ def random_program(rng, length=60):
         elif kind == "assert":
             emit("EQ", d, a, a, 1)
             emit("ASSERT", None, None, d)
+        elif kind == "block" and blocks[0] < 6:
+            # eight fresh cells, hashed with the POSEIDON builtin, three of them appended to the tape and read back: the
+            # digest and the loaded words are not shadowed exactly, so their registers / cells are marked "large"
+            base = 1000 + 64 * blocks[0]
+            blocks[0] += 1
+            emit("MOV", 0, None, ("imm", base), base)
+            for k in range(8):
+                v = int(rng.integers(0, 2**40))
+                emit("MOV", 1, None, ("imm", v), v)
+                emit("MSTORE", 1, 0, ("imm", k), v)
+                written[base + k] = v
+            emit("MOV", 2, None, ("imm", base + 16), base + 16)
+            emit("POSEIDON", 2, 0, ("imm", 8), base + 16)
+            emit("MLOAD", 3, 2, ("imm", int(rng.integers(0, 4))), unknown[0])
+            unknown[0] += 1
+            emit("TSTORE", None, 0, ("imm", 3))
+            emit("MOV", 4, None, ("imm", base + 32), base + 32)
+            emit("MOV", 5, None, ("imm", 1), 1)
+            emit("TLOAD", 4, 5, ("imm", 2), base + 32)
+            emit("MLOAD", 6, 4, ("imm", 1), written[base + 2])       # tape[tp-1] = the third stored word
         elif kind == "skip":                                              # a taken conditional jump over one instruction
             emit("EQ", d, a, a, 1)
             here = len(p.words()[0])
@@ -126,12 +147,12 @@ def random_program(rng, length=60):
 
 def test_random_programs_native_equals_python_and_all_airs_vanish(oracle):
     from tests.test_oracle_stark import _per_table_params
-    s = T.ola_stark(range_bits=4, limb_bits=2)
+    s = T.ola_stark(range_bits=8, limb_bits=2)          # 16-bit range checks: the blocks live at addresses around 1000
     rng = np.random.default_rng(4242)
     for trial in range(8):
         prog = random_program(rng)
-        want, params, _ = M.instance(prog)
-        got, _, _ = fastexec.instance(prog)
+        want, params, _ = M.instance(prog, range_bits=8, limb_bits=2)
+        got, _, _ = fastexec.instance(prog, range_bits=8, limb_bits=2)
         for t, (a, b) in enumerate(zip(want, got)):
             assert np.array_equal(a, b), (trial, t)
         for i, (tr, pr) in enumerate(zip(got, _per_table_params(s, params))):
