@@ -136,6 +136,13 @@ def random_program(rng, length=60):
             emit("MOV", 5, None, ("imm", 1), 1)
             emit("TLOAD", 4, 5, ("imm", 2), base + 32)
             emit("MLOAD", 6, 4, ("imm", 1), written[base + 2])       # tape[tp-1] = the third stored word
+            if blocks[0] == 1:
+                # the first block also goes through storage: slot key = its cells 0..3, value = cells 4..7, read back elsewhere
+                emit("MOV", 7, None, ("imm", base + 4), base + 4)
+                emit("SSTORE", None, 0, 7)
+                emit("MOV", 8, None, ("imm", base + 40), base + 40)
+                emit("SLOAD", None, 0, 8)
+                emit("MLOAD", 3, 8, ("imm", 3), written[base + 7])
         elif kind == "skip":                                              # a taken conditional jump over one instruction
             emit("EQ", d, a, a, 1)
             here = len(p.words()[0])
