@@ -72,7 +72,7 @@ def random_program(rng, length=60):
     p = M.Program()
     regs = [0] * 10
     written = {}
-    blocks, unknown = [0], [2**50]
+    blocks, unknown, calls = [0], [2**50], [0]
     small = lambda r: regs[r] < 256
 
     def emit(op, dst=None, op0=None, op1=None, val=None):
@@ -80,7 +80,7 @@ def random_program(rng, length=60):
         if dst is not None and val is not None:
             regs[dst] = val % Pm
     for _ in range(length):
-        kind = rng.choice(["mov", "add", "mul", "not", "eq", "bit", "gte", "rc", "store", "load", "assert", "skip", "block"])
+        kind = rng.choice(["mov", "add", "mul", "not", "eq", "bit", "gte", "rc", "store", "load", "assert", "skip", "block", "call"])
         d, a, b = (int(x) for x in rng.integers(0, 9, 3))          # r9 (fp) stays 0
         if kind == "mov":
             v = int(rng.integers(0, 256)) if rng.integers(0, 2) else int(rng.integers(0, 2**63)) % Pm
@@ -143,6 +143,20 @@ def random_program(rng, length=60):
                 emit("MOV", 8, None, ("imm", base + 40), base + 40)
                 emit("SLOAD", None, 0, 8)
                 emit("MLOAD", 3, 8, ("imm", 3), written[base + 7])
+        elif kind == "call" and calls[0] < 3:
+            # a frame at fp, the caller's frame pointer (0) saved at [fp - 2], a routine of one ADD behind a jump, CALL / RET
+            fp = 600 + 8 * calls[0]
+            calls[0] += 1
+            emit("MOV", 9, None, ("imm", fp), fp)
+            emit("MOV", 8, None, ("imm", 0), 0)
+            emit("MSTORE", 8, 9, ("imm", Pm - 2), 0)
+            here = len(p.words()[0])
+            emit("CALL", None, None, ("imm", here + 4))
+            emit("JMP", None, None, ("imm", here + 7))
+            emit("ADD", 7, 7, ("imm", 1), regs[7] + 1)
+            emit("RET")
+            regs[9] = 0                                                   # RET restored the saved frame pointer
+            written[fp - 2], written[fp - 1] = 0, here + 2
         elif kind == "skip":                                              # a taken conditional jump over one instruction
             emit("EQ", d, a, a, 1)
             here = len(p.words()[0])
