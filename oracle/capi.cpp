@@ -202,6 +202,17 @@ int oracle_verify_opening(const u64* caps, const int* num_polys, int degree_bits
 #include <omp.h>
 extern "C" {
 int oracle_num_threads() { return omp_get_max_threads(); }
+// Horner evaluation of one polynomial at a few points (full-size NTT spot checks in tests/: fft.rs:218-252 evaluates
+// naively at every point, which is out of reach at 2^24; a handful of points pins the same values)
+void oracle_eval_at_points(const u64* coeffs, size_t n, const u64* points, size_t k, u64* out) {
+#pragma omp parallel for schedule(dynamic, 1)
+    for (long j = 0; j < (long)k; j++) {
+        const u64 x = gl_canon(points[j]);
+        u64 acc = 0;
+        for (size_t i = n; i-- > 0;) acc = gl_add(gl_mul(acc, x), gl_canon(coeffs[i]));
+        out[j] = acc;
+    }
+}
 void oracle_evaluate_poly_batch(u64* data, size_t n, size_t batch) {
 #pragma omp parallel for schedule(dynamic, 1)
     for (long c = 0; c < (long)batch; c++) evaluate_poly(data + (size_t)c * n, n);

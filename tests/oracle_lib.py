@@ -39,6 +39,7 @@ class Oracle:
         L.oracle_evaluate_poly_with_offset.argtypes = [U64P, C.c_size_t, C.c_uint64, C.c_size_t, U64P]
         L.oracle_interpolate_poly_with_offset.argtypes = [U64P, C.c_size_t, C.c_uint64]
         L.oracle_naive_eval.argtypes = [U64P, C.c_size_t, C.c_size_t, C.c_uint64, U64P]
+        L.oracle_eval_at_points.argtypes = [U64P, C.c_size_t, U64P, C.c_size_t, U64P]
         L.oracle_poseidon.argtypes = [U64P]
         L.oracle_permuted_cols.argtypes = [U64P, U64P, C.c_size_t, U64P, U64P]
         L.oracle_hash_no_pad.argtypes = [U64P, C.c_size_t, U64P]
@@ -123,6 +124,14 @@ class Oracle:
         c = np.ascontiguousarray(coeffs, dtype=np.uint64)
         out = np.empty(domain, dtype=np.uint64)
         self.lib.oracle_naive_eval(ptr(c), c.size, domain, shift, ptr(out))
+        return out
+
+    def eval_at_points(self, coeffs, points):
+        """Horner value of the polynomial `coeffs` (low degree first) at each of `points`."""
+        c = np.ascontiguousarray(coeffs, dtype=np.uint64)
+        x = np.ascontiguousarray(points, dtype=np.uint64)
+        out = np.empty(x.size, dtype=np.uint64)
+        self.lib.oracle_eval_at_points(ptr(c), c.size, ptr(x), x.size, ptr(out))
         return out
 
     # ---- poseidon ----

@@ -1,0 +1,155 @@
+"""BASELINE.json's full-size configurations, run by the driver (`-m gpu`).
+
+config 2  standalone NTT / iNTT / coset LDE at 2^24 x 94 (and x 1): round trips plus output points against single-point
+          Horner evaluation by the oracle, on splitmix64 columns and on the adversarial tiling;
+config 3  full prove of an EXECUTED program with a 2^20-row CPU table, accepted by the oracle's restatement of the reference
+          verifier including the cross-table products -- the shape of the reference's own full-prove test
+          (circuits/src/stark/ola_stark.rs:819 test_by_asm_json: execute -> generate_traces -> prove -> verify);
+config 4  Poseidon-builtin-heavy execution: every row of a 2^22-row Poseidon table a live, looked-up permutation;
+          and the 2^16-row execution byte for byte against the oracle PROVER (slow: the CPU port needs about 100 s).
+The oracle is the checker only; everything measured or proven runs through the C ABI on the GPU.
+"""
+import time
+
+import numpy as np
+import pytest
+
+from olavm_amd.air import ola_tables as T
+
+pytestmark = pytest.mark.gpu
+
+P = 0xFFFFFFFF00000001
+
+
+@pytest.fixture(scope="module")
+def be():
+    import torch
+    from olavm_amd.backend import Backend
+    b = Backend(device=0, stream=torch.cuda.current_stream().cuda_stream)
+    yield b
+    b.close()
+
+
+def _bitrev(x, bits):
+    return int(format(x, "0%db" % bits)[::-1], 2) if bits else 0
+
+
+def _host_col(t):
+    return t.cpu().numpy().view(np.uint64)
+
+
+@pytest.mark.parametrize("log_n,cols", [(24, 94), (24, 1), (23, 94)])
+def test_config2_ntt_full_size(be, oracle, log_n, cols):
+    """evaluate_poly / interpolate_poly at the top of config 2's range: interpolate(evaluate(x)) == x for the whole batch and
+    >= 8 output points of three columns equal the Horner value of the polynomial at w^k (cfft/mod.rs:22-231 semantics)."""
+    import torch
+    from olavm_amd.backend import OLA_NTT_EVALUATE, OLA_NTT_INTERPOLATE
+    from tests.inputs import adversarial_columns, canonical, splitmix_columns
+    n = 1 << log_n
+    w = oracle.root_of_unity(log_n)
+    ks = [0, 1, 2, n // 2 - 1, n // 2, n - 1, 0x00ABCDEF % n, 0x00555555 % n, 0x00AAAAAA % n]
+    pts = np.array([oracle.pow(w, k) for k in ks], dtype=np.uint64)
+    for label, x in (("splitmix64", splitmix_columns(torch, cols, n)), ("adversarial", adversarial_columns(torch, cols, n))):
+        out, back, scratch = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
+        be.ntt_dev(OLA_NTT_EVALUATE, x.data_ptr(), out.data_ptr(), log_n, cols, scratch_ptr=scratch.data_ptr())
+        be.ntt_dev(OLA_NTT_INTERPOLATE, out.data_ptr(), back.data_ptr(), log_n, cols, scratch_ptr=scratch.data_ptr())
+        torch.cuda.synchronize()
+        assert torch.equal(back, canonical(torch, x)), label
+        idx = torch.tensor(ks, device="cuda")
+        for c in sorted({0, cols // 2, cols - 1}):
+            got = _host_col(out[c][idx])
+            want = oracle.eval_at_points(_host_col(x[c]), pts)
+            assert np.array_equal(got, want), (label, c)
+        del out, back, scratch, x
+        torch.cuda.empty_cache()
+    be.trim()
+
+
+@pytest.mark.parametrize("log_n,cols", [(24, 24), (22, 94)])
+def test_config2_coset_lde_full_size(be, oracle, log_n, cols):
+    """The x8 coset low-degree extension (PolynomialBatch::from_coeffs's transform, fri/oracle.rs:66-99) in natural and in
+    commitment-leaf order: leaf j = k*n + r holds natural LDE row bitrev_{8n}(j); points against Horner at 7*w_{8n}^i; and the
+    size-8n coset interpolation of the natural-order LDE returns the coefficients followed by zeros."""
+    import torch
+    from olavm_amd.backend import OLA_NTT_COSET_INTERPOLATE, OLA_NTT_COSET_LDE, OLA_NTT_COSET_LDE_LEAF_ORDER
+    from tests.inputs import splitmix_columns
+    n, N = 1 << log_n, 8 << log_n
+    x = splitmix_columns(torch, cols, n)
+    lde = torch.empty((cols, N), dtype=torch.int64, device="cuda")
+    scratch = torch.empty_like(lde)
+    be.ntt_dev(OLA_NTT_COSET_LDE, x.data_ptr(), lde.data_ptr(), log_n, cols, shift=7, blowup_log=3, scratch_ptr=scratch.data_ptr())
+    torch.cuda.synchronize()
+    w = oracle.root_of_unity(log_n + 3)
+    rows = [0, 1, 7, 8, N // 2 + 3, N - 1, 0x0ABCDEF1 % N, 0x05555555 % N, 0x0AAAAAAA % N]
+    pts = np.array([(7 * oracle.pow(w, i)) % P for i in rows], dtype=np.uint64)
+    want = {c: oracle.eval_at_points(_host_col(x[c]), pts) for c in sorted({0, cols - 1})}
+    idx = torch.tensor(rows, device="cuda")
+    for c, wv in want.items():
+        assert np.array_equal(_host_col(lde[c][idx]), wv), c
+    # inverse of the whole extension through a transform of a different size
+    coeffs = torch.empty_like(lde)
+    be.ntt_dev(OLA_NTT_COSET_INTERPOLATE, lde.data_ptr(), coeffs.data_ptr(), log_n + 3, cols, shift=7, scratch_ptr=scratch.data_ptr())
+    torch.cuda.synchronize()
+    assert torch.equal(coeffs[:, :n], x) and not bool(coeffs[:, n:].any())
+    del coeffs
+    # commitment-leaf order (what the prover hashes): same values, rows bit-reversed
+    be.ntt_dev(OLA_NTT_COSET_LDE_LEAF_ORDER, x.data_ptr(), lde.data_ptr(), log_n, cols, shift=7, blowup_log=3, scratch_ptr=scratch.data_ptr())
+    torch.cuda.synchronize()
+    leaf_idx = torch.tensor([_bitrev(i, log_n + 3) for i in rows], device="cuda")
+    for c, wv in want.items():
+        assert np.array_equal(_host_col(lde[c][leaf_idx]), wv), c
+    del lde, scratch, x
+    torch.cuda.empty_cache()
+    be.trim()
+
+
+def _prove_and_verify(be, oracle, traces, params, compress, blob):
+    t0 = time.perf_counter()
+    proof = be.prove_with_traces(blob, traces, params, compress)
+    dt = time.perf_counter() - t0
+    rc, why = oracle.verify_all_proof(blob, proof, params)
+    assert rc == 0, why
+    return proof, dt
+
+
+def test_config3_full_prove_of_a_2p20_row_execution(be, oracle):
+    """memory_program(70000): 980 k executed CPU rows (2^20), 2^19-row memory and range-check tables, a 2^21-row program
+    table, full-size fixed tables (2^16-entry range check, 2^18-row bitwise); five lookups carry these rows."""
+    from olavm_amd.air import fastexec, miniexec as M
+    blob = T.ola_stark().blob()
+    traces, params, compress = fastexec.instance(M.memory_program(70000), range_bits=16, limb_bits=8, max_steps=1 << 24)
+    heights = [int(t.shape[1]).bit_length() - 1 for t in traces]
+    assert heights[0] == 20 and traces[0].shape[0] == 94
+    proof, dt = _prove_and_verify(be, oracle, traces, params, compress, blob)
+    print("config 3: heights 2^%s, %d proof bytes, prove_with_traces %.3f s (first call of this shape)" % (heights, len(proof), dt))
+    # the proof is a function of the traces alone: a second call returns the same bytes
+    assert be.prove_with_traces(blob, traces, params, compress) == proof
+    be.trim()
+
+
+def test_config4_poseidon_heavy_2p22_rows(be, oracle):
+    """storage_heavy_program(4085, ...): 8170 storage accesses, each with its 256-level state-tree proof -> a 2^22-row Poseidon
+    table whose rows are live permutations looked up by the storage table (2^21 rows); CPU table kept small so that the
+    host-side trace generation stays within the test budget."""
+    from olavm_amd.air import fastexec, miniexec as M
+    blob = T.ola_stark().blob()
+    traces, params, compress = fastexec.instance(M.storage_heavy_program(4085, 1000), range_bits=16, limb_bits=8,
+                                                 max_steps=1 << 24, prove_program_hash=True)
+    names = [t.name for t in T.ola_stark().tables]
+    heights = dict(zip(names, [int(t.shape[1]).bit_length() - 1 for t in traces]))
+    assert heights["poseidon"] == 22 and heights["storage_access"] == 21, heights
+    proof, dt = _prove_and_verify(be, oracle, traces, params, compress, blob)
+    print("config 4: heights %s, %d proof bytes, prove_with_traces %.3f s" % (heights, len(proof), dt))
+    be.trim()
+
+
+def test_2p16_row_execution_bytes_equal_the_oracle_prover(be, oracle):
+    """The largest instance the CPU port proves in test time (about 100 s on the GPU box's host cores): memory_program(3000),
+    2^16 CPU rows, 2^17 program rows, full-size fixed tables -- AllProof bytes identical, byte for byte."""
+    from olavm_amd.air import fastexec, miniexec as M
+    blob = T.ola_stark().blob()
+    traces, params, compress = fastexec.instance(M.memory_program(3000), range_bits=16, limb_bits=8, max_steps=1 << 20)
+    assert traces[0].shape == (94, 1 << 16)
+    got, _ = _prove_and_verify(be, oracle, traces, params, compress, blob)
+    want = oracle.prove_with_traces(blob, traces, params, compress)
+    assert len(got) == len(want) and got == want

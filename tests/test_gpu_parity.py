@@ -288,3 +288,28 @@ def test_shard_batches_are_refused_where_a_full_commitment_is_needed(be):
         be.commit_shard(vals, 2, 2)
     with pytest.raises(OlaGpuError):
         be.commit_shard(vals, 0, 3)
+
+
+# ---------------------------------------------------------------- third-generation passes (2^18 and up, ntt3.hip)
+@pytest.mark.parametrize("log_n", [18, 19, 20, 21])
+def test_ntt3_sizes_match_oracle(be, oracle, log_n):
+    """Every pass shape the planner uses between 2^18 and 2^21 (strided widths 5..9, contiguous and natural-order closing
+    passes), full compare with the oracle: evaluate / interpolate in natural order, the x8 coset LDE in leaf order
+    (cosets 0, 3 and 7 compared), and non-canonical input words."""
+    from olavm_amd.backend import OLA_NTT_COSET_LDE_LEAF_ORDER, OLA_NTT_EVALUATE, OLA_NTT_INTERPOLATE
+    rng = np.random.default_rng(3000 + log_n)
+    n = 1 << log_n
+    c = rand_field(rng, (3, n))
+    c[2] = np.resize(EDGE, n)
+    c[2, ::7] = np.uint64(0xFFFFFFFFFFFFFFFF)
+    ev = be.ntt(OLA_NTT_EVALUATE, c)
+    back = be.ntt(OLA_NTT_INTERPOLATE, ev)
+    for b in range(3):
+        assert np.array_equal(ev[b], oracle.evaluate_poly(c[b])), b
+        assert np.array_equal(back[b], oracle.vec_op("add", c[b], np.zeros(n, dtype=np.uint64))), b      # canonical form of the input
+    assert np.array_equal(back[0], oracle.interpolate_poly(ev[0]))
+    leaf = be.ntt(OLA_NTT_COSET_LDE_LEAF_ORDER, c[:2], shift=7, blowup_log=3)
+    rev = bitrev_perm(log_n + 3)
+    want = oracle.evaluate_poly_with_offset(c[1], 7, 8)[rev]
+    for k in (0, 3, 7):
+        assert np.array_equal(leaf[1][k * n:(k + 1) * n], want[k * n:(k + 1) * n]), k
