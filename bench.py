@@ -261,7 +261,10 @@ def main():
             dist.init_process_group(backend)
 
     from olavm_amd.backend import Backend, OLA_NTT_EVALUATE
-    stream = torch.cuda.current_stream()
+    # one explicit stream for torch and the library (torch's default stream is the null handle, which would make the library
+    # create a stream of its own, unordered with torch's work)
+    stream = torch.cuda.Stream()
+    torch.cuda.set_stream(stream)
     be = Backend(device=local_rank, stream=stream.cuda_stream)
 
     n = 1 << args.log_n
@@ -280,6 +283,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    torch.cuda.synchronize()          # torch's default stream hands over a null handle: the context then runs on a stream of its own
     for _ in range(args.warmup):
         step()
     barrier()

@@ -66,6 +66,9 @@ int32_t ola_gpu_sync(OlaCtx* ctx);
 /* Scratch and commitment buffers are recycled through a per-context cache (tens of GB after a 2^22-row proof); this returns
  * the cached blocks to the driver.  Live OlaBatch objects are not affected. */
 int32_t ola_gpu_trim(OlaCtx* ctx);
+/* Device memory of the context's buffer pool, in bytes: out[0] handed out now, out[1] the most ever handed out at once,
+ * out[2] handed out + cached now, out[3] the most ever held (the high-water mark of a proof; reset = 1 restarts the marks). */
+int32_t ola_gpu_memory_stats(OlaCtx* ctx, uint64_t out[4], int32_t reset);
 
 /* ---- NTT family: replaces gpu_method and the cfft CPU paths --------------------------------------------
  * op selects the reference function (plonky2/field/src/cfft/mod.rs):

@@ -21,6 +21,9 @@ struct QuotParams {
     // `out_plane` values per challenge, and leaf j of the buffers is global leaf j + coset_first * n
     u32 coset_first;
     size_t out_plane;
+    // points this launch evaluates (0: out_plane of them).  A memory-lean proof evaluates one coset per launch into its slice
+    // of the full planes: npoints = n, out = planes + coset * n, out_plane = the full plane.
+    size_t npoints;
 };
 
 // Straight-line kernels printed by olavm_amd/air/codegen.py, one per table signature.  Descriptor D (u64 words):

@@ -21,8 +21,11 @@ struct OlaBatch {
     uint32_t ncols = 0, log_n = 0, rate_bits = 0, cap_height = 0;
     uint32_t full_rate_bits = 0, coset_first = 0;
     bool is_shard() const { return rate_bits != full_rate_bits; }
+    // lean: the LDE is not kept.  It was produced one coset at a time while the leaves were hashed, and whoever needs values
+    // again (quotient evaluation, opened rows) re-derives the coset from `coeffs` (batch_lde_slice); coefficients and digests stay.
+    bool lean = false;
     ola::u64* coeffs = nullptr;  // [ncols][n], natural coefficient order
-    ola::u64* lde = nullptr;     // [ncols][N], leaf order
+    ola::u64* lde = nullptr;     // [ncols][N], leaf order (nullptr when lean)
     ola::u64* heap = nullptr;    // 2N digests of 4 u64, heap[N + j] = leaf j, root at 1
     size_t n() const { return (size_t)1 << log_n; }
     size_t num_leaves() const { return (size_t)1 << (log_n + rate_bits); }
@@ -134,7 +137,7 @@ struct ColumnFeed {
 
 OlaBatch* batch_commit(DeviceCtx* ctx, NttTables& t, const uint64_t* const* cols_host, const u64* cols_dev, uint32_t ncols,
                        uint32_t log_n, uint32_t rate_bits, uint32_t cap_height, bool from_values, uint32_t shard_rank = 0,
-                       uint32_t shard_log_world = 0, const ColumnFeed* feed = nullptr) {
+                       uint32_t shard_log_world = 0, const ColumnFeed* feed = nullptr, bool lean = false) {
     if (shard_log_world > rate_bits || shard_log_world > cap_height || shard_rank >= (1u << shard_log_world))
         throw OlaError(-1, "shard count must divide both the number of cosets and the cap");
     OlaBatch* b = new OlaBatch();
@@ -147,6 +150,58 @@ OlaBatch* batch_commit(DeviceCtx* ctx, NttTables& t, const uint64_t* const* cols
     const size_t n = b->n(), N = b->num_leaves();
     u64* tmp = nullptr;
     bool lde_done = false;
+    if (lean && rate_bits > 0) {
+        // Memory-lean commitment (fri/oracle.rs:66-99 with the LDE streamed): values -> coefficients, then for every coset of the
+        // rank: extend (one n-point coset transform per column), hash its n leaves into the digest heap, drop the values.
+        // Peak: coefficients + one coset + the heap, instead of coefficients + 2^rate_bits cosets + the heap.
+        b->lean = true;
+        u64* stage = nullptr;
+        try {
+            b->coeffs = (u64*)ctx->alloc((size_t)ncols * n * 8);
+            b->heap = (u64*)ctx->alloc(2 * N * 32);
+            tmp = (u64*)ctx->alloc((size_t)ncols * n * 8);      // transform scratch, then the coset being hashed
+            if (from_values) {
+                const u64* vals = cols_dev;
+                if (cols_host) {
+                    stage = (u64*)ctx->alloc((size_t)ncols * n * 8);
+                    for (uint32_t c = 0; c < ncols; c++)
+                        HIP_CHECK(hipMemcpyAsync(stage + (size_t)c * n, cols_host[c], n * 8, hipMemcpyHostToDevice, ctx->stream));
+                    vals = stage;
+                }
+                if (feed && feed->chunk_cols && !cols_host) {
+                    for (uint32_t c0 = 0; c0 < ncols; c0 += feed->chunk_cols) {
+                        const uint32_t c1 = std::min(ncols, c0 + feed->chunk_cols);
+                        feed->before_chunk(c0, c1);
+                        ntt_interpolate(t, vals + (size_t)c0 * n, b->coeffs + (size_t)c0 * n, tmp, log_n, c1 - c0);
+                    }
+                } else {
+                    ntt_interpolate(t, vals, b->coeffs, tmp, log_n, ncols);
+                }
+            } else {
+                if (cols_host) {
+                    for (uint32_t c = 0; c < ncols; c++)
+                        HIP_CHECK(hipMemcpyAsync(b->coeffs + (size_t)c * n, cols_host[c], n * 8, hipMemcpyHostToDevice, ctx->stream));
+                } else {
+                    HIP_CHECK(hipMemcpyAsync(b->coeffs, cols_dev, (size_t)ncols * n * 8, hipMemcpyDeviceToDevice, ctx->stream));
+                }
+                canonicalize(ctx, b->coeffs, (size_t)ncols * n);
+            }
+            for (size_t c = 0; c < ((size_t)1 << rate_bits); c++) {
+                ntt_lde_leaf_order(t, b->coeffs, tmp, log_n, full_rate_bits, ncols, b->coset_first + c, 1);
+                launch_leaf_hash_colmajor(ctx, tmp, n, (int)ncols, n, b->heap + 4 * N + 4 * c * n);
+            }
+            launch_merkle_build(ctx, b->heap, N, cap_height);
+            HIP_CHECK(hipStreamSynchronize(ctx->stream));
+            ctx->free(tmp);
+            if (stage) ctx->free(stage);
+        } catch (...) {
+            if (tmp) ctx->free(tmp);
+            if (stage) ctx->free(stage);
+            batch_destroy(ctx, b);
+            throw;
+        }
+        return b;
+    }
     try {
         b->coeffs = (u64*)ctx->alloc((size_t)ncols * n * 8);
         b->lde = (u64*)ctx->alloc((size_t)ncols * N * 8);
@@ -206,10 +261,43 @@ void batch_read_cap(DeviceCtx* ctx, const OlaBatch& b, u64* cap_out) {
     HIP_CHECK(hipStreamSynchronize(ctx->stream));
 }
 
+// Coset `coset` (local numbering) of the batch's LDE in leaf order, [ncols][n], re-derived from the coefficients (lean batches)
+void batch_lde_slice(DeviceCtx* ctx, NttTables& t, const OlaBatch& b, size_t coset, u64* out) {
+    (void)ctx;
+    ntt_lde_leaf_order(t, b.coeffs, out, b.log_n, b.full_rate_bits, b.ncols, b.coset_first + coset, 1);
+}
+
 // rows_out: nq x ncols, paths_out: nq x depth x 4 (either may be null)
-void batch_get_leaves(DeviceCtx* ctx, const OlaBatch& b, const size_t* idx, size_t nq, u64* rows_out, u64* paths_out) {
+void batch_get_leaves(DeviceCtx* ctx, const OlaBatch& b, const size_t* idx, size_t nq, u64* rows_out, u64* paths_out, NttTables* tables = nullptr) {
     const size_t N = b.num_leaves();
     const int depth = (int)(b.log_n + b.rate_bits - b.cap_height);
+    if (b.lean && rows_out) {
+        // the opened rows of a lean batch: one coset at a time, only the cosets a query falls into
+        if (!tables) throw OlaError(-1, "rows of a memory-lean commitment need the transform tables");
+        const size_t n = b.n();
+        u64* slice = (u64*)ctx->alloc((size_t)b.ncols * n * 8);
+        unsigned long long* d_idx = (unsigned long long*)ctx->alloc(nq * 8);
+        u64* d_rows = (u64*)ctx->alloc(nq * b.ncols * 8);
+        try {
+            for (size_t c = 0; c < ((size_t)1 << b.rate_bits); c++) {
+                std::vector<unsigned long long> loc;
+                std::vector<size_t> pos;
+                for (size_t q = 0; q < nq; q++)
+                    if ((idx[q] >> b.log_n) == c) { loc.push_back(idx[q] & (n - 1)); pos.push_back(q); }
+                if (loc.empty()) continue;
+                batch_lde_slice(ctx, *tables, b, c, slice);
+                HIP_CHECK(hipMemcpyAsync(d_idx, loc.data(), loc.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+                hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)loc.size()), dim3(64), 0, ctx->stream, slice, n, (int)b.ncols, d_idx, d_rows);
+                std::vector<u64> h(loc.size() * b.ncols);
+                HIP_CHECK(hipMemcpyAsync(h.data(), d_rows, h.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+                HIP_CHECK(hipStreamSynchronize(ctx->stream));
+                for (size_t k = 0; k < pos.size(); k++) std::copy(h.begin() + k * b.ncols, h.begin() + (k + 1) * b.ncols, rows_out + pos[k] * b.ncols);
+            }
+        } catch (...) { ctx->free(slice); ctx->free(d_idx); ctx->free(d_rows); throw; }
+        ctx->free(slice); ctx->free(d_idx); ctx->free(d_rows);
+        rows_out = nullptr;          // the paths below come from the resident heap
+        if (!paths_out) return;
+    }
     std::vector<unsigned long long> h_idx(idx, idx + nq);
     unsigned long long* d_idx = (unsigned long long*)ctx->alloc(nq * 8);
     u64* d_rows = (u64*)ctx->alloc(nq * b.ncols * 8);
@@ -229,8 +317,8 @@ void batch_get_leaves(DeviceCtx* ctx, const OlaBatch& b, const size_t* idx, size
     } catch (...) { ctx->free(d_idx); ctx->free(d_rows); ctx->free(d_paths); throw; }
     ctx->free(d_idx); ctx->free(d_rows); ctx->free(d_paths);
 }
-void batch_get_leaf(DeviceCtx* ctx, const OlaBatch& b, size_t leaf, u64* row_out, u64* sib_out) {
-    batch_get_leaves(ctx, b, &leaf, 1, row_out, sib_out);
+void batch_get_leaf(DeviceCtx* ctx, const OlaBatch& b, size_t leaf, u64* row_out, u64* sib_out, NttTables* tables = nullptr) {
+    batch_get_leaves(ctx, b, &leaf, 1, row_out, sib_out, tables);
 }
 
 }  // namespace ola

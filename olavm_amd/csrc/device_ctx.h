@@ -54,6 +54,12 @@ struct DeviceCtx {
     std::multimap<size_t, void*> cache;        // free blocks by size
     std::unordered_map<void*, size_t> live;    // blocks handed out
     size_t cached_bytes = 0;
+    size_t live_bytes = 0, live_peak = 0, reserved_peak = 0;   // handed out now / at most; handed out + cached at most
+    void note_alloc(size_t sz) {
+        live_bytes += sz;
+        if (live_bytes > live_peak) live_peak = live_bytes;
+        if (live_bytes + cached_bytes > reserved_peak) reserved_peak = live_bytes + cached_bytes;
+    }
 
     static size_t round_size(size_t bytes) {
         const size_t g = bytes >= (1u << 20) ? (2u << 20) : 256;
@@ -80,6 +86,7 @@ struct DeviceCtx {
             void* p = it->second;
             live[p] = it->first;
             cached_bytes -= it->first;
+            note_alloc(it->first);
             cache.erase(it);
             return p;
         }
@@ -92,6 +99,7 @@ struct DeviceCtx {
         }
         if (e != hipSuccess) throw OlaError(-3, std::string("hipMalloc(") + std::to_string(want) + "): " + hipGetErrorString(e));
         live[p] = want;
+        note_alloc(want);
         return p;
     }
     void free(void* p) {
@@ -100,6 +108,7 @@ struct DeviceCtx {
         if (it == live.end()) { (void)hipFree(p); return; }
         cache.emplace(it->second, p);
         cached_bytes += it->second;
+        live_bytes -= it->second;
         live.erase(it);
     }
     ~DeviceCtx() {

@@ -301,8 +301,8 @@ static ExtPow make_ext_pow(DevBuf& mem, Ext2 z, int log_n) {
 // Opened rows and Merkle paths of the query indices.  Under the coset partition a leaf lives on the rank that owns its
 // coset: every rank fills the records of its own queries, the records are all-gathered and each query is read from its
 // owner's copy (paths end at the owner's cap slice, which is a slice of the full cap).
-static void query_leaves(DeviceCtx* ctx, const OlaBatch& b, const size_t* xs, int nq, int depth, u64* rows_out, u64* paths_out) {
-    if (!b.is_shard()) { batch_get_leaves(ctx, b, xs, nq, rows_out, paths_out); return; }
+static void query_leaves(DeviceCtx* ctx, NttTables& tables, const OlaBatch& b, const size_t* xs, int nq, int depth, u64* rows_out, u64* paths_out) {
+    if (!b.is_shard()) { batch_get_leaves(ctx, b, xs, nq, rows_out, paths_out, &tables); return; }
     const size_t n_loc = b.num_leaves(), first = (size_t)b.coset_first << b.log_n;
     const size_t dwords = (size_t)std::max(depth, 0) * 4, rec = b.ncols + dwords;
     const uint32_t world = ctx->shard.world;
@@ -311,7 +311,7 @@ static void query_leaves(DeviceCtx* ctx, const OlaBatch& b, const size_t* xs, in
     for (int r = 0; r < nq; r++)
         if (xs[r] >= first && xs[r] < first + n_loc) { mine_idx.push_back(xs[r] - first); mine_pos.push_back(r); }
     std::vector<u64> lrows(mine_idx.size() * b.ncols), lpaths(mine_idx.size() * std::max<size_t>(dwords, 1));
-    if (!mine_idx.empty()) batch_get_leaves(ctx, b, mine_idx.data(), mine_idx.size(), lrows.data(), lpaths.data());
+    if (!mine_idx.empty()) batch_get_leaves(ctx, b, mine_idx.data(), mine_idx.size(), lrows.data(), lpaths.data(), &tables);
     std::vector<u64> send((size_t)nq * rec, 0), recv((size_t)world * nq * rec);
     for (size_t k = 0; k < mine_idx.size(); k++) {
         u64* d = send.data() + (size_t)mine_pos[k] * rec;
@@ -562,7 +562,7 @@ void open_and_prove(DeviceCtx* ctx, NttTables& tables, const OlaGpuConfig& cfg, 
     for (int o = 0; o < 3; o++) {
         rows[o].resize((size_t)nq * oracles[o]->ncols);
         paths[o].resize((size_t)nq * (size_t)std::max(depth0, 1) * 4);
-        query_leaves(ctx, *oracles[o], xs.data(), nq, depth0, rows[o].data(), paths[o].data());
+        query_leaves(ctx, tables, *oracles[o], xs.data(), nq, depth0, rows[o].data(), paths[o].data());
     }
     // per layer: leaves (arity ext) and paths at x >> (sum of arity bits so far + this)
     std::vector<std::vector<u64>> lrows(layers.size()), lpaths(layers.size());

@@ -409,9 +409,11 @@ static std::vector<int> ntt3_strided_plan(int sb) {
     return split_even(sb, np);
 }
 
+// Off unless OLA_NTT3=1 (read at every call, so that tests can switch): on this chip the T-form passes come out level with the
+// second-generation ones (DESIGN.md "NTT: what the third generation measured"), and their multiplier tables cost memory.
 static bool ntt3_enabled() {
-    static const bool on = [] { const char* e = getenv("OLA_NTT3"); return !(e && *e == '0'); }();
-    return on;
+    const char* e = getenv("OLA_NTT3");
+    return e && *e == '1';
 }
 
 // Same contract as ntt2_run below, for L >= 18 and the coset family of the LDE (sc_rate_bits >= 0) or no pre-scale (-2).

@@ -9,13 +9,47 @@
 
 namespace ola {
 
-// 256 threads, 32 elements each; two workgroups per CU (64 KB of LDS each, <= 256 VGPRs).  Grid: x = column, y = tile, so
-// that workgroups launched together read the same 64 KB slice of the pass-multiplier table (p.col_major = 0 swaps the roles).
-template <int R, int MODE, bool INV>
-__global__ __launch_bounds__(N3_THREADS, 2) void ntt3_pass_kernel(N3Params p, int col_major) {
+// 256 threads, 32 elements each.  WPS = waves per SIMD the kernel is built for: 2 (two workgroups per CU, 64 KB of LDS each,
+// elements exchanged as two 8-byte halves) or 3 (three workgroups, <= 168 VGPRs, 32 KB of LDS, exchanged limb by limb).
+// Grid: x = column, y = tile, so that workgroups launched together read the same 64 KB slice of the pass-multiplier table
+// (col_major = 0 swaps the roles).
+template <int R, int MODE, bool INV, int RND, int WPS>
+__device__ __forceinline__ void n3_exchange(int tid, T4<i32> (&x)[N3_REGS], unsigned char* smem, bool first) {
+    if (WPS == 2) {
+        u64* lds = reinterpret_cast<u64*>(smem);
+        if (!first) __syncthreads();   // the buffer may still be read by the previous exchange
+        n3_xchg_write<R, MODE, RND, 0, i32>(tid, x, lds);
+        __syncthreads();
+        n3_xchg_read<R, MODE, RND, 0, i32>(tid, x, lds);
+        __syncthreads();
+        n3_xchg_write<R, MODE, RND, 1, i32>(tid, x, lds);
+        __syncthreads();
+        n3_xchg_read<R, MODE, RND, 1, i32>(tid, x, lds);
+    } else {
+        u32* lds = reinterpret_cast<u32*>(smem);
+        if (!first) __syncthreads();
+        n3_xchg4_write<R, MODE, RND, 0, i32>(tid, x, lds);
+        __syncthreads();
+        n3_xchg4_read<R, MODE, RND, 0, i32>(tid, x, lds);
+        __syncthreads();
+        n3_xchg4_write<R, MODE, RND, 1, i32>(tid, x, lds);
+        __syncthreads();
+        n3_xchg4_read<R, MODE, RND, 1, i32>(tid, x, lds);
+        __syncthreads();
+        n3_xchg4_write<R, MODE, RND, 2, i32>(tid, x, lds);
+        __syncthreads();
+        n3_xchg4_read<R, MODE, RND, 2, i32>(tid, x, lds);
+        __syncthreads();
+        n3_xchg4_write<R, MODE, RND, 3, i32>(tid, x, lds);
+        __syncthreads();
+        n3_xchg4_read<R, MODE, RND, 3, i32>(tid, x, lds);
+    }
+}
+
+template <int R, int MODE, bool INV, int WPS>
+__global__ __launch_bounds__(N3_THREADS, WPS) void ntt3_pass_kernel(N3Params p, int col_major) {
     typedef N3Cfg<R, MODE> C;
     extern __shared__ __attribute__((aligned(16))) unsigned char n3_smem[];
-    u64* lds = reinterpret_cast<u64*>(n3_smem);
     const int tid = threadIdx.x;
     const u32 coset = blockIdx.z;
     const u32 tile = col_major ? blockIdx.y : blockIdx.x;
@@ -25,53 +59,72 @@ __global__ __launch_bounds__(N3_THREADS, 2) void ntt3_pass_kernel(N3Params p, in
     const u64* __restrict__ in = p.in + col * p.in_col_stride + coset * p.in_coset_stride;
     u64* __restrict__ out = p.out + col * p.out_col_stride + coset * p.out_coset_stride;
     T4<i32> x[N3_REGS];
-    n3_load<R, MODE, i32>(p, a, in, tid, coset, x);
-    n3_round<R, MODE, INV, 0, i32>(p, a, tid, coset, x);
+    constexpr int G = (WPS == 2) ? 8 : 4;
+    n3_load<R, MODE, i32, G>(p, a, in, tid, coset, x);
+    n3_round<R, MODE, INV, 0, i32, G>(p, a, tid, coset, x);
     if constexpr (C::NR > 1) {
-        n3_xchg_write<R, MODE, 0, 0, i32>(tid, x, lds);
-        __syncthreads();
-        n3_xchg_read<R, MODE, 0, 0, i32>(tid, x, lds);
-        __syncthreads();
-        n3_xchg_write<R, MODE, 0, 1, i32>(tid, x, lds);
-        __syncthreads();
-        n3_xchg_read<R, MODE, 0, 1, i32>(tid, x, lds);
-        n3_round<R, MODE, INV, 1, i32>(p, a, tid, coset, x);
+        n3_exchange<R, MODE, INV, 0, WPS>(tid, x, n3_smem, true);
+        n3_round<R, MODE, INV, 1, i32, G>(p, a, tid, coset, x);
     }
     if constexpr (C::NR > 2) {
-        __syncthreads();
-        n3_xchg_write<R, MODE, 1, 0, i32>(tid, x, lds);
-        __syncthreads();
-        n3_xchg_read<R, MODE, 1, 0, i32>(tid, x, lds);
-        __syncthreads();
-        n3_xchg_write<R, MODE, 1, 1, i32>(tid, x, lds);
-        __syncthreads();
-        n3_xchg_read<R, MODE, 1, 1, i32>(tid, x, lds);
-        n3_round<R, MODE, INV, 2, i32>(p, a, tid, coset, x);
+        n3_exchange<R, MODE, INV, 1, WPS>(tid, x, n3_smem, false);
+        n3_round<R, MODE, INV, 2, i32, G>(p, a, tid, coset, x);
     }
     if (MODE == N3_LAST_BITREV) {
-        __syncthreads();
-        n3_final_write<R, MODE, i32>(tid, x, lds);
-        __syncthreads();
-        n3_final_store<R, MODE>(a, out, tid, lds);
+        if (WPS == 2) {
+            u64* lds = reinterpret_cast<u64*>(n3_smem);
+            __syncthreads();
+            n3_final_write<R, MODE, i32>(tid, x, lds);
+            __syncthreads();
+            n3_final_store<R, MODE>(a, out, tid, lds);
+        } else {
+            u32* lds = reinterpret_cast<u32*>(n3_smem);
+            u64 c[N3_REGS];
+#pragma unroll
+            for (int j = 0; j < N3_REGS; j++) c[j] = tf_to_u64(x[j]);
+            u32 wl[N3_REGS], wh[N3_REGS];
+            __syncthreads();
+            n3_final4_write<R, MODE, 0>(tid, c, lds);
+            __syncthreads();
+            n3_final4_read<0>(tid, wl, lds);
+            __syncthreads();
+            n3_final4_write<R, MODE, 1>(tid, c, lds);
+            __syncthreads();
+            n3_final4_read<1>(tid, wh, lds);
+#pragma unroll
+            for (int jj = 0; jj < N3_REGS; jj++) *n3_at(out + a.tile_base + (jj << 8), (u32)tid) = (u64)wl[jj] | ((u64)wh[jj] << 32);
+        }
     } else {
         n3_store_direct<R, MODE, i32>(a, out, tid, x);
     }
 }
 
-template <int R, int MODE, bool INV>
-static void n3_launch_t(const N3Params& p, size_t cols, size_t cosets, hipStream_t stream) {
-    auto kern = ntt3_pass_kernel<R, MODE, INV>;
-    const size_t lds_bytes = (size_t)8 << N3_TILE_BITS;
+static int n3_env(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+
+template <int R, int MODE, bool INV, int WPS>
+static void n3_launch_w(const N3Params& p, size_t cols, size_t cosets, hipStream_t stream) {
+    auto kern = ntt3_pass_kernel<R, MODE, INV, WPS>;
+    const size_t lds_bytes = (size_t)(WPS == 2 ? 8 : 4) << N3_TILE_BITS;
     static bool attr_set = false;
     if (!attr_set) {
         HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
         attr_set = true;
     }
-    static const int col_major = [] { const char* e = getenv("OLA_NTT3_COL_MAJOR"); return e ? atoi(e) : 1; }();
+    static const int col_major = n3_env("OLA_NTT3_COL_MAJOR", 1);
     const size_t tiles = (size_t)1 << (p.log_n - N3_TILE_BITS);
     const bool cm = col_major && tiles <= 65535;
     dim3 grid(cm ? (unsigned)cols : (unsigned)tiles, cm ? (unsigned)tiles : (unsigned)cols, (unsigned)cosets);
     hipLaunchKernelGGL(kern, grid, dim3(N3_THREADS), lds_bytes, stream, p, cm ? 1 : 0);
+}
+
+template <int R, int MODE, bool INV>
+static void n3_launch_t(const N3Params& p, size_t cols, size_t cosets, hipStream_t stream) {
+    static const int wps = n3_env("OLA_NTT3_WPS", 2);
+    if (wps == 3) n3_launch_w<R, MODE, INV, 3>(p, cols, cosets, stream);
+    else n3_launch_w<R, MODE, INV, 2>(p, cols, cosets, stream);
 }
 
 template <bool INV>

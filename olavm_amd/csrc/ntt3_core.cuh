@@ -187,7 +187,7 @@ GL_HD P* n3_at(P* uniform_base, u32 lane_elems) {   // uniform pointer + 32-bit 
 }
 
 // ---------------------------------------------------------------------------------------------------- per-thread phases
-template <int R, int MODE, class I>
+template <int R, int MODE, class I, int N3G = N3_GROUP>
 GL_HD void n3_load(const N3Params& p, const N3Addr<R, MODE>& a, const u64* in, int tid, u32 coset, T4<I> (&x)[N3_REGS]) {
     typedef N3Cfg<R, MODE> C;
     const int tt = C::tid_t(0, tid);
@@ -197,20 +197,25 @@ GL_HD void n3_load(const N3Params& p, const N3Addr<R, MODE>& a, const u64* in, i
     if (MODE == N3_STRIDED && p.sc_dig) {
         const u64* dig = p.sc_dig + ((size_t)coset << R);
         const u32 dl = (u32)C::d_of(tt);
+        u64 w[2][N3G];
+        auto fetch = [&](int g, u64 (&dst)[N3G]) {
 #pragma unroll
-        for (int g = 0; g < N3_REGS; g += N3_GROUP) {
-            u64 w[N3_GROUP];
+            for (int j = 0; j < N3G; j++) dst[j] = *n3_at(dig + C::d_of(C::reg_t(0, g + j)), dl);
+        };
+        fetch(0, w[0]);
 #pragma unroll
-            for (int j = 0; j < N3_GROUP; j++) w[j] = *n3_at(dig + C::d_of(C::reg_t(0, g + j)), dl);
+        for (int g = 0; g < N3_REGS; g += N3G) {
+            const int cur = (g / N3G) & 1;
+            if (g + N3G < N3_REGS) fetch(g + N3G, w[cur ^ 1]);
             N3_SCHED_FENCE();
 #pragma unroll
-            for (int j = 0; j < N3_GROUP; j++) x[g + j] = tf_mul(x[g + j], tf_split_u64(w[j]));
+            for (int j = 0; j < N3G; j++) x[g + j] = tf_mul(x[g + j], tf_split_u64(w[cur][j]));
             N3_SCHED_FENCE();
         }
     }
 }
 
-template <int R, int MODE, bool INV, int RND, class I>
+template <int R, int MODE, bool INV, int RND, class I, int N3G = N3_GROUP>
 GL_HD void n3_round(const N3Params& p, const N3Addr<R, MODE>& a, int tid, u32 coset, T4<I> (&x)[N3_REGS]) {
     typedef N3Cfg<R, MODE> C;
     constexpr int K = C::k(RND);
@@ -226,19 +231,25 @@ GL_HD void n3_round(const N3Params& p, const N3Addr<R, MODE>& a, int tid, u32 co
         // inside the pass: w_{2^(g+K)}^(m * qhat) = tw[m * qhat << (R - g - K)], m = the digits below this round's
         const int tt = C::tid_t(RND, tid);
         const int m = C::d_of(tt) & ((1 << C::g(RND)) - 1);
+        // table loads run one group of registers ahead of the multiplications that use them
+        u64 w[2][N3G];
+        auto fetch = [&](int g, u64 (&dst)[N3G]) {
 #pragma unroll
-        for (int g = 0; g < N3_REGS; g += N3_GROUP) {
-            u64 w[N3_GROUP];
-#pragma unroll
-            for (int j = 0; j < N3_GROUP; j++) {
+            for (int j = 0; j < N3G; j++) {
                 const int q = C::qhat(RND, g + j);
-                w[j] = q ? *n3_at(p.tw, (u32)(m * q) << (R - C::g(RND) - K)) : 1;
+                dst[j] = q ? *n3_at(p.tw, (u32)(m * q) << (R - C::g(RND) - K)) : 1;
             }
+        };
+        fetch(0, w[0]);
+#pragma unroll
+        for (int g = 0; g < N3_REGS; g += N3G) {
+            const int cur = (g / N3G) & 1;
+            if (g + N3G < N3_REGS) fetch(g + N3G, w[cur ^ 1]);
             N3_SCHED_FENCE();
 #pragma unroll
-            for (int j = 0; j < N3_GROUP; j++) {
+            for (int j = 0; j < N3G; j++) {
                 if (C::qhat(RND, g + j) == 0) x[g + j] = tf_norm(x[g + j]);   // multiplier 1: only bring the limbs back below 2^25
-                else x[g + j] = tf_mul(x[g + j], tf_split_u64(w[j]));
+                else x[g + j] = tf_mul(x[g + j], tf_split_u64(w[cur][j]));
             }
             N3_SCHED_FENCE();
         }
@@ -247,14 +258,19 @@ GL_HD void n3_round(const N3Params& p, const N3Addr<R, MODE>& a, int tid, u32 co
         const size_t mask = ((size_t)1 << (p.lo + R)) - 1;
         const u64* ptw = p.ptw + coset * p.ptw_coset_stride + (a.tile_base & mask);
         const u32 lane = (u32)a.wr_lin(C::tid_t(RND, tid));
+        u64 w[2][N3G];
+        auto fetch = [&](int g, u64 (&dst)[N3G]) {
 #pragma unroll
-        for (int g = 0; g < N3_REGS; g += N3_GROUP) {
-            u64 w[N3_GROUP];
+            for (int j = 0; j < N3G; j++) dst[j] = *n3_at(ptw + a.wr_lin(C::reg_t(RND, g + j)), lane);
+        };
+        fetch(0, w[0]);
 #pragma unroll
-            for (int j = 0; j < N3_GROUP; j++) w[j] = *n3_at(ptw + a.wr_lin(C::reg_t(RND, g + j)), lane);
+        for (int g = 0; g < N3_REGS; g += N3G) {
+            const int cur = (g / N3G) & 1;
+            if (g + N3G < N3_REGS) fetch(g + N3G, w[cur ^ 1]);
             N3_SCHED_FENCE();
 #pragma unroll
-            for (int j = 0; j < N3_GROUP; j++) x[g + j] = tf_mul(x[g + j], tf_split_u64(w[j]));
+            for (int j = 0; j < N3G; j++) x[g + j] = tf_mul(x[g + j], tf_split_u64(w[cur][j]));
             N3_SCHED_FENCE();
         }
     }
@@ -283,6 +299,38 @@ GL_HD void n3_xchg_read(int tid, T4<I> (&x)[N3_REGS], const u64* lds) {
         x[j].v[2 * H] = Tr::from_u32((u32)v);
         x[j].v[2 * H + 1] = Tr::from_u32((u32)(v >> 32));
     }
+}
+
+// the same exchange one limb (4 bytes) at a time: a 32 KB buffer, so that three workgroups fit a CU
+template <int R, int MODE, int RND, int H, class I>
+GL_HD void n3_xchg4_write(int tid, const T4<I> (&x)[N3_REGS], u32* lds) {
+    typedef N3Cfg<R, MODE> C;
+    typedef TfTraits<I> Tr;
+    const int sl = n3_slot(C::tid_t(RND, tid));
+#pragma unroll
+    for (int j = 0; j < N3_REGS; j++) lds[sl ^ n3_slot(C::reg_t(RND, j))] = Tr::to_u32_biased(x[j].v[H], 0u);
+}
+template <int R, int MODE, int RND, int H, class I>
+GL_HD void n3_xchg4_read(int tid, T4<I> (&x)[N3_REGS], const u32* lds) {
+    typedef N3Cfg<R, MODE> C;
+    typedef TfTraits<I> Tr;
+    const int sl = n3_slot(C::tid_t(RND + 1, tid));
+#pragma unroll
+    for (int j = 0; j < N3_REGS; j++) x[j].v[H] = Tr::from_u32(lds[sl ^ n3_slot(C::reg_t(RND + 1, j))]);
+}
+// ... and the closing transpose of the contiguous pass in two 4-byte halves (HALF = 0: low words)
+template <int R, int MODE, int HALF>
+GL_HD void n3_final4_write(int tid, const u64 (&c)[N3_REGS], u32* lds) {
+    typedef N3Cfg<R, MODE> C;
+    constexpr int last = C::NR - 1;
+    const int sl = n3_slot(C::tid_t(last, tid));
+#pragma unroll
+    for (int j = 0; j < N3_REGS; j++) lds[sl ^ n3_slot(C::reg_t(last, j))] = (u32)(c[j] >> (32 * HALF));
+}
+template <int HALF>
+GL_HD void n3_final4_read(int tid, u32 (&w)[N3_REGS], const u32* lds) {
+#pragma unroll
+    for (int jj = 0; jj < N3_REGS; jj++) w[jj] = lds[n3_slot(tid) ^ n3_slot(jj << 8)];
 }
 
 // strided and natural-order passes store straight from the last round's registers (lanes run along the batch bits)

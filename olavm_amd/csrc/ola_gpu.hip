@@ -311,7 +311,7 @@ int32_t ola_batch_get_leaf(OlaCtx* ctx, const OlaBatch* b, size_t leaf_index, ui
     OLA_TRY
     require(ctx && b && row_out, "null pointer");
     require(leaf_index < b->num_leaves(), "leaf index out of range");
-    batch_get_leaf(&ctx->dev, *b, leaf_index, (u64*)row_out, (u64*)siblings_out);
+    batch_get_leaf(&ctx->dev, *b, leaf_index, (u64*)row_out, (u64*)siblings_out, &*ctx->tables);
     OLA_CATCH
 }
 static void require_full(const OlaBatch* b) {
@@ -325,7 +325,7 @@ int32_t ola_batch_get_lde_row(OlaCtx* ctx, const OlaBatch* b, size_t index, size
     require(step == 0 || index <= b->num_leaves() / step, "row index out of range");
     const size_t nat = index * step;
     require(nat < b->num_leaves(), "row index out of range");
-    batch_get_leaf(&ctx->dev, *b, bitrev32((u32)nat, b->log_n + b->rate_bits), (u64*)row_out, nullptr);
+    batch_get_leaf(&ctx->dev, *b, bitrev32((u32)nat, b->log_n + b->rate_bits), (u64*)row_out, nullptr, &*ctx->tables);
     OLA_CATCH
 }
 
@@ -471,6 +471,15 @@ int32_t ola_gpu_trim(OlaCtx* ctx) {
     OLA_TRY
     require(ctx, "ctx");
     ctx->dev.release_cache();
+    OLA_CATCH
+}
+
+int32_t ola_gpu_memory_stats(OlaCtx* ctx, uint64_t out[4], int32_t reset) {
+    OLA_TRY
+    require(ctx && out, "null pointer");
+    DeviceCtx& d = ctx->dev;
+    out[0] = d.live_bytes; out[1] = d.live_peak; out[2] = d.live_bytes + d.cached_bytes; out[3] = d.reserved_peak;
+    if (reset) { d.live_peak = d.live_bytes; d.reserved_peak = d.live_bytes + d.cached_bytes; }
     OLA_CATCH
 }
 

@@ -303,7 +303,7 @@ __global__ __launch_bounds__(QW) void quotient_kernel(QuotParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u64* regs = reinterpret_cast<u64*>(smem_raw);
     const int lane = threadIdx.x;
-    const size_t size = P.out_plane;   // points this launch evaluates (the rank's cosets of the quotient domain)
+    const size_t size = P.npoints ? P.npoints : P.out_plane;   // points this launch evaluates (the rank's cosets of the quotient domain)
     const size_t j = (size_t)blockIdx.x * QW + lane;
     const bool active = j < size;
     const size_t jj = active ? j : 0;
@@ -409,7 +409,7 @@ __global__ __launch_bounds__(QW) void quotient_kernel(QuotParams P) {
     }
     if (active) {
         P.out[j] = gl_mul(acc0, zh_inv);
-        P.out[size + j] = gl_mul(acc1, zh_inv);
+        P.out[P.out_plane + j] = gl_mul(acc1, zh_inv);
     }
 }
 
@@ -451,11 +451,11 @@ static void write_cap(ByteWriter& w, const std::vector<u64>& cap) { w.cap(cap.da
 // PolynomialBatch::from_values / from_coeffs for the whole table, or -- under the coset partition -- this rank's share of
 // it; either way `cap_full` receives the complete Merkle cap (all-gathered from the ranks' slices when sharded).
 static OlaBatch* commit_shared(DeviceCtx* ctx, NttTables& t, const u64* dev_cols, uint32_t ncols, uint32_t log_n, const OlaGpuConfig& cfg,
-                               bool from_values, bool sharded, const ColumnFeed* feed, std::vector<u64>& cap_full) {
+                               bool from_values, bool sharded, const ColumnFeed* feed, std::vector<u64>& cap_full, bool lean = false) {
     const size_t len_cap = (size_t)1 << cfg.cap_height;
     cap_full.assign(len_cap * 4, 0);
     if (!sharded) {
-        OlaBatch* b = batch_commit(ctx, t, nullptr, dev_cols, ncols, log_n, cfg.rate_bits, cfg.cap_height, from_values, 0, 0, feed);
+        OlaBatch* b = batch_commit(ctx, t, nullptr, dev_cols, ncols, log_n, cfg.rate_bits, cfg.cap_height, from_values, 0, 0, feed, lean);
         try { batch_read_cap(ctx, *b, cap_full.data()); } catch (...) { batch_destroy(ctx, b); throw; }
         return b;
     }
@@ -573,7 +573,9 @@ static void prove_single_table(DeviceCtx* ctx, NttTables& tables, const OlaGpuCo
     std::unique_ptr<PhaseTimer> ph(new PhaseTimer(ctx, "    compute permutation/CTL Z commitment"));
     BatchHolder zs_c(ctx);
     std::vector<u64> zs_cap;
-    zs_c.b = commit_shared(ctx, tables, zvals, (uint32_t)nz, (uint32_t)degree_bits, cfg, true, sharded, nullptr, zs_cap);
+    const bool lean = trace_c.lean;   // the table is proven memory-lean: no LDE of its three batches is kept
+    if (lean && sharded) throw OlaError(OLA_E_INTERNAL, "a memory-lean table cannot be on the coset partition");
+    zs_c.b = commit_shared(ctx, tables, zvals, (uint32_t)nz, (uint32_t)degree_bits, cfg, true, sharded, nullptr, zs_cap, lean);
     challenger_observe(ch, zs_cap.data(), zs_cap.size());
     const u64 alpha0 = challenger_get(ch), alpha1 = challenger_get(ch);
 
@@ -587,12 +589,12 @@ static void prove_single_table(DeviceCtx* ctx, NttTables& tables, const OlaGpuCo
     const size_t size = n << qdb;
     // Lagrange first/last on the LDE domain (leaf order)
     u64* lag_coef = mem.alloc(2 * n);
-    u64* lag_lde = mem.alloc(2 * N_loc);
+    u64* lag_lde = mem.alloc(2 * (lean ? n : N_loc));
     {
         TwoLevel gt = get_two(tables, degree_bits, 0);
         const u64 n_inv = gl_inv(((u64)1 << degree_bits) % GL_P);
         hipLaunchKernelGGL(lagrange_coeffs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, lag_coef, n, n_inv, gt.lo, gt.hi, gt.h);
-        ntt_lde_leaf_order(tables, lag_coef, lag_lde, degree_bits, rate_bits, 2, coset_first, coset_count);
+        if (!lean) ntt_lde_leaf_order(tables, lag_coef, lag_lde, degree_bits, rate_bits, 2, coset_first, coset_count);
     }
     // descriptor for the kernel
     std::vector<u64> desc(18, 0);
@@ -643,18 +645,19 @@ static void prove_single_table(DeviceCtx* ctx, NttTables& tables, const OlaGpuCo
         for (auto& jb : ctl) twcs.push_back(jb.twc);
         // the specialised kernels address rows as "workgroup base + lane" and need n >= AIRQ_THREADS (airq.cuh)
         const AirKernelEntry* spec = (force_interp || n < AIRQ_THREADS) ? nullptr : find_air_kernel(air_signature(air, twcs));
-        auto run_interpreter = [&](u64* out) {
-            P.out = out;
-            const size_t lds = (size_t)air.n_regs * QW * 8;
-            if (lds > 160 * 1024) throw OlaError(OLA_E_INVALID_ARG, "constraint program needs too many registers");
-            if (lds > 48 * 1024)
-                HIP_CHECK(hipFuncSetAttribute((const void*)quotient_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(quotient_kernel, dim3((unsigned)((plane + QW - 1) / QW)), dim3(QW), lds, ctx->stream, P);
-        };
-        if (!spec) {
-            run_interpreter(qloc);
-        } else {
-            const int K = spec->n_emits;
+        // memory-lean: the trace and Z values of one coset at a time, re-derived from the coefficients; the quotient of a table
+        // with 2^qdb < 2^rate_bits cosets lives on the first 2^qdb cosets of the leaf order
+        u64 *slice_t = nullptr, *slice_z = nullptr;
+        const size_t lean_cosets = lean ? ((size_t)1 << qdb) : 1;
+        if (lean) {
+            slice_t = mem.alloc((size_t)trace_c.ncols * n);
+            slice_z = mem.alloc((size_t)zs_c.b->ncols * n);
+            P.trace_lde = slice_t; P.zs_lde = slice_z; P.N = n; P.npoints = n;
+        }
+        u64* d_sd = nullptr;
+        int K = 0;
+        if (spec) {
+            K = spec->n_emits;
             std::vector<u64> sd(8 + 2 * (size_t)K, 0);
             for (int c = 0; c < (1 << qdb); c++) sd[c] = desc[10 + c];
             const u64 al[2] = {alpha0, alpha1};
@@ -675,23 +678,48 @@ static void prove_single_table(DeviceCtx* ctx, NttTables& tables, const OlaGpuCo
                 u64 bp = 1;
                 for (size_t k = 0; k < jb.twc->columns.size(); k++) { sd.push_back(bp); bp = gl_mul(bp, jb.ch.beta); }
             }
-            u64* d_sd = mem.alloc(sd.size());
+            d_sd = mem.alloc(sd.size());
             HIP_CHECK(hipMemcpyAsync(d_sd, sd.data(), sd.size() * 8, hipMemcpyHostToDevice, ctx->stream));
             HIP_CHECK(hipStreamSynchronize(ctx->stream));   // sd is a stack-lifetime staging buffer
-            QuotParams S = P;
-            S.desc = d_sd;
-            hipLaunchKernelGGL(spec->kernel, dim3((unsigned)((plane + AIRQ_THREADS - 1) / AIRQ_THREADS)), dim3(AIRQ_THREADS), 0, ctx->stream, S);
-            if (crosscheck) {
-                u64* qv2 = mem.alloc(2 * plane);
-                run_interpreter(qv2);
-                unsigned* d_flag = (unsigned*)mem.alloc(1);
-                HIP_CHECK(hipMemsetAsync(d_flag, 0, 8, ctx->stream));
-                hipLaunchKernelGGL(any_diff_kernel, dim3((unsigned)((2 * plane + 255) / 256)), dim3(256), 0, ctx->stream, qloc, qv2, 2 * plane, d_flag);
-                unsigned flag = 0;
-                HIP_CHECK(hipMemcpyAsync(&flag, d_flag, 4, hipMemcpyDeviceToHost, ctx->stream));
-                HIP_CHECK(hipStreamSynchronize(ctx->stream));
-                if (flag) throw OlaError(OLA_E_INTERNAL, std::string("specialised quotient kernel disagrees with the interpreter: ") + spec->name);
+        }
+        u64* qv2 = (spec && crosscheck) ? mem.alloc(2 * plane) : nullptr;
+        for (size_t lc = 0; lc < lean_cosets; lc++) {
+            u64* out = qloc;
+            size_t points = plane;
+            if (lean) {
+                batch_lde_slice(ctx, tables, trace_c, lc, slice_t);
+                batch_lde_slice(ctx, tables, *zs_c.b, lc, slice_z);
+                ntt_lde_leaf_order(tables, lag_coef, lag_lde, degree_bits, rate_bits, 2, lc, 1);
+                P.coset_first = (u32)lc;
+                out = qloc + lc * n;
+                points = n;
             }
+            auto run_interp_on = [&](u64* o) {
+                P.out = o;
+                const size_t lds = (size_t)air.n_regs * QW * 8;
+                if (lds > 160 * 1024) throw OlaError(OLA_E_INVALID_ARG, "constraint program needs too many registers");
+                if (lds > 48 * 1024)
+                    HIP_CHECK(hipFuncSetAttribute((const void*)quotient_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                hipLaunchKernelGGL(quotient_kernel, dim3((unsigned)((points + QW - 1) / QW)), dim3(QW), lds, ctx->stream, P);
+            };
+            if (!spec) {
+                run_interp_on(out);
+            } else {
+                QuotParams S = P;
+                S.desc = d_sd;
+                S.out = out;
+                hipLaunchKernelGGL(spec->kernel, dim3((unsigned)((points + AIRQ_THREADS - 1) / AIRQ_THREADS)), dim3(AIRQ_THREADS), 0, ctx->stream, S);
+                if (crosscheck) run_interp_on(qv2 + (lean ? lc * n : 0));
+            }
+        }
+        if (spec && crosscheck) {
+            unsigned* d_flag = (unsigned*)mem.alloc(1);
+            HIP_CHECK(hipMemsetAsync(d_flag, 0, 8, ctx->stream));
+            hipLaunchKernelGGL(any_diff_kernel, dim3((unsigned)((2 * plane + 255) / 256)), dim3(256), 0, ctx->stream, qloc, qv2, 2 * plane, d_flag);
+            unsigned flag = 0;
+            HIP_CHECK(hipMemcpyAsync(&flag, d_flag, 4, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_CHECK(hipStreamSynchronize(ctx->stream));
+            if (flag) throw OlaError(OLA_E_INTERNAL, std::string("specialised quotient kernel disagrees with the interpreter: ") + spec->name);
         }
     }
     if (sharded) {
@@ -726,7 +754,7 @@ static void prove_single_table(DeviceCtx* ctx, NttTables& tables, const OlaGpuCo
     ph.reset(new PhaseTimer(ctx, "    compute quotient commitment"));
     BatchHolder q_c(ctx);
     std::vector<u64> q_cap;
-    q_c.b = commit_shared(ctx, tables, chunks, (uint32_t)(2 * q), (uint32_t)degree_bits, cfg, false, sharded, nullptr, q_cap);
+    q_c.b = commit_shared(ctx, tables, chunks, (uint32_t)(2 * q), (uint32_t)degree_bits, cfg, false, sharded, nullptr, q_cap, lean);
     challenger_observe(ch, q_cap.data(), q_cap.size());
 
     // ---- write_proof (serialization.rs:349-358): caps, then opening set + FRI proof ----
@@ -859,6 +887,33 @@ void prove_with_traces(DeviceCtx* ctx, NttTables& tables, const OlaGpuConfig& cf
     }
     // The traces are pageable host memory: a helper thread pushes them to the device in column groups on its own stream
     // while this thread already interpolates / extends / hashes what has arrived (H2D of a 2^22-row instance is ~75 ms).
+    // Memory-lean tables (OLA_LEAN=1 forces, =0 forbids, default: when keeping every LDE resident would not fit): the LDEs of
+    // the large tables are streamed coset by coset instead of kept (batch_commit lean) -- a 2^24-row CPU table then proves on
+    // one GPU (fri/oracle.rs:66-99 holds all of it; the reference's GPU shim was sized for 2^24, cfft/ntt/mod.rs:13).
+    std::vector<char> lean(nt, 0);
+    {
+        const char* e = getenv("OLA_LEAN");
+        const int mode = e ? atoi(e) : -1;
+        size_t need = 0;
+        std::vector<size_t> per(nt, 0);
+        for (size_t t = 0; t < nt; t++) {
+            const HTable& air = set.tables[t];
+            const size_t n_t = (size_t)1 << log_n[t];
+            size_t nctl = 0;
+            for (const HCtl& c : set.ctls) { for (const HTwc& w2 : c.looking) nctl += ((size_t)w2.table == t) ? nch : 0; nctl += ((size_t)c.looked.table == t) ? nch : 0; }
+            const size_t wz = air.num_permutation_batches(nch) + nctl, wq = (size_t)nch * air.quotient_degree_factor();
+            const size_t w_all = air.ncols + wz + wq;
+            per[t] = w_all * n_t * 8 * ((size_t)1 << cfg.rate_bits) + 3 * 2 * (n_t << cfg.rate_bits) * 32;   // LDEs + digest heaps
+            need += per[t] + (air.ncols + w_all) * n_t * 8;                                                   // + values + coefficients
+        }
+        size_t free_b = 0, total_b = 0;
+        (void)hipMemGetInfo(&free_b, &total_b);
+        const size_t budget = (size_t)(0.80 * (double)(free_b + ctx->cached_bytes));
+        const bool want = mode == 1 || (mode != 0 && need > budget);
+        if (want && ctx->shard.world <= 1)
+            for (size_t t = 0; t < nt; t++) lean[t] = (mode == 1) ? (log_n[t] >= 1) : (log_n[t] >= 20);
+        if (ctx->timing) fprintf(stderr, "[ola-timing] resident proof would need about %.1f GB, %.1f GB available: %s\n", need / 1e9, budget / 1e9, want ? "memory-lean (coset-streamed) large tables" : "all LDEs resident");
+    }
     TraceUploader up(ctx, nt);
     for (size_t t = 0; t < nt; t++) up.add(t, traces[t], dev[t].vals, (uint32_t)set.tables[t].ncols, (size_t)1 << log_n[t]);
     up.start();
@@ -873,7 +928,7 @@ void prove_with_traces(DeviceCtx* ctx, NttTables& tables, const OlaGpuConfig& cf
         };
         commits.emplace_back(new BatchHolder(ctx));
         commits[t]->b = commit_shared(ctx, tables, dev[t].vals, (uint32_t)set.tables[t].ncols, log_n[t], cfg, true,
-                                      table_is_sharded(ctx, cfg, set.tables[t], log_n[t]), &feed, caps[t]);
+                                      table_is_sharded(ctx, cfg, set.tables[t], log_n[t]), &feed, caps[t], lean[t] != 0);
     }
     up.finish();
     for (size_t t = 0; t < nt; t++) challenger_observe(ch, caps[t].data(), caps[t].size());

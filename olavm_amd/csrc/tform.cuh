@@ -44,7 +44,7 @@ struct T4 {
 template <class I> GL_HD void tf_pin(T4<I>&) {}
 GL_HD void tf_pin(T4<i32>& y) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    asm volatile("" : "+v"(y.v[0]), "+v"(y.v[1]), "+v"(y.v[2]), "+v"(y.v[3]));
+    asm("" : "+v"(y.v[0]), "+v"(y.v[1]), "+v"(y.v[2]), "+v"(y.v[3]));   // not volatile: only a data dependence, free to schedule
 #else
     (void)y;
 #endif
@@ -153,9 +153,14 @@ GL_HD TfTw tf_split_u64(u64 w) {
     return t;
 }
 template <class I>
-GL_HD T4<I> tf_mul(const T4<I>& x, const TfTw& w) {
+GL_HD T4<I> tf_mul(const T4<I>& x_in, const TfTw& w) {
     typedef TfTraits<I> Tr;
     typedef typename Tr::W W;
+    // Hide what the compiler knows about the limbs' bits.  When both factors are known to fit 24 bits (an element straight
+    // from tf_from_u64), hipcc 7.2 forms 24-bit multiplies, drops the operand masks they make redundant, and then re-combines
+    // some of them into v_mad_u64_u32 on the UNMASKED words: wrong products (found by tests/gpu_ntt3_selftest.cpp).
+    T4<I> x = x_in;
+    tf_pin(x);
     const I w0 = Tr::from_u32((u32)w.w0), w1 = Tr::from_u32((u32)w.w1), w2 = Tr::from_u32((u32)w.w2);
     const I n2 = -x.v[2], n3 = -x.v[3];
     // z_k = sum_{i+j=k} x_i w_j - sum_{i+j=k+4} x_i w_j

@@ -290,6 +290,7 @@ static int check_case(int L, bool inverse, bool natural_out, bool coset, const c
     return bad != 0;
 }
 
+#ifndef NTT3_NO_MAIN
 int main(int argc, char** argv) {
     int fails = 0;
     // arithmetic: T-form <-> canonical, multiply, shifts
@@ -336,3 +337,4 @@ int main(int argc, char** argv) {
     printf(fails ? "FAILED\n" : "all ok\n");
     return fails ? 1 : 0;
 }
+#endif

@@ -25,7 +25,7 @@ P = 0xFFFFFFFF00000001
 def be():
     import torch
     from olavm_amd.backend import Backend
-    b = Backend(device=0, stream=torch.cuda.current_stream().cuda_stream)
+    b = Backend(device=0)         # a stream of its own: the tests synchronise torch's work before every call
     yield b
     b.close()
 
@@ -51,6 +51,7 @@ def test_config2_ntt_full_size(be, oracle, log_n, cols):
     pts = np.array([oracle.pow(w, k) for k in ks], dtype=np.uint64)
     for label, x in (("splitmix64", splitmix_columns(torch, cols, n)), ("adversarial", adversarial_columns(torch, cols, n))):
         out, back, scratch = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
+        torch.cuda.synchronize()          # the library runs on its own stream: the inputs must be complete before it is called
         be.ntt_dev(OLA_NTT_EVALUATE, x.data_ptr(), out.data_ptr(), log_n, cols, scratch_ptr=scratch.data_ptr())
         be.ntt_dev(OLA_NTT_INTERPOLATE, out.data_ptr(), back.data_ptr(), log_n, cols, scratch_ptr=scratch.data_ptr())
         torch.cuda.synchronize()
@@ -77,6 +78,7 @@ def test_config2_coset_lde_full_size(be, oracle, log_n, cols):
     x = splitmix_columns(torch, cols, n)
     lde = torch.empty((cols, N), dtype=torch.int64, device="cuda")
     scratch = torch.empty_like(lde)
+    torch.cuda.synchronize()              # the library runs on its own stream: the inputs must be complete before it is called
     be.ntt_dev(OLA_NTT_COSET_LDE, x.data_ptr(), lde.data_ptr(), log_n, cols, shift=7, blowup_log=3, scratch_ptr=scratch.data_ptr())
     torch.cuda.synchronize()
     w = oracle.root_of_unity(log_n + 3)
@@ -88,6 +90,7 @@ def test_config2_coset_lde_full_size(be, oracle, log_n, cols):
         assert np.array_equal(_host_col(lde[c][idx]), wv), c
     # inverse of the whole extension through a transform of a different size
     coeffs = torch.empty_like(lde)
+    torch.cuda.synchronize()
     be.ntt_dev(OLA_NTT_COSET_INTERPOLATE, lde.data_ptr(), coeffs.data_ptr(), log_n + 3, cols, shift=7, scratch_ptr=scratch.data_ptr())
     torch.cuda.synchronize()
     assert torch.equal(coeffs[:, :n], x) and not bool(coeffs[:, n:].any())

@@ -332,3 +332,24 @@ def test_long_fibonacci_execution_verifies(be, oracle, monkeypatch):
     proof = be.prove_with_traces(blob, traces, params, compress)
     rc, why = oracle.verify_all_proof(blob, proof, params)
     assert rc == 0, why
+
+
+@pytest.mark.parametrize("program", ["mixed", "fibonacci"])
+def test_memory_lean_proof_is_the_same_proof(be, oracle, monkeypatch, program):
+    """OLA_LEAN=1: no LDE is kept -- commitments hash one coset at a time, the quotient is evaluated coset by coset from
+    re-derived values, opened rows are re-derived per queried coset.  Same transcript, so the AllProof bytes must equal the
+    resident-mode proof's (and the oracle's), for tables on the specialised kernels and on the interpreter."""
+    from olavm_amd.air import miniexec as M
+    s = T.ola_stark(range_bits=4, limb_bits=2)
+    blob = s.blob()
+    traces, params, compress = M.instance(M.mixed_program() if program == "mixed" else M.fibonacci(300))
+    monkeypatch.setenv("OLA_LEAN", "0")
+    resident = be.prove_with_traces(blob, traces, params, compress)
+    monkeypatch.setenv("OLA_LEAN", "1")
+    be.memory_stats(reset=True)
+    lean = be.prove_with_traces(blob, traces, params, compress)
+    assert lean == resident
+    if program == "mixed":
+        assert lean == oracle.prove_with_traces(blob, traces, params, compress)
+    monkeypatch.setenv("OLA_AIR_KERNELS", "crosscheck")
+    assert be.prove_with_traces(blob, traces, params, compress) == resident

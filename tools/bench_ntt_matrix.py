@@ -60,6 +60,7 @@ def main():
             scratch = torch.empty_like(data)
             lde = torch.empty((cols, 8 * n), dtype=torch.int64, device="cuda")
             lde_scratch = torch.empty_like(lde)
+            torch.cuda.synchronize()          # the library's stream is not torch's: inputs must be complete before it is called
             ops = [("ntt", OLA_NTT_EVALUATE, data, out, scratch, log_n, 0, 16),
                    ("intt", OLA_NTT_INTERPOLATE, data, out, scratch, log_n, 0, 16),
                    ("coset_lde8_leaf_order", OLA_NTT_COSET_LDE_LEAF_ORDER, data, lde, lde_scratch, log_n, 3, 72),   # what commitments use
@@ -78,6 +79,7 @@ def main():
                 lde = lde_scratch = None
                 torch.cuda.empty_cache()
             for label, x in (("splitmix64", data), ("adversarial", adversarial_columns(torch, cols, n))):
+                torch.cuda.synchronize()
                 be.ntt_dev(OLA_NTT_EVALUATE, x.data_ptr(), out.data_ptr(), log_n, cols, scratch_ptr=scratch.data_ptr())
                 back = torch.empty_like(x)
                 be.ntt_dev(OLA_NTT_INTERPOLATE, out.data_ptr(), back.data_ptr(), log_n, cols, scratch_ptr=scratch.data_ptr())
@@ -89,6 +91,7 @@ def main():
                 if lde_check:
                     be.ntt_dev(OLA_NTT_COSET_LDE, x.data_ptr(), lde.data_ptr(), log_n, cols, shift=7, blowup_log=3, scratch_ptr=lde_scratch.data_ptr())
                     coeffs = torch.empty_like(lde)
+                    torch.cuda.synchronize()
                     be.ntt_dev(OLA_NTT_COSET_INTERPOLATE, lde.data_ptr(), coeffs.data_ptr(), log_n + 3, cols, shift=7, scratch_ptr=lde_scratch.data_ptr())
                     torch.cuda.synchronize()
                     ok = bool(torch.equal(coeffs[:, :n], canon)) and not bool(coeffs[:, n:].any())

@@ -1,0 +1,22 @@
+"""Cold start of the prover, phase by phase: a fresh process and context prove the 2^22-row instance twice with OLA_TIMING=1;
+the first proof's phase lines against the second's show where the cold seconds go (stderr carries the [ola-timing] lines)."""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ["OLA_TIMING"] = "1"
+log_n = int(sys.argv[1]) if len(sys.argv) > 1 else 22
+from olavm_amd.air import ola_tables as T, tracegen  # noqa: E402
+from olavm_amd.backend import Backend  # noqa: E402
+
+blob = T.ola_stark().blob()
+traces, params, compress = tracegen.empty_program_instance(log_n=10, range_bits=16, limb_bits=8, log_n_cpu=log_n, log_n_mem=log_n)
+t0 = time.perf_counter()
+be = Backend(device=0)
+print("[cold] ola_gpu_init %.3f s" % (time.perf_counter() - t0), file=sys.stderr, flush=True)
+for i in range(3):
+    print("[cold] ---- proof %d ----" % i, file=sys.stderr, flush=True)
+    t0 = time.perf_counter()
+    p = be.prove_with_traces(blob, traces, params, compress)
+    print("[cold] proof %d: %.3f s, %d bytes" % (i, time.perf_counter() - t0, len(p)), file=sys.stderr, flush=True)

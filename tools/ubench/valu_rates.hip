@@ -4,6 +4,7 @@
 // build: hipcc --offload-arch=gfx950 -O3 -o valu_rates tools/ubench/valu_rates.hip ; run on the GPU box.
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 #define REP16(x) x x x x x x x x x x x x x x x x
@@ -56,16 +57,33 @@ BENCH_KERNEL(k_xor, "v_xor_b32 %0, %0, %1\n v_xor_b32 %1, %1, %2\n v_xor_b32 %2,
 BENCH_KERNEL(k_lshl_or, "v_lshl_or_b32 %0, %0, 3, %1\n v_lshl_or_b32 %1, %1, 5, %2\n v_lshl_or_b32 %2, %2, 7, %3\n v_lshl_or_b32 %3, %3, 9, %0", "memory")
 BENCH_KERNEL(k_sub_u32, "v_sub_u32 %0, %0, %1\n v_sub_u32 %1, %1, %2\n v_sub_u32 %2, %2, %3\n v_sub_u32 %3, %3, %0", "memory")
 
+BENCH_KERNEL(k_mad_i64_i32, "v_mad_i64_i32 %4, vcc, %0, %1, %4\n v_mad_i64_i32 %5, vcc, %1, %2, %5\n v_mad_i64_i32 %6, vcc, %2, %3, %6\n v_mad_i64_i32 %7, vcc, %3, %0, %7", "vcc")
+BENCH_KERNEL(k_and_lit, "v_and_b32 %0, 0xffffff, %1\n v_and_b32 %1, 0xffffff, %2\n v_and_b32 %2, 0xffffff, %3\n v_and_b32 %3, 0xffffff, %0", "memory")
+BENCH_KERNEL(k_ashr, "v_ashrrev_i32 %0, 16, %1\n v_ashrrev_i32 %1, 16, %2\n v_ashrrev_i32 %2, 16, %3\n v_ashrrev_i32 %3, 16, %0", "memory")
+BENCH_KERNEL(k_lshl32, "v_lshlrev_b32 %0, 6, %1\n v_lshlrev_b32 %1, 6, %2\n v_lshlrev_b32 %2, 6, %3\n v_lshlrev_b32 %3, 6, %0", "memory")
+BENCH_KERNEL(k_lshr32, "v_lshrrev_b32 %0, 6, %1\n v_lshrrev_b32 %1, 6, %2\n v_lshrrev_b32 %2, 6, %3\n v_lshrrev_b32 %3, 6, %0", "memory")
+BENCH_KERNEL(k_lshl_add_u32, "v_lshl_add_u32 %0, %1, 6, %2\n v_lshl_add_u32 %1, %2, 6, %3\n v_lshl_add_u32 %2, %3, 6, %0\n v_lshl_add_u32 %3, %0, 6, %1", "memory")
+BENCH_KERNEL(k_perm, "v_perm_b32 %0, %1, %2, %3\n v_perm_b32 %1, %2, %3, %0\n v_perm_b32 %2, %3, %0, %1\n v_perm_b32 %3, %0, %1, %2", "memory")
+BENCH_KERNEL(k_add_sdwa, "v_add_u32_sdwa %0, sext(%1), %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n v_add_u32_sdwa %1, sext(%2), %3 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n v_add_u32_sdwa %2, sext(%3), %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n v_add_u32_sdwa %3, sext(%0), %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD", "memory")
+BENCH_KERNEL(k_or, "v_or_b32 %0, %0, %1\n v_or_b32 %1, %1, %2\n v_or_b32 %2, %2, %3\n v_or_b32 %3, %3, %0", "memory")
+BENCH_KERNEL(k_bfe, "v_bfe_u32 %0, %1, 8, 24\n v_bfe_u32 %1, %2, 8, 24\n v_bfe_u32 %2, %3, 8, 24\n v_bfe_u32 %3, %0, 8, 24", "memory")
+BENCH_KERNEL(k_and_or, "v_and_or_b32 %0, %1, %2, %3\n v_and_or_b32 %1, %2, %3, %0\n v_and_or_b32 %2, %3, %0, %1\n v_and_or_b32 %3, %0, %1, %2", "memory")
+// the butterfly stream: dependent adds and subs on 8 registers (as the T-form radix kernels issue them)
+BENCH_KERNEL(k_bfly, "v_add_u32 %0, %0, %1\n v_sub_u32 %1, %0, %1\n v_add_u32 %2, %2, %3\n v_sub_u32 %3, %2, %3", "memory")
+BENCH_KERNEL(k_mix, "v_mad_i64_i32 %4, vcc, %0, %1, %4\n v_and_b32 %0, 0xffffff, %2\n v_alignbit_b32 %1, %2, %3, 24\n v_add_u32 %2, %2, %3", "vcc")
+
 typedef void (*kern_t)(unsigned*, unsigned);
 struct B { const char* name; kern_t k; };
 
-int main() {
+int main(int argc, char** argv) {
+    const int waves_per_simd = argc > 1 ? atoi(argv[1]) : 8;   // 8 = saturated; 2 = what a 200-VGPR kernel runs with
     hipDeviceProp_t prop;
     hipGetDeviceProperties(&prop, 0);
     const int cus = prop.multiProcessorCount;
     const double mhz = prop.clockRate / 1000.0;
     printf("device %s, %d CUs, %.0f MHz\n", prop.name, cus, mhz);
-    const int blocks = cus * 8;  // 8 blocks x 4 waves per CU = 8 waves per SIMD
+    const int blocks = cus * waves_per_simd;  // N blocks x 4 waves per CU = N waves per SIMD
+    printf("%d waves per SIMD\n", waves_per_simd);
     unsigned* out;
     hipMalloc(&out, (size_t)blocks * 256 * 4);
     B list[] = {{"v_mov_b32", k_mov}, {"v_add_u32", k_add_u32}, {"v_add3_u32", k_add3}, {"v_add_co/addc_co_u32", k_add_co}, {"v_mul_lo_u32", k_mul_lo},
@@ -75,7 +93,10 @@ int main() {
                 {"v_alignbit_b32", k_alignbit}, {"v_pk_add_u16", k_pk_add_u16}, {"v_mad_i32_i24", k_mad_i32_i24}, {"v_dot4_u32_u8", k_dot4_u8},
                 {"cmp(vcc)+cndmask", k_cmp_cnd}, {"cmp(sgpr)+cndmask", k_cmp_cnd_sgpr}, {"cndmask sgpr mask", k_cnd_sgpr_only}, {"cndmask vcc indep", k_cnd_indep},
                 {"add_co,subb,and,add", k_carry_mask}, {"v_and_b32", k_and}, {"v_sub_co/subb_co", k_sub_co}, {"v_mad_u64_u32 chain", k_mad_u64_chain},
-                {"v_add_u32 chain", k_add_u32_chain}, {"v_xor_b32", k_xor}, {"v_lshl_or_b32", k_lshl_or}, {"v_sub_u32", k_sub_u32}};
+                {"v_add_u32 chain", k_add_u32_chain}, {"v_xor_b32", k_xor}, {"v_lshl_or_b32", k_lshl_or}, {"v_sub_u32", k_sub_u32},
+                {"v_mad_i64_i32", k_mad_i64_i32}, {"v_and_b32 literal", k_and_lit}, {"v_ashrrev_i32", k_ashr}, {"v_lshlrev_b32", k_lshl32},
+                {"v_lshrrev_b32", k_lshr32}, {"v_lshl_add_u32", k_lshl_add_u32}, {"v_perm_b32", k_perm}, {"v_add_u32_sdwa sext", k_add_sdwa},
+                {"v_or_b32", k_or}, {"v_bfe_u32", k_bfe}, {"v_and_or_b32", k_and_or}, {"add/sub butterflies", k_bfly}, {"mad,and,alignbit,add", k_mix}};
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     for (auto& b : list) {
@@ -88,7 +109,7 @@ int main() {
         float ms; hipEventElapsedTime(&ms, e0, e1);
         ms /= 5;
         // per SIMD: 8 waves x ITER x 16 x 4 instructions
-        const double instr_per_simd = 8.0 * ITER * 16 * 4;
+        const double instr_per_simd = (double)waves_per_simd * ITER * 16 * 4;
         const double cycles = ms * 1e-3 * mhz * 1e6;
         printf("%-22s %8.3f ms  %6.2f cycles / wave-instruction\n", b.name, ms, cycles / instr_per_simd);
     }
