@@ -156,3 +156,22 @@ def test_2p16_row_execution_bytes_equal_the_oracle_prover(be, oracle):
     got, _ = _prove_and_verify(be, oracle, traces, params, compress, blob)
     want = oracle.prove_with_traces(blob, traces, params, compress)
     assert len(got) == len(want) and got == want
+
+
+def test_config5_2p24_row_tables_prove_on_one_gpu(be, oracle):
+    """BASELINE config 5's single-GPU point: 2^24-row CPU and memory tables (the reference's GPU shim was sized for 2^24,
+    plonky2/field/src/cfft/ntt/mod.rs:13).  Keeping every LDE resident would need about 300 GB; the prover notices and streams the
+    large tables coset by coset (memory-lean mode).  The oracle verifier accepts the proof; the pool's high-water mark is
+    printed and must stay well inside the 288 GB of one MI355X."""
+    from olavm_amd.air import tracegen
+    blob = T.ola_stark().blob()
+    traces, params, compress = tracegen.empty_program_instance(log_n=10, range_bits=16, limb_bits=8, log_n_cpu=24, log_n_mem=24)
+    assert traces[0].shape == (94, 1 << 24)
+    be.trim()
+    be.memory_stats(reset=True)
+    proof, dt = _prove_and_verify(be, oracle, traces, params, compress, blob)
+    st = be.memory_stats()
+    print("config 5 (N = 1): 2^24-row CPU and memory tables, %d proof bytes, prove_with_traces %.2f s, device pool high-water %.1f GB"
+          % (len(proof), dt, st["reserved_peak"] / 1e9))
+    assert st["reserved_peak"] < 200e9
+    be.trim()
