@@ -102,38 +102,66 @@ def verify_proofs(blob, proofs, params):
 COLD_CHILD = r"""
 import json, os, sys, time
 sys.path.insert(0, %(root)r)
-t_imp = time.perf_counter()
 from olavm_amd.air import ola_tables as T, tracegen
 from olavm_amd.backend import Backend
 blob = T.ola_stark().blob()
-traces, params, compress = tracegen.empty_program_instance(log_n=10, range_bits=16, limb_bits=8, log_n_cpu=%(log_n)d, log_n_mem=%(log_n)d)
+heights = [%(log_n)d, %(log_n)d, 18, 1, 16, 10, 10, 10, 10, 10, 10, 10]
 t0 = time.perf_counter()
 be = Backend(device=%(device)d)
 t1 = time.perf_counter()
-p1 = be.prove_with_traces(blob, traces, params, compress)
+if %(reserve)d:
+    be.reserve(blob, heights)          # returns at once; a helper thread allocates while the traces are produced below
+t_tr = time.perf_counter()
+traces, params, compress = tracegen.empty_program_instance(log_n=10, range_bits=16, limb_bits=8, log_n_cpu=%(log_n)d, log_n_mem=%(log_n)d)
+assert [int(t.shape[1]).bit_length() - 1 for t in traces] == heights, [int(t.shape[1]).bit_length() - 1 for t in traces]
 t2 = time.perf_counter()
-p2 = be.prove_with_traces(blob, traces, params, compress)
+p1 = be.prove_with_traces(blob, traces, params, compress)
 t3 = time.perf_counter()
-print(json.dumps({"init_seconds": round(t1 - t0, 4), "first_proof_seconds": round(t2 - t1, 4), "second_proof_seconds": round(t3 - t2, 4),
-                  "identical": p1 == p2}))
+p2 = be.prove_with_traces(blob, traces, params, compress)
+t4 = time.perf_counter()
+print(json.dumps({"init_seconds": round(t1 - t0, 4), "trace_generation_seconds": round(t2 - t_tr, 3), "first_proof_seconds": round(t3 - t2, 4),
+                  "second_proof_seconds": round(t4 - t3, 4), "identical": p1 == p2}))
 """
 
 
-def cold_process_prove(log_n, device):
-    """What `ola prove` sees (client/src/main.rs:174-214 proves once per process): a fresh process, ola_gpu_init, then the
-    FIRST proof on that context, next to the second one.  Same instance as `prove`."""
+def cold_process_prove(log_n, device, reserve):
+    """What `ola prove` sees (client/src/main.rs:174-214 proves once per process): a fresh process, ola_gpu_init, the traces
+    produced on the host, then the FIRST proof on that context, next to the second one.  Same instance as `prove`.  With
+    `reserve` the child calls ola_gpu_reserve right after ola_gpu_init, as INTEGRATION.md tells the Rust side to: the driver's
+    scrubbing of previously used VRAM inside hipMalloc (what makes a first proof slow) then overlaps the host's trace work."""
     import subprocess
     try:
-        out = subprocess.run([sys.executable, "-c", COLD_CHILD % {"root": ROOT, "log_n": log_n, "device": device}],
-                             capture_output=True, text=True, timeout=600)
+        out = subprocess.run([sys.executable, "-c", COLD_CHILD % {"root": ROOT, "log_n": log_n, "device": device, "reserve": 1 if reserve else 0}],
+                             capture_output=True, text=True, timeout=900)
         line = [l for l in out.stdout.splitlines() if l.startswith("{")]
         if out.returncode != 0 or not line:
-            return {"error": (out.stderr or out.stdout)[-200:]}
+            return {"error": (out.stderr or out.stdout)[-300:]}
         d = json.loads(line[-1])
         d["cold_over_warm"] = round(d["first_proof_seconds"] / max(d["second_proof_seconds"], 1e-9), 3)
         return d
     except Exception as e:          # noqa: BLE001 -- an extra: never at the price of the headline line
         return {"error": repr(e)[:200]}
+
+
+def prove_time_2p24(be):
+    """BASELINE config 5's single-GPU point: 2^24-row CPU and memory tables.  All LDEs resident would need about 350 GB, so the
+    prover streams the large tables coset by coset (memory-lean mode, chosen automatically); one timed proof, verified."""
+    from olavm_amd.air import ola_tables as T
+    from olavm_amd.air import tracegen
+    blob = T.ola_stark().blob()
+    traces, params, compress = tracegen.empty_program_instance(log_n=10, range_bits=16, limb_bits=8, log_n_cpu=24, log_n_mem=24)
+    be.trim()
+    be.memory_stats(reset=True)
+    be.prove_with_traces(blob, traces, params, compress)          # first call: allocations
+    t0 = time.perf_counter()
+    proof = be.prove_with_traces(blob, traces, params, compress)
+    dt = time.perf_counter() - t0
+    st = be.memory_stats()
+    res = {"seconds": round(dt, 3), "proof_bytes": len(proof), "device_pool_high_water_gb": round(st["reserved_peak"] / 1e9, 1),
+           "mode": "memory-lean (LDEs streamed coset by coset)", **verify_proofs(blob, [proof], params),
+           "workload": "prove_with_traces, 12 tables, CPU and memory tables 2^24 rows, one MI355X"}
+    be.trim()
+    return res
 
 
 def prove_time(be, log_n, reps=3):
@@ -238,6 +266,7 @@ def main():
     ap.add_argument("--cols", type=int, default=94)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prove", action="store_true", help="skip the end-to-end prove_with_traces timing")
+    ap.add_argument("--no-2p24", action="store_true", help="skip the 2^24-row single-GPU proof (BASELINE config 5's N = 1 point)")
     args = ap.parse_args()
 
     import torch
@@ -367,7 +396,13 @@ def main():
                 res["prove_real_execution"] = {"error": repr(e)[:200]}
             be.trim()
             torch.cuda.empty_cache()
-            res["prove"]["cold_process"] = cold_process_prove(args.log_n, local_rank)
+            res["prove"]["cold_process"] = cold_process_prove(args.log_n, local_rank, reserve=True)
+            res["prove"]["cold_process_without_reserve"] = cold_process_prove(args.log_n, local_rank, reserve=False)
+            if args.log_n == 22 and not args.no_2p24:
+                try:
+                    res["prove_2p24_rows"] = prove_time_2p24(be)
+                except Exception as e:      # an extra: never at the price of the headline line
+                    res["prove_2p24_rows"] = {"error": repr(e)[:200]}
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(args.log_n)
         print(json.dumps(res), flush=True)

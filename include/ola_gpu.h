@@ -69,6 +69,11 @@ int32_t ola_gpu_trim(OlaCtx* ctx);
 /* Device memory of the context's buffer pool, in bytes: out[0] handed out now, out[1] the most ever handed out at once,
  * out[2] handed out + cached now, out[3] the most ever held (the high-water mark of a proof; reset = 1 restarts the marks). */
 int32_t ola_gpu_memory_stats(OlaCtx* ctx, uint64_t out[4], int32_t reset);
+/* Start allocating, on a helper thread, the large device buffers that ola_prove_with_traces will need for this AIR set and these
+ * table heights (log2 rows per table); returns at once.  The driver scrubs previously used VRAM inside hipMalloc (about 30 ms per
+ * GB here), which is what makes the first proof of a process slow; called right after ola_gpu_init -- before the host reads or
+ * generates the traces -- it moves that cost off the proof.  Optional: proving without it is correct, only colder. */
+int32_t ola_gpu_reserve(OlaCtx* ctx, const uint64_t* airset, size_t airset_words, const uint32_t* log_n);
 
 /* ---- NTT family: replaces gpu_method and the cfft CPU paths --------------------------------------------
  * op selects the reference function (plonky2/field/src/cfft/mod.rs):

@@ -94,6 +94,7 @@ def load_library():
     L.ola_permuted_cols_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
     L.ola_set_shard.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, ALL_GATHER_FN, C.c_void_p]
     L.ola_gpu_memory_stats.argtypes = [C.c_void_p, U64P, C.c_int32]
+    L.ola_gpu_reserve.argtypes = [C.c_void_p, U64P, C.c_size_t, C.POINTER(C.c_uint32)]
     L.ola_air_kernels_available.argtypes = [U64P, C.c_size_t, C.POINTER(C.c_uint8), C.c_size_t]
     _lib = L
     return L
@@ -106,7 +107,7 @@ EXPORTS = [
     "ola_batch_get_leaf", "ola_batch_get_lde_row", "ola_challenger_init", "ola_challenger_observe",
     "ola_challenger_get", "ola_challenger_compact", "ola_open_and_prove", "ola_pow", "ola_prove_with_traces",
     "ola_air_kernels_available", "ola_commit_values_shard", "ola_commit_values_shard_dev", "ola_set_shard", "ola_gpu_trim", "ola_generate_poseidon_trace",
-    "ola_permuted_cols", "ola_permuted_cols_dev", "ola_prove_single_table", "ola_take_pending_proof", "ola_gpu_memory_stats",
+    "ola_permuted_cols", "ola_permuted_cols_dev", "ola_prove_single_table", "ola_take_pending_proof", "ola_gpu_memory_stats", "ola_gpu_reserve",
 ]
 
 
@@ -317,6 +318,12 @@ class Backend:
     def trim(self):
         """Return the context's cached device buffers to the driver (ola_gpu_trim)."""
         self._chk(self.lib.ola_gpu_trim(self.ctx))
+
+    def reserve(self, airset_blob, log_ns):
+        """Start allocating the buffers of a coming proof in the background (ola_gpu_reserve); returns at once."""
+        blob = np.ascontiguousarray(airset_blob, dtype=np.uint64)
+        logs = (C.c_uint32 * len(log_ns))(*[int(x) for x in log_ns])
+        self._chk(self.lib.ola_gpu_reserve(self.ctx, _p(blob), blob.size, logs))
 
     def memory_stats(self, reset=False):
         """Device memory of the context's pool in bytes: dict(live, live_peak, reserved, reserved_peak)."""

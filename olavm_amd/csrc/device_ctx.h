@@ -4,7 +4,11 @@
 #include <hip/hip_runtime.h>
 
 #include <chrono>
+#include <condition_variable>
 #include <cstdio>
+#include <mutex>
+#include <set>
+#include <thread>
 #include <cstdlib>
 #include <map>
 #include <stdexcept>
@@ -55,6 +59,33 @@ struct DeviceCtx {
     std::unordered_map<void*, size_t> live;    // blocks handed out
     size_t cached_bytes = 0;
     size_t live_bytes = 0, live_peak = 0, reserved_peak = 0;   // handed out now / at most; handed out + cached at most
+    // Background reservation (ola_gpu_reserve): a helper thread hipMallocs the blocks a coming proof will ask for and puts
+    // them into the cache, so that the driver's scrubbing of previously used VRAM (about 30 ms per GB on this stack, paid inside
+    // hipMalloc) overlaps whatever the caller does between creating the context and proving.  `mu` guards cache / live / pending.
+    std::mutex mu;
+    std::condition_variable cv;
+    std::multiset<size_t> pending;             // sizes the helper has not delivered yet
+    std::thread reserver;
+    void reserve_async(std::vector<size_t> sizes) {
+        join_reserver();
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            for (size_t& sz : sizes) { sz = round_size(sz); pending.insert(sz); }
+        }
+        reserver = std::thread([this, sizes] {
+            (void)hipSetDevice(device);
+            for (size_t sz : sizes) {
+                void* p = nullptr;
+                const hipError_t e = hipMalloc(&p, sz);
+                std::lock_guard<std::mutex> lk(mu);
+                pending.erase(pending.find(sz));
+                if (e == hipSuccess) { cache.emplace(sz, p); cached_bytes += sz; if (live_bytes + cached_bytes > reserved_peak) reserved_peak = live_bytes + cached_bytes; }
+                else (void)hipGetLastError();
+                cv.notify_all();
+            }
+        });
+    }
+    void join_reserver() { if (reserver.joinable()) reserver.join(); }
     void note_alloc(size_t sz) {
         live_bytes += sz;
         if (live_bytes > live_peak) live_peak = live_bytes;
@@ -72,6 +103,8 @@ struct DeviceCtx {
         return p;
     }
     void release_cache() {
+        join_reserver();
+        std::lock_guard<std::mutex> lk(mu);
         if (cache.empty()) return;
         if (timing) fprintf(stderr, "[ola-timing] device allocator: out of memory, releasing %.1f GB of cached blocks\n", cached_bytes / 1e9);
         (void)hipStreamSynchronize(stream);
@@ -81,14 +114,22 @@ struct DeviceCtx {
     }
     void* alloc(size_t bytes) {
         const size_t want = round_size(bytes);
-        auto it = cache.lower_bound(want);
-        if (it != cache.end() && it->first <= want + want / 4) {   // close enough fit
-            void* p = it->second;
-            live[p] = it->first;
-            cached_bytes -= it->first;
-            note_alloc(it->first);
-            cache.erase(it);
-            return p;
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            for (;;) {
+                auto it = cache.lower_bound(want);
+                if (it != cache.end() && it->first <= want + want / 4) {   // close enough fit
+                    void* p = it->second;
+                    live[p] = it->first;
+                    cached_bytes -= it->first;
+                    note_alloc(it->first);
+                    cache.erase(it);
+                    return p;
+                }
+                auto pd = pending.lower_bound(want);                       // a fitting block is on its way: wait for it
+                if (pd != pending.end() && *pd <= want + want / 4) { cv.wait(lk); continue; }
+                break;
+            }
         }
         void* p = nullptr;
         hipError_t e = hipMalloc(&p, want);
@@ -98,12 +139,14 @@ struct DeviceCtx {
             e = hipMalloc(&p, want);
         }
         if (e != hipSuccess) throw OlaError(-3, std::string("hipMalloc(") + std::to_string(want) + "): " + hipGetErrorString(e));
+        std::lock_guard<std::mutex> lk(mu);
         live[p] = want;
         note_alloc(want);
         return p;
     }
     void free(void* p) {
         if (!p) return;
+        std::lock_guard<std::mutex> lk(mu);
         auto it = live.find(p);
         if (it == live.end()) { (void)hipFree(p); return; }
         cache.emplace(it->second, p);
@@ -112,6 +155,7 @@ struct DeviceCtx {
         live.erase(it);
     }
     ~DeviceCtx() {
+        join_reserver();
         if (stream) (void)hipStreamSynchronize(stream);
         for (auto& kv : cache) (void)hipFree(kv.second);
         for (auto& kv : live) (void)hipFree(kv.first);

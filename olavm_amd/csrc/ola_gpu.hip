@@ -483,6 +483,13 @@ int32_t ola_gpu_memory_stats(OlaCtx* ctx, uint64_t out[4], int32_t reset) {
     OLA_CATCH
 }
 
+int32_t ola_gpu_reserve(OlaCtx* ctx, const uint64_t* airset, size_t airset_words, const uint32_t* log_n) {
+    OLA_TRY
+    require(ctx && airset && log_n, "null pointer");
+    reserve_for_proof(&ctx->dev, ctx->cfg, (const u64*)airset, airset_words, log_n);
+    OLA_CATCH
+}
+
 int32_t ola_set_shard(OlaCtx* ctx, uint32_t rank, uint32_t world, ola_all_gather_fn all_gather, void* user) {
     OLA_TRY
     require(ctx, "ctx");

@@ -865,6 +865,87 @@ class TraceUploader {
     hipStream_t stream_ = nullptr;
 };
 
+// Widths of a table's three batches (trace, Z, quotient chunks)
+struct TableWidths { size_t w, wz, wq; int qdb; };
+static TableWidths table_widths(const HAirSet& set, size_t t, int nch) {
+    const HTable& air = set.tables[t];
+    size_t nctl = 0;
+    for (const HCtl& c : set.ctls) { for (const HTwc& w2 : c.looking) nctl += ((size_t)w2.table == t) ? nch : 0; nctl += ((size_t)c.looked.table == t) ? nch : 0; }
+    TableWidths r;
+    r.w = (size_t)air.ncols; r.wz = air.num_permutation_batches(nch) + nctl; r.wq = (size_t)nch * air.quotient_degree_factor();
+    r.qdb = 0;
+    while ((1 << r.qdb) < air.quotient_degree_factor()) r.qdb++;
+    return r;
+}
+
+// Memory-lean tables (OLA_LEAN=1 forces, =0 forbids, default: when keeping every LDE resident would not fit): the LDEs of the
+// large tables are streamed coset by coset instead of kept (batch_commit lean) -- a 2^24-row CPU table then proves on one GPU
+// (fri/oracle.rs:66-99 holds all of it; the reference's GPU shim was sized for 2^24, cfft/ntt/mod.rs:13).
+static std::vector<char> plan_lean_tables(DeviceCtx* ctx, const OlaGpuConfig& cfg, const HAirSet& set, const uint32_t* log_n) {
+    const size_t nt = set.tables.size();
+    const int nch = (int)cfg.num_challenges;
+    std::vector<char> lean(nt, 0);
+    const char* e = getenv("OLA_LEAN");
+    const int mode = e ? atoi(e) : -1;
+    size_t need = 0;
+    for (size_t t = 0; t < nt; t++) {
+        const TableWidths tw = table_widths(set, t, nch);
+        const size_t n_t = (size_t)1 << log_n[t], w_all = tw.w + tw.wz + tw.wq;
+        need += w_all * n_t * 8 * ((size_t)1 << cfg.rate_bits) + 3 * 2 * (n_t << cfg.rate_bits) * 32;   // LDEs + digest heaps
+        need += (tw.w + w_all) * n_t * 8;                                                                // + values + coefficients
+    }
+    size_t free_b = 0, total_b = 0;
+    (void)hipMemGetInfo(&free_b, &total_b);
+    size_t cached;
+    { std::lock_guard<std::mutex> lk(ctx->mu); cached = ctx->cached_bytes; for (size_t sz : ctx->pending) cached += sz; }
+    const size_t budget = (size_t)(0.80 * (double)(free_b + cached));
+    const bool want = mode == 1 || (mode != 0 && need > budget);
+    if (want && ctx->shard.world <= 1)
+        for (size_t t = 0; t < nt; t++) lean[t] = (mode == 1) ? (log_n[t] >= 1) : (log_n[t] >= 20);
+    if (ctx->timing) fprintf(stderr, "[ola-timing] resident proof would need about %.1f GB, %.1f GB available: %s\n", need / 1e9, budget / 1e9, want ? "memory-lean (coset-streamed) large tables" : "all LDEs resident");
+    return lean;
+}
+
+// ola_gpu_reserve: the large device buffers prove_with_traces will ask for with these table heights, allocated by a helper
+// thread into the context's pool while the caller is still busy elsewhere (reading the trace file, say).
+void reserve_for_proof(DeviceCtx* ctx, const OlaGpuConfig& cfg, const u64* airset, size_t airset_words, const uint32_t* log_n) {
+    HAirSet set = parse_airset(airset, airset_words);
+    const size_t nt = set.tables.size();
+    const int nch = (int)cfg.num_challenges;
+    const std::vector<char> lean = plan_lean_tables(ctx, cfg, set, log_n);
+    std::vector<size_t> sizes;
+    size_t big = 0;
+    for (size_t t = 0; t < nt; t++) if (log_n[t] > log_n[big]) big = t;
+    auto batch_blocks = [&](size_t w, size_t n, bool is_lean) {
+        const size_t N = n << cfg.rate_bits;
+        sizes.push_back(w * n * 8);                      // coefficients
+        sizes.push_back(2 * N * 32);                     // digest heap
+        if (!is_lean) sizes.push_back(w * N * 8);        // LDE
+    };
+    for (size_t t = 0; t < nt; t++) {
+        const TableWidths tw = table_widths(set, t, nch);
+        const size_t n = (size_t)1 << log_n[t];
+        if (tw.w * n * 8 < (64u << 20)) continue;        // small tables allocate in microseconds
+        sizes.push_back(tw.w * n * 8);                   // the trace values
+        batch_blocks(tw.w, n, lean[t] != 0);
+        if (lean[t]) sizes.push_back(tw.w * n * 8);      // the coset being hashed / transform scratch
+    }
+    {   // Z and quotient buffers are recycled from table to table: reserve them for the largest one
+        const TableWidths tw = table_widths(set, big, nch);
+        const size_t n = (size_t)1 << log_n[big], size = n << tw.qdb;
+        if (tw.w * n * 8 >= (64u << 20)) {
+            sizes.push_back(tw.wz * n * 8);              // Z values
+            batch_blocks(tw.wz, n, lean[big] != 0);
+            for (int i = 0; i < 4; i++) sizes.push_back(2 * size * 8);   // quotient values, natural order, coefficients, scratch
+            sizes.push_back(tw.wq * n * 8);              // chunks
+            batch_blocks(tw.wq, n, lean[big] != 0);
+            if (lean[big]) { sizes.push_back(tw.w * n * 8); sizes.push_back(tw.wz * n * 8); }
+        }
+    }
+    std::sort(sizes.begin(), sizes.end(), std::greater<size_t>());   // the big ones first: they are asked for first
+    ctx->reserve_async(sizes);
+}
+
 // prove_with_traces (prover.rs:79-327).  traces[t]: host pointer to a column-major ncols x 2^log_n[t] table.
 void prove_with_traces(DeviceCtx* ctx, NttTables& tables, const OlaGpuConfig& cfg, const u64* airset, size_t airset_words,
                        const u64* const* traces, const uint32_t* log_n, const u64* params, const u64* compress,
@@ -887,33 +968,7 @@ void prove_with_traces(DeviceCtx* ctx, NttTables& tables, const OlaGpuConfig& cf
     }
     // The traces are pageable host memory: a helper thread pushes them to the device in column groups on its own stream
     // while this thread already interpolates / extends / hashes what has arrived (H2D of a 2^22-row instance is ~75 ms).
-    // Memory-lean tables (OLA_LEAN=1 forces, =0 forbids, default: when keeping every LDE resident would not fit): the LDEs of
-    // the large tables are streamed coset by coset instead of kept (batch_commit lean) -- a 2^24-row CPU table then proves on
-    // one GPU (fri/oracle.rs:66-99 holds all of it; the reference's GPU shim was sized for 2^24, cfft/ntt/mod.rs:13).
-    std::vector<char> lean(nt, 0);
-    {
-        const char* e = getenv("OLA_LEAN");
-        const int mode = e ? atoi(e) : -1;
-        size_t need = 0;
-        std::vector<size_t> per(nt, 0);
-        for (size_t t = 0; t < nt; t++) {
-            const HTable& air = set.tables[t];
-            const size_t n_t = (size_t)1 << log_n[t];
-            size_t nctl = 0;
-            for (const HCtl& c : set.ctls) { for (const HTwc& w2 : c.looking) nctl += ((size_t)w2.table == t) ? nch : 0; nctl += ((size_t)c.looked.table == t) ? nch : 0; }
-            const size_t wz = air.num_permutation_batches(nch) + nctl, wq = (size_t)nch * air.quotient_degree_factor();
-            const size_t w_all = air.ncols + wz + wq;
-            per[t] = w_all * n_t * 8 * ((size_t)1 << cfg.rate_bits) + 3 * 2 * (n_t << cfg.rate_bits) * 32;   // LDEs + digest heaps
-            need += per[t] + (air.ncols + w_all) * n_t * 8;                                                   // + values + coefficients
-        }
-        size_t free_b = 0, total_b = 0;
-        (void)hipMemGetInfo(&free_b, &total_b);
-        const size_t budget = (size_t)(0.80 * (double)(free_b + ctx->cached_bytes));
-        const bool want = mode == 1 || (mode != 0 && need > budget);
-        if (want && ctx->shard.world <= 1)
-            for (size_t t = 0; t < nt; t++) lean[t] = (mode == 1) ? (log_n[t] >= 1) : (log_n[t] >= 20);
-        if (ctx->timing) fprintf(stderr, "[ola-timing] resident proof would need about %.1f GB, %.1f GB available: %s\n", need / 1e9, budget / 1e9, want ? "memory-lean (coset-streamed) large tables" : "all LDEs resident");
-    }
+    const std::vector<char> lean = plan_lean_tables(ctx, cfg, set, log_n);
     TraceUploader up(ctx, nt);
     for (size_t t = 0; t < nt; t++) up.add(t, traces[t], dev[t].vals, (uint32_t)set.tables[t].ncols, (size_t)1 << log_n[t]);
     up.start();
