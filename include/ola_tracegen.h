@@ -32,6 +32,11 @@ typedef struct OlaTraceSet OlaTraceSet;
 /* flags: close the program-hash chain with a result line and a state-tree proof that the hash is the leaf at the code
  * address (256 storage rows, 512 Poseidon rows) */
 #define OLA_TRACEGEN_PROVE_PROGRAM_HASH 1u
+/* flags: take the compress challenges of the bitwise and program tables from the bitwise_beta / program_beta arguments (tests).
+ * Without it they are derived as the reference derives them -- a Fiat-Shamir transcript observes the limb columns of the bitwise
+ * table (generation/builtin.rs:120-131) and the state roots before and after the run (generation/prog.rs:23-29) -- and the two
+ * arguments are ignored; ola_tracegen_betas returns the values used (they are the proof's compress_challenges). */
+#define OLA_TRACEGEN_EXPLICIT_BETAS 2u
 
 /* Executes the program (at most max_steps CPU rows) and builds the 12 tables of ola_stark(range_bits, limb_bits) in
  * `enum Table` order.  range_bits / limb_bits are 16 / 8 in the reference; smaller values give structurally identical
@@ -43,6 +48,8 @@ int32_t ola_tracegen_run(const OlaInstr* program, size_t n_instr, const uint64_t
 int32_t ola_tracegen_table(const OlaTraceSet* set, uint32_t table, uint32_t* ncols, uint32_t* log_n, const uint64_t** data);
 /* Number of executed CPU rows (before padding). */
 uint64_t ola_tracegen_cpu_rows(const OlaTraceSet* set);
+/* out[0] = the bitwise table's compress challenge, out[1] = the program table's. */
+int32_t ola_tracegen_betas(const OlaTraceSet* set, uint64_t out[2]);
 void ola_tracegen_free(OlaTraceSet* set);
 const char* ola_tracegen_last_error(void);
 

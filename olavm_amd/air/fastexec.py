@@ -15,7 +15,8 @@ class OlaInstr(C.Structure):
     _fields_ = [("op", C.c_uint32), ("dst", C.c_int32), ("op0", C.c_int32), ("op1", C.c_int32), ("op1_is_imm", C.c_uint32), ("imm", C.c_uint64)]
 
 
-EXPORTS = ["ola_tracegen_run", "ola_tracegen_table", "ola_tracegen_cpu_rows", "ola_tracegen_free", "ola_tracegen_last_error"]
+EXPORTS = ["ola_tracegen_run", "ola_tracegen_table", "ola_tracegen_cpu_rows", "ola_tracegen_free", "ola_tracegen_last_error", "ola_tracegen_betas"]
+OLA_TRACEGEN_PROVE_PROGRAM_HASH, OLA_TRACEGEN_EXPLICIT_BETAS = 1, 2
 
 
 def lib_path():
@@ -35,6 +36,7 @@ def load_library():
         L.ola_tracegen_cpu_rows.restype = C.c_uint64
         L.ola_tracegen_free.argtypes = [C.c_void_p]
         L.ola_tracegen_last_error.restype = C.c_char_p
+        L.ola_tracegen_betas.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
         _lib = L
     return _lib
 
@@ -49,14 +51,19 @@ def encode(prog):
     return arr
 
 
-def instance(prog, range_bits=4, limb_bits=2, bitwise_beta=12345, program_beta=67890, prove_program_hash=False, max_steps=1 << 16):
-    """Same contract as miniexec.instance(prog, ...).  -> (traces, params, compress)."""
+def instance(prog, range_bits=4, limb_bits=2, bitwise_beta=None, program_beta=None, prove_program_hash=False, max_steps=1 << 16):
+    """Same contract as miniexec.instance(prog, ...).  -> (traces, params, compress).  Betas left at None are derived by the
+    generator's own Fiat-Shamir transcript, as the reference does; explicit values (both or neither) are for tests."""
+    assert (bitwise_beta is None) == (program_beta is None), "give both compress challenges or neither"
+    explicit = bitwise_beta is not None
     L = load_library()
     ins = encode(prog)
     code = (C.c_uint64 * 4)(*prog.code_addr)
     stor = (C.c_uint64 * 4)(*prog.storage_addr)
     handle = C.c_void_p()
-    rc = L.ola_tracegen_run(ins, len(prog.ins), code, stor, range_bits, limb_bits, bitwise_beta, program_beta, max_steps, int(bool(prove_program_hash)), C.byref(handle))
+    flags = (OLA_TRACEGEN_PROVE_PROGRAM_HASH if prove_program_hash else 0) | (OLA_TRACEGEN_EXPLICIT_BETAS if explicit else 0)
+    rc = L.ola_tracegen_run(ins, len(prog.ins), code, stor, range_bits, limb_bits, bitwise_beta if explicit else 0, program_beta if explicit else 0,
+                            max_steps, flags, C.byref(handle))
     if rc != 0:
         raise RuntimeError("ola_tracegen_run: " + L.ola_tracegen_last_error().decode())
     try:
@@ -66,6 +73,9 @@ def instance(prog, range_bits=4, limb_bits=2, bitwise_beta=12345, program_beta=6
             assert L.ola_tracegen_table(handle, t, C.byref(ncols), C.byref(log_n), C.byref(data)) == 0
             n = 1 << log_n.value
             traces.append(np.ctypeslib.as_array(data, shape=(ncols.value, n)).copy())
+        betas = (C.c_uint64 * 2)()
+        assert L.ola_tracegen_betas(handle, betas) == 0
+        bitwise_beta, program_beta = int(betas[0]), int(betas[1])
     finally:
         L.ola_tracegen_free(handle)
     return traces, [bitwise_beta, program_beta], [0, 0, bitwise_beta, 0, 0, 0, 0, 0, 0, 0, program_beta, 0]

@@ -623,9 +623,26 @@ def tape_trace(cells):
     return t
 
 
-def instance(prog, range_bits=4, limb_bits=2, bitwise_beta=12345, program_beta=67890, prove_program_hash=False, max_steps=1 << 16):
+def _transcript():
+    """Fiat-Shamir transcript for the generators' compress challenges: the library's host-side Challenger
+    (iop/challenger.rs:36-162; host code of libola_gpu.so, no GPU involved)."""
+    from olavm_amd.backend import Challenger
+    return Challenger()
+
+
+def derive_program_beta(start_root, end_root):
+    """generation/prog.rs:23-29: the transcript observes the state roots before and after the run, limb by limb."""
+    ch = _transcript()
+    for a, b in zip(start_root, end_root):
+        ch.observe([int(a) % P, int(b) % P])
+    return ch.get()
+
+
+def instance(prog, range_bits=4, limb_bits=2, bitwise_beta=None, program_beta=None, prove_program_hash=False, max_steps=1 << 16):
     """The 12 traces (enum Table order), params and compress challenges of ola_stark(range_bits, limb_bits) for one run of
-    `prog`.  With miniature fixed tables, RC / GTE operands must stay below 2^(2*range_bits) and bitwise operands below
+    `prog`.  The compress challenges of the bitwise and program tables are derived as the reference derives them (a
+    transcript over the bitwise limb columns, generation/builtin.rs:120-131, and over the start / end state roots,
+    generation/prog.rs:23-29); explicit values are for tests only.  With miniature fixed tables, RC / GTE operands must stay below 2^(2*range_bits) and bitwise operands below
     2^(4*limb_bits).  `prove_program_hash`: close the program-hash chain with a result line and a state-tree proof that
     the hash is the leaf at the code address (256 storage rows, 512 Poseidon rows)."""
     listing = prog.words()[0]
@@ -633,7 +650,10 @@ def instance(prog, range_bits=4, limb_bits=2, bitwise_beta=12345, program_beta=6
     tree = StorageTree()
     if prove_program_hash:
         tree.set(prog.code_addr, program_hash(listing))
+    start_root = tree.root()
     rows, side, executed = execute(prog, max_steps=max_steps, tree=tree)
+    if program_beta is None:
+        program_beta = derive_program_beta(start_root, tree.root())
     cpu = cpu_trace(rows)
     program, words = program_trace(prog, executed, program_beta)
     pchunk, builtin_rows = poseidon_chunk_trace(side["psdn"])
@@ -650,8 +670,11 @@ def instance(prog, range_bits=4, limb_bits=2, bitwise_beta=12345, program_beta=6
     mem, mem_rc, mem_cond = memory_trace(side["mem"])
     rc_rows = ([(v, 1, 0, 0, 0) for v in side["rc"]] + [(r[3], 0, 0, 0, 1) for r in cmp_rows] + [(v, 0, 1, 0, 0) for v in mem_rc]
                + [(v, 0, 0, 1, 0) for v in mem_cond])
+    bitwise = TG.bitwise_trace(bitwise_beta, limb_bits, side["bitwise"], looked_by_cpu=True, transcript=_transcript if bitwise_beta is None else None)
+    if bitwise_beta is None:
+        bitwise, bitwise_beta = bitwise
     traces = [
-        cpu, mem, TG.bitwise_trace(bitwise_beta, limb_bits, side["bitwise"], looked_by_cpu=True),
+        cpu, mem, bitwise,
         TG.generate_cmp_trace(cmp_rows), TG.generate_rc_trace(rc_rows, range_bits), poseidon,
         pchunk,
         storage_trace(side["storage"], prog_reads),

@@ -132,11 +132,13 @@ def memory_padding_trace(n):
     return t
 
 
-def bitwise_trace(beta, limb_bits=8, ops=(), looked_by_cpu=False):
+def bitwise_trace(beta, limb_bits=8, ops=(), looked_by_cpu=False, transcript=None):
     """generation/builtin.rs:35-205 with `limb_bits`-wide limbs: the fixed AND/OR/XOR table, and one row per operation in
     `ops` = [(name, op0, op1)] (operands of 4 limbs) with its limbs, compressed limbs and the permuted lookup columns.
     The rows carry FILTER = 0 (nothing in the CPU table looks them up, but every bitwise constraint and in-table lookup
-    is live on them) unless looked_by_cpu, in which case they are the looked-up side of the CPU's AND / OR / XOR rows."""
+    is live on them) unless looked_by_cpu, in which case they are the looked-up side of the CPU's AND / OR / XOR rows.
+    `transcript` (a factory of Challenger objects): derive the compress challenge from the twelve limb columns as
+    generation/builtin.rs:120-131 does and return (trace, beta) instead of using `beta`."""
     size = 1 << limb_bits
     per = size * size
     n = next_pow2(max(size, 3 * per, len(ops)))
@@ -149,22 +151,30 @@ def bitwise_trace(beta, limb_bits=8, ops=(), looked_by_cpu=False):
                 r = k * per + index
                 t[T.BW_FIX_BITWSIE_OP0, r], t[T.BW_FIX_BITWSIE_OP1, r], t[T.BW_FIX_BITWSIE_RES, r], t[T.BW_FIX_TAG, r] = op0, op1, res, tag
             index += 1
-    b = int(beta) % P
-    compress = lambda tag, x, y, z: (tag + x * b + y * b * b + z * b * b * b) % P
-    fix = [compress(int(t[T.BW_FIX_TAG, i]), int(t[T.BW_FIX_BITWSIE_OP0, i]), int(t[T.BW_FIX_BITWSIE_OP1, i]), int(t[T.BW_FIX_BITWSIE_RES, i]))
-           for i in range(n)]
-    t[T.BW_FIX_COMPRESS] = fix
     fn = {"AND": lambda x, y: x & y, "OR": lambda x, y: x | y, "XOR": lambda x, y: x ^ y}
     limbs = lambda v: [(v >> (limb_bits * i)) & (size - 1) for i in range(4)]
     for r, (name, x, y) in enumerate(ops):
         assert x < size ** 4 and y < size ** 4
         z = fn[name](x, y)
-        tag = T.op_mask(name)
-        t[T.BW_TAG, r], t[T.BW_OP0, r], t[T.BW_OP1, r], t[T.BW_RES, r] = tag, x, y, z
+        t[T.BW_TAG, r], t[T.BW_OP0, r], t[T.BW_OP1, r], t[T.BW_RES, r] = T.op_mask(name), x, y, z
         t[T.BW_FILTER, r] = int(looked_by_cpu)
         for i, (lx, ly, lz) in enumerate(zip(limbs(x), limbs(y), limbs(z))):
             t[T.BW_OP0_LIMBS.start + i, r], t[T.BW_OP1_LIMBS.start + i, r], t[T.BW_RES_LIMBS.start + i, r] = lx, ly, lz
-            t[T.BW_COMPRESS_LIMBS.start + i, r] = compress(tag, lx, ly, lz)
+    if transcript is not None:
+        ch = transcript()
+        for cols in (T.BW_OP0_LIMBS, T.BW_OP1_LIMBS, T.BW_RES_LIMBS):
+            for i in range(4):
+                ch.observe(t[cols.start + i])
+        beta = ch.get()
+    b = int(beta) % P
+    compress = lambda tag, x, y, z: (tag + x * b + y * b * b + z * b * b * b) % P
+    fix = [compress(int(t[T.BW_FIX_TAG, i]), int(t[T.BW_FIX_BITWSIE_OP0, i]), int(t[T.BW_FIX_BITWSIE_OP1, i]), int(t[T.BW_FIX_BITWSIE_RES, i]))
+           for i in range(n)]
+    t[T.BW_FIX_COMPRESS] = fix
+    for r in range(len(ops)):
+        for i in range(4):
+            t[T.BW_COMPRESS_LIMBS.start + i, r] = compress(int(t[T.BW_TAG, r]), int(t[T.BW_OP0_LIMBS.start + i, r]), int(t[T.BW_OP1_LIMBS.start + i, r]),
+                                                           int(t[T.BW_RES_LIMBS.start + i, r]))
     rc8 = [int(x) for x in t[T.BW_FIX_RANGE_CHECK_U8]]
     for i in range(4):
         for src, limbs_perm, off in ((T.BW_OP0_LIMBS, T.BW_OP0_LIMBS_PERMUTED, 0), (T.BW_OP1_LIMBS, T.BW_OP1_LIMBS_PERMUTED, 4),
@@ -173,7 +183,7 @@ def bitwise_trace(beta, limb_bits=8, ops=(), looked_by_cpu=False):
             t[limbs_perm.start + i], t[T.BW_FIX_RANGE_CHECK_U8_PERMUTED.start + off + i] = pi, pt
         pi, pt = permuted_cols([int(v) for v in t[T.BW_COMPRESS_LIMBS.start + i]], fix)
         t[T.BW_COMPRESS_PERMUTED.start + i], t[T.BW_FIX_COMPRESS_PERMUTED.start + i] = pi, pt
-    return t
+    return (t, b) if transcript is not None else t
 
 
 def bitwise_padding_trace(beta, limb_bits=8):

@@ -270,10 +270,11 @@ struct DevBuf {
     DeviceCtx* ctx;
     std::vector<void*> ptrs;
     explicit DevBuf(DeviceCtx* c) : ctx(c) {}
-    u64* alloc(size_t elems) {
-        void* p = ctx->alloc(elems * 8);
+    u64* alloc(size_t elems) { return (u64*)alloc_bytes(elems * 8); }
+    void* alloc_bytes(size_t bytes) {
+        void* p = ctx->alloc(bytes);
         ptrs.push_back(p);
-        return (u64*)p;
+        return p;
     }
     ~DevBuf() {
         (void)hipStreamSynchronize(ctx->stream);

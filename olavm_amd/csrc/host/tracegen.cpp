@@ -100,6 +100,31 @@ void poseidon_permute(u64 s[12]) {
 }
 
 // ---- lookup.rs:68-132
+// Fiat-Shamir transcript of the trace generators (iop/challenger.rs:36-162: overwrite-mode duplex sponge, rate 8, challenges
+// popped from the end of the output buffer) -- the compress challenges of the bitwise and program tables come out of it
+// (generation/builtin.rs:120-131, generation/prog.rs:23-29), not from the caller.
+struct HostChallenger {
+    u64 state[12] = {0};
+    u64 in[8], out[8];
+    int nin = 0, nout = 0;
+    void duplex() {
+        for (int i = 0; i < nin; i++) state[i] = in[i];
+        nin = 0;
+        poseidon_permute(state);
+        for (int i = 0; i < 8; i++) out[i] = state[i];
+        nout = 8;
+    }
+    void observe(u64 e) {
+        nout = 0;
+        in[nin++] = e % P;
+        if (nin == 8) duplex();
+    }
+    u64 get() {
+        if (nin != 0 || nout == 0) duplex();
+        return out[--nout];
+    }
+};
+
 void permuted_cols(const std::vector<u64>& inputs, const std::vector<u64>& table, std::vector<u64>& pi, std::vector<u64>& pt) {
     const size_t n = inputs.size();
     pi = inputs;
@@ -799,7 +824,9 @@ void rc_table(const std::vector<RcRow>& rows, uint32_t range_bits, Table& t) {
 }
 
 // generation/builtin.rs:35-205 with limb_bits-wide limbs
-void bitwise_table(u64 beta, uint32_t limb_bits, const std::vector<BwOp>& ops, Table& t) {
+// `derive`: the compress challenge is drawn from a transcript that has observed the twelve limb columns (OP0, OP1, RES limbs
+// over the whole padded height), as generation/builtin.rs:120-131 does; otherwise the caller's `beta` is used (tests only)
+u64 bitwise_table(u64 beta, bool derive, uint32_t limb_bits, const std::vector<BwOp>& ops, Table& t) {
     const size_t size = (size_t)1 << limb_bits, per = size * size;
     const size_t n = next_pow2(std::max(std::max(size, 3 * per), ops.size()));
     t.init(COL_NUM_BITWISE, n);
@@ -816,11 +843,6 @@ void bitwise_table(u64 beta, uint32_t limb_bits, const std::vector<BwOp>& ops, T
             index++;
         }
     }
-    const u64 b1 = beta % P, b2 = mulm(b1, b1), b3 = mulm(b2, b1);
-    auto compress = [&](u64 tag, u64 x, u64 y, u64 z) { return addm(addm(tag % P, mulm(x, b1)), addm(mulm(y, b2), mulm(z, b3))); };
-    std::vector<u64> fix(n);
-    for (size_t i = 0; i < n; i++) fix[i] = compress(t.at(BW_FIX_TAG, i), t.at(BW_FIX_BITWSIE_OP0, i), t.at(BW_FIX_BITWSIE_OP1, i), t.at(BW_FIX_BITWSIE_RES, i));
-    t.set_column(BW_FIX_COMPRESS, fix);
     for (size_t r = 0; r < ops.size(); r++) {
         const u64 x = ops[r].a, y = ops[r].b;
         need(limb_bits >= 16 || (x < ((u64)1 << (4 * limb_bits)) && y < ((u64)1 << (4 * limb_bits))), "bitwise operand does not fit four limbs");
@@ -831,9 +853,24 @@ void bitwise_table(u64 beta, uint32_t limb_bits, const std::vector<BwOp>& ops, T
         for (int i = 0; i < 4; i++) {
             const u64 lx = (x >> (limb_bits * i)) & (size - 1), ly = (y >> (limb_bits * i)) & (size - 1), lz = (z >> (limb_bits * i)) & (size - 1);
             t.at(BW_OP0_LIMBS_START + i, r) = lx; t.at(BW_OP1_LIMBS_START + i, r) = ly; t.at(BW_RES_LIMBS_START + i, r) = lz;
-            t.at(BW_COMPRESS_LIMBS_START + i, r) = compress(tag, lx, ly, lz);
         }
     }
+    if (derive) {
+        HostChallenger ch;
+        const u64 starts[3] = {BW_OP0_LIMBS_START, BW_OP1_LIMBS_START, BW_RES_LIMBS_START};
+        for (int k = 0; k < 3; k++)
+            for (int i = 0; i < 4; i++)
+                for (size_t r = 0; r < n; r++) ch.observe(t.at(starts[k] + i, r));
+        beta = ch.get();
+    }
+    const u64 b1 = beta % P, b2 = mulm(b1, b1), b3 = mulm(b2, b1);
+    auto compress = [&](u64 tag, u64 x, u64 y, u64 z) { return addm(addm(tag % P, mulm(x, b1)), addm(mulm(y, b2), mulm(z, b3))); };
+    std::vector<u64> fix(n);
+    for (size_t i = 0; i < n; i++) fix[i] = compress(t.at(BW_FIX_TAG, i), t.at(BW_FIX_BITWSIE_OP0, i), t.at(BW_FIX_BITWSIE_OP1, i), t.at(BW_FIX_BITWSIE_RES, i));
+    t.set_column(BW_FIX_COMPRESS, fix);
+    for (size_t r = 0; r < ops.size(); r++)
+        for (int i = 0; i < 4; i++)
+            t.at(BW_COMPRESS_LIMBS_START + i, r) = compress(t.at(BW_TAG, r), t.at(BW_OP0_LIMBS_START + i, r), t.at(BW_OP1_LIMBS_START + i, r), t.at(BW_RES_LIMBS_START + i, r));
     const std::vector<u64> rc8 = t.column(BW_FIX_RANGE_CHECK_U8);
     std::vector<u64> pi, pt;
     for (int i = 0; i < 4; i++) {
@@ -848,6 +885,7 @@ void bitwise_table(u64 beta, uint32_t limb_bits, const std::vector<BwOp>& ops, T
         t.set_column(BW_COMPRESS_PERMUTED_START + i, pi);
         t.set_column(BW_FIX_COMPRESS_PERMUTED_START + i, pt);
     }
+    return beta % P;
 }
 
 void flag_padding(Table& t, size_t ncols, size_t n, size_t flag_col) { t.init(ncols, n); t.fill(flag_col, 1); }
@@ -859,6 +897,7 @@ thread_local std::string g_err;
 struct OlaTraceSet {
     std::array<Table, 12> tables;
     uint64_t cpu_rows = 0;
+    uint64_t bitwise_beta = 0, program_beta = 0;   // the compress challenges the tables were built with
 };
 
 extern "C" {
@@ -873,6 +912,7 @@ int32_t ola_tracegen_run(const OlaInstr* program, size_t n_instr, const uint64_t
         need(range_bits >= 1 && range_bits <= 16 && limb_bits >= 1 && limb_bits <= 8, "range_bits / limb_bits out of range");
         std::unique_ptr<OlaTraceSet> set(new OlaTraceSet());
         const bool prove_program_hash = flags & OLA_TRACEGEN_PROVE_PROGRAM_HASH;
+        const bool explicit_betas = flags & OLA_TRACEGEN_EXPLICIT_BETAS;
         Run R;
         StorageTree tree;
         const Hash4 code_key{code_addr[0], code_addr[1], code_addr[2], code_addr[3]};
@@ -883,8 +923,17 @@ int32_t ola_tracegen_run(const OlaInstr* program, size_t n_instr, const uint64_t
             while (listing.size() % 8) listing.push_back(0);
             tree.write(StorageTree::key_of(code_key), program_hash(listing));
         }
+        const Hash4 start_root = tree.root();
         execute(program, n_instr, code_addr, storage_addr, max_steps, tree, R);
         set->cpu_rows = R.nrows();
+        if (!explicit_betas) {
+            // generation/prog.rs:23-29: the transcript observes the state roots before and after the run, limb by limb
+            const Hash4 end_root = tree.root();
+            HostChallenger ch;
+            for (int i = 0; i < 4; i++) { ch.observe(start_root[i]); ch.observe(end_root[i]); }
+            program_beta = ch.get();
+        }
+        set->program_beta = program_beta % P;
         auto& T = set->tables;
         cpu_table(R, T[CPU]);
         std::vector<u64> words;
@@ -909,7 +958,7 @@ int32_t ola_tracegen_run(const OlaInstr* program, size_t n_instr, const uint64_t
         for (u64 v : mem_rc) rc.push_back({v, {0, 1, 0, 0}});
         for (u64 v : mem_cond) rc.push_back({v, {0, 0, 1, 0}});
         rc_table(rc, range_bits, T[RANGECHECK]);
-        bitwise_table(bitwise_beta, limb_bits, R.bitwise, T[BITWISE]);
+        set->bitwise_beta = bitwise_table(bitwise_beta, !explicit_betas, limb_bits, R.bitwise, T[BITWISE]);
         storage_table(R.storage, prog_reads, T[STORAGE_ACCESS]);
         tape_table(R.tape, T[TAPE]);
         flag_padding(T[SCCALL], NUM_COL_SCCALL, 8, COL_SCCALL_IS_PADDING);
@@ -931,6 +980,12 @@ int32_t ola_tracegen_table(const OlaTraceSet* set, uint32_t table, uint32_t* nco
 }
 
 uint64_t ola_tracegen_cpu_rows(const OlaTraceSet* set) { return set ? set->cpu_rows : 0; }
+
+int32_t ola_tracegen_betas(const OlaTraceSet* set, uint64_t out[2]) {
+    if (!set || !out) { g_err = "invalid argument"; return -1; }
+    out[0] = set->bitwise_beta; out[1] = set->program_beta;
+    return 0;
+}
 
 void ola_tracegen_free(OlaTraceSet* set) { delete set; }
 

@@ -63,6 +63,23 @@ static void require(bool ok, const char* what) {
     if (!ok) throw OlaError(OLA_E_INVALID_ARG, std::string("invalid argument: ") + what);
 }
 
+// The HIP current device is a property of the calling host thread: every entry point that works on a context makes the
+// context's device current for its duration (and puts the caller's back), so that hipMalloc and constant uploads land on the
+// right GPU when the host drives several contexts or calls from a thread that never called hipSetDevice.
+struct DeviceGuard {
+    int prev = -1, want = -1;
+    explicit DeviceGuard(const OlaCtx* ctx);
+    ~DeviceGuard() { if (prev >= 0 && prev != want) (void)hipSetDevice(prev); }
+};
+#define OLA_ON_DEVICE(ctx) DeviceGuard ola_device_guard_(ctx)
+
+DeviceGuard::DeviceGuard(const OlaCtx* ctx) {
+    if (!ctx) return;
+    want = ctx->dev.device;
+    if (hipGetDevice(&prev) != hipSuccess) { prev = -1; (void)hipGetLastError(); }
+    if (prev != want) HIP_CHECK(hipSetDevice(want));
+}
+
 extern "C" {
 
 const char* ola_gpu_last_error(void) { return g_last_error.c_str(); }
@@ -78,6 +95,16 @@ int32_t ola_gpu_init(const OlaGpuConfig* cfg, OlaCtx** out_ctx) {
     d.device = -1; d.stream = nullptr; d.rate_bits = 3; d.cap_height = 4; d.proof_of_work_bits = 16;
     d.fri_arity_bits = 4; d.fri_final_poly_bits = 5; d.num_query_rounds = 28; d.num_challenges = 2;
     c->cfg = cfg ? *cfg : d;
+    // the structure parameters every later call relies on (a zero arity would loop forever in fri_arities, zero proof-of-work
+    // bits shift by 64 in the grinding kernel, ...)
+    require(c->cfg.rate_bits >= 1 && c->cfg.rate_bits <= 8, "rate_bits must be in 1..8");
+    require(c->cfg.cap_height <= 16, "cap_height must be at most 16");
+    require(c->cfg.proof_of_work_bits >= 1 && c->cfg.proof_of_work_bits <= 40, "proof_of_work_bits must be in 1..40");
+    require(c->cfg.fri_arity_bits >= 1 && c->cfg.fri_arity_bits <= 8, "fri_arity_bits must be in 1..8");
+    require(c->cfg.fri_final_poly_bits <= 16, "fri_final_poly_bits must be at most 16");
+    require(c->cfg.num_query_rounds >= 1 && c->cfg.num_query_rounds <= 1024, "num_query_rounds must be in 1..1024");
+    require(c->cfg.num_challenges == 2, "num_challenges must be 2 (circuits/src/stark/config.rs)");
+    require(c->cfg.device < ndev, "device index out of range");
     if (c->cfg.device >= 0) HIP_CHECK(hipSetDevice(c->cfg.device));
     HIP_CHECK(hipGetDevice(&c->dev.device));
     if (c->cfg.stream) { c->dev.stream = (hipStream_t)c->cfg.stream; c->dev.owns_stream = false; }
@@ -103,6 +130,7 @@ int32_t ola_gpu_free(OlaCtx* ctx) {
 
 int32_t ola_gpu_sync(OlaCtx* ctx) {
     OLA_TRY
+    OLA_ON_DEVICE(ctx);
     require(ctx, "ctx");
     HIP_CHECK(hipStreamSynchronize(ctx->dev.stream));
     OLA_CATCH
@@ -115,9 +143,9 @@ static void ntt_dev(OlaCtx* ctx, int32_t op, const u64* in, u64* out, u64* scrat
     if (batch == 0) return;
     const size_t n = (size_t)1 << log_n;
     NttTables& t = *ctx->tables;
-    u64* own_scratch = nullptr;
+    DevBuf own(&ctx->dev);   // a scratch buffer of our own is released on every path
     auto need_scratch = [&](size_t elems) {
-        if (!scratch) { own_scratch = (u64*)ctx->dev.alloc(elems * 8); scratch = own_scratch; }
+        if (!scratch) scratch = own.alloc(elems);
     };
     switch (op) {
         case OLA_NTT_EVALUATE:
@@ -153,12 +181,12 @@ static void ntt_dev(OlaCtx* ctx, int32_t op, const u64* in, u64* out, u64* scrat
         }
         default: require(false, "unknown NTT op");
     }
-    if (own_scratch) { HIP_CHECK(hipStreamSynchronize(ctx->dev.stream)); ctx->dev.free(own_scratch); }
 }
 
 int32_t ola_ntt_batch_dev(OlaCtx* ctx, int32_t op, const uint64_t* in_dev, uint64_t* out_dev, uint64_t* scratch_dev,
                           uint32_t log_n, uint32_t batch, uint64_t shift, uint32_t blowup_log) {
     OLA_TRY
+    OLA_ON_DEVICE(ctx);
     require(ctx && in_dev && out_dev, "null pointer");
     ntt_dev(ctx, op, (const u64*)in_dev, (u64*)out_dev, (u64*)scratch_dev, log_n, batch, shift, blowup_log);
     HIP_CHECK(hipStreamSynchronize(ctx->dev.stream));
@@ -168,80 +196,75 @@ int32_t ola_ntt_batch_dev(OlaCtx* ctx, int32_t op, const uint64_t* in_dev, uint6
 int32_t ola_ntt_batch(OlaCtx* ctx, int32_t op, const uint64_t* in, uint64_t* out, uint32_t log_n, uint32_t batch,
                       uint64_t shift, uint32_t blowup_log) {
     OLA_TRY
+    OLA_ON_DEVICE(ctx);
     require(ctx && in && out, "null pointer");
+    require(log_n <= 32 && blowup_log <= 8, "log_n too large");          // before any size arithmetic
     const size_t n = (size_t)1 << log_n;
     const bool grows = (op == OLA_NTT_COSET_LDE || op == OLA_NTT_COSET_LDE_LEAF_ORDER);
     const size_t in_elems = n * batch, out_elems = grows ? (n << blowup_log) * batch : n * batch;
     if (batch == 0) return OLA_OK;
-    u64* d_in = (u64*)ctx->dev.alloc(in_elems * 8);
-    u64* d_out = (u64*)ctx->dev.alloc(out_elems * 8);
-    try {
-        HIP_CHECK(hipMemcpyAsync(d_in, in, in_elems * 8, hipMemcpyHostToDevice, ctx->dev.stream));
-        ntt_dev(ctx, op, d_in, d_out, nullptr, log_n, batch, shift, blowup_log);
-        HIP_CHECK(hipMemcpyAsync(out, d_out, out_elems * 8, hipMemcpyDeviceToHost, ctx->dev.stream));
-        HIP_CHECK(hipStreamSynchronize(ctx->dev.stream));
-    } catch (...) { ctx->dev.free(d_in); ctx->dev.free(d_out); throw; }
-    ctx->dev.free(d_in);
-    ctx->dev.free(d_out);
+    DevBuf mem(&ctx->dev);   // released on every path, also when a later allocation throws
+    u64* d_in = (u64*)mem.alloc_bytes(in_elems * 8);
+    u64* d_out = (u64*)mem.alloc_bytes(out_elems * 8);
+    HIP_CHECK(hipMemcpyAsync(d_in, in, in_elems * 8, hipMemcpyHostToDevice, ctx->dev.stream));
+    ntt_dev(ctx, op, d_in, d_out, nullptr, log_n, batch, shift, blowup_log);
+    HIP_CHECK(hipMemcpyAsync(out, d_out, out_elems * 8, hipMemcpyDeviceToHost, ctx->dev.stream));
+    HIP_CHECK(hipStreamSynchronize(ctx->dev.stream));
     OLA_CATCH
 }
 
 // ------------------------------------------------------------------------------------------------ hashing
 int32_t ola_poseidon_permute(OlaCtx* ctx, uint64_t* states, size_t n) {
     OLA_TRY
+    OLA_ON_DEVICE(ctx);
     require(ctx && (states || n == 0), "null pointer");
     if (n == 0) return OLA_OK;
-    u64* d = (u64*)ctx->dev.alloc(n * 96);
-    try {
-        HIP_CHECK(hipMemcpyAsync(d, states, n * 96, hipMemcpyHostToDevice, ctx->dev.stream));
-        launch_poseidon_states(&ctx->dev, d, n);
-        HIP_CHECK(hipMemcpyAsync(states, d, n * 96, hipMemcpyDeviceToHost, ctx->dev.stream));
-        HIP_CHECK(hipStreamSynchronize(ctx->dev.stream));
-    } catch (...) { ctx->dev.free(d); throw; }
-    ctx->dev.free(d);
+    DevBuf mem(&ctx->dev);   // released on every path, also when a later allocation throws
+    u64* d = (u64*)mem.alloc_bytes(n * 96);
+    HIP_CHECK(hipMemcpyAsync(d, states, n * 96, hipMemcpyHostToDevice, ctx->dev.stream));
+    launch_poseidon_states(&ctx->dev, d, n);
+    HIP_CHECK(hipMemcpyAsync(states, d, n * 96, hipMemcpyDeviceToHost, ctx->dev.stream));
+    HIP_CHECK(hipStreamSynchronize(ctx->dev.stream));
     OLA_CATCH
 }
 
 int32_t ola_hash_rows(OlaCtx* ctx, const uint64_t* rows, size_t num_rows, size_t row_len, uint64_t* digests) {
     OLA_TRY
+    OLA_ON_DEVICE(ctx);
     require(ctx && digests && (rows || num_rows * row_len == 0), "null pointer");
     if (num_rows == 0) return OLA_OK;
-    u64* d_rows = (u64*)ctx->dev.alloc(num_rows * row_len * 8);
-    u64* d_dig = (u64*)ctx->dev.alloc(num_rows * 32);
-    try {
-        if (row_len) HIP_CHECK(hipMemcpyAsync(d_rows, rows, num_rows * row_len * 8, hipMemcpyHostToDevice, ctx->dev.stream));
-        launch_leaf_hash_rowmajor(&ctx->dev, d_rows, row_len, num_rows, d_dig);
-        HIP_CHECK(hipMemcpyAsync(digests, d_dig, num_rows * 32, hipMemcpyDeviceToHost, ctx->dev.stream));
-        HIP_CHECK(hipStreamSynchronize(ctx->dev.stream));
-    } catch (...) { ctx->dev.free(d_rows); ctx->dev.free(d_dig); throw; }
-    ctx->dev.free(d_rows);
-    ctx->dev.free(d_dig);
+    DevBuf mem(&ctx->dev);   // released on every path, also when a later allocation throws
+    u64* d_rows = (u64*)mem.alloc_bytes(num_rows * row_len * 8);
+    u64* d_dig = (u64*)mem.alloc_bytes(num_rows * 32);
+    if (row_len) HIP_CHECK(hipMemcpyAsync(d_rows, rows, num_rows * row_len * 8, hipMemcpyHostToDevice, ctx->dev.stream));
+    launch_leaf_hash_rowmajor(&ctx->dev, d_rows, row_len, num_rows, d_dig);
+    HIP_CHECK(hipMemcpyAsync(digests, d_dig, num_rows * 32, hipMemcpyDeviceToHost, ctx->dev.stream));
+    HIP_CHECK(hipStreamSynchronize(ctx->dev.stream));
     OLA_CATCH
 }
 
 int32_t ola_merkle_cap(OlaCtx* ctx, const uint64_t* leaves, size_t num_leaves, size_t leaf_len, uint32_t cap_height,
                        uint64_t* cap_out) {
     OLA_TRY
+    OLA_ON_DEVICE(ctx);
     require(ctx && leaves && cap_out, "null pointer");
     require(num_leaves && (num_leaves & (num_leaves - 1)) == 0, "num_leaves must be a power of two");
     require(((size_t)1 << cap_height) <= num_leaves, "cap height should be at most log2(leaves.len())");
-    u64* d_rows = (u64*)ctx->dev.alloc(num_leaves * leaf_len * 8);
-    u64* heap = (u64*)ctx->dev.alloc(2 * num_leaves * 32);
-    try {
-        HIP_CHECK(hipMemcpyAsync(d_rows, leaves, num_leaves * leaf_len * 8, hipMemcpyHostToDevice, ctx->dev.stream));
-        launch_leaf_hash_rowmajor(&ctx->dev, d_rows, leaf_len, num_leaves, heap + 4 * num_leaves);
-        launch_merkle_build(&ctx->dev, heap, num_leaves, cap_height);
-        const size_t len_cap = (size_t)1 << cap_height;
-        HIP_CHECK(hipMemcpyAsync(cap_out, heap + 4 * len_cap, len_cap * 32, hipMemcpyDeviceToHost, ctx->dev.stream));
-        HIP_CHECK(hipStreamSynchronize(ctx->dev.stream));
-    } catch (...) { ctx->dev.free(d_rows); ctx->dev.free(heap); throw; }
-    ctx->dev.free(d_rows);
-    ctx->dev.free(heap);
+    DevBuf mem(&ctx->dev);   // released on every path, also when a later allocation throws
+    u64* d_rows = (u64*)mem.alloc_bytes(num_leaves * leaf_len * 8);
+    u64* heap = (u64*)mem.alloc_bytes(2 * num_leaves * 32);
+    HIP_CHECK(hipMemcpyAsync(d_rows, leaves, num_leaves * leaf_len * 8, hipMemcpyHostToDevice, ctx->dev.stream));
+    launch_leaf_hash_rowmajor(&ctx->dev, d_rows, leaf_len, num_leaves, heap + 4 * num_leaves);
+    launch_merkle_build(&ctx->dev, heap, num_leaves, cap_height);
+    const size_t len_cap = (size_t)1 << cap_height;
+    HIP_CHECK(hipMemcpyAsync(cap_out, heap + 4 * len_cap, len_cap * 32, hipMemcpyDeviceToHost, ctx->dev.stream));
+    HIP_CHECK(hipStreamSynchronize(ctx->dev.stream));
     OLA_CATCH
 }
 
 int32_t ola_pow(OlaCtx* ctx, const uint64_t h[4], uint32_t bits, uint64_t* witness) {
     OLA_TRY
+    OLA_ON_DEVICE(ctx);
     require(ctx && h && witness && bits >= 1 && bits <= 40, "bad argument");
     u64 hh[4] = {gl_canon(h[0]), gl_canon(h[1]), gl_canon(h[2]), gl_canon(h[3])};
     *witness = run_pow(&ctx->dev, hh, bits);
@@ -288,6 +311,7 @@ int32_t ola_commit_values_shard_dev(OlaCtx* ctx, const uint64_t* cols_dev, uint3
 }
 int32_t ola_batch_free(OlaCtx* ctx, OlaBatch* batch) {
     OLA_TRY
+    OLA_ON_DEVICE(ctx);
     require(ctx, "ctx");
     if (batch) { HIP_CHECK(hipStreamSynchronize(ctx->dev.stream)); batch_destroy(&ctx->dev, batch); }
     OLA_CATCH
@@ -302,6 +326,7 @@ int32_t ola_batch_shape(const OlaBatch* b, uint32_t* ncols, uint32_t* log_n, uin
 }
 int32_t ola_batch_get_coeffs(OlaCtx* ctx, const OlaBatch* b, uint64_t* out) {
     OLA_TRY
+    OLA_ON_DEVICE(ctx);
     require(ctx && b && out, "null pointer");
     HIP_CHECK(hipMemcpyAsync(out, b->coeffs, ((size_t)b->ncols << b->log_n) * 8, hipMemcpyDeviceToHost, ctx->dev.stream));
     HIP_CHECK(hipStreamSynchronize(ctx->dev.stream));
@@ -309,6 +334,7 @@ int32_t ola_batch_get_coeffs(OlaCtx* ctx, const OlaBatch* b, uint64_t* out) {
 }
 int32_t ola_batch_get_leaf(OlaCtx* ctx, const OlaBatch* b, size_t leaf_index, uint64_t* row_out, uint64_t* siblings_out) {
     OLA_TRY
+    OLA_ON_DEVICE(ctx);
     require(ctx && b && row_out, "null pointer");
     require(leaf_index < b->num_leaves(), "leaf index out of range");
     batch_get_leaf(&ctx->dev, *b, leaf_index, (u64*)row_out, (u64*)siblings_out, &*ctx->tables);
@@ -320,6 +346,7 @@ static void require_full(const OlaBatch* b) {
 
 int32_t ola_batch_get_lde_row(OlaCtx* ctx, const OlaBatch* b, size_t index, size_t step, uint64_t* row_out) {
     OLA_TRY
+    OLA_ON_DEVICE(ctx);
     require(ctx && b && row_out, "null pointer");
     require_full(b);   // natural-order LDE rows interleave the cosets of all shards
     require(step == 0 || index <= b->num_leaves() / step, "row index out of range");
@@ -359,6 +386,7 @@ int32_t ola_open_and_prove(OlaCtx* ctx, const OlaBatch* trace, const OlaBatch* z
                            uint32_t num_permutation_zs, OlaChallenger* challenger, uint8_t* out, size_t cap,
                            size_t* out_len, size_t* openings_len) {
     OLA_TRY
+    OLA_ON_DEVICE(ctx);
     require(ctx && trace && zs && quotient && challenger && out_len, "null pointer");
     require_full(trace); require_full(zs); require_full(quotient);
     require(trace->log_n == zs->log_n && trace->log_n == quotient->log_n, "degree mismatch between commitments");
@@ -379,6 +407,7 @@ int32_t ola_prove_with_traces(OlaCtx* ctx, const uint64_t* airset, size_t airset
                               const uint32_t* log_n, const uint64_t* params, const uint64_t* compress_challenges, uint8_t* out,
                               size_t cap, size_t* out_len) {
     OLA_TRY
+    OLA_ON_DEVICE(ctx);
     require(ctx && airset && traces && log_n && out_len, "null pointer");
     std::vector<uint8_t> bytes;
     prove_with_traces(&ctx->dev, *ctx->tables, ctx->cfg, (const u64*)airset, airset_words, (const u64* const*)traces, log_n,
@@ -395,6 +424,7 @@ int32_t ola_prove_with_traces(OlaCtx* ctx, const uint64_t* airset, size_t airset
 
 int32_t ola_take_pending_proof(OlaCtx* ctx, uint8_t* out, size_t cap, size_t* out_len) {
     OLA_TRY
+    OLA_ON_DEVICE(ctx);
     require(ctx && out_len, "null pointer");
     require(!ctx->pending_proof.empty(), "no proof is pending");
     *out_len = ctx->pending_proof.size();
@@ -410,6 +440,7 @@ int32_t ola_prove_single_table(OlaCtx* ctx, const uint64_t* airset, size_t airse
                                const uint64_t* ctl_challenges, const uint64_t* params, OlaChallenger* challenger, uint8_t* out,
                                size_t cap, size_t* out_len) {
     OLA_TRY
+    OLA_ON_DEVICE(ctx);
     require(ctx && airset && trace_cols && trace_commitment && trace_cap && ctl_challenges && challenger && out_len, "null pointer");
     std::vector<uint8_t> bytes;
     OlaChallenger ch = *challenger;          // the caller's transcript only advances when the proof was produced
@@ -424,25 +455,25 @@ int32_t ola_prove_single_table(OlaCtx* ctx, const uint64_t* airset, size_t airse
 
 int32_t ola_generate_poseidon_trace(OlaCtx* ctx, const uint64_t* inputs, const uint64_t* filters, size_t n, uint64_t* out) {
     OLA_TRY
+    OLA_ON_DEVICE(ctx);
     require(ctx && inputs && out, "null pointer");
     if (n == 0) return OLA_OK;
-    u64* d_in = (u64*)ctx->dev.alloc(12 * n * 8);
-    u64* d_f = filters ? (u64*)ctx->dev.alloc(4 * n * 8) : nullptr;
-    u64* d_out = (u64*)ctx->dev.alloc(134 * n * 8);
-    try {
-        HIP_CHECK(hipMemcpyAsync(d_in, inputs, 12 * n * 8, hipMemcpyHostToDevice, ctx->dev.stream));
-        if (filters) HIP_CHECK(hipMemcpyAsync(d_f, filters, 4 * n * 8, hipMemcpyHostToDevice, ctx->dev.stream));
-        launch_poseidon_trace(&ctx->dev, d_in, d_f, n, d_out);
-        HIP_CHECK(hipMemcpyAsync(out, d_out, 134 * n * 8, hipMemcpyDeviceToHost, ctx->dev.stream));
-        HIP_CHECK(hipStreamSynchronize(ctx->dev.stream));
-    } catch (...) { ctx->dev.free(d_in); ctx->dev.free(d_f); ctx->dev.free(d_out); throw; }
-    ctx->dev.free(d_in); ctx->dev.free(d_f); ctx->dev.free(d_out);
+    DevBuf mem(&ctx->dev);   // released on every path, also when a later allocation throws
+    u64* d_in = (u64*)mem.alloc_bytes(12 * n * 8);
+    u64* d_f = filters ? (u64*)mem.alloc_bytes(4 * n * 8) : nullptr;
+    u64* d_out = (u64*)mem.alloc_bytes(134 * n * 8);
+    HIP_CHECK(hipMemcpyAsync(d_in, inputs, 12 * n * 8, hipMemcpyHostToDevice, ctx->dev.stream));
+    if (filters) HIP_CHECK(hipMemcpyAsync(d_f, filters, 4 * n * 8, hipMemcpyHostToDevice, ctx->dev.stream));
+    launch_poseidon_trace(&ctx->dev, d_in, d_f, n, d_out);
+    HIP_CHECK(hipMemcpyAsync(out, d_out, 134 * n * 8, hipMemcpyDeviceToHost, ctx->dev.stream));
+    HIP_CHECK(hipStreamSynchronize(ctx->dev.stream));
     OLA_CATCH
 }
 
 int32_t ola_permuted_cols_dev(OlaCtx* ctx, const uint64_t* inputs_dev, const uint64_t* table_dev, size_t n,
-                              uint64_t* permuted_inputs_dev, uint64_t* permuted_table_dev) {
+                          uint64_t* permuted_inputs_dev, uint64_t* permuted_table_dev) {
     OLA_TRY
+    OLA_ON_DEVICE(ctx);
     require(ctx && ((inputs_dev && table_dev && permuted_inputs_dev && permuted_table_dev) || n == 0), "null pointer");
     permuted_cols_dev(&ctx->dev, (const u64*)inputs_dev, (const u64*)table_dev, n, (u64*)permuted_inputs_dev, (u64*)permuted_table_dev);
     HIP_CHECK(hipStreamSynchronize(ctx->dev.stream));
@@ -450,25 +481,25 @@ int32_t ola_permuted_cols_dev(OlaCtx* ctx, const uint64_t* inputs_dev, const uin
 }
 
 int32_t ola_permuted_cols(OlaCtx* ctx, const uint64_t* inputs, const uint64_t* table, size_t n, uint64_t* permuted_inputs,
-                          uint64_t* permuted_table) {
+                      uint64_t* permuted_table) {
     OLA_TRY
+    OLA_ON_DEVICE(ctx);
     require(ctx && ((inputs && table && permuted_inputs && permuted_table) || n == 0), "null pointer");
     if (n == 0) return OLA_OK;
-    u64* d = (u64*)ctx->dev.alloc(4 * n * 8);
-    try {
-        HIP_CHECK(hipMemcpyAsync(d, inputs, n * 8, hipMemcpyHostToDevice, ctx->dev.stream));
-        HIP_CHECK(hipMemcpyAsync(d + n, table, n * 8, hipMemcpyHostToDevice, ctx->dev.stream));
-        permuted_cols_dev(&ctx->dev, d, d + n, n, d + 2 * n, d + 3 * n);
-        HIP_CHECK(hipMemcpyAsync(permuted_inputs, d + 2 * n, n * 8, hipMemcpyDeviceToHost, ctx->dev.stream));
-        HIP_CHECK(hipMemcpyAsync(permuted_table, d + 3 * n, n * 8, hipMemcpyDeviceToHost, ctx->dev.stream));
-        HIP_CHECK(hipStreamSynchronize(ctx->dev.stream));
-    } catch (...) { ctx->dev.free(d); throw; }
-    ctx->dev.free(d);
+    DevBuf mem(&ctx->dev);
+    u64* d = mem.alloc(4 * n);
+    HIP_CHECK(hipMemcpyAsync(d, inputs, n * 8, hipMemcpyHostToDevice, ctx->dev.stream));
+    HIP_CHECK(hipMemcpyAsync(d + n, table, n * 8, hipMemcpyHostToDevice, ctx->dev.stream));
+    permuted_cols_dev(&ctx->dev, d, d + n, n, d + 2 * n, d + 3 * n);
+    HIP_CHECK(hipMemcpyAsync(permuted_inputs, d + 2 * n, n * 8, hipMemcpyDeviceToHost, ctx->dev.stream));
+    HIP_CHECK(hipMemcpyAsync(permuted_table, d + 3 * n, n * 8, hipMemcpyDeviceToHost, ctx->dev.stream));
+    HIP_CHECK(hipStreamSynchronize(ctx->dev.stream));
     OLA_CATCH
 }
 
 int32_t ola_gpu_trim(OlaCtx* ctx) {
     OLA_TRY
+    OLA_ON_DEVICE(ctx);
     require(ctx, "ctx");
     ctx->dev.release_cache();
     OLA_CATCH
@@ -476,6 +507,7 @@ int32_t ola_gpu_trim(OlaCtx* ctx) {
 
 int32_t ola_gpu_memory_stats(OlaCtx* ctx, uint64_t out[4], int32_t reset) {
     OLA_TRY
+    OLA_ON_DEVICE(ctx);
     require(ctx && out, "null pointer");
     DeviceCtx& d = ctx->dev;
     out[0] = d.live_bytes; out[1] = d.live_peak; out[2] = d.live_bytes + d.cached_bytes; out[3] = d.reserved_peak;
@@ -485,6 +517,7 @@ int32_t ola_gpu_memory_stats(OlaCtx* ctx, uint64_t out[4], int32_t reset) {
 
 int32_t ola_gpu_reserve(OlaCtx* ctx, const uint64_t* airset, size_t airset_words, const uint32_t* log_n) {
     OLA_TRY
+    OLA_ON_DEVICE(ctx);
     require(ctx && airset && log_n, "null pointer");
     reserve_for_proof(&ctx->dev, ctx->cfg, (const u64*)airset, airset_words, log_n);
     OLA_CATCH
@@ -492,6 +525,7 @@ int32_t ola_gpu_reserve(OlaCtx* ctx, const uint64_t* airset, size_t airset_words
 
 int32_t ola_set_shard(OlaCtx* ctx, uint32_t rank, uint32_t world, ola_all_gather_fn all_gather, void* user) {
     OLA_TRY
+    OLA_ON_DEVICE(ctx);
     require(ctx, "ctx");
     require(world >= 1 && world <= 8 && (world & (world - 1)) == 0 && rank < world, "world must be 1, 2, 4 or 8 and rank < world");
     require(world == 1 || all_gather, "a sharded context needs an all_gather callback");

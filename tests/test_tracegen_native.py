@@ -178,3 +178,32 @@ def test_random_programs_native_equals_python_and_all_airs_vanish(oracle):
             assert np.array_equal(a, b), (trial, t)
         for i, (tr, pr) in enumerate(zip(got, _per_table_params(s, params))):
             assert oracle.check_constraints(s.blob(), i, tr, pr) == -1, (trial, s.tables[i].name)
+
+
+def test_compress_challenges_come_from_the_generators_transcript():
+    """The bitwise and program compress challenges are Fiat-Shamir outputs (generation/builtin.rs:120-131, generation/prog.rs:
+    23-29), not caller inputs: both generators derive the same pair, it changes with the run, and the explicit-beta test path
+    still reproduces given values."""
+    from olavm_amd.air import fastexec, miniexec as M
+    from olavm_amd.backend import Challenger
+    a = fastexec.instance(M.mixed_program())
+    b = fastexec.instance(M.hash_program(2))
+    assert a[1] != b[1] and a[2][2] == a[1][0] and a[2][10] == a[1][1]
+    # the program challenge restated here: start / end state roots, limb by limb
+    tree = M.StorageTree()
+    start = tree.root()
+    M.execute(M.mixed_program(), tree=tree)
+    ch = Challenger()
+    for x, y in zip(start, tree.root()):
+        ch.observe([x, y])
+    assert ch.get() == a[1][1]
+    # the bitwise challenge restated here: the twelve limb columns in order
+    bw = a[0][2]
+    ch = Challenger()
+    from olavm_amd.air import ola_tables as T
+    for cols in (T.BW_OP0_LIMBS, T.BW_OP1_LIMBS, T.BW_RES_LIMBS):
+        for i in range(4):
+            ch.observe(bw[cols.start + i])
+    assert ch.get() == a[1][0]
+    c = fastexec.instance(M.mixed_program(), bitwise_beta=12345, program_beta=67890)
+    assert c[1] == [12345, 67890]
