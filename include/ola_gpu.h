@@ -75,6 +75,31 @@ int32_t ola_gpu_memory_stats(OlaCtx* ctx, uint64_t out[4], int32_t reset);
  * generates the traces -- it moves that cost off the proof.  Optional: proving without it is correct, only colder. */
 int32_t ola_gpu_reserve(OlaCtx* ctx, const uint64_t* airset, size_t airset_words, const uint32_t* log_n);
 
+/* ---- per-phase entry points: one `timed!` scope of prove_single_table at a time ---------------------------------------
+ * The Rust host keeps its transcript and draws the challenges exactly where the reference does; each call replaces the body of
+ * one scope (circuits/src/stark/prover.rs:374-480) and hands host arrays back, so a port can move to the GPU one scope at a
+ * time and compare with the CPU prover after every step.  ola_prove_single_table is the same sequence in one call. */
+/* out[6] = columns, public-parameter words, permutation Z columns, CTL Z columns, quotient_degree_factor,
+ * permutation_batch_size of table `table` of the AIR set (for config.num_challenges of the context). */
+int32_t ola_table_shape(OlaCtx* ctx, const uint64_t* airset, size_t airset_words, uint32_t table, uint32_t out[6]);
+/* compute_permutation_z_polys (permutation.rs:103-187).  trace_cols: host columns of 2^log_n rows; perm_challenges:
+ * [permutation_batch_size][num_challenges][2] = (beta, gamma) in get_n_grand_product_challenge_sets order (prover.rs:360-367);
+ * z_out: [permutation Z columns][n], column-major values (the head of the reference's `z_polys`). */
+int32_t ola_perm_z(OlaCtx* ctx, const uint64_t* airset, size_t airset_words, uint32_t table, uint32_t log_n,
+                   const uint64_t* const* trace_cols, const uint64_t* perm_challenges, uint64_t* z_out);
+/* The table's columns of cross_table_lookup_data (cross_table_lookup.rs:224-311), looking sides before looked sides, lookups in
+ * declaration order, challenge-minor.  ctl_challenges: [num_challenges][2] = (beta, gamma).  z_out: [CTL Z columns][n].
+ * "Non-binary filter?" is reported as OLA_E_INVALID_ARG. */
+int32_t ola_ctl_z(OlaCtx* ctx, const uint64_t* airset, size_t airset_words, uint32_t table, uint32_t log_n,
+                  const uint64_t* const* trace_cols, const uint64_t* ctl_challenges, uint64_t* z_out);
+/* compute_quotient_polys and the split into chunks (prover.rs:441-480, 571-705).  trace / zs: the table's trace and Z commitments
+ * (ola_commit_values of the trace columns and of perm Z columns followed by CTL Z columns); alphas: [num_challenges];
+ * chunks_out: [num_challenges * quotient_degree_factor][n] coefficients, the input of from_coeffs (ola_commit_coeffs).
+ * OLA_E_QUOTIENT_DEGREE when the trace does not satisfy the constraints. */
+int32_t ola_quotient(OlaCtx* ctx, const uint64_t* airset, size_t airset_words, uint32_t table, const OlaBatch* trace,
+                     const OlaBatch* zs, const uint64_t* perm_challenges, const uint64_t* ctl_challenges, const uint64_t* alphas,
+                     const uint64_t* params, uint64_t* chunks_out);
+
 /* ---- NTT family: replaces gpu_method and the cfft CPU paths --------------------------------------------
  * op selects the reference function (plonky2/field/src/cfft/mod.rs):
  *   OLA_NTT_EVALUATE              evaluate_poly               :22   coeffs -> values on <w>, natural order

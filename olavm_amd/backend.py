@@ -93,6 +93,10 @@ def load_library():
     L.ola_permuted_cols.argtypes = [C.c_void_p, U64P, U64P, C.c_size_t, U64P, U64P]
     L.ola_permuted_cols_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
     L.ola_set_shard.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, ALL_GATHER_FN, C.c_void_p]
+    L.ola_table_shape.argtypes = [C.c_void_p, U64P, C.c_size_t, C.c_uint32, C.POINTER(C.c_uint32)]
+    L.ola_perm_z.argtypes = [C.c_void_p, U64P, C.c_size_t, C.c_uint32, C.c_uint32, C.POINTER(U64P), U64P, U64P]
+    L.ola_ctl_z.argtypes = [C.c_void_p, U64P, C.c_size_t, C.c_uint32, C.c_uint32, C.POINTER(U64P), U64P, U64P]
+    L.ola_quotient.argtypes = [C.c_void_p, U64P, C.c_size_t, C.c_uint32, C.c_void_p, C.c_void_p, U64P, U64P, U64P, U64P, U64P]
     L.ola_gpu_memory_stats.argtypes = [C.c_void_p, U64P, C.c_int32]
     L.ola_gpu_reserve.argtypes = [C.c_void_p, U64P, C.c_size_t, C.POINTER(C.c_uint32)]
     L.ola_air_kernels_available.argtypes = [U64P, C.c_size_t, C.POINTER(C.c_uint8), C.c_size_t]
@@ -108,6 +112,7 @@ EXPORTS = [
     "ola_challenger_get", "ola_challenger_compact", "ola_open_and_prove", "ola_pow", "ola_prove_with_traces",
     "ola_air_kernels_available", "ola_commit_values_shard", "ola_commit_values_shard_dev", "ola_set_shard", "ola_gpu_trim", "ola_generate_poseidon_trace",
     "ola_permuted_cols", "ola_permuted_cols_dev", "ola_prove_single_table", "ola_take_pending_proof", "ola_gpu_memory_stats", "ola_gpu_reserve",
+    "ola_table_shape", "ola_perm_z", "ola_ctl_z", "ola_quotient",
 ]
 
 
@@ -318,6 +323,44 @@ class Backend:
     def trim(self):
         """Return the context's cached device buffers to the driver (ola_gpu_trim)."""
         self._chk(self.lib.ola_gpu_trim(self.ctx))
+
+    # ---- per-phase entry points (one `timed!` scope of prove_single_table at a time) ----
+    def table_shape(self, airset_blob, table):
+        """-> dict(ncols, n_params, perm_zs, ctl_zs, quotient_degree_factor, permutation_batch_size)."""
+        blob = np.ascontiguousarray(airset_blob, dtype=np.uint64)
+        out = (C.c_uint32 * 6)()
+        self._chk(self.lib.ola_table_shape(self.ctx, _p(blob), blob.size, table, out))
+        return dict(zip(("ncols", "n_params", "perm_zs", "ctl_zs", "quotient_degree_factor", "permutation_batch_size"), (int(x) for x in out)))
+
+    def _zs_phase(self, fn, airset_blob, table, trace, challenges, count):
+        blob = np.ascontiguousarray(airset_blob, dtype=np.uint64)
+        tr = np.ascontiguousarray(trace, dtype=np.uint64)
+        ptrs = (U64P * tr.shape[0])(*[_p(tr[c]) for c in range(tr.shape[0])])
+        cc = np.ascontiguousarray(np.array(challenges, dtype=np.uint64).reshape(-1))
+        out = np.zeros((count, tr.shape[1]), dtype=np.uint64)
+        self._chk(fn(self.ctx, _p(blob), blob.size, table, int(tr.shape[1]).bit_length() - 1, ptrs, _p(cc), _p(out) if count else _p(np.zeros(1, dtype=np.uint64))))
+        return out
+
+    def perm_z(self, airset_blob, table, trace, perm_challenges):
+        """Permutation Z columns (values): perm_challenges = [batch_size][num_challenges] pairs (beta, gamma)."""
+        return self._zs_phase(self.lib.ola_perm_z, airset_blob, table, trace, perm_challenges, self.table_shape(airset_blob, table)["perm_zs"])
+
+    def ctl_z(self, airset_blob, table, trace, ctl_challenges):
+        """CTL Z columns (values): ctl_challenges = [num_challenges] pairs (beta, gamma)."""
+        return self._zs_phase(self.lib.ola_ctl_z, airset_blob, table, trace, ctl_challenges, self.table_shape(airset_blob, table)["ctl_zs"])
+
+    def quotient(self, airset_blob, table, trace_batch, zs_batch, perm_challenges, ctl_challenges, alphas, params, n):
+        """Coefficients of the 2 * quotient_degree_factor quotient chunk polynomials, [chunks][n]."""
+        blob = np.ascontiguousarray(airset_blob, dtype=np.uint64)
+        q = self.table_shape(airset_blob, table)["quotient_degree_factor"]
+        pc = None if perm_challenges is None else np.ascontiguousarray(np.array(perm_challenges, dtype=np.uint64).reshape(-1))
+        cc = np.ascontiguousarray(np.array(ctl_challenges, dtype=np.uint64).reshape(-1))
+        al = np.ascontiguousarray(alphas, dtype=np.uint64)
+        pr = None if params is None or len(params) == 0 else np.ascontiguousarray(params, dtype=np.uint64)
+        out = np.zeros((2 * q, n), dtype=np.uint64)
+        self._chk(self.lib.ola_quotient(self.ctx, _p(blob), blob.size, table, trace_batch.h, zs_batch.h, None if pc is None else _p(pc), _p(cc), _p(al),
+                                        None if pr is None else _p(pr), _p(out)))
+        return out
 
     def reserve(self, airset_blob, log_ns):
         """Start allocating the buffers of a coming proof in the background (ola_gpu_reserve); returns at once."""

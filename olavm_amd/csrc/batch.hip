@@ -221,6 +221,7 @@ OlaBatch* batch_commit(DeviceCtx* ctx, NttTables& t, const uint64_t* const* cols
                 // interpolate AND extend each group as it arrives, so that only the leaf hashing waits for the last column
                 // (the transform scratch cannot live inside the LDE buffer here: earlier groups already wrote theirs)
                 if (!tmp) tmp = (u64*)ctx->alloc((size_t)feed->chunk_cols * n * 8);
+                PhaseTimer tp(ctx, "      IFFT + FFT + blinding (column groups as the upload delivers them)");
                 for (uint32_t c0 = 0; c0 < ncols; c0 += feed->chunk_cols) {
                     const uint32_t c1 = std::min(ncols, c0 + feed->chunk_cols);
                     feed->before_chunk(c0, c1);
@@ -230,6 +231,7 @@ OlaBatch* batch_commit(DeviceCtx* ctx, NttTables& t, const uint64_t* const* cols
                 }
                 lde_done = true;
             } else {
+                PhaseTimer tp(ctx, "      IFFT");
                 ntt_interpolate(t, vals, b->coeffs, scratch, log_n, ncols);
             }
         } else {
@@ -241,9 +243,14 @@ OlaBatch* batch_commit(DeviceCtx* ctx, NttTables& t, const uint64_t* const* cols
             }
             canonicalize(ctx, b->coeffs, (size_t)ncols * n);
         }
-        if (!lde_done) ntt_lde_leaf_order(t, b->coeffs, b->lde, log_n, full_rate_bits, ncols, b->coset_first, (size_t)1 << rate_bits);
-        launch_leaf_hash_colmajor(ctx, b->lde, N, (int)ncols, N, b->heap + 4 * N);
-        launch_merkle_build(ctx, b->heap, N, cap_height);
+        // (OLA_TIMING scopes carry the reference's `timed!` names, fri/oracle.rs:56-90; "transpose LDEs" has no counterpart:
+        // the LDE is produced in leaf order)
+        if (!lde_done) { PhaseTimer tp(ctx, "      FFT + blinding"); ntt_lde_leaf_order(t, b->coeffs, b->lde, log_n, full_rate_bits, ncols, b->coset_first, (size_t)1 << rate_bits); }
+        {
+            PhaseTimer tp(ctx, "      build Merkle tree");
+            launch_leaf_hash_colmajor(ctx, b->lde, N, (int)ncols, N, b->heap + 4 * N);
+            launch_merkle_build(ctx, b->heap, N, cap_height);
+        }
         HIP_CHECK(hipStreamSynchronize(ctx->stream));
         if (tmp) ctx->free(tmp);
     } catch (...) {

@@ -506,6 +506,8 @@ void open_and_prove(DeviceCtx* ctx, NttTables& tables, const OlaGpuConfig& cfg, 
                        w1, w2, use2 ? 1 : 0, coef, coef + N, N);
 
     // ---- FRI commit phase (fri/prover.rs:72-121) ----
+    // (OLA_TIMING scopes carry the reference's `timed!` names: fri/oracle.rs:221-225, fri/prover.rs:41-58)
+    std::unique_ptr<PhaseTimer> t_fold;
     std::vector<FriLayer> layers;
     u64 shift = GL_GENERATOR;
     size_t len = N;
@@ -520,7 +522,11 @@ void open_and_prove(DeviceCtx* ctx, NttTables& tables, const OlaGpuConfig& cfg, 
         L.len = len; L.arity_bits = ab;
         L.va = mem.alloc(2 * len);
         L.vb = L.va + len;
-        ntt_coset_evaluate(tables, cur_coef, L.va, nullptr, cur_bits, 2, shift, false);
+        {
+            std::unique_ptr<PhaseTimer> t_fft(li == 0 ? new PhaseTimer(ctx, "      perform final FFT " + std::to_string(len)) : nullptr);
+            ntt_coset_evaluate(tables, cur_coef, L.va, nullptr, cur_bits, 2, shift, false);
+        }
+        if (li == 0) t_fold.reset(new PhaseTimer(ctx, "      fold codewords in the commitment phase"));
         const size_t nleaves = len >> ab;
         L.heap = mem.alloc(2 * nleaves * 4);
         launch_leaf_hash_ext(ctx, L.va, L.vb, arity, nleaves, L.heap + 4 * nleaves);
@@ -551,7 +557,12 @@ void open_and_prove(DeviceCtx* ctx, NttTables& tables, const OlaGpuConfig& cfg, 
     // ---- proof of work (prover.rs:126-148), minimal witness ----
     u64 hsh[4];
     for (int i = 0; i < 4; i++) hsh[i] = challenger_get(ch);
-    const u64 pow_witness = run_pow(ctx, hsh, cfg.proof_of_work_bits);
+    t_fold.reset();
+    u64 pow_witness;
+    {
+        PhaseTimer t_pow(ctx, "      find proof-of-work witness");
+        pow_witness = run_pow(ctx, hsh, cfg.proof_of_work_bits);
+    }
 
     // ---- query rounds (prover.rs:150-204) ----
     const int nq = (int)cfg.num_query_rounds;

@@ -453,6 +453,49 @@ int32_t ola_prove_single_table(OlaCtx* ctx, const uint64_t* airset, size_t airse
     OLA_CATCH
 }
 
+int32_t ola_table_shape(OlaCtx* ctx, const uint64_t* airset, size_t airset_words, uint32_t table, uint32_t out[6]) {
+    OLA_TRY
+    require(ctx && airset && out, "null pointer");
+    table_shape_host(ctx->cfg, (const u64*)airset, airset_words, table, out);
+    OLA_CATCH
+}
+
+static int32_t ola_zs_phase(OlaCtx* ctx, const uint64_t* airset, size_t airset_words, uint32_t table, uint32_t log_n,
+                            const uint64_t* const* trace_cols, const uint64_t* perm_ch, const uint64_t* ctl_ch, int which, uint64_t* z_out) {
+    OLA_TRY
+    OLA_ON_DEVICE(ctx);
+    require(ctx && airset && trace_cols && z_out, "null pointer");
+    require(log_n + ctx->cfg.rate_bits <= 32, "log_n too large");
+    std::vector<u64> cols;
+    phase_zs_host(&ctx->dev, *ctx->tables, ctx->cfg, (const u64*)airset, airset_words, table, log_n, (const u64* const*)trace_cols,
+                  (const u64*)perm_ch, (const u64*)ctl_ch, which, cols);
+    if (!cols.empty()) memcpy(z_out, cols.data(), cols.size() * 8);
+    OLA_CATCH
+}
+int32_t ola_perm_z(OlaCtx* ctx, const uint64_t* airset, size_t airset_words, uint32_t table, uint32_t log_n,
+                   const uint64_t* const* trace_cols, const uint64_t* perm_challenges, uint64_t* z_out) {
+    if (!perm_challenges) { g_last_error = "invalid argument: null pointer"; return OLA_E_INVALID_ARG; }
+    return ola_zs_phase(ctx, airset, airset_words, table, log_n, trace_cols, perm_challenges, nullptr, 0, z_out);
+}
+int32_t ola_ctl_z(OlaCtx* ctx, const uint64_t* airset, size_t airset_words, uint32_t table, uint32_t log_n,
+                  const uint64_t* const* trace_cols, const uint64_t* ctl_challenges, uint64_t* z_out) {
+    if (!ctl_challenges) { g_last_error = "invalid argument: null pointer"; return OLA_E_INVALID_ARG; }
+    return ola_zs_phase(ctx, airset, airset_words, table, log_n, trace_cols, nullptr, ctl_challenges, 1, z_out);
+}
+
+int32_t ola_quotient(OlaCtx* ctx, const uint64_t* airset, size_t airset_words, uint32_t table, const OlaBatch* trace, const OlaBatch* zs,
+                     const uint64_t* perm_challenges, const uint64_t* ctl_challenges, const uint64_t* alphas, const uint64_t* params,
+                     uint64_t* chunks_out) {
+    OLA_TRY
+    OLA_ON_DEVICE(ctx);
+    require(ctx && airset && trace && zs && ctl_challenges && alphas && chunks_out, "null pointer");
+    std::vector<u64> chunks;
+    phase_quotient_host(&ctx->dev, *ctx->tables, ctx->cfg, (const u64*)airset, airset_words, table, *trace, *zs, (const u64*)perm_challenges,
+                        (const u64*)ctl_challenges, (const u64*)alphas, (const u64*)params, chunks);
+    memcpy(chunks_out, chunks.data(), chunks.size() * 8);
+    OLA_CATCH
+}
+
 int32_t ola_generate_poseidon_trace(OlaCtx* ctx, const uint64_t* inputs, const uint64_t* filters, size_t n, uint64_t* out) {
     OLA_TRY
     OLA_ON_DEVICE(ctx);

@@ -436,6 +436,18 @@ static GpChallenge get_gp(OlaChallenger& ch) { const u64 b = challenger_get(ch);
 
 struct CtlJob { const HTwc* twc; GpChallenge ch; };
 
+// Phase-level entry points (ola_perm_z / ola_ctl_z / ola_quotient) run prove_single_table with a tap: challenges come from the
+// caller instead of the transcript, and the function hands back an intermediate result and stops.
+struct PhaseTap {
+    const u64* perm_challenges = nullptr;    // [batch_size][num_challenges][2] (beta, gamma)
+    const u64* alphas = nullptr;             // [num_challenges]
+    const OlaBatch* zs = nullptr;            // the caller's Z commitment (quotient phase: the Z columns are not recomputed)
+    int stop_after = 0;                      // 1: after the Z columns, 2: after the quotient chunks
+    std::vector<u64>* zs_out = nullptr;      // [nz][n] column-major
+    std::vector<u64>* chunks_out = nullptr;  // [num_challenges * q][n] coefficients
+    int nperm = 0, nz = 0, q = 0;
+};
+
 struct BatchHolder {
     DeviceCtx* ctx;
     OlaBatch* b = nullptr;
@@ -485,7 +497,7 @@ static bool table_is_sharded(const DeviceCtx* ctx, const OlaGpuConfig& cfg, cons
 
 static void prove_single_table(DeviceCtx* ctx, NttTables& tables, const OlaGpuConfig& cfg, const HTable& air, const DevTable& tv,
                                const OlaBatch& trace_c, const std::vector<u64>& trace_cap, const std::vector<CtlJob>& ctl,
-                               const u64* params, OlaChallenger& ch, std::vector<uint8_t>& bytes, bool sharded) {
+                               const u64* params, OlaChallenger& ch, std::vector<uint8_t>& bytes, bool sharded, PhaseTap* tap = nullptr) {
     DevBuf mem(ctx);
     const int nch = (int)cfg.num_challenges;
     if (nch != 2) throw OlaError(OLA_E_INVALID_ARG, "num_challenges must be 2");
@@ -505,9 +517,19 @@ static void prove_single_table(DeviceCtx* ctx, NttTables& tables, const OlaGpuCo
     const int bs = air.permutation_batch_size();
     std::vector<std::vector<GpChallenge>> perm_sets;
     if (!air.perm_pairs.empty())
-        for (int i = 0; i < bs; i++) { std::vector<GpChallenge> s; for (int c = 0; c < nch; c++) s.push_back(get_gp(ch)); perm_sets.push_back(s); }
+        for (int i = 0; i < bs; i++) {
+            std::vector<GpChallenge> s;
+            for (int c = 0; c < nch; c++) {
+                if (tap && tap->perm_challenges) s.push_back({gl_canon(tap->perm_challenges[(i * nch + c) * 2]), gl_canon(tap->perm_challenges[(i * nch + c) * 2 + 1])});
+                else s.push_back(get_gp(ch));
+            }
+            perm_sets.push_back(s);
+        }
+    const bool have_zs = tap && tap->zs;     // quotient phase on a caller-held Z commitment: descriptors only
     const int nz = nperm + (int)ctl.size();
     if (nz == 0) throw OlaError(OLA_E_INVALID_ARG, "No CTL?");
+    // OLA_TIMING scopes carry the reference's `timed!` names (prover.rs:374-544)
+    std::unique_ptr<PhaseTimer> ph(new PhaseTimer(ctx, "    compute permutation Z(x) polys"));
     u64* zvals = mem.alloc((size_t)nz * n);
     u64* tot = mem.alloc(pscan_tot_stride(n) * std::max<size_t>(1, ctl.size()));
     u64* tmpcol = mem.alloc(n);
@@ -529,7 +551,7 @@ static void prove_single_table(DeviceCtx* ctx, NttTables& tables, const OlaGpuCo
             perm_desc[at] = cnt;
         }
     }
-    if (nperm) {
+    if (nperm && !have_zs) {
         u64* d_pd = mem.alloc(perm_desc.size());
         HIP_CHECK(hipMemcpyAsync(d_pd, perm_desc.data(), perm_desc.size() * 8, hipMemcpyHostToDevice, ctx->stream));
         // offsets of each batch descriptor
@@ -553,7 +575,7 @@ static void prove_single_table(DeviceCtx* ctx, NttTables& tables, const OlaGpuCo
     if (!ctl_desc.empty()) HIP_CHECK(hipMemcpyAsync(d_cd, ctl_desc.data(), ctl_desc.size() * 8, hipMemcpyHostToDevice, ctx->stream));
     unsigned* d_bad_filter = (unsigned*)mem.alloc(1);
     HIP_CHECK(hipMemsetAsync(d_bad_filter, 0, 8, ctx->stream));
-    if (!ctl.empty()) {   // all CTL Z columns of the table in one launch per step
+    if (!ctl.empty() && !have_zs) {   // all CTL Z columns of the table in one launch per step
         std::vector<u64> offs(ctl_off.begin(), ctl_off.end());
         u64* d_offs = mem.alloc(offs.size());
         HIP_CHECK(hipMemcpyAsync(d_offs, offs.data(), offs.size() * 8, hipMemcpyHostToDevice, ctx->stream));
@@ -563,21 +585,37 @@ static void prove_single_table(DeviceCtx* ctx, NttTables& tables, const OlaGpuCo
         product_scan_inclusive(ctx, zc, n, tot, ctl.size());
         HIP_CHECK(hipStreamSynchronize(ctx->stream));   // offs is a stack-lifetime staging buffer
     }
-    if (!ctl.empty()) {
+    if (!ctl.empty() && !have_zs) {
         unsigned bad = 0;
         HIP_CHECK(hipMemcpyAsync(&bad, d_bad_filter, 4, hipMemcpyDeviceToHost, ctx->stream));
         HIP_CHECK(hipStreamSynchronize(ctx->stream));
         if (bad) throw OlaError(OLA_E_INVALID_ARG, "Non-binary filter?");
     }
+    if (tap) { tap->nperm = nperm; tap->nz = nz; tap->q = air.quotient_degree_factor(); }
+    if (tap && tap->stop_after == 1) {
+        tap->zs_out->resize((size_t)nz * n);
+        HIP_CHECK(hipMemcpyAsync(tap->zs_out->data(), zvals, (size_t)nz * n * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        return;
+    }
     // ---- Zs commitment ----
-    std::unique_ptr<PhaseTimer> ph(new PhaseTimer(ctx, "    compute permutation/CTL Z commitment"));
-    BatchHolder zs_c(ctx);
+    ph.reset();
+    ph.reset(new PhaseTimer(ctx, "    compute Zs commitment"));
+    struct ZsRef { BatchHolder own; const OlaBatch* b = nullptr; explicit ZsRef(DeviceCtx* c) : own(c) {} } zs_c(ctx);
     std::vector<u64> zs_cap;
     const bool lean = trace_c.lean;   // the table is proven memory-lean: no LDE of its three batches is kept
     if (lean && sharded) throw OlaError(OLA_E_INTERNAL, "a memory-lean table cannot be on the coset partition");
-    zs_c.b = commit_shared(ctx, tables, zvals, (uint32_t)nz, (uint32_t)degree_bits, cfg, true, sharded, nullptr, zs_cap, lean);
-    challenger_observe(ch, zs_cap.data(), zs_cap.size());
-    const u64 alpha0 = challenger_get(ch), alpha1 = challenger_get(ch);
+    if (have_zs) {
+        if (tap->zs->ncols != (uint32_t)nz || tap->zs->log_n != (uint32_t)degree_bits || tap->zs->lean != lean || tap->zs->is_shard())
+            throw OlaError(OLA_E_INVALID_ARG, "Z commitment does not match the table");
+        zs_c.b = tap->zs;
+    } else {
+        zs_c.own.b = commit_shared(ctx, tables, zvals, (uint32_t)nz, (uint32_t)degree_bits, cfg, true, sharded, nullptr, zs_cap, lean);
+        zs_c.b = zs_c.own.b;
+        challenger_observe(ch, zs_cap.data(), zs_cap.size());
+    }
+    const u64 alpha0 = (tap && tap->alphas) ? gl_canon(tap->alphas[0]) : challenger_get(ch);
+    const u64 alpha1 = (tap && tap->alphas) ? gl_canon(tap->alphas[1]) : challenger_get(ch);
 
     // ---- quotient (prover.rs:571-705) ----
     ph.reset();
@@ -747,9 +785,17 @@ static void prove_single_table(DeviceCtx* ctx, NttTables& tables, const OlaGpuCo
         if (flag) throw OlaError(OLA_E_QUOTIENT_DEGREE, "Quotient has failed, the vanishing polynomial is not divisible by Z_H");
     }
     // chunks of n coefficients: [challenge][k] -> column challenge*q + k
+    ph.reset();
+    ph.reset(new PhaseTimer(ctx, "    split quotient polys"));
     u64* chunks = mem.alloc((size_t)2 * q * n);
     for (int c = 0; c < 2; c++)
         HIP_CHECK(hipMemcpyAsync(chunks + (size_t)c * q * n, qcoef + (size_t)c * size, keep * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    if (tap && tap->stop_after == 2) {
+        tap->chunks_out->resize((size_t)2 * q * n);
+        HIP_CHECK(hipMemcpyAsync(tap->chunks_out->data(), chunks, (size_t)2 * q * n * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        return;
+    }
     ph.reset();
     ph.reset(new PhaseTimer(ctx, "    compute quotient commitment"));
     BatchHolder q_c(ctx);
@@ -764,7 +810,7 @@ static void prove_single_table(DeviceCtx* ctx, NttTables& tables, const OlaGpuCo
     write_cap(w, q_cap);
     size_t olen = 0;
     ph.reset();
-    ph.reset(new PhaseTimer(ctx, "    openings + FRI"));
+    ph.reset(new PhaseTimer(ctx, "    compute openings proof"));
     open_and_prove(ctx, tables, cfg, trace_c, *zs_c.b, *q_c.b, (uint32_t)nperm, ch, bytes, olen);
 }
 
@@ -805,6 +851,93 @@ void prove_single_table_host(DeviceCtx* ctx, NttTables& tables, const OlaGpuConf
     std::vector<u64> zero_params(64, 0);
     if (!params && air.n_params > 64) throw OlaError(OLA_E_INVALID_ARG, "params required");
     prove_single_table(ctx, tables, cfg, air, tv, trace_c, cap, jobs[table], params ? params : zero_params.data(), ch, bytes, false);
+}
+
+// Widths of a table's three batches (trace, Z, quotient chunks)
+struct TableWidths { size_t w, wz, wq; int qdb; };
+static TableWidths table_widths(const HAirSet& set, size_t t, int nch) {
+    const HTable& air = set.tables[t];
+    size_t nctl = 0;
+    for (const HCtl& c : set.ctls) { for (const HTwc& w2 : c.looking) nctl += ((size_t)w2.table == t) ? nch : 0; nctl += ((size_t)c.looked.table == t) ? nch : 0; }
+    TableWidths r;
+    r.w = (size_t)air.ncols; r.wz = air.num_permutation_batches(nch) + nctl; r.wq = (size_t)nch * air.quotient_degree_factor();
+    r.qdb = 0;
+    while ((1 << r.qdb) < air.quotient_degree_factor()) r.qdb++;
+    return r;
+}
+
+// ---- phase-level entry points (one `timed!` scope of the reference at a time) --------------------------------
+// out[6] = ncols, n_params, permutation Z columns, CTL Z columns, quotient_degree_factor, permutation batch size
+void table_shape_host(const OlaGpuConfig& cfg, const u64* airset, size_t airset_words, uint32_t table, uint32_t out[6]) {
+    HAirSet set = parse_airset(airset, airset_words);
+    if (table >= set.tables.size()) throw OlaError(OLA_E_INVALID_ARG, "table index out of range");
+    const TableWidths tw = table_widths(set, table, (int)cfg.num_challenges);
+    const HTable& air = set.tables[table];
+    const uint32_t nperm = (uint32_t)air.num_permutation_batches((int)cfg.num_challenges);
+    out[0] = (uint32_t)air.ncols; out[1] = (uint32_t)air.n_params; out[2] = nperm; out[3] = (uint32_t)tw.wz - nperm;
+    out[4] = (uint32_t)air.quotient_degree_factor(); out[5] = (uint32_t)air.permutation_batch_size();
+}
+
+// compute_permutation_z_polys (permutation.rs:103-187) and the table's share of cross_table_lookup_data
+// (cross_table_lookup.rs:224-311): the Z columns as values over the trace domain.  which = 0: permutation columns, 1: CTL columns.
+void phase_zs_host(DeviceCtx* ctx, NttTables& tables, const OlaGpuConfig& cfg, const u64* airset, size_t airset_words, uint32_t table,
+                   uint32_t log_n, const u64* const* trace_cols, const u64* perm_challenges, const u64* ctl_challenges, int which,
+                   std::vector<u64>& out_cols) {
+    HAirSet set = parse_airset(airset, airset_words);
+    if (table >= set.tables.size()) throw OlaError(OLA_E_INVALID_ARG, "table index out of range");
+    const HTable& air = set.tables[table];
+    std::vector<GpChallenge> ctl_ch;
+    for (uint32_t c = 0; c < cfg.num_challenges; c++) ctl_ch.push_back(ctl_challenges ? GpChallenge{gl_canon(ctl_challenges[2 * c]), gl_canon(ctl_challenges[2 * c + 1])} : GpChallenge{1, 1});
+    const std::vector<std::vector<CtlJob>> jobs = ctl_jobs(set, ctl_ch);
+    DevBuf mem(ctx);
+    DevTable tv;
+    tv.log_n = log_n;
+    const size_t n = tv.n();
+    tv.vals = mem.alloc((size_t)air.ncols * n);
+    for (int c = 0; c < air.ncols; c++)
+        HIP_CHECK(hipMemcpyAsync(tv.vals + (size_t)c * n, trace_cols[c], n * 8, hipMemcpyHostToDevice, ctx->stream));
+    canonicalize(ctx, tv.vals, (size_t)air.ncols * n);
+    std::vector<u64> dummy_perm((size_t)air.permutation_batch_size() * cfg.num_challenges * 2, 1);
+    PhaseTap tap;
+    tap.perm_challenges = perm_challenges ? perm_challenges : dummy_perm.data();
+    tap.stop_after = 1;
+    std::vector<u64> zs;
+    tap.zs_out = &zs;
+    OlaBatch shape;            // only its flags are looked at before the Z columns exist
+    shape.ncols = (uint32_t)air.ncols; shape.log_n = log_n;
+    OlaChallenger ch;
+    memset(&ch, 0, sizeof(ch));
+    std::vector<uint8_t> bytes;
+    std::vector<u64> zero_params(64, 0), cap;
+    prove_single_table(ctx, tables, cfg, air, tv, shape, cap, jobs[table], zero_params.data(), ch, bytes, false, &tap);
+    const size_t first = which == 0 ? 0 : (size_t)tap.nperm, count = which == 0 ? (size_t)tap.nperm : (size_t)(tap.nz - tap.nperm);
+    out_cols.assign(zs.begin() + first * n, zs.begin() + (first + count) * n);
+}
+
+// compute_quotient_polys + the split into degree-n chunks (prover.rs:441-480, 571-705): coefficients of the 2 * q chunk
+// polynomials, ready for PolynomialBatch::from_coeffs.
+void phase_quotient_host(DeviceCtx* ctx, NttTables& tables, const OlaGpuConfig& cfg, const u64* airset, size_t airset_words, uint32_t table,
+                         const OlaBatch& trace_c, const OlaBatch& zs_c, const u64* perm_challenges, const u64* ctl_challenges, const u64* alphas,
+                         const u64* params, std::vector<u64>& chunks) {
+    HAirSet set = parse_airset(airset, airset_words);
+    if (table >= set.tables.size()) throw OlaError(OLA_E_INVALID_ARG, "table index out of range");
+    if (ctx->shard.world != 1) throw OlaError(OLA_E_INVALID_ARG, "per-phase proving needs an unsharded context");
+    const HTable& air = set.tables[table];
+    if (trace_c.ncols != (uint32_t)air.ncols || trace_c.is_shard()) throw OlaError(OLA_E_INVALID_ARG, "trace commitment does not match the table");
+    if (!air.perm_pairs.empty() && !perm_challenges) throw OlaError(OLA_E_INVALID_ARG, "the table has permutation arguments: perm_challenges required");
+    std::vector<GpChallenge> ctl_ch;
+    for (uint32_t c = 0; c < cfg.num_challenges; c++) ctl_ch.push_back({gl_canon(ctl_challenges[2 * c]), gl_canon(ctl_challenges[2 * c + 1])});
+    const std::vector<std::vector<CtlJob>> jobs = ctl_jobs(set, ctl_ch);
+    DevTable tv;
+    tv.log_n = trace_c.log_n;
+    PhaseTap tap;
+    tap.perm_challenges = perm_challenges; tap.alphas = alphas; tap.zs = &zs_c; tap.stop_after = 2; tap.chunks_out = &chunks;
+    OlaChallenger ch;
+    memset(&ch, 0, sizeof(ch));
+    std::vector<uint8_t> bytes;
+    std::vector<u64> zero_params(64, 0), cap;
+    if (!params && air.n_params > 64) throw OlaError(OLA_E_INVALID_ARG, "params required");
+    prove_single_table(ctx, tables, cfg, air, tv, trace_c, cap, jobs[table], params ? params : zero_params.data(), ch, bytes, false, &tap);
 }
 
 // Host -> device transfer of the trace tables on a helper thread and a dedicated stream, in groups of columns of about
@@ -864,19 +997,6 @@ class TraceUploader {
     std::string error_;
     hipStream_t stream_ = nullptr;
 };
-
-// Widths of a table's three batches (trace, Z, quotient chunks)
-struct TableWidths { size_t w, wz, wq; int qdb; };
-static TableWidths table_widths(const HAirSet& set, size_t t, int nch) {
-    const HTable& air = set.tables[t];
-    size_t nctl = 0;
-    for (const HCtl& c : set.ctls) { for (const HTwc& w2 : c.looking) nctl += ((size_t)w2.table == t) ? nch : 0; nctl += ((size_t)c.looked.table == t) ? nch : 0; }
-    TableWidths r;
-    r.w = (size_t)air.ncols; r.wz = air.num_permutation_batches(nch) + nctl; r.wq = (size_t)nch * air.quotient_degree_factor();
-    r.qdb = 0;
-    while ((1 << r.qdb) < air.quotient_degree_factor()) r.qdb++;
-    return r;
-}
 
 // Memory-lean tables (OLA_LEAN=1 forces, =0 forbids, default: when keeping every LDE resident would not fit): the LDEs of the
 // large tables are streamed coset by coset instead of kept (batch_commit lean) -- a 2^24-row CPU table then proves on one GPU
@@ -972,8 +1092,9 @@ void prove_with_traces(DeviceCtx* ctx, NttTables& tables, const OlaGpuConfig& cf
     TraceUploader up(ctx, nt);
     for (size_t t = 0; t < nt; t++) up.add(t, traces[t], dev[t].vals, (uint32_t)set.tables[t].ncols, (size_t)1 << log_n[t]);
     up.start();
+    std::unique_ptr<PhaseTimer> t_commit(new PhaseTimer(ctx, "compute trace commitments"));
     for (size_t t = 0; t < nt; t++) {
-        PhaseTimer tt(ctx, "  table " + std::to_string(t) + " compute trace commitment (upload overlapped)");
+        PhaseTimer tt(ctx, "  table " + std::to_string(t) + " trace commitment (upload overlapped)");
         const size_t n_t = (size_t)1 << log_n[t];
         ColumnFeed feed;
         feed.chunk_cols = up.chunk_cols(t);
@@ -986,6 +1107,7 @@ void prove_with_traces(DeviceCtx* ctx, NttTables& tables, const OlaGpuConfig& cf
                                       table_is_sharded(ctx, cfg, set.tables[t], log_n[t]), &feed, caps[t], lean[t] != 0);
     }
     up.finish();
+    t_commit.reset();
     for (size_t t = 0; t < nt; t++) challenger_observe(ch, caps[t].data(), caps[t].size());
     // CTL challenges and per-table job lists, in cross_table_lookup_data order
     std::vector<GpChallenge> ctl_ch;

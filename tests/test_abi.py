@@ -83,3 +83,22 @@ def test_specialised_kernels_are_paired_with_the_blob_by_signature(lib):
     assert got == [i != 8 for i in range(12)]
     other = T.ola_stark(range_bits=5, limb_bits=2)                                 # a range-check table nobody generated
     assert available(other) == [i != 4 for i in range(12)]
+
+
+def test_checked_in_airset_blob_is_the_ola_stark_and_fully_specialised():
+    """include/ola_airset.bin is what the Rust side `include_bytes!`s: it must be exactly
+    ola_stark().blob() -- the reference's 12 tables and 19 lookups at full size -- and every table must have its generated
+    straight-line quotient kernel in this build."""
+    import ctypes as C
+    import os
+    import numpy as np
+    from olavm_amd.air import ola_tables as T
+    from olavm_amd.backend import load_library, U64P
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "ola_airset.bin")
+    disk = np.fromfile(path, dtype="<u8")
+    blob = np.ascontiguousarray(T.ola_stark().blob(), dtype=np.uint64)
+    assert disk.shape == blob.shape and np.array_equal(disk, blob), "regenerate include/ola_airset.bin (olavm_amd/air/ola_tables.py changed)"
+    lib = load_library()
+    flags = (C.c_uint8 * 12)()
+    assert lib.ola_air_kernels_available(disk.ctypes.data_as(U64P), disk.size, flags, 12) == 0
+    assert all(flags), [bool(f) for f in flags]

@@ -353,3 +353,66 @@ def test_memory_lean_proof_is_the_same_proof(be, oracle, monkeypatch, program):
         assert lean == oracle.prove_with_traces(blob, traces, params, compress)
     monkeypatch.setenv("OLA_AIR_KERNELS", "crosscheck")
     assert be.prove_with_traces(blob, traces, params, compress) == resident
+
+
+def test_phase_entry_points_reassemble_prove_single_table(be, oracle):
+    """The reference's prove_single_table scope by scope (prover.rs:330-567), every scope one C-ABI call, the transcript on the
+    host: compact -> permutation challenges -> ola_perm_z + ola_ctl_z ("compute permutation Z(x) polys") -> from_values of the Zs
+    -> alphas -> ola_quotient ("compute quotient polys" + split) -> from_coeffs -> ola_open_and_prove.  The bytes equal
+    ola_prove_single_table's for every table of an executed program (tables with and without permutation arguments)."""
+    import struct
+    from olavm_amd.air import miniexec as M
+    from olavm_amd.backend import Challenger
+    s = T.ola_stark(range_bits=4, limb_bits=2)
+    blob = s.blob()
+    traces, params, compress = M.instance(M.mixed_program())
+    batches = [be.commit(t) for t in traces]
+    ch = Challenger()
+    for b in batches:
+        ch.observe(b.cap())
+    ctl = [(ch.get(), ch.get()) for _ in range(2)]
+    ch_whole = ch.clone()
+
+    def cap_bytes(cap):
+        return struct.pack("<I", cap.shape[0]) + b"".join(struct.pack("<Q", int(x)) for x in cap.reshape(-1))
+
+    poff, seen_perm = 0, 0
+    for t, tr in enumerate(traces):
+        shape = be.table_shape(blob, t)
+        k = shape["n_params"]
+        pr = params[poff:poff + k]
+        poff += k
+        want = be.prove_single_table(blob, t, tr, batches[t], ctl, pr, ch_whole)
+        # --- the same, one scope at a time
+        ch.compact()
+        perm_ch = None
+        if shape["perm_zs"]:
+            seen_perm += 1
+            perm_ch = [[(ch.get(), ch.get()) for _ in range(2)] for _ in range(shape["permutation_batch_size"])]
+        n = tr.shape[1]
+        zp = be.perm_z(blob, t, tr, perm_ch) if shape["perm_zs"] else np.zeros((0, n), dtype=np.uint64)
+        zc = be.ctl_z(blob, t, tr, ctl)
+        assert zp.shape[0] == shape["perm_zs"] and zc.shape[0] == shape["ctl_zs"]
+        zs = be.commit(np.concatenate([zp, zc]))
+        ch.observe(zs.cap())
+        alphas = [ch.get(), ch.get()]
+        chunks = be.quotient(blob, t, batches[t], zs, perm_ch, ctl, alphas, pr, n)
+        qb = be.commit(chunks, from_coeffs=True)
+        ch.observe(qb.cap())
+        openings, fri = be.open_and_prove(batches[t], zs, qb, shape["perm_zs"], ch)
+        got = cap_bytes(batches[t].cap()) + cap_bytes(zs.cap()) + cap_bytes(qb.cap()) + openings + fri
+        assert got == want, s.tables[t].name
+        assert np.array_equal(ch.state(), ch_whole.state())
+        zs.free(); qb.free()
+    assert seen_perm >= 3
+    # a wrong trace surfaces where the reference's prover notices it: the quotient is not a polynomial of the right degree
+    from olavm_amd.backend import OlaGpuError
+    bad = traces[0].copy()
+    bad[T.COL_DST, 3] = (int(bad[T.COL_DST, 3]) + 1) % tracegen.P
+    bb = be.commit(bad)
+    zc = be.ctl_z(blob, 0, bad, ctl)
+    zb = be.commit(zc)
+    with pytest.raises(OlaGpuError, match="not divisible"):
+        be.quotient(blob, 0, bb, zb, None, ctl, [5, 7], [], bad.shape[1])
+    for b in batches + [bb, zb]:
+        b.free()
