@@ -251,15 +251,25 @@ int32_t ola_permuted_cols_dev(OlaCtx* ctx, const uint64_t* inputs_dev, const uin
 /* ---- coset-partitioned proving over several GPUs ---------------------------------------------------------
  * One process per GPU; every process calls ola_prove_with_traces with the SAME traces.  Because the transcript is a
  * function of the (identical) commitments, all ranks draw the same challenges without talking to each other; only the
- * heavy work is divided: for every table with at least 2^12 rows whose quotient domain is the whole LDE (CPU, memory and
- * Poseidon tables), rank r extends / hashes / evaluates the quotient on cosets [r*8/world, (r+1)*8/world) only.  Three
- * exchanges go through `all_gather` -- Merkle cap slices (512 B per tree), the quotient values (16 * 8n bytes per table)
- * and the opened rows of the 28 queries -- and every rank ends up with the complete, identical AllProof bytes.
+ * heavy work is divided.  For every table with at least 2^12 rows, rank r uploads 1/world of the columns (the values are
+ * all-gathered device to device: xGMI instead of `world` copies over PCIe), extends and hashes cosets
+ * [r*8/world, (r+1)*8/world) of all three commitments, and evaluates the quotient on those of its cosets that belong to the
+ * quotient domain (the first 2^qdb cosets; all of them for the CPU, memory and Poseidon tables).  The exchanges go through
+ * `all_gather` -- the trace values (8n bytes per column, once), Merkle cap slices (512 B per tree), the quotient values
+ * (16 * 8n bytes per table) and the opened rows of the 28 queries -- and every rank ends up with the complete, identical
+ * AllProof bytes.
  * all_gather(user, send_dev, recv_dev, bytes): gather `bytes` bytes of DEVICE memory from every rank into recv_dev in rank
- * order (world * bytes); return 0 when recv_dev is complete.  The library synchronises its stream before the call.
- * world must be 1, 2, 4 or 8; world = 1 (or a NULL callback) restores single-GPU proving. */
+ * order (world * bytes); return 0 when recv_dev is complete (or, with OLA_SHARD_STREAM_ORDERED, when the collective has been
+ * enqueued on the context's stream).  world must be 1, 2, 4 or 8; world = 1 (or a NULL callback) restores single-GPU proving. */
 typedef int32_t (*ola_all_gather_fn)(void* user, const void* send_dev, void* recv_dev, size_t bytes);
 int32_t ola_set_shard(OlaCtx* ctx, uint32_t rank, uint32_t world, ola_all_gather_fn all_gather, void* user);
+/* OLA_SHARD_STREAM_ORDERED: the callback enqueues the collective on the context's stream (ola_gpu_get_stream) -- RCCL launched
+ * on that stream -- so the library neither synchronises before the call nor needs the result on return; without the flag the
+ * library drains its stream before the call and expects recv_dev complete on return (host-staged collectives). */
+#define OLA_SHARD_STREAM_ORDERED 1u
+int32_t ola_set_shard_options(OlaCtx* ctx, uint32_t flags);
+/* The hipStream_t all of the context's device work is issued on (the one given to ola_gpu_init, or the context's own). */
+int32_t ola_gpu_get_stream(OlaCtx* ctx, void** stream_out);
 
 /* Which tables of `airset` have an ahead-of-time specialised constraint-quotient kernel in this build (the counterpart of
  * the reference compiling each table's eval_packed_generic, e.g. cpu/cpu_stark.rs:325): has_kernel[t] = 1 or 0 for every

@@ -93,6 +93,8 @@ def load_library():
     L.ola_permuted_cols.argtypes = [C.c_void_p, U64P, U64P, C.c_size_t, U64P, U64P]
     L.ola_permuted_cols_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
     L.ola_set_shard.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, ALL_GATHER_FN, C.c_void_p]
+    L.ola_set_shard_options.argtypes = [C.c_void_p, C.c_uint32]
+    L.ola_gpu_get_stream.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
     L.ola_table_shape.argtypes = [C.c_void_p, U64P, C.c_size_t, C.c_uint32, C.POINTER(C.c_uint32)]
     L.ola_perm_z.argtypes = [C.c_void_p, U64P, C.c_size_t, C.c_uint32, C.c_uint32, C.POINTER(U64P), U64P, U64P]
     L.ola_ctl_z.argtypes = [C.c_void_p, U64P, C.c_size_t, C.c_uint32, C.c_uint32, C.POINTER(U64P), U64P, U64P]
@@ -112,7 +114,7 @@ EXPORTS = [
     "ola_challenger_get", "ola_challenger_compact", "ola_open_and_prove", "ola_pow", "ola_prove_with_traces",
     "ola_air_kernels_available", "ola_commit_values_shard", "ola_commit_values_shard_dev", "ola_set_shard", "ola_gpu_trim", "ola_generate_poseidon_trace",
     "ola_permuted_cols", "ola_permuted_cols_dev", "ola_prove_single_table", "ola_take_pending_proof", "ola_gpu_memory_stats", "ola_gpu_reserve",
-    "ola_table_shape", "ola_perm_z", "ola_ctl_z", "ola_quotient",
+    "ola_table_shape", "ola_perm_z", "ola_ctl_z", "ola_quotient", "ola_set_shard_options", "ola_gpu_get_stream",
 ]
 
 
@@ -388,18 +390,27 @@ class Backend:
 
         self.shard_calls = 0          # exchanges performed so far (observability / tests)
 
+        # RCCL path: the collective is launched on the context's own stream (torch ExternalStream), so it is ordered with the
+        # library's kernels by the stream itself -- no host synchronisation per exchange (OLA_SHARD_STREAM_ORDERED).
+        ext = None
+        if on_device:
+            sp = C.c_void_p()
+            self._chk(self.lib.ola_gpu_get_stream(self.ctx, C.byref(sp)))
+            ext = torch.cuda.ExternalStream(sp.value)
+
         def all_gather(_user, send, recv, nbytes):
             self.shard_calls += 1
             try:
                 src = torch.as_tensor(_DeviceBytes(send, nbytes), device="cuda")
                 dst = torch.as_tensor(_DeviceBytes(recv, nbytes * world), device="cuda")
                 if on_device:
-                    dist.all_gather_into_tensor(dst, src, group=group)
+                    with torch.cuda.stream(ext):
+                        dist.all_gather_into_tensor(dst, src, group=group)
                 else:
                     parts = [torch.empty(nbytes, dtype=torch.uint8) for _ in range(world)]
                     dist.all_gather(parts, src.cpu(), group=group)
                     dst.copy_(torch.cat(parts))
-                torch.cuda.synchronize()
+                    torch.cuda.synchronize()
                 return 0
             except Exception as e:          # noqa: BLE001 -- must not unwind through the C frame
                 import sys
@@ -408,6 +419,7 @@ class Backend:
 
         self._shard_cb = ALL_GATHER_FN(all_gather)      # keep the trampoline alive as long as the context uses it
         self._chk(self.lib.ola_set_shard(self.ctx, rank, world, self._shard_cb, None))
+        self._chk(self.lib.ola_set_shard_options(self.ctx, 1 if on_device else 0))
 
     def prove_with_traces(self, airset_blob, traces, params=None, compress=None, cap=8 << 20):
         """AllProof bytes for the multi-table STARK described by `airset_blob` (olavm_amd.air.AirSet.blob())."""

@@ -46,6 +46,9 @@ struct ShardInfo {
     uint32_t min_log_n = 12;   // smaller tables are proven replicated: sharding them costs more latency than it saves
     int32_t (*all_gather)(void* user, const void* send_dev, void* recv_dev, size_t bytes) = nullptr;
     void* user = nullptr;
+    // the callback enqueues the collective ON THE CONTEXT'S STREAM (RCCL through a torch ExternalStream, say): stream order
+    // already puts it after the kernels that produced `send` and before the ones that read `recv`, no host synchronisation
+    bool stream_ordered = false;
 };
 
 struct DeviceCtx {
@@ -167,7 +170,7 @@ struct DeviceCtx {
 // all-gather of device buffers through the host-supplied collective (ShardInfo)
 inline void shard_all_gather(DeviceCtx* ctx, const void* send_dev, void* recv_dev, size_t bytes) {
     if (!ctx->shard.all_gather) throw OlaError(-1, "sharded proving needs ola_set_shard with an all_gather callback");
-    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (!ctx->shard.stream_ordered) HIP_CHECK(hipStreamSynchronize(ctx->stream));
     const int32_t rc = ctx->shard.all_gather(ctx->shard.user, send_dev, recv_dev, bytes);
     if (rc != 0) throw OlaError(-7, "all_gather callback failed with code " + std::to_string(rc));
 }

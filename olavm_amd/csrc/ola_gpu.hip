@@ -558,6 +558,21 @@ int32_t ola_gpu_memory_stats(OlaCtx* ctx, uint64_t out[4], int32_t reset) {
     OLA_CATCH
 }
 
+int32_t ola_set_shard_options(OlaCtx* ctx, uint32_t flags) {
+    OLA_TRY
+    require(ctx, "ctx");
+    require((flags & ~OLA_SHARD_STREAM_ORDERED) == 0, "unknown flag");
+    ctx->dev.shard.stream_ordered = (flags & OLA_SHARD_STREAM_ORDERED) != 0;
+    OLA_CATCH
+}
+
+int32_t ola_gpu_get_stream(OlaCtx* ctx, void** stream_out) {
+    OLA_TRY
+    require(ctx && stream_out, "null pointer");
+    *stream_out = (void*)ctx->dev.stream;
+    OLA_CATCH
+}
+
 int32_t ola_gpu_reserve(OlaCtx* ctx, const uint64_t* airset, size_t airset_words, const uint32_t* log_n) {
     OLA_TRY
     OLA_ON_DEVICE(ctx);

@@ -485,14 +485,13 @@ static OlaBatch* commit_shared(DeviceCtx* ctx, NttTables& t, const u64* dev_cols
     return b;
 }
 
-// Which tables run on the coset partition: large ones whose quotient domain is the whole LDE (2^qdb = 2^rate_bits cosets,
-// so every rank evaluates an equal share) -- CPU, memory and Poseidon tables in OlaVM.
+// Which tables run on the coset partition: every table large enough to be worth the exchanges.  The COMMITMENTS of a table
+// split over the 2^rate_bits LDE cosets whatever its constraint degree; its quotient lives on the first 2^qdb cosets of the
+// leaf order and is evaluated by the ranks that own them (all ranks when 2^qdb = 2^rate_bits: CPU, memory, Poseidon tables).
 static bool table_is_sharded(const DeviceCtx* ctx, const OlaGpuConfig& cfg, const HTable& air, uint32_t log_n) {
+    (void)air;
     if (ctx->shard.world <= 1) return false;
-    int qdb = 0;
-    while ((1 << qdb) < air.quotient_degree_factor()) qdb++;
-    return log_n >= ctx->shard.min_log_n && qdb == (int)cfg.rate_bits && ctx->shard.log_world <= cfg.rate_bits &&
-           ctx->shard.log_world <= cfg.cap_height;
+    return log_n >= ctx->shard.min_log_n && ctx->shard.log_world <= cfg.rate_bits && ctx->shard.log_world <= cfg.cap_height;
 }
 
 static void prove_single_table(DeviceCtx* ctx, NttTables& tables, const OlaGpuConfig& cfg, const HTable& air, const DevTable& tv,
@@ -662,9 +661,12 @@ static void prove_single_table(DeviceCtx* ctx, NttTables& tables, const OlaGpuCo
     u64* d_desc = mem.alloc(desc.size());
     HIP_CHECK(hipMemcpyAsync(d_desc, desc.data(), desc.size() * 8, hipMemcpyHostToDevice, ctx->stream));
     u64* qv = mem.alloc(2 * size);
-    // points this rank evaluates: the whole quotient domain, or (sharded: 2^qdb = 2^rate_bits) its cosets of it
+    // points this rank evaluates: the whole quotient domain, or (sharded) those of its cosets that belong to the quotient
+    // domain -- the first 2^qdb cosets of the leaf order; a rank that owns none of them only takes part in the exchange
     const size_t plane = sharded ? N_loc : size;
     u64* qloc = sharded ? mem.alloc(2 * plane) : qv;
+    const size_t q_cosets = (size_t)1 << qdb;
+    const size_t my_q_cosets = !sharded ? q_cosets : (coset_first >= q_cosets ? 0 : std::min(coset_count, q_cosets - coset_first));
     {
         QuotParams P = {};
         P.trace_lde = trace_c.lde; P.zs_lde = zs_c.b->lde; P.lag_lde = lag_lde;
@@ -723,7 +725,8 @@ static void prove_single_table(DeviceCtx* ctx, NttTables& tables, const OlaGpuCo
         u64* qv2 = (spec && crosscheck) ? mem.alloc(2 * plane) : nullptr;
         for (size_t lc = 0; lc < lean_cosets; lc++) {
             u64* out = qloc;
-            size_t points = plane;
+            size_t points = sharded ? my_q_cosets * n : plane;
+            if (sharded) { P.npoints = points; if (points == 0) break; }
             if (lean) {
                 batch_lde_slice(ctx, tables, trace_c, lc, slice_t);
                 batch_lde_slice(ctx, tables, *zs_c.b, lc, slice_z);
@@ -753,7 +756,10 @@ static void prove_single_table(DeviceCtx* ctx, NttTables& tables, const OlaGpuCo
         if (spec && crosscheck) {
             unsigned* d_flag = (unsigned*)mem.alloc(1);
             HIP_CHECK(hipMemsetAsync(d_flag, 0, 8, ctx->stream));
-            hipLaunchKernelGGL(any_diff_kernel, dim3((unsigned)((2 * plane + 255) / 256)), dim3(256), 0, ctx->stream, qloc, qv2, 2 * plane, d_flag);
+            const size_t evaluated = sharded ? my_q_cosets * n : plane;       // per plane
+            for (int c = 0; c < 2 && evaluated; c++)
+                hipLaunchKernelGGL(any_diff_kernel, dim3((unsigned)((evaluated + 255) / 256)), dim3(256), 0, ctx->stream, qloc + (size_t)c * plane,
+                                   qv2 + (size_t)c * plane, evaluated, d_flag);
             unsigned flag = 0;
             HIP_CHECK(hipMemcpyAsync(&flag, d_flag, 4, hipMemcpyDeviceToHost, ctx->stream));
             HIP_CHECK(hipStreamSynchronize(ctx->stream));
@@ -761,8 +767,17 @@ static void prove_single_table(DeviceCtx* ctx, NttTables& tables, const OlaGpuCo
         }
     }
     if (sharded) {
-        // every rank needs all cosets for the inverse transform: gather the two planes (8 * size bytes each in total)
-        for (int c = 0; c < 2; c++) shard_all_gather(ctx, qloc + (size_t)c * plane, qv + (size_t)c * size, plane * 8);
+        // every rank needs the whole quotient for the inverse transform: gather the ranks' planes (rank order = leaf order) and
+        // keep the first n * 2^qdb values of each
+        if (N == size) {
+            for (int c = 0; c < 2; c++) shard_all_gather(ctx, qloc + (size_t)c * plane, qv + (size_t)c * size, plane * 8);
+        } else {
+            u64* gath = mem.alloc(N);
+            for (int c = 0; c < 2; c++) {
+                shard_all_gather(ctx, qloc + (size_t)c * plane, gath, plane * 8);
+                HIP_CHECK(hipMemcpyAsync(qv + (size_t)c * size, gath, size * 8, hipMemcpyDeviceToDevice, ctx->stream));
+            }
+        }
     }
     // qv is in bit-reversed order of the size-domain: un-reverse, coset iNTT (prover.rs:700-704)
     const int size_bits = degree_bits + qdb;
@@ -951,7 +966,7 @@ class TraceUploader {
     void add(size_t t, const u64* src, u64* dst, uint32_t ncols, size_t n) {
         const size_t target = (size_t)64 << 20;
         uint32_t cc = (uint32_t)std::max<size_t>(1, target / (n * 8));
-        jobs_[t] = {src, dst, ncols, n, std::min(cc, ncols)};
+        jobs_[t] = {src, dst, ncols, n, std::max(1u, std::min(cc, ncols))};      // ncols may be 0: a rank without columns of its own
     }
     uint32_t chunk_cols(size_t t) const { return jobs_[t].chunk; }
     void start() {
@@ -1081,16 +1096,33 @@ void prove_with_traces(DeviceCtx* ctx, NttTables& tables, const OlaGpuConfig& cf
     OlaChallenger ch;
     memset(&ch, 0, sizeof(ch));
     PhaseTimer t_all(ctx, "prove_with_traces total");
+    // Coset partition: a sharded table's columns are uploaded 1/world per rank and all-gathered device to device (xGMI instead of
+    // `world` copies of the trace over the host's PCIe links); cpr = columns per rank, the last ranks may hold fewer or none.
+    const uint32_t world = ctx->shard.world, rank = ctx->shard.rank;
+    std::vector<uint32_t> cpr(nt, 0);
     for (size_t t = 0; t < nt; t++) {
         if (log_n[t] + cfg.rate_bits > 32 || log_n[t] + cfg.rate_bits < cfg.cap_height) throw OlaError(OLA_E_INVALID_ARG, "table size out of range");
         dev[t].log_n = log_n[t];
-        dev[t].vals = mem.alloc((size_t)set.tables[t].ncols << log_n[t]);
+        const uint32_t w = (uint32_t)set.tables[t].ncols;
+        if (table_is_sharded(ctx, cfg, set.tables[t], log_n[t])) cpr[t] = (w + world - 1) / world;
+        dev[t].vals = mem.alloc((size_t)(cpr[t] ? cpr[t] * world : w) << log_n[t]);
     }
     // The traces are pageable host memory: a helper thread pushes them to the device in column groups on its own stream
     // while this thread already interpolates / extends / hashes what has arrived (H2D of a 2^22-row instance is ~75 ms).
     const std::vector<char> lean = plan_lean_tables(ctx, cfg, set, log_n);
     TraceUploader up(ctx, nt);
-    for (size_t t = 0; t < nt; t++) up.add(t, traces[t], dev[t].vals, (uint32_t)set.tables[t].ncols, (size_t)1 << log_n[t]);
+    std::vector<uint32_t> own_cols(nt, 0);
+    for (size_t t = 0; t < nt; t++) {
+        const size_t n_t = (size_t)1 << log_n[t];
+        const uint32_t w = (uint32_t)set.tables[t].ncols;
+        if (cpr[t]) {
+            const uint32_t c0 = std::min(w, rank * cpr[t]), c1 = std::min(w, (rank + 1) * cpr[t]);
+            own_cols[t] = c1 - c0;
+            up.add(t, traces[t] + (size_t)c0 * n_t, dev[t].vals + (size_t)c0 * n_t, own_cols[t], n_t);
+        } else {
+            up.add(t, traces[t], dev[t].vals, w, n_t);
+        }
+    }
     up.start();
     std::unique_ptr<PhaseTimer> t_commit(new PhaseTimer(ctx, "compute trace commitments"));
     for (size_t t = 0; t < nt; t++) {
@@ -1103,6 +1135,18 @@ void prove_with_traces(DeviceCtx* ctx, NttTables& tables, const OlaGpuConfig& cf
             canonicalize(ctx, dev[t].vals + (size_t)c0 * n_t, (size_t)(c1 - c0) * n_t);
         };
         commits.emplace_back(new BatchHolder(ctx));
+        if (cpr[t]) {
+            // this rank's columns have to be on the device, then every rank receives everybody's
+            up.wait(t, own_cols[t]);
+            const size_t blk = (size_t)cpr[t] * n_t;
+            DevBuf tmp(ctx);
+            u64* send = tmp.alloc(blk);
+            HIP_CHECK(hipMemcpyAsync(send, dev[t].vals + (size_t)rank * blk, blk * 8, hipMemcpyDeviceToDevice, ctx->stream));
+            shard_all_gather(ctx, send, dev[t].vals, blk * 8);
+            canonicalize(ctx, dev[t].vals, (size_t)set.tables[t].ncols * n_t);
+            commits[t]->b = commit_shared(ctx, tables, dev[t].vals, (uint32_t)set.tables[t].ncols, log_n[t], cfg, true, true, nullptr, caps[t], false);
+            continue;
+        }
         commits[t]->b = commit_shared(ctx, tables, dev[t].vals, (uint32_t)set.tables[t].ncols, log_n[t], cfg, true,
                                       table_is_sharded(ctx, cfg, set.tables[t], log_n[t]), &feed, caps[t], lean[t] != 0);
     }

@@ -72,12 +72,20 @@ std::vector<Ext2> divide_by_linear(const std::vector<Ext2>& p, Ext2 z) {
 }
 
 u64 fri_proof_of_work(const HashOut& h, const FriConfig& cfg) {
-    // Minimal satisfying nonce (the reference's find_any is schedule dependent).
-    for (u64 i = 0;; i++) {
-        u64 in[5] = {h[0], h[1], h[2], h[3], i};
-        u64 r = hash_no_pad(in, 5)[0];
-        // leading_zeros(r) >= pow_bits + (64 - 64)
-        if ((r >> (64 - cfg.proof_of_work_bits)) == 0) return i;
+    // Minimal satisfying nonce (the reference's find_any is schedule dependent).  Searched in blocks so that the
+    // candidates of a block can be hashed in parallel; the smallest hit of the first block with a hit is the minimum.
+    const u64 block = 1 << 12;
+    for (u64 base = 0;; base += block) {
+        u64 best = ~(u64)0;
+#pragma omp parallel for reduction(min : best)
+        for (long k = 0; k < (long)block; k++) {
+            const u64 i = base + (u64)k;
+            u64 in[5] = {h[0], h[1], h[2], h[3], i};
+            const u64 r = hash_no_pad(in, 5)[0];
+            // leading_zeros(r) >= pow_bits + (64 - 64)
+            if ((r >> (64 - cfg.proof_of_work_bits)) == 0 && i < best) best = i;
+        }
+        if (best != ~(u64)0) return best;
     }
 }
 

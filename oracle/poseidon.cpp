@@ -26,7 +26,7 @@ static void mds_layer(u64 s[12]) {
         u128 acc = 0;  // 12 * 2^64 * 41 < 2^74
         for (int i = 0; i < 12; i++) acc += (u128)s[(i + r) % 12] * OLA_POSEIDON_MDS_CIRC[i];
         acc += (u128)s[r] * OLA_POSEIDON_MDS_DIAG[r];
-        out[r] = (u64)(acc % GL_P);
+        out[r] = gl_reduce128(acc);          // same value as acc % p (a 128-bit division here made the oracle's grinding take seconds)
     }
     for (int r = 0; r < 12; r++) s[r] = out[r];
 }
