@@ -54,35 +54,39 @@ def cpu_baseline(log_n, seconds_budget=20.0):
             "sample": f"{cols} columns x 2^{log_n} forward NTT (oracle evaluate_poly, OpenMP over columns) in {dt:.2f}s"}
 
 
-def valu_roofline(log_n, cols, ms_per_transform):
-    """The ceiling that actually binds the NTT (DESIGN.md "NTT roofline accounting"): VALU issue slots.  Instructions per
-    element are the SQ_INSTS_VALU counts of profiles/r01_sq_counters_and_ubench.txt (173 per element in each strided pass,
-    126 in the closing pass, measured on the 94 x 2^22 shape and reported for that size only); the peak is one
-    wave64 instruction per SIMD every 4 cycles (tools/ubench/valu_rates.hip: 4.4-4.8 cycles for the 64-bit / multiply class,
-    2.6 for plain 32-bit VOP2) on 256 CUs x 4 SIMDs at 2.4 GHz."""
-    if log_n != 22:
+def pmc_record(log_n, cols):
+    """HBM bytes per launch and VALU instructions per element of the NTT pass kernels from the rocprofv3 PMC record
+    profiles/r02_ntt_pmc.json (tools/pmc_ntt.sh: FETCH_SIZE with the gfx950 x2 correction + WRITE_SIZE + SQ_INSTS_VALU, separate
+    passes over the same 94 x 2^22 transform).  bench.py cannot run the profiler on itself; the record carries the hash of the
+    kernel sources it was taken from and is used only while those sources are unchanged -- otherwise the fields are null."""
+    import hashlib
+    path = os.path.join(ROOT, "profiles", "r02_ntt_pmc.json")
+    try:
+        d = json.load(open(path))
+        h = hashlib.sha256()
+        for f in d["sources"]:
+            h.update(open(os.path.join(ROOT, f), "rb").read())
+        if h.hexdigest()[:16] != d["source_sha16"] or (log_n, cols) != (d["shape"]["log_n"], d["shape"]["columns"]):
+            return None
+        r = d["ntt_94x2^22"]
+        return {"traffic": r["traffic_bytes_per_launch"], "valu_insts_per_element": r["valu_insts_per_element"],
+                "source": f"profiles/r02_ntt_pmc.json ({d['timestamp']}, kernel sources {d['source_sha16']} unchanged)"}
+    except (OSError, KeyError, ValueError, TypeError):
         return None
-    insts_per_elem = 173 * 2 + 126
-    wave_insts = insts_per_elem * cols * (1 << log_n) / 64.0
+
+
+def valu_roofline(rec, log_n, cols, ms_per_transform):
+    """The ceiling that binds the NTT (DESIGN.md "NTT roofline accounting"): VALU issue slots.  Instructions per element from
+    the PMC record above; the peak is one wave64 instruction per SIMD every 4 cycles (tools/ubench/valu_rates.hip: 4.3-4.7 cycles
+    for the 64-bit / multiply class that 64-bit modular arithmetic is made of) on 256 CUs x 4 SIMDs at 2.4 GHz."""
+    if not rec or not rec.get("valu_insts_per_element"):
+        return None
+    ipe = rec["valu_insts_per_element"]
+    wave_insts = ipe * cols * (1 << log_n) / 64.0
     peak = 256 * 4 * 2.4e9 / 4.0
     achieved = wave_insts / (ms_per_transform * 1e-3)
-    return {"insts_per_element": insts_per_elem, "achieved": round(achieved / 1e9, 1), "peak": round(peak / 1e9, 1),
-            "unit": "G wave-instructions/s", "frac": round(achieved / peak, 3),
-            "source": "profiles/r01_sq_counters_and_ubench.txt (rocprofv3 --pmc SQ_INSTS_VALU)"}
-
-
-def pmc_traffic(log_n, cols):
-    """HBM bytes per launch of the NTT pass kernel from the committed rocprofv3 PMC summary (tools/pmc.sh; FETCH_SIZE with the
-    gfx950 x2 correction + WRITE_SIZE, separate passes).  bench.py cannot run the profiler on itself, so this is the
-    figure of the last profiled run of the same shape, or None."""
-    try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r01_ntt_pmc.json")))
-        if (log_n, cols) != (22, 94):
-            return None, None
-        p = d["ntt_94x2^22_per_pass"]
-        return (p["fetch_kib_corrected"] + p["write_kib"]) * 1024.0, "profiles/r01_ntt_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
-    except (OSError, KeyError, ValueError):
-        return None, None
+    return {"insts_per_element": round(ipe, 1), "achieved": round(achieved / 1e9, 1), "peak": round(peak / 1e9, 1),
+            "unit": "G wave-instructions/s", "frac": round(achieved / peak, 3), "source": rec["source"]}
 
 
 def verify_proofs(blob, proofs, params):
@@ -233,28 +237,49 @@ def sharded_commit_time(be, rank, world, log_n, cols, coll_dev, reps=2):
             "replicated iNTT + caps all-gather (RCCL)", "cap_word0": int(cap[0, 0])}
 
 
-def sharded_prove_time(be, rank, world, log_n, coll_dev, reps=2):
-    """N > 1 only: the end-to-end proof on the coset partition (ola_set_shard): every rank proves the same traces with
-    its 8/N cosets of the CPU, memory and Poseidon tables; exchanges go through RCCL.  Same instance as `prove` at N = 1."""
+def sharded_prove_time(be, rank, world, log_n, coll_dev, reps=2, real=False):
+    """N > 1 only: the end-to-end proof on the coset partition (ola_set_shard): every rank proves the same traces with its
+    8/N cosets of every large table's commitments and quotient; each rank uploads 1/N of the trace columns and the values are
+    all-gathered over xGMI; exchanges go through RCCL on the context's stream.  STRONG scaling: the instance is `prove`'s at
+    N = 1 (or `prove_real_execution`'s with real=True); rank 0 also proves it unsharded in the same process, so the line carries
+    the speed-up measured on this very box."""
     import torch
     import torch.distributed as dist
     from olavm_amd import sharding
     from olavm_amd.air import ola_tables as T
     from olavm_amd.air import tracegen
     blob = T.ola_stark().blob()
-    traces, params, compress = tracegen.empty_program_instance(log_n=10, range_bits=16, limb_bits=8, log_n_cpu=log_n, log_n_mem=log_n)
+    if real:
+        from olavm_amd.air import fastexec, miniexec
+        count = ((1 << log_n) - 8) // 14
+        traces, params, compress = fastexec.instance(miniexec.memory_program(count), range_bits=16, limb_bits=8, max_steps=1 << (log_n + 1))
+    else:
+        traces, params, compress = tracegen.empty_program_instance(log_n=10, range_bits=16, limb_bits=8, log_n_cpu=log_n, log_n_mem=log_n)
     be.set_shard(rank, world)
-    times, nbytes = [], 0
+    times, proof = [], b""
     for _ in range(reps + 1):
         dist.barrier(); torch.cuda.synchronize()
         t0 = time.perf_counter()
-        nbytes = len(be.prove_with_traces(blob, traces, params, compress))
+        proof = be.prove_with_traces(blob, traces, params, compress)
         torch.cuda.synchronize(); dist.barrier()
         times.append(time.perf_counter() - t0)
+    exchanges = be.shard_calls // (reps + 1)
     be.set_shard(0, 1)
     t = sharding.max_over_ranks([min(times[1:])], device=coll_dev)[0]
-    return {"seconds": round(t, 4), "proof_bytes": nbytes, "exchanges_per_proof": be.shard_calls // (reps + 1),
-            "workload": f"prove_with_traces on the coset partition over {world} GPUs, 12 tables, CPU/memory 2^{log_n} rows"}
+    res = {"seconds": round(t, 4), "proof_bytes": len(proof), "exchanges_per_proof": exchanges, "scaling": "strong",
+           "workload": f"prove_with_traces on the coset partition over {world} GPUs, 12 tables, heights 2^{[int(x.shape[1]).bit_length() - 1 for x in traces]}"}
+    single = 0.0
+    if rank == 0:           # the same proof on one GPU of the same box, for the speed-up and the byte comparison
+        be.prove_with_traces(blob, traces, params, compress)
+        t0 = time.perf_counter()
+        one = be.prove_with_traces(blob, traces, params, compress)
+        single = time.perf_counter() - t0
+        res.update(verify_proofs(blob, [proof, one], params))
+    dist.barrier()
+    single = sharding.max_over_ranks([single], device=coll_dev)[0]
+    res["single_gpu_seconds_same_box"] = round(single, 4)
+    res["speedup_over_one_gpu"] = round(single / t, 3) if t > 0 else None
+    return res
 
 
 def main():
@@ -330,7 +355,7 @@ def main():
 
     # N > 1 extras (coset-partitioned commitment and proof).  They run in a helper thread under a wall-clock guard: whatever
     # happens there -- an exception or a collective that never returns -- the headline line below is still printed.
-    sharded = sharded_prove = None
+    sharded = sharded_prove = sharded_prove_real = None
     extras_hung = False
     if world > 1 and world in (2, 4, 8) and os.environ.get("OLA_BENCH_SHARDED", "1") != "0":
         import threading
@@ -349,22 +374,28 @@ def main():
                     box["prove"] = sharded_prove_time(be, rank, world, args.log_n, coll_dev)
                 except Exception as e:               # noqa: BLE001
                     box["prove"] = {"error": repr(e)[:200]}
+                try:
+                    box["prove_real"] = sharded_prove_time(be, rank, world, args.log_n, coll_dev, real=True)
+                except Exception as e:               # noqa: BLE001
+                    box["prove_real"] = {"error": repr(e)[:200]}
 
         th = threading.Thread(target=extras, daemon=True)
         th.start()
-        th.join(timeout=float(os.environ.get("OLA_BENCH_SHARDED_TIMEOUT", "240")))
+        th.join(timeout=float(os.environ.get("OLA_BENCH_SHARDED_TIMEOUT", "420")))
         extras_hung = th.is_alive()
         sharded = box.get("commit", {"error": "timed out"} if extras_hung else None)
         sharded_prove = box.get("prove", {"error": "timed out"} if extras_hung and not args.no_prove else None)
+        sharded_prove_real = box.get("prove_real")
 
     if rank == 0:
         bytes_per_step = 16.0 * n * cols            # algorithmic: one read + one write of every element
         value = sharding.aggregate_throughput(cols, 16.0 * n, world, args.steps, elapsed)
         # dominant kernel = ntt_pass_kernel; a 2^22 natural-order transform launches it `passes` times over the batch
-        passes = 1 if args.log_n <= 13 else (2 if args.log_n <= 18 else 3)
+        passes = 1 if args.log_n <= 13 else (2 if args.log_n <= 16 else 3)      # ntt2_run: (log_n + 7) / 8 passes from 2^14 on
         launch_ms = dev_ms / args.steps / passes
         achieved = bytes_per_step / passes / (launch_ms * 1e-3) / 1e9
-        traffic, traffic_src = pmc_traffic(args.log_n, cols)
+        rec = pmc_record(args.log_n, cols)
+        traffic, traffic_src = (rec["traffic"], rec["source"]) if rec else (None, None)
         res = {
             "metric": "goldilocks_ntt_throughput", "value": round(value, 2), "unit": "GB/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
@@ -378,7 +409,7 @@ def main():
                          "algorithmic_bytes_per_launch": bytes_per_step / passes,
                          "kernel": "ntt2_pass_kernel", "launches_per_step": passes,
                          "avg_launch_ms": round(launch_ms, 4),
-                         "valu": valu_roofline(args.log_n, cols, launch_ms * passes),
+                         "valu": valu_roofline(rec, args.log_n, cols, launch_ms * passes),
                          "note": "every pass streams the whole batch once (traffic = 3 x algorithmic per launch); the kernel is "
                                  "VALU-issue bound (64-bit modular arithmetic on the 32-bit integer pipe), see DESIGN.md"},
         }
@@ -386,6 +417,8 @@ def main():
             res["commit_sharded"] = sharded
         if sharded_prove is not None:
             res["prove_sharded"] = sharded_prove
+        if sharded_prove_real is not None:
+            res["prove_real_execution_sharded"] = sharded_prove_real
         if world == 1 and not args.no_prove:
             del data, out, scratch
             torch.cuda.empty_cache()
