@@ -89,7 +89,7 @@ def valu_roofline(rec, log_n, cols, ms_per_transform):
             "unit": "G wave-instructions/s", "frac": round(achieved / peak, 3), "source": rec["source"]}
 
 
-def verify_proofs(blob, proofs, params):
+def verify_proofs(blob, proofs, params, hasher="poseidon"):
     """Every proof that was timed is checked AFTER the timed region: all runs must have produced the same bytes (the proof is
     a function of the traces; the PoW witness is the minimal one) and the oracle's restatement of the reference verifier
     (verifier.rs:35-206, incl. the cross-table products) must accept them.  The oracle is the checker here, nothing it
@@ -98,7 +98,8 @@ def verify_proofs(blob, proofs, params):
     o = oracle_lib.load()
     same = all(p == proofs[0] for p in proofs[1:])
     t0 = time.perf_counter()
-    rc, why = o.verify_all_proof(blob, proofs[-1], params)
+    with o.hasher(hasher):
+        rc, why = o.verify_all_proof(blob, proofs[-1], params)
     return {"verified": bool(rc == 0 and same), "all_runs_identical": bool(same), "verifier": "oracle verify_all_proof",
             "verifier_seconds": round(time.perf_counter() - t0, 2), **({} if rc == 0 else {"verifier_error": str(why)[:200]})}
 
@@ -168,15 +169,7 @@ def prove_time_2p24(be):
     return res
 
 
-def prove_time(be, log_n, reps=3):
-    """Second half of BASELINE.json's metric: wall-clock of the whole multi-table proof (ola_prove_with_traces, host
-    traces in, AllProof bytes out -- so H2D of the traces is inside the timed region) for the 12-table OlaStark with a
-    2^log_n-row CPU and memory trace.  The traces are an empty-program execution (padding rows, olavm_amd/air/tracegen.py: the
-    image has no Rust executor to produce a program trace); prover work does not depend on cell values."""
-    from olavm_amd.air import ola_tables as T
-    from olavm_amd.air import tracegen
-    blob = T.ola_stark().blob()
-    traces, params, compress = tracegen.empty_program_instance(log_n=10, range_bits=16, limb_bits=8, log_n_cpu=log_n, log_n_mem=log_n)
+def timed_proofs(be, blob, traces, params, compress, reps, hasher="poseidon"):
     times, proofs = [], []
     for _ in range(reps + 1):
         t0 = time.perf_counter()
@@ -185,12 +178,40 @@ def prove_time(be, log_n, reps=3):
     first = times[0]
     times = sorted(times[1:])
     return {"seconds": round(times[len(times) // 2], 4), "min_seconds": round(times[0], 4), "reps": reps, "proof_bytes": len(proofs[-1]),
-            "first_call_seconds": round(first, 4), **verify_proofs(blob, proofs, params),
+            "first_call_seconds": round(first, 4), **verify_proofs(blob, proofs, params, hasher)}
+
+
+def blake3_config(be_b3, blob, traces, params, compress, reps):
+    """The same traces under the reference's Blake3GoldilocksConfig (plonk/config.rs:153-161: BLAKE3 Merkle trees and challenger,
+    Poseidon proof of work) -- the configuration of the reference's README numbers and of its own full-prove tests -- on a
+    second context created with hasher = OLA_HASH_BLAKE3; verified by the oracle verifier switched to the same configuration."""
+    if be_b3 is None:
+        return {}
+    try:
+        r = timed_proofs(be_b3, blob, traces, params, compress, reps, hasher="blake3")
+        r["config"] = "Blake3GoldilocksConfig, field elements hashed as canonical words"
+    except Exception as e:              # an extra: never at the price of the headline line
+        r = {"error": repr(e)[:200]}
+    be_b3.trim()
+    return {"blake3_config": r}
+
+
+def prove_time(be, log_n, reps=3, be_b3=None):
+    """Second half of BASELINE.json's metric: wall-clock of the whole multi-table proof (ola_prove_with_traces, host
+    traces in, AllProof bytes out -- so H2D of the traces is inside the timed region) for the 12-table OlaStark with a
+    2^log_n-row CPU and memory trace.  The traces are an empty-program execution (padding rows, olavm_amd/air/tracegen.py: the
+    image has no Rust executor to produce a program trace); prover work does not depend on cell values."""
+    from olavm_amd.air import ola_tables as T
+    from olavm_amd.air import tracegen
+    blob = T.ola_stark().blob()
+    traces, params, compress = tracegen.empty_program_instance(log_n=10, range_bits=16, limb_bits=8, log_n_cpu=log_n, log_n_mem=log_n)
+    return {**timed_proofs(be, blob, traces, params, compress, reps),
             "workload": f"prove_with_traces, 12 tables, heights 2^{[int(t.shape[1]).bit_length() - 1 for t in traces]}, "
-                        "Poseidon config, rate_bits 3, 28 queries, 16 PoW bits; host traces in, proof bytes out"}
+                        "Poseidon config, rate_bits 3, 28 queries, 16 PoW bits; host traces in, proof bytes out",
+            **blake3_config(be_b3, blob, traces, params, compress, reps)}
 
 
-def prove_time_real(be, log_n, reps=3):
+def prove_time_real(be, log_n, reps=3, be_b3=None):
     """The same call on the traces of a REAL execution: the native trace generator (include/ola_tracegen.h, the f-1 row of
     SURVEY 8) runs the executor's memory program -- a store loop and a load / add / store / load loop -- long enough to fill a
     2^log_n-row CPU table against the full-size fixed tables; memory, range-check and program tables grow with it (the program
@@ -201,18 +222,11 @@ def prove_time_real(be, log_n, reps=3):
     t0 = time.perf_counter()
     traces, params, compress = fastexec.instance(miniexec.memory_program(count), range_bits=16, limb_bits=8, max_steps=1 << (log_n + 1))
     gen_s = time.perf_counter() - t0
-    times, proofs = [], []
-    for _ in range(reps + 1):
-        t0 = time.perf_counter()
-        proofs.append(be.prove_with_traces(blob, traces, params, compress))
-        times.append(time.perf_counter() - t0)
-    first = times[0]
-    times = sorted(times[1:])
-    return {"seconds": round(times[len(times) // 2], 4), "min_seconds": round(times[0], 4), "reps": reps, "proof_bytes": len(proofs[-1]),
-            "first_call_seconds": round(first, 4), **verify_proofs(blob, proofs, params),
+    return {**timed_proofs(be, blob, traces, params, compress, reps),
             "trace_generation_seconds": round(gen_s, 2),
             "workload": f"prove_with_traces on an executed program ({14 * count + 5} CPU rows, {4 * count} memory accesses), 12 tables, "
-                        f"heights 2^{[int(t.shape[1]).bit_length() - 1 for t in traces]}; host traces in, proof bytes out"}
+                        f"heights 2^{[int(t.shape[1]).bit_length() - 1 for t in traces]}; host traces in, proof bytes out",
+            **blake3_config(be_b3, blob, traces, params, compress, reps)}
 
 
 def sharded_commit_time(be, rank, world, log_n, cols, coll_dev, reps=2):
@@ -422,11 +436,18 @@ def main():
         if world == 1 and not args.no_prove:
             del data, out, scratch
             torch.cuda.empty_cache()
-            res["prove"] = prove_time(be, args.log_n)
             try:
-                res["prove_real_execution"] = prove_time_real(be, args.log_n)
+                be_b3 = Backend(device=local_rank, stream=stream.cuda_stream, hasher="blake3")
+            except Exception:
+                be_b3 = None
+            res["prove"] = prove_time(be, args.log_n, be_b3=be_b3)
+            be.trim()
+            try:
+                res["prove_real_execution"] = prove_time_real(be, args.log_n, be_b3=be_b3)
             except Exception as e:          # an extra: never at the price of the headline line
                 res["prove_real_execution"] = {"error": repr(e)[:200]}
+            if be_b3 is not None:
+                be_b3.close()
             be.trim()
             torch.cuda.empty_cache()
             res["prove"]["cold_process"] = cold_process_prove(args.log_n, local_rank, reserve=True)

@@ -56,7 +56,13 @@ typedef struct OlaGpuConfig {
     uint32_t fri_final_poly_bits;
     uint32_t num_query_rounds;  /* 28                                                                        */
     uint32_t num_challenges;    /* 2                                                                         */
+    uint32_t hasher;            /* GenericConfig::Hasher of the Merkle trees and the challenger (plonk/config.rs:112-161):
+                                 * OLA_HASH_POSEIDON = PoseidonGoldilocksConfig (0, the default),
+                                 * OLA_HASH_BLAKE3 = Blake3GoldilocksConfig.  InnerHasher (proof of work) is Poseidon in both.
+                                 * The field takes the place of the struct's tail padding: sizeof is unchanged.             */
 } OlaGpuConfig;
+#define OLA_HASH_POSEIDON 0u
+#define OLA_HASH_BLAKE3 1u
 
 /* ---- lifetime (replaces gpu_init / gpu_free, cfft/ntt/mod.rs:89-121 and core/src/storage/db.rs:248) ---- */
 int32_t ola_gpu_init(const OlaGpuConfig* cfg, OlaCtx** out_ctx);
@@ -176,9 +182,18 @@ typedef struct OlaChallenger {
     uint64_t output_buffer[8];
     uint32_t input_len;
     uint32_t output_len;
+    uint32_t hasher;            /* OLA_HASH_*: the permutation (Poseidon, or Blake3Permutation, hash/blake3.rs:166-201) and  */
+    uint32_t reserved;          /* how a digest is observed; set by the init calls, do not change afterwards                 */
 } OlaChallenger;
 
-int32_t ola_challenger_init(OlaChallenger* ch);
+int32_t ola_challenger_init(OlaChallenger* ch);                          /* Challenger::<F, PoseidonHash>::new()          */
+int32_t ola_challenger_init_hasher(OlaChallenger* ch, uint32_t hasher);  /* Challenger::<F, C::Hasher>::new()             */
+/* observe_cap (iop/challenger.rs:75-84) of n digests of 4 words: a Poseidon digest is 4 elements, a Blake3 digest is observed
+ * as the 5 elements BytesHash::to_vec cuts it into (7 bytes each, hash/hash_types.rs:142-152). */
+int32_t ola_challenger_observe_cap(OlaChallenger* ch, const uint64_t* digests, size_t n);
+/* Blake3_256::hash_no_pad of n field elements as this backend computes it on the device (canonical little-endian words,
+ * hash/blake3.rs:203-213), on the host: for digests the integrator needs outside a proof, and the CPU-side test of the kernel code. */
+int32_t ola_blake3_hash_elements(const uint64_t* elems, size_t n, uint64_t out[4]);
 int32_t ola_challenger_observe(OlaChallenger* ch, const uint64_t* elems, size_t n);
 int32_t ola_challenger_get(OlaChallenger* ch, uint64_t* out, size_t n);
 int32_t ola_challenger_compact(OlaChallenger* ch);

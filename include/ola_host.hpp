@@ -57,6 +57,8 @@ inline uint32_t log2_strict(size_t n) {   // util/src/lib.rs log2_strict: panics
 struct StarkConfig {
     uint32_t rate_bits = 3, cap_height = 4, proof_of_work_bits = 16, fri_arity_bits = 4, fri_final_poly_bits = 5, num_query_rounds = 28,
              num_challenges = 2;
+    // GenericConfig::Hasher (plonk/config.rs:112-161): OLA_HASH_POSEIDON = PoseidonGoldilocksConfig, OLA_HASH_BLAKE3 = Blake3GoldilocksConfig
+    uint32_t hasher = OLA_HASH_POSEIDON;
     static StarkConfig standard_fast_config() { return StarkConfig{}; }
 };
 
@@ -67,7 +69,7 @@ public:
         OlaGpuConfig g{};
         g.device = device; g.stream = stream; g.rate_bits = c.rate_bits; g.cap_height = c.cap_height;
         g.proof_of_work_bits = c.proof_of_work_bits; g.fri_arity_bits = c.fri_arity_bits; g.fri_final_poly_bits = c.fri_final_poly_bits;
-        g.num_query_rounds = c.num_query_rounds; g.num_challenges = c.num_challenges;
+        g.num_query_rounds = c.num_query_rounds; g.num_challenges = c.num_challenges; g.hasher = c.hasher;
         check(ola_gpu_init(&g, &ctx_));
     }
     ~Gpu() { if (ctx_) ola_gpu_free(ctx_); }
@@ -212,13 +214,14 @@ public:
     const uint32_t degree_log, rate_bits;
 };
 
-// ---- iop/challenger.rs:19-170 (duplex sponge over the Poseidon permutation; host arithmetic, no device needed) -------------
+// ---- iop/challenger.rs:19-170 (duplex sponge over the hasher's permutation; host arithmetic, no device needed) -----------
 class Challenger {
 public:
     Challenger() { check(ola_challenger_init(&ch_)); }                                                        // :37
+    explicit Challenger(const Gpu& g) { check(ola_challenger_init_hasher(&ch_, g.config.hasher)); }           // Challenger::<F, C::Hasher>::new()
     void observe_element(F e) { check(ola_challenger_observe(&ch_, &e, 1)); }                                  // :46
     void observe_elements(const std::vector<F>& es) { check(ola_challenger_observe(&ch_, es.data(), es.size())); }   // :64
-    void observe_hash(const HashOut& h) { check(ola_challenger_observe(&ch_, h.data(), 4)); }                  // :79
+    void observe_hash(const HashOut& h) { check(ola_challenger_observe_cap(&ch_, h.data(), 1)); }              // :79
     void observe_cap(const MerkleCap& cap) { for (const auto& h : cap) observe_hash(h); }                      // :83
     F get_challenge() { F c; check(ola_challenger_get(&ch_, &c, 1)); return c; }                               // :89
     std::vector<F> get_n_challenges(size_t n) { std::vector<F> v(n); for (auto& c : v) c = get_challenge(); return v; }   // :102

@@ -23,12 +23,17 @@ class OlaGpuError(RuntimeError):
 class OlaGpuConfig(C.Structure):
     _fields_ = [("device", C.c_int32), ("stream", C.c_void_p), ("rate_bits", C.c_uint32), ("cap_height", C.c_uint32),
                 ("proof_of_work_bits", C.c_uint32), ("fri_arity_bits", C.c_uint32), ("fri_final_poly_bits", C.c_uint32),
-                ("num_query_rounds", C.c_uint32), ("num_challenges", C.c_uint32)]
+                ("num_query_rounds", C.c_uint32), ("num_challenges", C.c_uint32), ("hasher", C.c_uint32)]
 
 
 class OlaChallenger(C.Structure):
     _fields_ = [("sponge_state", C.c_uint64 * 12), ("input_buffer", C.c_uint64 * 8), ("output_buffer", C.c_uint64 * 8),
-                ("input_len", C.c_uint32), ("output_len", C.c_uint32)]
+                ("input_len", C.c_uint32), ("output_len", C.c_uint32), ("hasher", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+# GenericConfig::Hasher (plonk/config.rs:112-161): PoseidonGoldilocksConfig / Blake3GoldilocksConfig
+OLA_HASH_POSEIDON, OLA_HASH_BLAKE3 = 0, 1
+HASHERS = {"poseidon": OLA_HASH_POSEIDON, "blake3": OLA_HASH_BLAKE3, OLA_HASH_POSEIDON: OLA_HASH_POSEIDON, OLA_HASH_BLAKE3: OLA_HASH_BLAKE3}
 
 
 def lib_path():
@@ -75,6 +80,9 @@ def load_library():
     L.ola_batch_get_leaf.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, U64P, U64P]
     L.ola_batch_get_lde_row.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, U64P]
     L.ola_challenger_init.argtypes = [C.POINTER(OlaChallenger)]
+    L.ola_challenger_init_hasher.argtypes = [C.POINTER(OlaChallenger), C.c_uint32]
+    L.ola_challenger_observe_cap.argtypes = [C.POINTER(OlaChallenger), U64P, C.c_size_t]
+    L.ola_blake3_hash_elements.argtypes = [U64P, C.c_size_t, U64P]
     L.ola_challenger_observe.argtypes = [C.POINTER(OlaChallenger), U64P, C.c_size_t]
     L.ola_challenger_get.argtypes = [C.POINTER(OlaChallenger), U64P, C.c_size_t]
     L.ola_challenger_compact.argtypes = [C.POINTER(OlaChallenger)]
@@ -111,7 +119,7 @@ EXPORTS = [
     "ola_poseidon_permute", "ola_hash_rows", "ola_merkle_cap", "ola_commit_values", "ola_commit_coeffs",
     "ola_commit_values_dev", "ola_commit_coeffs_dev", "ola_batch_free", "ola_batch_shape", "ola_batch_get_coeffs",
     "ola_batch_get_leaf", "ola_batch_get_lde_row", "ola_challenger_init", "ola_challenger_observe",
-    "ola_challenger_get", "ola_challenger_compact", "ola_open_and_prove", "ola_pow", "ola_prove_with_traces",
+    "ola_challenger_get", "ola_challenger_compact", "ola_challenger_init_hasher", "ola_challenger_observe_cap", "ola_blake3_hash_elements", "ola_open_and_prove", "ola_pow", "ola_prove_with_traces",
     "ola_air_kernels_available", "ola_commit_values_shard", "ola_commit_values_shard_dev", "ola_set_shard", "ola_gpu_trim", "ola_generate_poseidon_trace",
     "ola_permuted_cols", "ola_permuted_cols_dev", "ola_prove_single_table", "ola_take_pending_proof", "ola_gpu_memory_stats", "ola_gpu_reserve",
     "ola_table_shape", "ola_perm_z", "ola_ctl_z", "ola_quotient", "ola_set_shard_options", "ola_gpu_get_stream",
@@ -135,10 +143,17 @@ class _DeviceBytes:
 class Challenger:
     """Host-side Fiat-Shamir transcript (iop/challenger.rs:36-162), state lives in an OlaChallenger struct."""
 
-    def __init__(self, lib=None):
+    def __init__(self, lib=None, hasher="poseidon"):
         self.lib = lib or load_library()
         self.c = OlaChallenger()
-        self.lib.ola_challenger_init(C.byref(self.c))
+        rc = self.lib.ola_challenger_init_hasher(C.byref(self.c), HASHERS[hasher])
+        if rc != 0:
+            raise OlaGpuError(rc, self.lib.ola_gpu_last_error().decode())
+
+    def observe_cap(self, digests):
+        """observe_cap: 4 elements per Poseidon digest, 5 (7 bytes each) per Blake3 digest."""
+        d = np.ascontiguousarray(digests, dtype=np.uint64).reshape(-1, 4)
+        self.lib.ola_challenger_observe_cap(C.byref(self.c), _p(d), d.shape[0])
 
     def observe(self, elems):
         e = np.ascontiguousarray(elems, dtype=np.uint64).ravel()
@@ -156,7 +171,7 @@ class Challenger:
         return np.array(list(self.c.sponge_state), dtype=np.uint64)
 
     def clone(self):
-        o = Challenger(self.lib)
+        o = Challenger(self.lib, int(self.c.hasher))
         C.memmove(C.byref(o.c), C.byref(self.c), C.sizeof(OlaChallenger))
         return o
 
@@ -209,7 +224,9 @@ class Backend:
         self.lib = load_library()
         c = OlaGpuConfig(device, stream, cfg.get("rate_bits", 3), cfg.get("cap_height", 4),
                          cfg.get("proof_of_work_bits", 16), cfg.get("fri_arity_bits", 4),
-                         cfg.get("fri_final_poly_bits", 5), cfg.get("num_query_rounds", 28), cfg.get("num_challenges", 2))
+                         cfg.get("fri_final_poly_bits", 5), cfg.get("num_query_rounds", 28), cfg.get("num_challenges", 2),
+                         HASHERS[cfg.get("hasher", "poseidon")])
+        self.hasher = int(c.hasher)
         self.cap_height = c.cap_height
         self.rate_bits = c.rate_bits
         self.ctx = C.c_void_p()

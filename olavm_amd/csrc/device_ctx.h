@@ -56,6 +56,7 @@ struct DeviceCtx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool owns_stream = false;
+    int hasher = 0;                            // OLA_HASH_POSEIDON / OLA_HASH_BLAKE3: GenericConfig::Hasher of the Merkle trees and the challenger
     bool timing = false;                       // OLA_TIMING=1: per-phase wall-clock on stderr (synchronises at phase edges)
     std::vector<void*> persistent;
     std::multimap<size_t, void*> cache;        // free blocks by size

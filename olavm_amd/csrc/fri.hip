@@ -25,6 +25,7 @@
 #include "device_ctx.h"
 #include "gl.cuh"
 #include "poseidon_host.h"
+#include "blake3.cuh"
 
 namespace ola {
 
@@ -34,7 +35,8 @@ static void challenger_duplex(OlaChallenger& ch) {
     ch.input_len = 0;
     u64 s[12];
     for (int i = 0; i < 12; i++) s[i] = ch.sponge_state[i];
-    poseidon_permute_host(s);
+    if (ch.hasher == OLA_HASH_BLAKE3) b3_permutation_host(s);   // H::Permutation of Challenger<F, H> (challenger.rs:134-153)
+    else poseidon_permute_host(s);
     for (int i = 0; i < 12; i++) ch.sponge_state[i] = s[i];
     for (int i = 0; i < 8; i++) ch.output_buffer[i] = s[i];
     ch.output_len = 8;
@@ -45,6 +47,19 @@ void challenger_observe(OlaChallenger& ch, const u64* e, size_t n) {
         ch.input_buffer[ch.input_len++] = gl_canon(e[i]);
         if (ch.input_len == 8) challenger_duplex(ch);
     }
+}
+// observe_cap (challenger.rs:75-84): GenericHashOut::to_vec of every digest
+void challenger_observe_cap(OlaChallenger& ch, const u64* digests, size_t n) {
+    if (ch.hasher != OLA_HASH_BLAKE3) { challenger_observe(ch, digests, 4 * n); return; }
+    for (size_t i = 0; i < n; i++) {
+        u64 e[5];
+        b3_digest_elements(digests + 4 * i, e);
+        challenger_observe(ch, e, 5);
+    }
+}
+void challenger_init(OlaChallenger& ch, uint32_t hasher) {
+    memset(&ch, 0, sizeof(ch));
+    ch.hasher = hasher;
 }
 u64 challenger_get(OlaChallenger& ch) {
     if (ch.input_len != 0 || ch.output_len == 0) challenger_duplex(ch);
@@ -386,13 +401,19 @@ static void scan_plane(DevBuf& mem, u64* plane, size_t n, u64* tot) {
 
 struct ByteWriter {
     std::vector<uint8_t>& b;
+    bool bytes_hash = false;   // Blake3 digests are 32 bytes (BytesHash::to_bytes), written as they are; a HashOut is 4 canonical words
     void u8(uint8_t x) { b.push_back(x); }
     void u32(uint32_t x) { for (int i = 0; i < 4; i++) b.push_back((uint8_t)(x >> (8 * i))); }
     void field(u64 x) { x = gl_canon(x); for (int i = 0; i < 8; i++) b.push_back((uint8_t)(x >> (8 * i))); }
     void ext(Ext2 e) { field(e.a); field(e.b); }
     void ext_vec(const std::vector<Ext2>& v) { u32((uint32_t)v.size()); for (auto& e : v) ext(e); }
     void field_vec(const u64* v, size_t n) { u32((uint32_t)n); for (size_t i = 0; i < n; i++) field(v[i]); }
-    void hash(const u64* h) { for (int i = 0; i < 4; i++) field(h[i]); }
+    void hash(const u64* h) {
+        for (int i = 0; i < 4; i++) {
+            if (bytes_hash) { for (int k = 0; k < 8; k++) b.push_back((uint8_t)(h[i] >> (8 * k))); }
+            else field(h[i]);
+        }
+    }
     void cap(const u64* c, size_t len) { u32((uint32_t)len); for (size_t i = 0; i < len; i++) hash(c + 4 * i); }
     void merkle_proof(const u64* sib, int depth) { u8((uint8_t)depth); for (int i = 0; i < depth; i++) hash(sib + 4 * i); }
 };
@@ -454,7 +475,7 @@ void open_and_prove(DeviceCtx* ctx, NttTables& tables, const OlaGpuConfig& cfg, 
     std::vector<u64> ctl_last;
     for (int i = (int)nperm; i < Z; i++) ctl_last.push_back(zs_last_all[i].a);
 
-    ByteWriter w{bytes};
+    ByteWriter w{bytes, ctx->hasher == (int)OLA_HASH_BLAKE3};
     w.ext_vec(local); w.ext_vec(next); w.ext_vec(zs_local); w.ext_vec(zs_next);
     w.field_vec(ctl_last.data(), ctl_last.size());
     w.ext_vec(q_local);
@@ -534,7 +555,7 @@ void open_and_prove(DeviceCtx* ctx, NttTables& tables, const OlaGpuConfig& cfg, 
         L.cap.resize(len_cap * 4);
         HIP_CHECK(hipMemcpyAsync(L.cap.data(), L.heap + 4 * len_cap, len_cap * 32, hipMemcpyDeviceToHost, ctx->stream));
         HIP_CHECK(hipStreamSynchronize(ctx->stream));
-        challenger_observe(ch, L.cap.data(), L.cap.size());
+        challenger_observe_cap(ch, L.cap.data(), L.cap.size() / 4);
         const Ext2 beta = challenger_get_ext(ch);
         const size_t out_len = len >> ab;
         u64* folded = mem.alloc(2 * out_len);

@@ -1,4 +1,4 @@
-// Poseidon-Goldilocks sponge + Merkle tree kernels for gfx950.
+// Poseidon-Goldilocks sponge + Merkle tree kernels for gfx950 (and the Blake3 leaves / nodes of Blake3GoldilocksConfig, blake3.cuh).
 //
 // Replaces (reference, relative to plonky2/plonky2/src/hash):
 //   hashing.rs:84-107            hash_n_to_m_no_pad  -- overwrite-mode sponge, rate 8, 4-element digest
@@ -16,6 +16,7 @@
 #include "device_ctx.h"
 #include "gl.cuh"
 #include "poseidon.cuh"
+#include "blake3.cuh"
 
 namespace ola {
 
@@ -273,11 +274,74 @@ __global__ __launch_bounds__(256) void pow_kernel(u64 h0, u64 h1, u64 h2, u64 h3
     if ((s[0] >> (64 - bits)) == 0) atomicMin(best, (unsigned long long)nonce);
 }
 
+// ---- Blake3GoldilocksConfig (blake3.cuh): the same three leaf shapes and the same heap, one thread per leaf / node ----
+// MULTI = leaves of more than one 1024-byte chunk (more than 128 elements: the 134-column Poseidon table); the single-chunk
+// kernels need no stack of chaining values and therefore no scratch memory.
+template <bool MULTI, class WordFn>
+__device__ __forceinline__ void b3_leaf(WordFn word, u32 nwords, u32 (&d)[8]) {
+    if (MULTI) b3_hash_words(word, nwords, d);
+    else b3_chunk_cv(word, 0, nwords, 0, true, d);
+}
+template <bool MULTI>
+__global__ __launch_bounds__(256) void leaf_b3_colmajor_kernel(const u64* __restrict__ base, size_t col_stride, int ncols,
+                                                               size_t num_leaves, u64* __restrict__ out) {
+    const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= num_leaves) return;
+    u32 d[8];
+    b3_leaf<MULTI>([&](u32 i) { return gl_canon(base[(size_t)i * col_stride + j]); }, (u32)ncols, d);
+    b3_store_digest(out + j * 4, d);
+}
+template <bool MULTI>
+__global__ __launch_bounds__(256) void leaf_b3_rowmajor_kernel(const u64* __restrict__ rows, size_t row_len, size_t num_leaves,
+                                                               u64* __restrict__ out) {
+    const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= num_leaves) return;
+    const u64* r = rows + j * row_len;
+    u32 d[8];
+    b3_leaf<MULTI>([&](u32 i) { return gl_canon(r[i]); }, (u32)row_len, d);
+    b3_store_digest(out + j * 4, d);
+}
+template <bool MULTI>
+__global__ __launch_bounds__(256) void leaf_b3_ext_kernel(const u64* __restrict__ plane_a, const u64* __restrict__ plane_b, int arity,
+                                                          size_t num_leaves, u64* __restrict__ out) {
+    const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= num_leaves) return;
+    u32 d[8];
+    b3_leaf<MULTI>([&](u32 i) { return gl_canon(((i & 1) ? plane_b : plane_a)[j * arity + (i >> 1)]); }, (u32)(2 * arity), d);
+    b3_store_digest(out + j * 4, d);
+}
+__global__ __launch_bounds__(256) void merkle_level_b3_kernel(u64* __restrict__ heap, size_t first, size_t count) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= count) return;
+    b3_node(heap + 8 * (first + t), heap + 4 * (first + t));
+}
+// levels of `first` nodes and fewer (first <= blockDim.x) down to the level of `last` nodes in one workgroup
+__global__ __launch_bounds__(256) void merkle_top_b3_kernel(u64* __restrict__ heap, size_t first, size_t last) {
+    for (size_t level = first; level >= last && level >= 1; level >>= 1) {
+        if (threadIdx.x < level) b3_node(heap + 8 * (level + threadIdx.x), heap + 4 * (level + threadIdx.x));
+        __threadfence_block();
+        __syncthreads();
+    }
+}
+static inline bool is_b3(const DeviceCtx* ctx) { return ctx->hasher == 1; }
+static void require_leaf_width(size_t words) {
+    if (words == 0 || words > 4096) throw OlaError(-1, "Blake3 leaves hold 1..4096 field elements");
+}
+
 // ---- host launchers ----
 void poseidon_init(DeviceCtx*) { poseidon_upload_constants(); }
 
 void launch_leaf_hash_colmajor(DeviceCtx* ctx, const u64* base, size_t col_stride, int ncols, size_t num_leaves,
                                u64* out) {
+    if (is_b3(ctx)) {
+        require_leaf_width((size_t)ncols);
+        if (num_leaves) {
+            const dim3 grid((unsigned)((num_leaves + 255) / 256));
+            if ((size_t)ncols > (size_t)B3_CHUNK_WORDS) hipLaunchKernelGGL(leaf_b3_colmajor_kernel<true>, grid, dim3(256), 0, ctx->stream, base, col_stride, ncols, num_leaves, out);
+            else hipLaunchKernelGGL(leaf_b3_colmajor_kernel<false>, grid, dim3(256), 0, ctx->stream, base, col_stride, ncols, num_leaves, out);
+        }
+        return;
+    }
     if (num_leaves <= QUAD_MAX) {
         hipLaunchKernelGGL(leaf_hash_colmajor_quad_kernel, dim3((unsigned)((4 * num_leaves + 255) / 256)), dim3(256), 0, ctx->stream, base,
                            col_stride, ncols, num_leaves, out);
@@ -288,6 +352,15 @@ void launch_leaf_hash_colmajor(DeviceCtx* ctx, const u64* base, size_t col_strid
                        num_leaves, out);
 }
 void launch_leaf_hash_rowmajor(DeviceCtx* ctx, const u64* rows, size_t row_len, size_t num_leaves, u64* out) {
+    if (is_b3(ctx)) {
+        require_leaf_width(row_len);
+        if (num_leaves) {
+            const dim3 grid((unsigned)((num_leaves + 255) / 256));
+            if (row_len > (size_t)B3_CHUNK_WORDS) hipLaunchKernelGGL(leaf_b3_rowmajor_kernel<true>, grid, dim3(256), 0, ctx->stream, rows, row_len, num_leaves, out);
+            else hipLaunchKernelGGL(leaf_b3_rowmajor_kernel<false>, grid, dim3(256), 0, ctx->stream, rows, row_len, num_leaves, out);
+        }
+        return;
+    }
     if (num_leaves <= QUAD_MAX) {
         hipLaunchKernelGGL(leaf_hash_rowmajor_quad_kernel, dim3((unsigned)((4 * num_leaves + 255) / 256)), dim3(256), 0, ctx->stream, rows,
                            row_len, num_leaves, out);
@@ -297,6 +370,15 @@ void launch_leaf_hash_rowmajor(DeviceCtx* ctx, const u64* rows, size_t row_len, 
     hipLaunchKernelGGL(leaf_hash_rowmajor_kernel, dim3(blocks), dim3(256), 0, ctx->stream, rows, row_len, num_leaves, out);
 }
 void launch_leaf_hash_ext(DeviceCtx* ctx, const u64* pa, const u64* pb, int arity, size_t num_leaves, u64* out) {
+    if (is_b3(ctx)) {
+        require_leaf_width((size_t)(2 * arity));
+        if (num_leaves) {
+            const dim3 grid((unsigned)((num_leaves + 255) / 256));
+            if ((size_t)(2 * arity) > (size_t)B3_CHUNK_WORDS) hipLaunchKernelGGL(leaf_b3_ext_kernel<true>, grid, dim3(256), 0, ctx->stream, pa, pb, arity, num_leaves, out);
+            else hipLaunchKernelGGL(leaf_b3_ext_kernel<false>, grid, dim3(256), 0, ctx->stream, pa, pb, arity, num_leaves, out);
+        }
+        return;
+    }
     if (num_leaves <= QUAD_MAX) {
         hipLaunchKernelGGL(leaf_hash_ext_quad_kernel, dim3((unsigned)((4 * num_leaves + 255) / 256)), dim3(256), 0, ctx->stream, pa, pb, arity,
                            num_leaves, out);
@@ -310,6 +392,12 @@ void launch_leaf_hash_ext(DeviceCtx* ctx, const u64* pa, const u64* pb, int arit
 void launch_merkle_build(DeviceCtx* ctx, u64* heap, size_t num_leaves, uint32_t cap_height) {
     const size_t last = (size_t)1 << cap_height, top = 256;   // levels of <= `top` nodes share one launch (1024 threads)
     size_t level = num_leaves / 2;
+    if (is_b3(ctx)) {
+        for (; level >= last && level > top; level /= 2)
+            hipLaunchKernelGGL(merkle_level_b3_kernel, dim3((unsigned)((level + 255) / 256)), dim3(256), 0, ctx->stream, heap, level, level);
+        if (level >= last && level >= 1) hipLaunchKernelGGL(merkle_top_b3_kernel, dim3(1), dim3(256), 0, ctx->stream, heap, level, last);
+        return;
+    }
     for (; level >= last && level > top; level /= 2) {
         if (level <= QUAD_MAX) {
             hipLaunchKernelGGL(merkle_level_quad_kernel, dim3((unsigned)((4 * level + 255) / 256)), dim3(256), 0, ctx->stream, heap, level, level);

@@ -104,6 +104,8 @@ int32_t ola_gpu_init(const OlaGpuConfig* cfg, OlaCtx** out_ctx) {
     require(c->cfg.fri_final_poly_bits <= 16, "fri_final_poly_bits must be at most 16");
     require(c->cfg.num_query_rounds >= 1 && c->cfg.num_query_rounds <= 1024, "num_query_rounds must be in 1..1024");
     require(c->cfg.num_challenges == 2, "num_challenges must be 2 (circuits/src/stark/config.rs)");
+    require(c->cfg.hasher == OLA_HASH_POSEIDON || c->cfg.hasher == OLA_HASH_BLAKE3, "hasher must be OLA_HASH_POSEIDON or OLA_HASH_BLAKE3");
+    c->dev.hasher = (int)c->cfg.hasher;
     require(c->cfg.device < ndev, "device index out of range");
     if (c->cfg.device >= 0) HIP_CHECK(hipSetDevice(c->cfg.device));
     HIP_CHECK(hipGetDevice(&c->dev.device));
@@ -360,7 +362,28 @@ int32_t ola_batch_get_lde_row(OlaCtx* ctx, const OlaBatch* b, size_t index, size
 int32_t ola_challenger_init(OlaChallenger* ch) {
     OLA_TRY
     require(ch, "challenger");
-    memset(ch, 0, sizeof(*ch));
+    challenger_init(*ch, OLA_HASH_POSEIDON);
+    OLA_CATCH
+}
+int32_t ola_challenger_init_hasher(OlaChallenger* ch, uint32_t hasher) {
+    OLA_TRY
+    require(ch, "challenger");
+    require(hasher == OLA_HASH_POSEIDON || hasher == OLA_HASH_BLAKE3, "hasher must be OLA_HASH_POSEIDON or OLA_HASH_BLAKE3");
+    challenger_init(*ch, hasher);
+    OLA_CATCH
+}
+int32_t ola_challenger_observe_cap(OlaChallenger* ch, const uint64_t* digests, size_t n) {
+    OLA_TRY
+    require(ch && (digests || n == 0), "null pointer");
+    challenger_observe_cap(*ch, (const u64*)digests, n);
+    OLA_CATCH
+}
+int32_t ola_blake3_hash_elements(const uint64_t* elems, size_t n, uint64_t out[4]) {
+    OLA_TRY
+    require(elems && out && n >= 1 && n <= 4096, "1..4096 elements");
+    std::vector<u64> w(n);
+    for (size_t i = 0; i < n; i++) w[i] = gl_canon(elems[i]);
+    b3_hash_bytes32_host(w.data(), (u32)n, (u64*)out);
     OLA_CATCH
 }
 int32_t ola_challenger_observe(OlaChallenger* ch, const uint64_t* e, size_t n) {
@@ -391,6 +414,7 @@ int32_t ola_open_and_prove(OlaCtx* ctx, const OlaBatch* trace, const OlaBatch* z
     require_full(trace); require_full(zs); require_full(quotient);
     require(trace->log_n == zs->log_n && trace->log_n == quotient->log_n, "degree mismatch between commitments");
     require(num_permutation_zs <= zs->ncols, "num_permutation_zs");
+    require(challenger->hasher == ctx->cfg.hasher, "the challenger was not initialised for this context's hasher (ola_challenger_init_hasher)");
     OlaChallenger ch = *challenger;  // only committed on success
     std::vector<uint8_t> bytes;
     size_t olen = 0;
@@ -442,6 +466,7 @@ int32_t ola_prove_single_table(OlaCtx* ctx, const uint64_t* airset, size_t airse
     OLA_TRY
     OLA_ON_DEVICE(ctx);
     require(ctx && airset && trace_cols && trace_commitment && trace_cap && ctl_challenges && challenger && out_len, "null pointer");
+    require(challenger->hasher == ctx->cfg.hasher, "the challenger was not initialised for this context's hasher (ola_challenger_init_hasher)");
     std::vector<uint8_t> bytes;
     OlaChallenger ch = *challenger;          // the caller's transcript only advances when the proof was produced
     prove_single_table_host(&ctx->dev, *ctx->tables, ctx->cfg, (const u64*)airset, airset_words, table, (const u64* const*)trace_cols,

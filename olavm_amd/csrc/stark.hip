@@ -611,7 +611,7 @@ static void prove_single_table(DeviceCtx* ctx, NttTables& tables, const OlaGpuCo
     } else {
         zs_c.own.b = commit_shared(ctx, tables, zvals, (uint32_t)nz, (uint32_t)degree_bits, cfg, true, sharded, nullptr, zs_cap, lean);
         zs_c.b = zs_c.own.b;
-        challenger_observe(ch, zs_cap.data(), zs_cap.size());
+        challenger_observe_cap(ch, zs_cap.data(), zs_cap.size() / 4);
     }
     const u64 alpha0 = (tap && tap->alphas) ? gl_canon(tap->alphas[0]) : challenger_get(ch);
     const u64 alpha1 = (tap && tap->alphas) ? gl_canon(tap->alphas[1]) : challenger_get(ch);
@@ -816,10 +816,10 @@ static void prove_single_table(DeviceCtx* ctx, NttTables& tables, const OlaGpuCo
     BatchHolder q_c(ctx);
     std::vector<u64> q_cap;
     q_c.b = commit_shared(ctx, tables, chunks, (uint32_t)(2 * q), (uint32_t)degree_bits, cfg, false, sharded, nullptr, q_cap, lean);
-    challenger_observe(ch, q_cap.data(), q_cap.size());
+    challenger_observe_cap(ch, q_cap.data(), q_cap.size() / 4);
 
     // ---- write_proof (serialization.rs:349-358): caps, then opening set + FRI proof ----
-    ByteWriter w{bytes};
+    ByteWriter w{bytes, ctx->hasher == (int)OLA_HASH_BLAKE3};
     write_cap(w, trace_cap);
     write_cap(w, zs_cap);
     write_cap(w, q_cap);
@@ -921,7 +921,7 @@ void phase_zs_host(DeviceCtx* ctx, NttTables& tables, const OlaGpuConfig& cfg, c
     OlaBatch shape;            // only its flags are looked at before the Z columns exist
     shape.ncols = (uint32_t)air.ncols; shape.log_n = log_n;
     OlaChallenger ch;
-    memset(&ch, 0, sizeof(ch));
+    challenger_init(ch, (uint32_t)ctx->hasher);
     std::vector<uint8_t> bytes;
     std::vector<u64> zero_params(64, 0), cap;
     prove_single_table(ctx, tables, cfg, air, tv, shape, cap, jobs[table], zero_params.data(), ch, bytes, false, &tap);
@@ -948,7 +948,7 @@ void phase_quotient_host(DeviceCtx* ctx, NttTables& tables, const OlaGpuConfig& 
     PhaseTap tap;
     tap.perm_challenges = perm_challenges; tap.alphas = alphas; tap.zs = &zs_c; tap.stop_after = 2; tap.chunks_out = &chunks;
     OlaChallenger ch;
-    memset(&ch, 0, sizeof(ch));
+    challenger_init(ch, (uint32_t)ctx->hasher);
     std::vector<uint8_t> bytes;
     std::vector<u64> zero_params(64, 0), cap;
     if (!params && air.n_params > 64) throw OlaError(OLA_E_INVALID_ARG, "params required");
@@ -1094,7 +1094,7 @@ void prove_with_traces(DeviceCtx* ctx, NttTables& tables, const OlaGpuConfig& cf
     std::vector<std::unique_ptr<BatchHolder>> commits;
     std::vector<std::vector<u64>> caps(nt, std::vector<u64>(len_cap * 4));
     OlaChallenger ch;
-    memset(&ch, 0, sizeof(ch));
+    challenger_init(ch, (uint32_t)ctx->hasher);
     PhaseTimer t_all(ctx, "prove_with_traces total");
     // Coset partition: a sharded table's columns are uploaded 1/world per rank and all-gathered device to device (xGMI instead of
     // `world` copies of the trace over the host's PCIe links); cpr = columns per rank, the last ranks may hold fewer or none.
@@ -1152,12 +1152,12 @@ void prove_with_traces(DeviceCtx* ctx, NttTables& tables, const OlaGpuConfig& cf
     }
     up.finish();
     t_commit.reset();
-    for (size_t t = 0; t < nt; t++) challenger_observe(ch, caps[t].data(), caps[t].size());
+    for (size_t t = 0; t < nt; t++) challenger_observe_cap(ch, caps[t].data(), caps[t].size() / 4);
     // CTL challenges and per-table job lists, in cross_table_lookup_data order
     std::vector<GpChallenge> ctl_ch;
     for (int c = 0; c < nch; c++) ctl_ch.push_back(get_gp(ch));
     const std::vector<std::vector<CtlJob>> jobs = ctl_jobs(set, ctl_ch);
-    ByteWriter w{bytes};
+    ByteWriter w{bytes, ctx->hasher == (int)OLA_HASH_BLAKE3};
     w.u32((uint32_t)nt);
     size_t poff = 0;
     std::vector<u64> zero_params(64, 0);

@@ -94,6 +94,17 @@ void oracle_two_to_one(const u64* l, const u64* r, u64* out) {
     memcpy(out, h.data(), 32);
 }
 
+// ---- the configuration's hasher (blake3.cpp) ----
+void oracle_set_hasher(int kind) { set_hasher(kind); }
+int oracle_get_hasher() { return get_hasher(); }
+void oracle_blake3(const uint8_t* in, size_t len, uint8_t* out32) { blake3_hash(in, len, out32); }
+void oracle_blake3_permutation(u64* s) { blake3_permutation(s); }
+void oracle_merkle_hash_leaf(const u64* in, size_t n, u64* out) { HashOut h = merkle_hash_leaf(in, n); memcpy(out, h.data(), 32); }
+void oracle_merkle_two_to_one(const u64* l, const u64* r, u64* out) {
+    HashOut h = merkle_two_to_one(HashOut{l[0], l[1], l[2], l[3]}, HashOut{r[0], r[1], r[2], r[3]});
+    memcpy(out, h.data(), 32);
+}
+
 // ---- merkle ----
 // cap_out: (1<<cap_height)*4;  leaf_hash_out (optional): num_leaves*4;  nodes_out (optional): num_leaves*4 (heap order)
 void oracle_merkle(const u64* leaves, size_t num_leaves, size_t leaf_len, int cap_height, u64* cap_out,
@@ -151,6 +162,9 @@ void* oracle_challenger_new() { return new Challenger(); }
 void oracle_challenger_free(void* h) { delete (Challenger*)h; }
 void oracle_challenger_observe(void* h, const u64* e, size_t n) { ((Challenger*)h)->observe_elements(e, n); }
 u64 oracle_challenger_get(void* h) { return ((Challenger*)h)->get_challenge(); }
+void oracle_challenger_observe_cap(void* h, const u64* digests, size_t n) {
+    for (size_t i = 0; i < n; i++) ((Challenger*)h)->observe_hash(HashOut{digests[4 * i], digests[4 * i + 1], digests[4 * i + 2], digests[4 * i + 3]});
+}
 void oracle_challenger_compact(void* h) { ((Challenger*)h)->compact(); }
 void oracle_challenger_state(void* h, u64* out12) { memcpy(out12, ((Challenger*)h)->sponge_state, 96); }
 

@@ -26,7 +26,8 @@ u64 Challenger::get_challenge() {
 void Challenger::duplexing() {
     for (size_t i = 0; i < input_buffer.size(); i++) sponge_state[i] = input_buffer[i];
     input_buffer.clear();
-    poseidon_naive(sponge_state);
+    if (hasher == HASH_BLAKE3) blake3_permutation(sponge_state);   // H::Permutation (challenger.rs:134-153 is generic over it)
+    else poseidon_naive(sponge_state);
     output_buffer.assign(sponge_state, sponge_state + 8);
 }
 void Challenger::compact() {

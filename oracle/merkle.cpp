@@ -7,6 +7,7 @@
 //   merkle_tree/mod.rs:228-259   digests re-laid per cap sub-tree (sibling pairs interleaved by layer)
 //   merkle_tree/mod.rs:273-308   prove(): sibling lookup formula in that layout
 //   merkle_proofs.rs:52-80       verify_merkle_proof_to_cap
+// The hash is the configuration's Hasher (Poseidon, or Blake3_256 after set_hasher(HASH_BLAKE3), blake3.cpp).
 #include "oracle.hpp"
 
 namespace ola_oracle {
@@ -19,12 +20,12 @@ MerkleTree merkle_new_v2(std::vector<u64> leaves, size_t num_leaves, size_t leaf
     t.leaves = std::move(leaves);
     t.leaf_hash.resize(num_leaves);
 #pragma omp parallel for schedule(static)
-    for (long i = 0; i < (long)num_leaves; i++) t.leaf_hash[i] = hash_no_pad(t.get(i), leaf_len);
+    for (long i = 0; i < (long)num_leaves; i++) t.leaf_hash[i] = merkle_hash_leaf(t.get(i), leaf_len);
     size_t n = num_leaves / 2;
     t.nodes.assign(2 * n > 0 ? 2 * n : 1, HashOut{0, 0, 0, 0});
 #pragma omp parallel for schedule(static)
-    for (long i = 0; i < (long)n; i++) t.nodes[n + i] = two_to_one(t.leaf_hash[2 * i], t.leaf_hash[2 * i + 1]);
-    for (size_t i = n; i-- > 1;) t.nodes[i] = two_to_one(t.nodes[2 * i], t.nodes[2 * i + 1]);
+    for (long i = 0; i < (long)n; i++) t.nodes[n + i] = merkle_two_to_one(t.leaf_hash[2 * i], t.leaf_hash[2 * i + 1]);
+    for (size_t i = n; i-- > 1;) t.nodes[i] = merkle_two_to_one(t.nodes[2 * i], t.nodes[2 * i + 1]);
     size_t len_cap = (size_t)1 << cap_height;
     t.cap.resize(len_cap);
     for (size_t i = 0; i < len_cap; i++) t.cap[i] = (len_cap == num_leaves) ? t.leaf_hash[i] : t.nodes[len_cap + i];
@@ -96,9 +97,9 @@ std::vector<HashOut> merkle_prove_via_digests(const MerkleTree& t, const std::ve
 bool verify_merkle_proof_to_cap(const u64* leaf, size_t leaf_len, size_t leaf_index, const std::vector<HashOut>& cap,
                                 const std::vector<HashOut>& siblings) {
     size_t index = leaf_index;
-    HashOut cur = hash_no_pad(leaf, leaf_len);
+    HashOut cur = merkle_hash_leaf(leaf, leaf_len);
     for (const HashOut& s : siblings) {
-        cur = (index & 1) ? two_to_one(s, cur) : two_to_one(cur, s);
+        cur = (index & 1) ? merkle_two_to_one(s, cur) : merkle_two_to_one(cur, s);
         index >>= 1;
     }
     return index < cap.size() && cur == cap[index];

@@ -31,6 +31,20 @@ State poseidon(const State& in);
 HashOut hash_no_pad(const u64* in, size_t n);
 HashOut two_to_one(const HashOut& l, const HashOut& r);
 
+// ---------------- blake3.cpp ----------------
+// GenericConfig::Hasher (plonk/config.rs:112-161): Poseidon (PoseidonGoldilocksConfig, the default) or Blake3_256
+// (Blake3GoldilocksConfig).  A process-wide switch of the checker; InnerHasher (proof of work) is Poseidon in both.
+enum { HASH_POSEIDON = 0, HASH_BLAKE3 = 1 };
+void set_hasher(int kind);
+int get_hasher();
+void blake3_hash(const uint8_t* in, size_t len, uint8_t out[32]);
+HashOut blake3_hash_no_pad(const u64* in, size_t n);               // digest = 32 bytes as 4 little-endian words, never reduced
+HashOut blake3_two_to_one(const HashOut& l, const HashOut& r);
+void blake3_permutation(u64 state[12]);
+void blake3_digest_elements(const HashOut& h, u64 out[5]);
+HashOut merkle_hash_leaf(const u64* in, size_t n);                 // Hasher::hash_no_pad of the selected configuration
+HashOut merkle_two_to_one(const HashOut& l, const HashOut& r);
+
 // ---------------- merkle.cpp ----------------
 struct MerkleTree {
     size_t num_leaves = 0, leaf_len = 0;
@@ -53,10 +67,14 @@ bool verify_merkle_proof_to_cap(const u64* leaf, size_t leaf_len, size_t leaf_in
 struct Challenger {
     u64 sponge_state[12] = {0};
     std::vector<u64> input_buffer, output_buffer;
+    int hasher = get_hasher();      // Challenger<F, C::Hasher>: the permutation and what observing a digest means
     void observe_element(u64 e);
     void observe_elements(const u64* e, size_t n);
     void observe_ext(Ext2 e) { observe_element(e.a); observe_element(e.b); }
-    void observe_hash(const HashOut& h) { observe_elements(h.data(), 4); }
+    void observe_hash(const HashOut& h) {
+        if (hasher == HASH_BLAKE3) { u64 e[5]; blake3_digest_elements(h, e); observe_elements(e, 5); }
+        else observe_elements(h.data(), 4);
+    }
     void observe_cap(const std::vector<HashOut>& cap) { for (auto& h : cap) observe_hash(h); }
     u64 get_challenge();
     Ext2 get_extension_challenge() { u64 a = get_challenge(); u64 b = get_challenge(); return Ext2{a, b}; }
@@ -155,7 +173,9 @@ struct ByteBuf {
     void ext(Ext2 e) { field(e.a); field(e.b); }
     void field_vec(const std::vector<u64>& v) { u32((uint32_t)v.size()); for (u64 x : v) field(x); }
     void ext_vec(const std::vector<Ext2>& v) { u32((uint32_t)v.size()); for (auto& x : v) ext(x); }
-    void hash(const HashOut& h) { for (int i = 0; i < 4; i++) field(h[i]); }
+    void raw64(u64 x) { for (int i = 0; i < 8; i++) b.push_back((uint8_t)(x >> (8 * i))); }
+    // write_hash = GenericHashOut::to_bytes: canonical words of a HashOut, the 32 bytes of a BytesHash as they are
+    void hash(const HashOut& h) { for (int i = 0; i < 4; i++) { if (get_hasher() == HASH_BLAKE3) raw64(h[i]); else field(h[i]); } }
     void cap(const std::vector<HashOut>& c) { u32((uint32_t)c.size()); for (auto& h : c) hash(h); }
     void merkle_proof(const std::vector<HashOut>& p) { u8((uint8_t)p.size()); for (auto& h : p) hash(h); }
     void opening_set(const StarkOpeningSet& s);

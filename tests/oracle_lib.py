@@ -80,6 +80,13 @@ class Oracle:
         L.oracle_verify_all_proof.restype = C.c_int
         L.oracle_check_constraints.argtypes = [U64P, C.c_size_t, C.c_int, U64P, C.c_uint32, U64P]
         L.oracle_check_constraints.restype = C.c_long
+        L.oracle_set_hasher.argtypes = [C.c_int]
+        L.oracle_get_hasher.restype = C.c_int
+        L.oracle_blake3.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p]
+        L.oracle_blake3_permutation.argtypes = [U64P]
+        L.oracle_merkle_hash_leaf.argtypes = [U64P, C.c_size_t, U64P]
+        L.oracle_merkle_two_to_one.argtypes = [U64P, U64P, U64P]
+        L.oracle_challenger_observe_cap.argtypes = [C.c_void_p, U64P, C.c_size_t]
         L.oracle_ext_mul.argtypes = [U64P, U64P, U64P]
         L.oracle_ext_inv.argtypes = [U64P, U64P]
 
@@ -160,6 +167,48 @@ class Oracle:
         r = np.ascontiguousarray(r, dtype=np.uint64)
         out = np.empty(4, dtype=np.uint64)
         self.lib.oracle_two_to_one(ptr(l), ptr(r), ptr(out))
+        return out
+
+    # ---- the configuration's hasher: "poseidon" (PoseidonGoldilocksConfig) or "blake3" (Blake3GoldilocksConfig) ----
+    HASHERS = {"poseidon": 0, "blake3": 1}
+
+    def hasher(self, kind):
+        """Context manager: Merkle trees, challengers, provers and verifiers of the oracle use `kind` inside the block.
+        (Trace generation derives its compress challenges with a Poseidon challenger in both configurations --
+        generation/builtin.rs:121, generation/prog.rs:24 -- so build the traces outside.)"""
+        import contextlib
+
+        @contextlib.contextmanager
+        def cm():
+            old = self.lib.oracle_get_hasher()
+            self.lib.oracle_set_hasher(self.HASHERS[kind])
+            try:
+                yield self
+            finally:
+                self.lib.oracle_set_hasher(old)
+        return cm()
+
+    def blake3(self, data: bytes) -> bytes:
+        out = C.create_string_buffer(32)
+        self.lib.oracle_blake3(data, len(data), out)
+        return out.raw
+
+    def blake3_permutation(self, state):
+        s = np.array(state, dtype=np.uint64)
+        self.lib.oracle_blake3_permutation(ptr(s))
+        return s
+
+    def merkle_hash_leaf(self, data):
+        d = np.ascontiguousarray(data, dtype=np.uint64)
+        out = np.empty(4, dtype=np.uint64)
+        self.lib.oracle_merkle_hash_leaf(ptr(d), d.size, ptr(out))
+        return out
+
+    def merkle_two_to_one(self, l, r):
+        l = np.ascontiguousarray(l, dtype=np.uint64)
+        r = np.ascontiguousarray(r, dtype=np.uint64)
+        out = np.empty(4, dtype=np.uint64)
+        self.lib.oracle_merkle_two_to_one(ptr(l), ptr(r), ptr(out))
         return out
 
     # ---- merkle ----
@@ -305,6 +354,12 @@ class OracleChallenger:
         self.log.append(("o", e.copy()))
         self.o.lib.oracle_challenger_observe(self.h, ptr(e), e.size)
 
+    def observe_cap(self, digests):
+        """observe_cap (challenger.rs:75-84): 4 elements per Poseidon digest, 5 (7-byte chunks) per Blake3 digest."""
+        d = np.ascontiguousarray(digests, dtype=np.uint64).reshape(-1, 4)
+        self.log.append(("h", d.copy()))
+        self.o.lib.oracle_challenger_observe_cap(self.h, ptr(d), d.shape[0])
+
     def get(self):
         self.log.append(("g", None))
         return int(self.o.lib.oracle_challenger_get(self.h))
@@ -323,6 +378,8 @@ class OracleChallenger:
         for k, v in self.log:
             if k == "o":
                 c.observe(v)
+            elif k == "h":
+                c.observe_cap(v)
             elif k == "g":
                 c.get()
             else:

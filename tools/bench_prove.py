@@ -15,12 +15,15 @@ blob = s.blob()
 t0 = time.time()
 traces, params, compress = tracegen.empty_program_instance(log_n=10, range_bits=16, limb_bits=8, log_n_cpu=L, log_n_mem=L, log_n_poseidon=LP)
 print("tracegen %.1fs; heights" % (time.time() - t0), [int(t.shape[1]).bit_length() - 1 for t in traces], flush=True)
-be = Backend(device=0)
+HASHER = os.environ.get("OLA_HASHER", "poseidon")      # blake3 = the reference's Blake3GoldilocksConfig
+be = Backend(device=0, hasher=HASHER)
 for r in range(reps):
     t0 = time.time()
     proof = be.prove_with_traces(blob, traces, params, compress)
     print("prove_with_traces: %.3f s, proof %d bytes" % (time.time() - t0, len(proof)), flush=True)
 if os.environ.get("OLA_VERIFY"):
     from tests import oracle_lib
-    rc, why = oracle_lib.load().verify_all_proof(blob, proof, params)
+    o = oracle_lib.load()
+    with o.hasher(HASHER):
+        rc, why = o.verify_all_proof(blob, proof, params)
     print("oracle verifier:", rc, why)

@@ -7,7 +7,10 @@ count = 70000 gives 980 k executed CPU rows (2^20), 280 k memory cells, a 2^21-r
 immediate word) and 280 k range-checked sort values.  The proof is checked with the oracle's verifier; with OLA_TIMING=1 the
 library prints its per-phase times (named after the reference's `timed!` scopes) to stderr.
 
-    python tools/bench_prove_real.py [count] [reps] [--json out.json] [--phases] [--oracle] [--python] [--storage-slots N]
+    python tools/bench_prove_real.py [count] [reps] [--json out.json] [--phases] [--oracle] [--python] [--storage-slots N] [--hasher blake3]
+
+--hasher blake3 proves under the reference's Blake3GoldilocksConfig (the configuration of its README numbers): BLAKE3 Merkle
+trees and challenger, Poseidon proof of work; the oracle checks under the same configuration.
 """
 import json
 import os
@@ -22,6 +25,7 @@ def main():
     count = int(args[0]) if args else 70000
     reps = int(args[1]) if len(args) > 1 else 3
     out = sys.argv[sys.argv.index("--json") + 1] if "--json" in sys.argv else None
+    hasher = sys.argv[sys.argv.index("--hasher") + 1] if "--hasher" in sys.argv else "poseidon"
     from olavm_amd.air import fastexec, miniexec as M, ola_tables as T
     from olavm_amd.backend import Backend
     s = T.ola_stark()
@@ -37,7 +41,7 @@ def main():
     gen_s = time.time() - t0
     heights = [int(t.shape[1]).bit_length() - 1 for t in traces]
     print("executed + filled 12 tables in %.1f s; log2 heights %s" % (gen_s, heights), flush=True)
-    be = Backend(device=0)
+    be = Backend(device=0, hasher=hasher)
     times = []
     for _ in range(reps):
         t0 = time.time()
@@ -46,19 +50,23 @@ def main():
         print("prove_with_traces: %.3f s, proof %d bytes" % (times[-1], len(proof)), flush=True)
     if "--phases" in sys.argv:          # one more proof on a context created with OLA_TIMING=1 (phase lines go to stderr)
         os.environ["OLA_TIMING"] = "1"
-        be2 = Backend(device=0)
+        be2 = Backend(device=0, hasher=hasher)
         be2.prove_with_traces(blob, traces, params, compress)          # cold context: tables, twiddles, allocations
         print("[ola-timing] ---- warm proof ----", file=sys.stderr, flush=True)
         be2.prove_with_traces(blob, traces, params, compress)
         be2.close()
     from tests import oracle_lib
     o = oracle_lib.load()
-    rc, why = o.verify_all_proof(blob, proof, params)
-    print("oracle verifier:", rc, why, flush=True)
+    import contextlib
+    cfg = o.hasher(hasher)
+    with cfg:
+        rc, why = o.verify_all_proof(blob, proof, params)
+    print("oracle verifier (%s configuration):" % hasher, rc, why, flush=True)
     oracle_s = None
     if "--oracle" in sys.argv:          # the CPU restatement on the same traces (all host cores it uses), byte comparison included
         t0 = time.time()
-        ref = o.prove_with_traces(blob, traces, params, compress)
+        with o.hasher(hasher):
+            ref = o.prove_with_traces(blob, traces, params, compress)
         oracle_s = time.time() - t0
         print("oracle prove_with_traces (CPU port, %d threads): %.1f s, bytes identical: %s" % (o.lib.oracle_num_threads(), oracle_s, ref == proof), flush=True)
         if ref != proof:
@@ -66,7 +74,7 @@ def main():
     if out:
         os.makedirs(os.path.dirname(out) or ".", exist_ok=True)
         with open(out, "w") as f:
-            json.dump({"workload": ("storage_heavy_program(%d, %d)" % (slots, count) if slots else "memory_program(%d)" % count) + ", ola_stark(range_bits=16, limb_bits=8)", "log2_heights": heights,
+            json.dump({"workload": ("storage_heavy_program(%d, %d)" % (slots, count) if slots else "memory_program(%d)" % count) + ", ola_stark(range_bits=16, limb_bits=8)", "log2_heights": heights, "hasher": hasher,
                        "trace_generation_s": round(gen_s, 1), "prove_s": [round(t, 4) for t in times], "proof_bytes": len(proof),
                        "oracle_verifier_rc": rc, "oracle_cpu_port_prove_s": None if oracle_s is None else round(oracle_s, 1)}, f, indent=1)
     if rc != 0:
