@@ -131,7 +131,10 @@ int32_t ola_ntt_batch(OlaCtx* ctx, int32_t op, const uint64_t* in, uint64_t* out
 int32_t ola_ntt_batch_dev(OlaCtx* ctx, int32_t op, const uint64_t* in_dev, uint64_t* out_dev, uint64_t* scratch_dev,
                           uint32_t log_n, uint32_t batch, uint64_t shift, uint32_t blowup_log);
 
-/* ---- Poseidon / Merkle: replaces hash/poseidon.rs:593-603, hashing.rs:84-111, merkle_tree/mod.rs:180-337 -- */
+/* ---- Poseidon / Merkle: replaces hash/poseidon.rs:593-603, hashing.rs:84-111, merkle_tree/mod.rs:180-337 --
+ * ola_hash_rows, ola_merkle_cap and every commitment hash with the context's Hasher: the Poseidon sponge, or under
+ * OLA_HASH_BLAKE3 Blake3_256 (hash/blake3.rs:203-233) of the canonical little-endian words; a digest is 4 words (32 bytes)
+ * either way, and a Blake3 digest is bytes -- its words may be >= p and are never reduced. */
 /* n states of 12 elements each, permuted in place (host memory). */
 int32_t ola_poseidon_permute(OlaCtx* ctx, uint64_t* states, size_t n);
 /* hash_no_pad over each row of a row-major num_rows x row_len host matrix -> digests (num_rows x 4). */
