@@ -39,7 +39,7 @@ __device__ __forceinline__ void acc_mad(Acc160& a, u64 x, u64 w) {
     a.top += (a.hi < phi) ? 1u : 0u;
 }
 // lo + hi*2^64 + top*2^128 mod p, with 2^128 = -2^32 (mod p) and top*2^32 <= p - 1
-__device__ __forceinline__ u64 acc_reduce(const Acc160& a) { return gl_sub(gl_reduce128(a.lo, a.hi), (u64)a.top << 32); }
+__device__ __forceinline__ u64 acc_reduce(const Acc160& a) { return gl_sub(gl_reduce128_cc(a.lo, a.hi), (u64)a.top << 32); }
 
 #define AIRQ_THREADS 256
 #ifdef AIRQ_GENERATED_TU

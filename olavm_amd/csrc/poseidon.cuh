@@ -35,15 +35,7 @@ __device__ __forceinline__ void mul_wide32(u64 a, u64 b, u64& lo, u64& hi) {
     hi = (u64)a1 * b1 + (u >> 32) + (v >> 32);
     lo = (v << 32) | (u32)t;
 }
-__device__ __forceinline__ u64 reduce128_weak(u64 lo, u64 hi) {
-    const u32 hh = (u32)(hi >> 32), hl = (u32)hi;
-    u64 t0 = lo - hh;
-    t0 -= (lo < (u64)hh) ? GL_EPS : 0;     // borrowed: + p
-    const u64 t1 = (u64)hl * 0xFFFFFFFFu;  // hl * (2^32 - 1)
-    u64 t2 = t0 + t1;
-    t2 += (t2 < t1) ? GL_EPS : 0;          // wrapped: 2^64 = EPS (mod p); cannot wrap twice
-    return t2;
-}
+__device__ __forceinline__ u64 reduce128_weak(u64 lo, u64 hi) { return gl_reduce128_weak_cc(lo, hi); }   // carry-flag form, gl.cuh
 __device__ __forceinline__ u64 mul_weak(u64 a, u64 b) {
     u64 lo, hi;
     mul_wide32(a, b, lo, hi);
