@@ -436,6 +436,11 @@ def main():
         if world == 1 and not args.no_prove:
             del data, out, scratch
             torch.cuda.empty_cache()
+            # The first proof of a fresh process, measured before this process has cycled hundreds of GB through the driver:
+            # VRAM that a still-living process has freed is handed out dirty and is scrubbed inside the next owner's hipMalloc
+            # (about 30 ms per GB), which would be charged to whichever child runs first (cold start).
+            cold = {"cold_process": cold_process_prove(args.log_n, local_rank, reserve=True),
+                    "cold_process_without_reserve": cold_process_prove(args.log_n, local_rank, reserve=False)}
             try:
                 be_b3 = Backend(device=local_rank, stream=stream.cuda_stream, hasher="blake3")
             except Exception:
@@ -450,8 +455,7 @@ def main():
                 be_b3.close()
             be.trim()
             torch.cuda.empty_cache()
-            res["prove"]["cold_process"] = cold_process_prove(args.log_n, local_rank, reserve=True)
-            res["prove"]["cold_process_without_reserve"] = cold_process_prove(args.log_n, local_rank, reserve=False)
+            res["prove"].update(cold)
             if args.log_n == 22 and not args.no_2p24:
                 try:
                     res["prove_2p24_rows"] = prove_time_2p24(be)

@@ -75,6 +75,11 @@ int32_t ola_gpu_trim(OlaCtx* ctx);
 /* Device memory of the context's buffer pool, in bytes: out[0] handed out now, out[1] the most ever handed out at once,
  * out[2] handed out + cached now, out[3] the most ever held (the high-water mark of a proof; reset = 1 restarts the marks). */
 int32_t ola_gpu_memory_stats(OlaCtx* ctx, uint64_t out[4], int32_t reset);
+/* Self-test of the device field arithmetic: the kernels' modular reduction is written with explicit carry chains in inline
+ * assembly (olavm_amd/csrc/gl.cuh); this compares it with the plain C++ reduction on a table of edge values and on `pairs`
+ * pseudo-random operand pairs and returns the number of disagreements (0 expected; about 10^9 pairs per 50 ms).  Meant to be
+ * run once after ola_gpu_init on a new driver or compiler. */
+int32_t ola_gpu_selftest(OlaCtx* ctx, uint64_t pairs, uint64_t* mismatches);
 /* Start allocating, on a helper thread, the large device buffers that ola_prove_with_traces will need for this AIR set and these
  * table heights (log2 rows per table); returns at once.  The driver scrubs previously used VRAM inside hipMalloc (about 30 ms per
  * GB here), which is what makes the first proof of a process slow; called right after ola_gpu_init -- before the host reads or

@@ -108,6 +108,7 @@ def load_library():
     L.ola_ctl_z.argtypes = [C.c_void_p, U64P, C.c_size_t, C.c_uint32, C.c_uint32, C.POINTER(U64P), U64P, U64P]
     L.ola_quotient.argtypes = [C.c_void_p, U64P, C.c_size_t, C.c_uint32, C.c_void_p, C.c_void_p, U64P, U64P, U64P, U64P, U64P]
     L.ola_gpu_memory_stats.argtypes = [C.c_void_p, U64P, C.c_int32]
+    L.ola_gpu_selftest.argtypes = [C.c_void_p, C.c_uint64, U64P]
     L.ola_gpu_reserve.argtypes = [C.c_void_p, U64P, C.c_size_t, C.POINTER(C.c_uint32)]
     L.ola_air_kernels_available.argtypes = [U64P, C.c_size_t, C.POINTER(C.c_uint8), C.c_size_t]
     _lib = L
@@ -121,7 +122,7 @@ EXPORTS = [
     "ola_batch_get_leaf", "ola_batch_get_lde_row", "ola_challenger_init", "ola_challenger_observe",
     "ola_challenger_get", "ola_challenger_compact", "ola_challenger_init_hasher", "ola_challenger_observe_cap", "ola_blake3_hash_elements", "ola_open_and_prove", "ola_pow", "ola_prove_with_traces",
     "ola_air_kernels_available", "ola_commit_values_shard", "ola_commit_values_shard_dev", "ola_set_shard", "ola_gpu_trim", "ola_generate_poseidon_trace",
-    "ola_permuted_cols", "ola_permuted_cols_dev", "ola_prove_single_table", "ola_take_pending_proof", "ola_gpu_memory_stats", "ola_gpu_reserve",
+    "ola_permuted_cols", "ola_permuted_cols_dev", "ola_prove_single_table", "ola_take_pending_proof", "ola_gpu_memory_stats", "ola_gpu_selftest", "ola_gpu_reserve",
     "ola_table_shape", "ola_perm_z", "ola_ctl_z", "ola_quotient", "ola_set_shard_options", "ola_gpu_get_stream",
 ]
 
@@ -386,6 +387,12 @@ class Backend:
         blob = np.ascontiguousarray(airset_blob, dtype=np.uint64)
         logs = (C.c_uint32 * len(log_ns))(*[int(x) for x in log_ns])
         self._chk(self.lib.ola_gpu_reserve(self.ctx, _p(blob), blob.size, logs))
+
+    def selftest(self, pairs=1 << 28):
+        """Device field-arithmetic self-test (carry-flag reduction against the C++ form): number of mismatches."""
+        out = np.zeros(1, dtype=np.uint64)
+        self._chk(self.lib.ola_gpu_selftest(self.ctx, int(pairs), _p(out)))
+        return int(out[0])
 
     def memory_stats(self, reset=False):
         """Device memory of the context's pool in bytes: dict(live, live_peak, reserved, reserved_peak)."""

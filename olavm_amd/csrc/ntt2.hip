@@ -83,7 +83,7 @@ constexpr int ntt2_lds_elems() {
 // the coset pre-scale weights, 2-3 of the ~5 general multiplications per element of a strided pass -- is computed once
 // and reused for the workgroup's CB columns.
 template <int R, int MODE, bool INV, int CB, bool PRE>
-__global__ __launch_bounds__(256) void ntt2_pass_kernel(Ntt2Params p) {
+__device__ __forceinline__ void ntt2_pass_body(const Ntt2Params& p) {
     static_assert(!PRE || MODE == N2_STRIDED, "only the first (strided) pass of a coset transform pre-scales");
     static_assert(R >= 4 && R <= 8, "pass width");
     constexpr int K2 = R - 4;     // bits of the second round
@@ -281,6 +281,18 @@ __global__ __launch_bounds__(256) void ntt2_pass_kernel(Ntt2Params p) {
     }
 }
 
+template <int R, int MODE, bool INV, int CB, bool PRE>
+__global__ __launch_bounds__(256) void ntt2_pass_kernel(Ntt2Params p) { ntt2_pass_body<R, MODE, INV, CB, PRE>(p); }
+// The same pass held to 128 VGPRs (four waves per SIMD instead of the three its natural 130-138 allow): the strided pass
+// without pre-scale of the plain transform (4 spilled dwords; OLA_NTT2_W4=0 goes back to the unconstrained kernel).
+template <int R, int MODE, bool INV, int CB>
+__global__ __launch_bounds__(256, 4) void ntt2_pass_kernel_w4(Ntt2Params p) { ntt2_pass_body<R, MODE, INV, CB, false>(p); }
+
+static bool ntt2_w4() {
+    static const bool on = [] { const char* e = getenv("OLA_NTT2_W4"); return !(e && *e == '0'); }();   // default on: +1 % (4.66 -> 4.61 ms)
+    return on;
+}
+
 // ------------------------------------------------------------------------------------------------ host side
 template <int R, int MODE, bool INV>
 static void ntt2_launch(const Ntt2Params& p0, size_t cols, size_t cosets, hipStream_t stream) {
@@ -290,6 +302,7 @@ static void ntt2_launch(const Ntt2Params& p0, size_t cols, size_t cosets, hipStr
     const size_t lds_bytes = (size_t)(ntt2_lds_elems<R, MODE>() + (R > 4 ? (1 << R) : 0)) * 8;
     dim3 grid((unsigned)(((size_t)1 << p.log_n) >> 12), (unsigned)((cols + CB - 1) / CB), (unsigned)cosets);
     if (MODE == N2_STRIDED && p.sc_lo) hipLaunchKernelGGL((ntt2_pass_kernel<R, MODE, INV, CB, MODE == N2_STRIDED>), grid, dim3(256), lds_bytes, stream, p);
+    else if (MODE == N2_STRIDED && ntt2_w4()) hipLaunchKernelGGL((ntt2_pass_kernel_w4<R, MODE, INV, CB>), grid, dim3(256), lds_bytes, stream, p);
     else hipLaunchKernelGGL((ntt2_pass_kernel<R, MODE, INV, CB, false>), grid, dim3(256), lds_bytes, stream, p);
 }
 template <int MODE, bool INV>

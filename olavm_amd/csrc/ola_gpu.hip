@@ -22,6 +22,7 @@
 #include "batch.hip"
 #include "fri.hip"
 #include "stark.hip"
+#include "selftest.hip"
 
 using namespace ola;
 
@@ -570,6 +571,14 @@ int32_t ola_gpu_trim(OlaCtx* ctx) {
     OLA_ON_DEVICE(ctx);
     require(ctx, "ctx");
     ctx->dev.release_cache();
+    OLA_CATCH
+}
+
+int32_t ola_gpu_selftest(OlaCtx* ctx, uint64_t pairs, uint64_t* mismatches) {
+    OLA_TRY
+    OLA_ON_DEVICE(ctx);
+    require(ctx && mismatches, "null pointer");
+    *mismatches = field_selftest(&ctx->dev, pairs);
     OLA_CATCH
 }
 

@@ -24,6 +24,15 @@ def bitrev_perm(bits):
     return np.array([int(format(j, "0%db" % bits)[::-1], 2) if bits else 0 for j in range(1 << bits)])
 
 
+# ---------------------------------------------------------------- field arithmetic
+def test_carry_flag_reduction_equals_the_plain_form(be):
+    """gl.cuh's modular reduction for general products is inline assembly with explicit carry chains and hand-placed wait
+    states; ola_gpu_selftest compares it on the device with the plain C++ reduction (45 k edge-value pairs + 2^31 random pairs
+    biased towards all-ones / all-zero halves).  Everything downstream (NTT, Poseidon, quotient) is checked against the oracle
+    anyway; this one names the culprit if a driver or compiler update breaks the hazard spacing."""
+    assert be.selftest(1 << 31) == 0
+
+
 # ---------------------------------------------------------------- Poseidon / sponge / Merkle
 def test_poseidon_kats_on_device(be):
     kat = json.load(open(os.path.join(HERE, "golden", "poseidon_kat.json")))["vectors"]
