@@ -1,5 +1,6 @@
 // ORACLE -- test infrastructure only (see gl.hpp header).  Plain C entry points over the CPU restatement so
 // that tests/ (ctypes + numpy) and bench.py's cpu_baseline leg can drive it.  Not part of the product.
+#include <cstdlib>
 #include <cstring>
 
 #include "oracle.hpp"
@@ -214,6 +215,30 @@ int oracle_verify_opening(const u64* caps, const int* num_polys, int degree_bits
 
 // ---- batch helpers for bench.py's cpu_baseline leg (OpenMP over independent columns) ----
 #include <omp.h>
+#include <sched.h>
+
+#include <cstdio>
+namespace {
+// Threads the checker may really use: the OpenMP default is the number of visible CPUs, but a container's CPU quota can be far
+// below it (a GPU box with 128 visible CPUs and a 16-CPU quota ran the oracle prover 8x slower, its 128 threads spinning on 16).
+int usable_cpus() {
+    int n = omp_get_max_threads();
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) { const int a = CPU_COUNT(&set); if (a >= 1 && a < n) n = a; }
+    long long quota = -1, period = -1;
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {            // cgroup v2: "<quota|max> <period>"
+        char q[32] = {0};
+        if (fscanf(f, "%31s %lld", q, &period) == 2 && q[0] != 'm') quota = atoll(q);
+        fclose(f);
+    } else {                                                           // cgroup v1
+        if (FILE* g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (fscanf(g, "%lld", &quota) != 1) quota = -1; fclose(g); }
+        if (FILE* g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(g, "%lld", &period) != 1) period = -1; fclose(g); }
+    }
+    if (quota > 0 && period > 0) { const int c = (int)((quota + period - 1) / period); if (c >= 1 && c < n) n = c; }
+    return n < 1 ? 1 : n;
+}
+struct ThreadCap { ThreadCap() { omp_set_num_threads(usable_cpus()); } } g_thread_cap;
+}  // namespace
 extern "C" {
 int oracle_num_threads() { return omp_get_max_threads(); }
 // Horner evaluation of one polynomial at a few points (full-size NTT spot checks in tests/: fft.rs:218-252 evaluates
