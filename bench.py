@@ -205,10 +205,27 @@ def prove_time(be, log_n, reps=3, be_b3=None):
     from olavm_amd.air import tracegen
     blob = T.ola_stark().blob()
     traces, params, compress = tracegen.empty_program_instance(log_n=10, range_bits=16, limb_bits=8, log_n_cpu=log_n, log_n_mem=log_n)
-    return {**timed_proofs(be, blob, traces, params, compress, reps),
-            "workload": f"prove_with_traces, 12 tables, heights 2^{[int(t.shape[1]).bit_length() - 1 for t in traces]}, "
-                        "Poseidon config, rate_bits 3, 28 queries, 16 PoW bits; host traces in, proof bytes out",
-            **blake3_config(be_b3, blob, traces, params, compress, reps)}
+    res = {**timed_proofs(be, blob, traces, params, compress, reps),
+           "workload": f"prove_with_traces, 12 tables, heights 2^{[int(t.shape[1]).bit_length() - 1 for t in traces]}, "
+                       "Poseidon config, rate_bits 3, 28 queries, 16 PoW bits; host traces in, proof bytes out"}
+    try:        # the same call with the tables already resident in HBM (no PCIe upload inside the timed region)
+        import numpy as np
+        import torch
+        want = be.prove_with_traces(blob, traces, params, compress)
+        dev = [torch.from_numpy(np.ascontiguousarray(t).view(np.int64)).cuda() for t in traces]
+        torch.cuda.synchronize()
+        ts, same = [], True
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            same &= be.prove_with_traces(blob, dev, params, compress) == want
+            ts.append(time.perf_counter() - t0)
+        res["tables_resident_in_hbm"] = {"seconds": round(sorted(ts)[len(ts) // 2], 4), "identical_to_host_table_proof": bool(same)}
+        del dev
+        torch.cuda.empty_cache()
+    except Exception as e:      # an extra: never at the price of the headline line
+        res["tables_resident_in_hbm"] = {"error": repr(e)[:200]}
+    res.update(blake3_config(be_b3, blob, traces, params, compress, reps))
+    return res
 
 
 def prove_time_real(be, log_n, reps=3, be_b3=None):

@@ -223,8 +223,11 @@ int32_t ola_pow(OlaCtx* ctx, const uint64_t h[4], uint32_t bits, uint64_t* witne
  * airset: the AIR-set description (tables, constraint programs, permutation pairs, cross-table lookups) as a u64
  *   array -- the data form of the reference's OlaStark (stark/ola_stark.rs:29-64, 122-560); format and generator in
  *   olavm_amd/air/dsl.py.
- * traces[t]: host pointer to table t, column-major ncols x 2^log_n[t] (the [Vec<PolynomialValues<F>>; NUM_TABLES]
- *   that generate_traces returns, generation/mod.rs:77-213).
+ * traces[t]: pointer to table t, column-major ncols x 2^log_n[t] (the [Vec<PolynomialValues<F>>; NUM_TABLES]
+ *   that generate_traces returns, generation/mod.rs:77-213): host memory (pageable is fine; the upload overlaps the first
+ *   commitments), or memory of this GPU for a table that is already resident -- table by table, the library looks at the
+ *   pointer.  A resident table must be complete on the context's stream (or the device idle) when the call is made; the
+ *   tables are not modified.
  * params: concatenated per-table constraint parameters (e.g. the bitwise/program compress challenge read inside
  *   the AIR), may be NULL when no table has any; compress_challenges: one per table as carried in AllProof
  *   (prover.rs:307-320), may be NULL (zeros).

@@ -448,8 +448,13 @@ class Backend:
     def prove_with_traces(self, airset_blob, traces, params=None, compress=None, cap=8 << 20):
         """AllProof bytes for the multi-table STARK described by `airset_blob` (olavm_amd.air.AirSet.blob())."""
         blob = np.ascontiguousarray(airset_blob, dtype=np.uint64)
-        tr = [np.ascontiguousarray(t, dtype=np.uint64) for t in traces]
-        ptrs = (U64P * len(tr))(*[_p(t) for t in tr])
+        # a table is a numpy array (host) or anything with data_ptr() and a shape -- a contiguous int64 / uint64 torch tensor
+        # resident on this GPU -- table by table
+        tr = [t if hasattr(t, "data_ptr") else np.ascontiguousarray(t, dtype=np.uint64) for t in traces]
+        for t in tr:
+            if hasattr(t, "data_ptr") and not (t.is_contiguous() and t.element_size() == 8):
+                raise ValueError("device-resident tables must be contiguous 64-bit tensors")
+        ptrs = (U64P * len(tr))(*[C.cast(C.c_void_p(t.data_ptr()), U64P) if hasattr(t, "data_ptr") else _p(t) for t in tr])
         logs = (C.c_uint32 * len(tr))(*[int(t.shape[1]).bit_length() - 1 for t in tr])
         pr = None if params is None else np.ascontiguousarray(params, dtype=np.uint64)
         cc = None if compress is None else np.ascontiguousarray(compress, dtype=np.uint64)

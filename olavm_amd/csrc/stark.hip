@@ -955,8 +955,8 @@ void phase_quotient_host(DeviceCtx* ctx, NttTables& tables, const OlaGpuConfig& 
     prove_single_table(ctx, tables, cfg, air, tv, trace_c, cap, jobs[table], params ? params : zero_params.data(), ch, bytes, false, &tap);
 }
 
-// Host -> device transfer of the trace tables on a helper thread and a dedicated stream, in groups of columns of about
-// 64 MB; wait(t, c) blocks until columns [0, c) of table t are on the device.
+// Transfer of the trace tables (host memory, or device memory of the same GPU) into the prover's buffers on a helper thread and a
+// dedicated stream, in groups of columns of about 64 MB; wait(t, c) blocks until columns [0, c) of table t are on the device.
 class TraceUploader {
   public:
     TraceUploader(DeviceCtx* ctx, size_t ntables) : ctx_(ctx), jobs_(ntables), done_(ntables) {
@@ -991,8 +991,10 @@ class TraceUploader {
             const Job& j = jobs_[t];
             for (uint32_t c0 = 0; c0 < j.ncols && !cancel_.load(); c0 += j.chunk) {
                 const uint32_t c1 = std::min(j.ncols, c0 + j.chunk);
+                // hipMemcpyDefault: a table may already be resident in HBM (generated there, or kept from an earlier step) -- the
+                // copy is then device to device (the prover canonicalises and works in its own buffer)
                 hipError_t e = hipMemcpyAsync(j.dst + (size_t)c0 * j.n, j.src + (size_t)c0 * j.n, (size_t)(c1 - c0) * j.n * 8,
-                                              hipMemcpyHostToDevice, stream_);
+                                              hipMemcpyDefault, stream_);
                 if (e == hipSuccess) e = hipStreamSynchronize(stream_);
                 std::lock_guard<std::mutex> lk(mu_);
                 if (e != hipSuccess) { failed_ = true; error_ = hipGetErrorString(e); cv_.notify_all(); return; }

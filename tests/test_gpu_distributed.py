@@ -60,7 +60,7 @@ def test_two_ranks_one_gpu_sharded_commit():
     assert (rng0, rng1) == ((0, 4), (4, 8)) and rb0 == rb1 == 2
 
 
-def _prove_worker(rank, world, port, q, log_n=12, real=False):
+def _prove_worker(rank, world, port, q, log_n=12, real=False, hasher="poseidon"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     import torch.distributed as dist
@@ -78,7 +78,7 @@ def _prove_worker(rank, world, port, q, log_n=12, real=False):
         # 2^12-row (or 2^15-row: the large-transform kernels) tables: CPU, memory and Poseidon run on the coset partition,
         # the small / low-degree ones replicated
         traces, params, compress = tracegen.empty_program_instance(log_n=log_n, live=np.random.default_rng(12))
-    be = Backend(device=0)
+    be = Backend(device=0, hasher=hasher)
     be.set_shard(rank, world)
     sharded = be.prove_with_traces(blob, traces, params, compress)
     calls = be.shard_calls
@@ -93,8 +93,9 @@ def _prove_worker(rank, world, port, q, log_n=12, real=False):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,log_n", [(2, 12), (4, 12), (8, 12), (2, 15)])
-def test_coset_partitioned_proof_equals_the_single_gpu_proof(world, log_n, oracle):
+@pytest.mark.parametrize("world,log_n,hasher", [(2, 12, "poseidon"), (4, 12, "poseidon"), (8, 12, "poseidon"), (2, 15, "poseidon"),
+                                                 (2, 12, "blake3"), (4, 12, "blake3")])
+def test_coset_partitioned_proof_equals_the_single_gpu_proof(world, log_n, hasher, oracle):
     """SURVEY 8e end to end: `world` ranks (sharing the one test GPU, gloo for the exchanges) each prove with their share
     of the cosets; every rank's AllProof bytes equal the single-GPU proof, which the oracle verifier accepts."""
     import torch.multiprocessing as mp
@@ -102,7 +103,7 @@ def test_coset_partitioned_proof_equals_the_single_gpu_proof(world, log_n, oracl
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_prove_worker, args=(r, world, port, q, log_n)) for r in range(world)]
+    procs = [ctx.Process(target=_prove_worker, args=(r, world, port, q, log_n, False, hasher)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted(q.get(timeout=600) for _ in range(world))
@@ -117,7 +118,8 @@ def test_coset_partitioned_proof_equals_the_single_gpu_proof(world, log_n, oracl
         # slices, 2 quotient planes, 3 of opened rows
         assert calls > 0 and calls % 9 == 0, calls
     blob = T.ola_stark(range_bits=4, limb_bits=2).blob()
-    rc, why = oracle.verify_all_proof(blob, single, res[0][4])
+    with oracle.hasher(hasher):          # either of the reference's hash configurations (plonk/config.rs:112-161)
+        rc, why = oracle.verify_all_proof(blob, single, res[0][4])
     assert rc == 0, why
 
 

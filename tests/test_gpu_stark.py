@@ -416,3 +416,20 @@ def test_phase_entry_points_reassemble_prove_single_table(be, oracle):
         be.quotient(blob, 0, bb, zb, None, ctl, [5, 7], [], bad.shape[1])
     for b in batches + [bb, zb]:
         b.free()
+
+
+def test_device_resident_tables_give_the_same_proof(be, oracle):
+    """ola_prove_with_traces looks at each table pointer: tables already in HBM (here: all of them, then a mix) are copied
+    device to device instead of uploaded; the proof is the one the host tables give."""
+    import torch
+    from olavm_amd.air import miniexec as M
+    blob = T.ola_stark(range_bits=4, limb_bits=2).blob()
+    traces, params, compress = M.instance(M.mixed_program())
+    want = be.prove_with_traces(blob, traces, params, compress)
+    dev = [torch.from_numpy(np.ascontiguousarray(t).view(np.int64)).cuda() for t in traces]
+    torch.cuda.synchronize()
+    assert be.prove_with_traces(blob, dev, params, compress) == want
+    mixed = [d if i % 2 == 0 else t for i, (d, t) in enumerate(zip(dev, traces))]
+    assert be.prove_with_traces(blob, mixed, params, compress) == want
+    for d, t in zip(dev, traces):           # the caller's tables are not modified
+        assert np.array_equal(d.cpu().numpy().view(np.uint64), t)
