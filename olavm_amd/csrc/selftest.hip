@@ -45,8 +45,9 @@ u64 field_selftest(DeviceCtx* ctx, u64 pairs) {
                           0xFFFFFFFF00000000ull, 0xFFFFFFFEFFFFFFFFull, 0x8000000000000000ull, 0x7FFFFFFFFFFFFFFFull, 0xFFFFFFFF00000002ull,
                           0x00000001FFFFFFFFull, 0xFFFFFFFE00000001ull, 0xFFFFFFFE00000000ull};
     for (int s = 1; s < 64; s++) { e.push_back(1ull << s); e.push_back((1ull << s) - 1); e.push_back(~0ull << s); }
-    u64* d_e = (u64*)ctx->alloc(e.size() * 8);
-    unsigned long long* d_bad = (unsigned long long*)ctx->alloc(8);
+    DevBuf mem(ctx);                              // released on every path, errors included
+    u64* d_e = mem.alloc(e.size());
+    unsigned long long* d_bad = (unsigned long long*)mem.alloc_bytes(8);
     unsigned long long bad = 0;
     HIP_CHECK(hipMemcpyAsync(d_e, e.data(), e.size() * 8, hipMemcpyHostToDevice, ctx->stream));
     HIP_CHECK(hipMemsetAsync(d_bad, 0, 8, ctx->stream));
@@ -54,8 +55,6 @@ u64 field_selftest(DeviceCtx* ctx, u64 pairs) {
     hipLaunchKernelGGL(field_selftest_kernel, dim3(blocks), dim3(256), 0, ctx->stream, d_e, (int)e.size(), (pairs + blocks * 256 - 1) / (blocks * 256), d_bad);
     HIP_CHECK(hipMemcpyAsync(&bad, d_bad, 8, hipMemcpyDeviceToHost, ctx->stream));
     HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    ctx->free(d_e);
-    ctx->free(d_bad);
     return bad;
 }
 
