@@ -116,6 +116,22 @@ def test_product_host_code_matches_the_oracle(oracle):
     assert L.ola_challenger_init_hasher(C.byref(p.c), bad) != 0
 
 
+@pytest.mark.skipif(not os.path.exists(LLVM_LIB), reason="LLVM's BLAKE3 is not on this machine")
+def test_product_host_code_matches_llvm_blake3_directly():
+    """The product's BLAKE3 (host instantiation of the header the kernels are compiled from) against the official C implementation
+    itself, without the oracle in between: every leaf width 1..300 and a sample of wider ones, canonical little-endian words."""
+    from olavm_amd.backend import _p, load_library
+    from tests.golden.make_blake3_vectors import hasher
+    L = load_library()
+    h, _ = hasher()
+    rng = np.random.default_rng(11)
+    out = np.empty(4, dtype=np.uint64)
+    for n in list(range(1, 301)) + [383, 384, 385, 511, 512, 513, 1023, 1024, 1025, 2047, 2048, 2049, 4095, 4096]:
+        x = rng.integers(0, P, n, dtype=np.uint64)           # canonical already: the bytes hashed are the array's bytes
+        assert L.ola_blake3_hash_elements(_p(x), n, _p(out)) == 0
+        assert out.tobytes() == h(x.tobytes()), n
+
+
 def test_oracle_proves_and_verifies_under_the_blake3_configuration(oracle):
     """prove_with_traces::<F, Blake3GoldilocksConfig, 2> -> verify (the configuration of the reference's own full-prove tests,
     circuits/src/stark/ola_stark.rs:684): same proof length as under Poseidon, different bytes, and neither verifier accepts
