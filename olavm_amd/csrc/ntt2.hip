@@ -21,7 +21,7 @@ namespace ola {
 
 enum { N2_STRIDED = 0, N2_BITREV_LAST = 1, N2_NATURAL_LAST = 2 };
 #ifndef NTT2_STRIDED_COLS
-#define NTT2_STRIDED_COLS 4   // columns per workgroup of a strided pass (see ntt2_pass_kernel)
+#define NTT2_STRIDED_COLS 8   // columns per workgroup of a strided pass (see ntt2_pass_kernel): 8 against 4 is +1.4 % on the NTT, +3 % on the LDE
 #endif
 
 struct Ntt2Params {

@@ -39,7 +39,8 @@ def main():
     n, cols = 1 << 22, 94
     elems = n * cols
     # the 2^22 natural-order transform is two strided 7-bit passes and the closing natural-order 8-bit pass
-    names = ("ntt2_pass_kernel<7, 0, false, 4, false>", "ntt2_pass_kernel_w4<7, 0, false, 4>", "ntt2_pass_kernel<8, 2, false, 1, false>")
+    names = ("ntt2_pass_kernel<7, 0, false, 4, false>", "ntt2_pass_kernel_w4<7, 0, false, 4>", "ntt2_pass_kernel<7, 0, false, 8, false>",
+             "ntt2_pass_kernel_w4<7, 0, false, 8>", "ntt2_pass_kernel<8, 2, false, 1, false>")
     passes = {k: v for k, v in kernels.items() if any(nm in k for nm in names) and "WRITE_SIZE" in v}
     launches = sum(v["WRITE_SIZE"]["dispatches"] for v in passes.values())
     fetch = sum(v["FETCH_SIZE"]["per_dispatch"] * v["FETCH_SIZE"]["dispatches"] for v in passes.values() if "FETCH_SIZE" in v)
