@@ -71,7 +71,7 @@ def main():
     from tests import oracle_lib
     o = oracle_lib.load()
     blob = T.ola_stark().blob()
-    be = None
+    be = be3 = None
     if use_gpu:
         from olavm_amd.backend import Backend
         be = Backend(device=0)
@@ -94,6 +94,20 @@ def main():
             all_ok &= compare(name, got, want, "GPU prover vs reference")
             rc, why = o.verify_all_proof(blob, got, params)
             all_ok &= rc == 0
+        # the same traces under Blake3GoldilocksConfig (<name>.blake3.proof, written by pin_dump.rs next to the Poseidon proof)
+        b3 = os.path.join(d, name + ".blake3.proof")
+        if os.path.exists(b3):
+            want3 = open(b3, "rb").read()
+            with o.hasher("blake3"):
+                rc, why = o.verify_all_proof(blob, want3, params)
+                print(f"  {name}: oracle verifier (Blake3 configuration) on the reference's proof: {'accepts' if rc == 0 else 'REJECTS: ' + str(why)}")
+                all_ok &= rc == 0
+                if max(t.shape[1] for t in traces) <= (1 << 14):
+                    all_ok &= compare(name, o.prove_with_traces(blob, traces, params, compress), want3, "oracle prover vs reference, Blake3")
+            if use_gpu:
+                if be3 is None:
+                    be3 = Backend(device=0, hasher="blake3")
+                all_ok &= compare(name, be3.prove_with_traces(blob, traces, params, compress), want3, "GPU prover vs reference, Blake3")
     print("ALL OK" if all_ok else "DIFFERENCES FOUND")
     return 0 if all_ok else 1
 

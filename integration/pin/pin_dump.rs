@@ -23,7 +23,7 @@ use executor::{Process, TxScopeCacheManager};
 use core::types::storage::{StorageLog, WitnessStorageLog};
 use plonky2::field::polynomial::PolynomialValues;
 use plonky2::field::types::PrimeField64;
-use plonky2::plonk::config::{GenericConfig, PoseidonGoldilocksConfig};
+use plonky2::plonk::config::{Blake3GoldilocksConfig, GenericConfig, PoseidonGoldilocksConfig};
 use plonky2::util::timing::TimingTree;
 
 use crate::generation::{generate_traces, GenerationInputs};
@@ -35,6 +35,7 @@ use crate::stark::verifier::verify_proof;
 
 const D: usize = 2;
 type C = PoseidonGoldilocksConfig;
+type CB = Blake3GoldilocksConfig; // the configuration of the reference's own tests and benches (ola_stark.rs:684, fibo_loop.rs:26)
 type F = <C as GenericConfig<D>>::F;
 
 fn write_traces(path: &PathBuf, traces: &[Vec<PolynomialValues<F>>; NUM_TABLES], compress: &[F]) {
@@ -115,6 +116,8 @@ fn dump_one(file_name: &str, call_data: Option<Vec<GoldilocksField>>) {
     let config = StarkConfig::standard_fast_config();
     // the traces as the prover receives them; the compress challenges are read back from the proof below
     let traces_copy: [Vec<PolynomialValues<F>>; NUM_TABLES] = traces.clone();
+    let proof_b3 = prove_with_traces::<F, CB, D>(&ola_stark, &config, traces.clone(), public_values.clone(), &mut TimingTree::default())
+        .expect("prove (Blake3GoldilocksConfig)");
     let proof = prove_with_traces::<F, C, D>(&ola_stark, &config, traces, public_values, &mut TimingTree::default()).expect("prove");
 
     let stem = file_name.trim_end_matches(".json");
@@ -122,6 +125,13 @@ fn dump_one(file_name: &str, call_data: Option<Vec<GoldilocksField>>) {
     let mut buf = Buffer::new(Vec::new());
     buf.write_all_proof(&proof).unwrap();
     File::create(out_dir.join(format!("{stem}.proof"))).unwrap().write_all(&buf.bytes()).unwrap();
+    // The same traces under Blake3GoldilocksConfig -> <name>.blake3.proof.  The GPU backend hashes CANONICAL words, the CPU prover
+    // the words as they lie in memory (hash/blake3.rs:204-207); at these sizes (< 10^7 hashed words, a non-canonical word every
+    // ~2^32 field operations) the two agree, and the reference verifier -- which hashes deserialised, canonical words -- says so.
+    let mut buf_b3 = Buffer::new(Vec::new());
+    buf_b3.write_all_proof(&proof_b3).unwrap();
+    File::create(out_dir.join(format!("{stem}.blake3.proof"))).unwrap().write_all(&buf_b3.bytes()).unwrap();
+    verify_proof(OlaStark::default(), proof_b3, &config).expect("the reference verifier must accept its own Blake3 proof");
     let degree_bits = proof.degree_bits(&config);
     verify_proof(OlaStark::default(), proof, &config).expect("the reference verifier must accept its own proof");
     println!("pin_dump: {stem}: table heights 2^{:?}, {} proof bytes", degree_bits, buf.len());
