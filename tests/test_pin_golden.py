@@ -55,6 +55,12 @@ def test_oracle_prover_reproduces_the_rust_proof(oracle, name):
     blob, params = T.ola_stark().blob(), [compress[2], compress[10]]
     assert oracle.verify_all_proof(blob, want, params)[0] == 0
     assert m.compare(name, oracle.prove_with_traces(blob, traces, params, compress), want, "oracle vs reference")
+    b3 = os.path.join(PIN, name + ".blake3.proof")            # the same traces under Blake3GoldilocksConfig, when dumped
+    if os.path.exists(b3):
+        want3 = open(b3, "rb").read()
+        with oracle.hasher("blake3"):
+            assert oracle.verify_all_proof(blob, want3, params)[0] == 0
+            assert m.compare(name, oracle.prove_with_traces(blob, traces, params, compress), want3, "oracle vs reference, Blake3")
 
 
 @pytest.mark.gpu
@@ -72,3 +78,10 @@ def test_gpu_prover_reproduces_the_rust_proof(oracle, name):
         assert m.compare(name, be.prove_with_traces(blob, traces, params, compress), want, "GPU vs reference")
     finally:
         be.close()
+    b3 = os.path.join(PIN, name + ".blake3.proof")
+    if os.path.exists(b3):
+        be = Backend(device=0, hasher="blake3")
+        try:
+            assert m.compare(name, be.prove_with_traces(blob, traces, params, compress), open(b3, "rb").read(), "GPU vs reference, Blake3")
+        finally:
+            be.close()
