@@ -15,11 +15,13 @@
 
 #include "device_ctx.h"
 #include "gl.cuh"
-#include "ntt3.h"
 
 namespace ola {
 
 enum { N2_STRIDED = 0, N2_BITREV_LAST = 1, N2_NATURAL_LAST = 2 };
+#ifndef NTT2_DEFAULT_GROUP_MB
+#define NTT2_DEFAULT_GROUP_MB 0   // Infinity-Cache blocking of ntt2_run (see there); the environment overrides it
+#endif
 #ifndef NTT2_STRIDED_COLS
 #define NTT2_STRIDED_COLS 8   // columns per workgroup of a strided pass (see ntt2_pass_kernel): 8 against 4 is +1.4 % on the NTT, +3 % on the LDE
 #endif
@@ -345,145 +347,12 @@ static const u64* get_coset_steps(NttTables& t, int log_n, int rate_bits, int e,
     return upload(t.ctx, v);  // small; lives in the persistent pool
 }
 
-// ------------------------------------------------------------------------------------------------ third generation
-// Transforms of 2^18 points and more run on the T-form passes of ntt3.hip (ntt3_core.cuh): two launches for a bit-reversed-
-// order result up to 2^22 (strided pass of L-13 bits + contiguous pass of 13), three for natural order.  This part owns the
-// plan and the tables; the kernels are behind ntt3_launch.
-static const int NTT3_MIN_LOG = 18;
-
-// pass-multiplier table of a strided pass, laid out like the data (ntt3_core.cuh N3Params::ptw)
-__global__ __launch_bounds__(256) void ntt3_ptw_kernel(u64* __restrict__ out, int lo, int R, const u64* __restrict__ tw_lo,
-                                                       const u64* __restrict__ tw_hi, int tw_h, u64 scale, const u64* __restrict__ sc_lo,
-                                                       const u64* __restrict__ sc_hi, int sc_h, size_t sc_coset_stride) {
-    const size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t coset = blockIdx.y;
-    const u64 M = o & (((u64)1 << lo) - 1);
-    const u64 q = bitrev32((u32)(o >> lo), R);
-    u64 w = gl_mul(two_level(tw_lo, tw_hi, tw_h, M * q), scale);
-    if (sc_lo) w = gl_mul(w, two_level(sc_lo + coset * sc_coset_stride, sc_hi + coset * sc_coset_stride, sc_h, M));
-    out[(coset << (lo + R)) + o] = w;
-}
-
-struct Ntt3Tables {
-    std::map<std::tuple<int, int, int, int, int, int>, const u64*> ptw;   // (L, lo, R, inverse, scaled, rate_bits) -> table
-    std::map<std::tuple<int, int, int>, const u64*> dig;                  // (L, rate_bits, R) -> s_c^(d * 2^(L-R))
-};
-static std::map<NttTables*, Ntt3Tables>& ntt3_tables() {
-    static std::map<NttTables*, Ntt3Tables> m;   // device tables die with their context (persistent pool)
-    return m;
-}
-
-static const u64* ntt3_get_ptw(NttTables& t, int L, int lo, int R, bool inverse, bool scaled, int rate_bits) {
-    Ntt3Tables& n3 = ntt3_tables()[&t];
-    const auto key = std::make_tuple(L, lo, R, (int)inverse, (int)scaled, rate_bits);
-    auto it = n3.ptw.find(key);
-    if (it != n3.ptw.end()) return it->second;
-    const size_t cosets = rate_bits >= 0 ? ((size_t)1 << rate_bits) : 1, blk = (size_t)1 << (lo + R);
-    u64* d = (u64*)t.ctx->alloc_persistent(cosets * blk * 8);
-    TwoLevel tw = get_two(t, lo + R, inverse);
-    TwoLevel sc;
-    size_t stride = 0;
-    if (rate_bits >= 0) sc = get_coset(t, L, rate_bits, &stride);
-    const u64 scale = scaled ? gl_inv(((u64)1 << L) % GL_P) : 1;
-    hipLaunchKernelGGL(ntt3_ptw_kernel, dim3((unsigned)(blk / 256), (unsigned)cosets), dim3(256), 0, t.ctx->stream, d, lo, R, tw.lo, tw.hi,
-                       tw.h, scale, sc.lo, sc.hi, sc.h, stride);
-    return n3.ptw[key] = d;
-}
-
-static const u64* ntt3_get_dig(NttTables& t, int L, int rate_bits, int R) {
-    Ntt3Tables& n3 = ntt3_tables()[&t];
-    const auto key = std::make_tuple(L, rate_bits, R);
-    auto it = n3.dig.find(key);
-    if (it != n3.dig.end()) return it->second;
-    std::vector<u64> v;
-    const u64 g = gl_root_of_unity(L + rate_bits);
-    for (int c = 0; c < (1 << rate_bits); c++) {
-        const u64 s = gl_mul(gl_pow(g, bitrev32((u32)c, rate_bits)), GL_GENERATOR);
-        const std::vector<u64> pw = powers(gl_pow(s, (u64)1 << (L - R)), (size_t)1 << R);
-        v.insert(v.end(), pw.begin(), pw.end());
-    }
-    return n3.dig[key] = upload(t.ctx, v);
-}
-
-// widths of the strided passes for `sb` bits (each 5..9): as few passes as possible, then as few register rounds as possible
-static std::vector<int> ntt3_strided_plan(int sb) {
-    const int np = (sb + 8) / 9;
-    if (np == 1) return {sb};
-    if (np == 2) {
-        int best_a = -1, best_cost = 1 << 30;
-        for (int a = 9; a >= 5; a--) {   // the wider pass first: the second pass then has the smaller multiplier table
-            const int b = sb - a;
-            if (b < 5 || b > 9 || b > a) continue;
-            const int cost = (a + 4) / 5 + (b + 4) / 5;
-            if (cost < best_cost) { best_cost = cost; best_a = a; }
-        }
-        return {best_a, sb - best_a};
-    }
-    return split_even(sb, np);
-}
-
-// Off unless OLA_NTT3=1 (read at every call, so that tests can switch): on this chip the T-form passes come out level with the
-// second-generation ones (DESIGN.md "NTT: what the third generation measured"), and their multiplier tables cost memory.
-static bool ntt3_enabled() {
-    const char* e = getenv("OLA_NTT3");
-    return e && *e == '1';
-}
-
-// Same contract as ntt2_run below, for L >= 18 and the coset family of the LDE (sc_rate_bits >= 0) or no pre-scale (-2).
-static void ntt3_run(NttTables& t, const u64* in, size_t in_col_stride, u64* out, size_t out_col_stride, u64* scratch,
-                     size_t scratch_col_stride, int L, size_t cols, bool inverse, bool natural_out, int sc_rate_bits, size_t cosets,
-                     size_t out_coset_stride, size_t coset_first) {
-    hipStream_t stream = t.ctx->stream;
-    const int last_R = natural_out ? 9 : 13;
-    const std::vector<int> Rs = ntt3_strided_plan(L - last_R);
-    u64* work = natural_out ? scratch : out;
-    const size_t work_col_stride = natural_out ? scratch_col_stride : out_col_stride;
-    const size_t work_coset_stride = natural_out ? 0 : out_coset_stride;
-    if (natural_out && cosets > 1) throw OlaError(-7, "ntt3: natural-order output is produced one coset at a time");
-    const u64* cur_in = in;
-    size_t cur_in_stride = in_col_stride, cur_in_coset = 0;
-    int lo = L;
-    for (size_t i = 0; i < Rs.size(); i++) {
-        const int R = Rs[i];
-        lo -= R;
-        N3Params p = {};
-        p.log_n = L; p.lo = lo;
-        p.in = cur_in; p.in_col_stride = cur_in_stride; p.in_coset_stride = cur_in_coset;
-        p.out = work; p.out_col_stride = work_col_stride; p.out_coset_stride = work_coset_stride;
-        p.tw = get_full_small(t, R, inverse);
-        const bool first = (i == 0), last_strided = (i + 1 == Rs.size());
-        const int rb = (first && sc_rate_bits >= 0) ? sc_rate_bits : -2;
-        p.ptw = ntt3_get_ptw(t, L, lo, R, inverse, inverse && last_strided, rb);
-        p.ptw_coset_stride = (size_t)1 << (lo + R);
-        if (rb >= 0) {
-            p.ptw += coset_first * p.ptw_coset_stride;
-            p.sc_dig = ntt3_get_dig(t, L, rb, R) + (coset_first << R);
-        } else {
-            p.ptw_coset_stride = 0;
-        }
-        ntt3_launch(p, R, N3_STRIDED, inverse, cols, cosets, stream);
-        cur_in = work; cur_in_stride = work_col_stride; cur_in_coset = work_coset_stride;
-    }
-    N3Params p = {};
-    p.log_n = L; p.lo = 0;
-    p.in = cur_in; p.in_col_stride = cur_in_stride; p.in_coset_stride = cur_in_coset;
-    p.out = out; p.out_col_stride = out_col_stride; p.out_coset_stride = out_coset_stride;
-    p.tw = get_full_small(t, last_R, inverse);
-    ntt3_launch(p, last_R, natural_out ? N3_LAST_NATURAL : N3_LAST_BITREV, inverse, cols, cosets, stream);
-}
-
 // Same contract as ntt_run (ntt.hip) for L >= 14.  prescale: rate_bits >= 0 selects the LDE coset family
 // (7*g^bitrev(c)) of which cosets [coset_first, coset_first + cosets) are produced, rate_bits = -1 with `shift` a single
 // coset, -2 none.
-void ntt2_run(NttTables& t, const u64* in, size_t in_col_stride, u64* out, size_t out_col_stride, u64* scratch,
-              size_t scratch_col_stride, int L, size_t cols, bool inverse, bool natural_out, int sc_rate_bits, u64 sc_shift,
-              size_t cosets, size_t out_coset_stride, size_t coset_first) {
-    if (cols == 0) return;
-    if (L >= NTT3_MIN_LOG && sc_rate_bits != -1 && ntt3_enabled()) {
-        ntt3_run(t, in, in_col_stride, out, out_col_stride, scratch, scratch_col_stride, L, cols, inverse, natural_out, sc_rate_bits, cosets,
-                 out_coset_stride, coset_first);
-        return;
-    }
+static void ntt2_run_group(NttTables& t, const u64* in, size_t in_col_stride, u64* out, size_t out_col_stride, u64* scratch,
+                           size_t scratch_col_stride, int L, size_t cols, bool inverse, bool natural_out, int sc_rate_bits, u64 sc_shift,
+                           size_t cosets, size_t out_coset_stride, size_t coset_first) {
     hipStream_t stream = t.ctx->stream;
     const int P = (L + 7) / 8;
     std::vector<int> Rs = split_even(L, P);          // largest first ...
@@ -533,4 +402,41 @@ void ntt2_run(NttTables& t, const u64* in, size_t in_col_stride, u64* out, size_
     }
 }
 
+// Column-group blocking for the Infinity Cache (256 MiB, memory side): a transform of P passes launched over the whole batch
+// streams the batch through HBM P times (3.15 GB per pass at 94 x 2^22 -- nothing survives on-die between launches).  Run
+// group by group instead -- all P passes over `gc` columns (and `gk` cosets of an LDE) back to back -- and the intermediate of
+// pass i is still in the cache when pass i + 1 reads it, as long as a group's working set (gc * gk * 8n bytes, twice that for
+// an out-of-place natural-order transform) stays well under the cache size.  OLA_NTT2_GROUP_MB sets the working-set target
+// (0 = one group: the whole batch per launch); columns per group are a multiple of the strided kernel's columns per workgroup.
+static size_t ntt2_group_bytes() {
+    const char* e = getenv("OLA_NTT2_GROUP_MB");
+    return e ? (size_t)atol(e) << 20 : (size_t)NTT2_DEFAULT_GROUP_MB << 20;
+}
+
+void ntt2_run(NttTables& t, const u64* in, size_t in_col_stride, u64* out, size_t out_col_stride, u64* scratch,
+              size_t scratch_col_stride, int L, size_t cols, bool inverse, bool natural_out, int sc_rate_bits, u64 sc_shift,
+              size_t cosets, size_t out_coset_stride, size_t coset_first) {
+    if (cols == 0) return;
+    const size_t budget = ntt2_group_bytes(), col_bytes = ((size_t)8 << L) * (natural_out ? 2 : 1);
+    size_t gc = cols, gk = cosets;
+    if (budget && L >= 18 && col_bytes * cols * cosets > budget) {
+        // whole cosets first (a coset of a column group is an independent transform), then columns in units of the
+        // workgroup's column block
+        const size_t unit = NTT2_STRIDED_COLS;
+        gk = 1;
+        gc = std::max<size_t>(unit, budget / col_bytes / unit * unit);
+        if (gc >= cols) { gc = cols; gk = std::max<size_t>(1, std::min(cosets, budget / (col_bytes * cols))); }
+    }
+    for (size_t c0 = 0; c0 < cols; c0 += gc) {
+        const size_t nc = std::min(gc, cols - c0);
+        for (size_t k0 = 0; k0 < cosets; k0 += gk) {
+            const size_t nk = std::min(gk, cosets - k0);
+            ntt2_run_group(t, in + c0 * in_col_stride, in_col_stride, out + c0 * out_col_stride + k0 * out_coset_stride, out_col_stride,
+                           scratch ? scratch + c0 * scratch_col_stride : nullptr, scratch_col_stride, L, nc, inverse, natural_out,
+                           sc_rate_bits, sc_shift, nk, out_coset_stride, coset_first + k0);
+        }
+    }
+}
+
 }  // namespace ola
+

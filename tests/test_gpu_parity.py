@@ -299,14 +299,12 @@ def test_shard_batches_are_refused_where_a_full_commitment_is_needed(be):
         be.commit_shard(vals, 0, 3)
 
 
-# ---------------------------------------------------------------- third-generation passes (2^18 and up, ntt3.hip)
-@pytest.mark.parametrize("log_n", [18, 19, 20, 21])
-def test_ntt3_sizes_match_oracle(be, oracle, log_n, monkeypatch):
-    """The third-generation (T-form) passes, switched on with OLA_NTT3=1.  Every pass shape the planner uses between 2^18 and 2^21 (strided widths 5..9, contiguous and natural-order closing
-    passes), full compare with the oracle: evaluate / interpolate in natural order, the x8 coset LDE in leaf order
-    (cosets 0, 3 and 7 compared), and non-canonical input words."""
+# ---------------------------------------------------------------- three-pass sizes (2^19 and up) against the oracle
+@pytest.mark.parametrize("log_n", [19, 20, 21])
+def test_ntt_three_pass_sizes_match_oracle(be, oracle, log_n):
+    """Every pass split the planner uses between 2^19 and 2^21 (three launches), full compare with the oracle: evaluate /
+    interpolate in natural order, the x8 coset LDE in leaf order (cosets 0, 3 and 7 compared), and non-canonical input words."""
     from olavm_amd.backend import OLA_NTT_COSET_LDE_LEAF_ORDER, OLA_NTT_EVALUATE, OLA_NTT_INTERPOLATE
-    monkeypatch.setenv("OLA_NTT3", "1")
     rng = np.random.default_rng(3000 + log_n)
     n = 1 << log_n
     c = rand_field(rng, (3, n))
