@@ -66,6 +66,17 @@ typedef struct OlaGpuConfig {
 
 /* ---- lifetime (replaces gpu_init / gpu_free, cfft/ntt/mod.rs:89-121 and core/src/storage/db.rs:248) ---- */
 int32_t ola_gpu_init(const OlaGpuConfig* cfg, OlaCtx** out_ctx);
+/* One context that spans n_devices GPUs of the node (1, 2, 4 or 8; devices = HIP ordinals, NULL = 0..n-1): the caller stays the
+ * single process the reference's prover is (client/src/main.rs:174-214, one `prove` per process; the reference's own GPU state is
+ * process-wide, cfft/ntt/mod.rs:14-17,48-50) and calls ola_prove_with_traces ONCE; inside, rank r is a worker thread on
+ * devices[r] with its own stream and buffer pool, the proof runs on the coset partition described under ola_set_shard below, and
+ * the exchanges are the library's own all-gather over xGMI (peer-to-peer pulls ordered by events on the ranks' streams, no host
+ * synchronisation; olavm_amd/csrc/peer_group.h).  Every other entry point of such a context works on devices[0] as on a
+ * single-device context.  Entries of devices[] may repeat (logical ranks sharing a GPU: how the one-GPU test box exercises the
+ * path).  cfg->device is ignored, cfg->stream must be NULL when n_devices > 1.  Needs peer access between the devices
+ * (OLA_E_HIP otherwise). */
+int32_t ola_gpu_init_multi(const OlaGpuConfig* cfg, const int32_t* devices, uint32_t n_devices, OlaCtx** out_ctx);
+int32_t ola_gpu_device_count(OlaCtx* ctx, uint32_t* n_devices);
 int32_t ola_gpu_free(OlaCtx* ctx);
 const char* ola_gpu_last_error(void);
 int32_t ola_gpu_sync(OlaCtx* ctx);
@@ -75,6 +86,18 @@ int32_t ola_gpu_trim(OlaCtx* ctx);
 /* Device memory of the context's buffer pool, in bytes: out[0] handed out now, out[1] the most ever handed out at once,
  * out[2] handed out + cached now, out[3] the most ever held (the high-water mark of a proof; reset = 1 restarts the marks). */
 int32_t ola_gpu_memory_stats(OlaCtx* ctx, uint64_t out[4], int32_t reset);
+/* Where the device time of a proof goes with respect to the coset partition.  enable: 1 / 0 switches the accounting on / off for
+ * the proofs that follow (a few hundred event records per proof, no synchronisation), -1 leaves it as it is.  out (may be NULL)
+ * describes the LAST ola_prove_with_traces of this context:
+ *   out[0]  wall-clock milliseconds of the call
+ *   out[1..3]  milliseconds of kernel time in work that the partition divides among the ranks, by the largest world that still
+ *           divides it: [1] at most 2 ranks, [2] at most 4, [3] 8 (commitment LDEs, leaf hashing, Merkle sub-trees, quotient
+ *           evaluation on 2^qdb cosets, opening evaluations, the first FRI layer).  On a multi-rank run this is rank 0's SHARE.
+ *   out[4], out[5]  bytes gathered by the partition's exchanges (all ranks' payload together; a rank receives (G-1)/G of it)
+ *           and their number -- counted on a single-GPU run as well, which is what makes a projection from one GPU possible:
+ *           T(G) ~ out[0] - sum_k out[k] * (1 - 1/min(G, 2^k)) + out[4] * (G-1)/G / (xGMI rate) + out[5] * latency
+ *   out[6], out[7]  multi-device context only: exchanges performed by the library's own all-gather and the bytes they moved. */
+int32_t ola_gpu_proof_stats(OlaCtx* ctx, int32_t enable, double out[8]);
 /* Self-test of the device field arithmetic: the kernels' modular reduction is written with explicit carry chains in inline
  * assembly (olavm_amd/csrc/gl.cuh); this compares it with the plain C++ reduction on a table of edge values and on `pairs`
  * pseudo-random operand pairs and returns the number of disagreements (0 expected; about 10^9 pairs per 50 ms).  Meant to be

@@ -61,6 +61,9 @@ def load_library():
     L = C.CDLL(p)
     L.ola_gpu_last_error.restype = C.c_char_p
     L.ola_gpu_init.argtypes = [C.POINTER(OlaGpuConfig), C.POINTER(C.c_void_p)]
+    L.ola_gpu_init_multi.argtypes = [C.POINTER(OlaGpuConfig), C.POINTER(C.c_int32), C.c_uint32, C.POINTER(C.c_void_p)]
+    L.ola_gpu_device_count.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
+    L.ola_gpu_proof_stats.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_double)]
     L.ola_gpu_free.argtypes = [C.c_void_p]
     L.ola_gpu_sync.argtypes = [C.c_void_p]
     L.ola_ntt_batch.argtypes = [C.c_void_p, C.c_int32, U64P, U64P, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32]
@@ -124,6 +127,7 @@ EXPORTS = [
     "ola_air_kernels_available", "ola_commit_values_shard", "ola_commit_values_shard_dev", "ola_set_shard", "ola_gpu_trim", "ola_generate_poseidon_trace",
     "ola_permuted_cols", "ola_permuted_cols_dev", "ola_prove_single_table", "ola_take_pending_proof", "ola_gpu_memory_stats", "ola_gpu_selftest", "ola_gpu_reserve",
     "ola_table_shape", "ola_perm_z", "ola_ctl_z", "ola_quotient", "ola_set_shard_options", "ola_gpu_get_stream",
+    "ola_gpu_init_multi", "ola_gpu_device_count", "ola_gpu_proof_stats",
 ]
 
 
@@ -219,9 +223,11 @@ class Batch:
 
 
 class Backend:
-    """One OlaCtx.  `stream` may be a raw hipStream_t (e.g. torch.cuda.current_stream().cuda_stream)."""
+    """One OlaCtx.  `stream` may be a raw hipStream_t (e.g. torch.cuda.current_stream().cuda_stream).
+    devices=[d0, d1, ...] makes it ONE context spanning those GPUs (ola_gpu_init_multi): prove_with_traces then runs on the
+    coset partition inside the library, one call, one process; entries may repeat (logical ranks sharing a GPU)."""
 
-    def __init__(self, device=-1, stream=None, **cfg):
+    def __init__(self, device=-1, stream=None, devices=None, **cfg):
         self.lib = load_library()
         c = OlaGpuConfig(device, stream, cfg.get("rate_bits", 3), cfg.get("cap_height", 4),
                          cfg.get("proof_of_work_bits", 16), cfg.get("fri_arity_bits", 4),
@@ -231,7 +237,23 @@ class Backend:
         self.cap_height = c.cap_height
         self.rate_bits = c.rate_bits
         self.ctx = C.c_void_p()
-        self._chk(self.lib.ola_gpu_init(C.byref(c), C.byref(self.ctx)))
+        if devices is not None:
+            dv = (C.c_int32 * len(devices))(*[int(d) for d in devices])
+            self._chk(self.lib.ola_gpu_init_multi(C.byref(c), dv, len(devices), C.byref(self.ctx)))
+        else:
+            self._chk(self.lib.ola_gpu_init(C.byref(c), C.byref(self.ctx)))
+
+    def device_count(self):
+        n = C.c_uint32()
+        self._chk(self.lib.ola_gpu_device_count(self.ctx, C.byref(n)))
+        return n.value
+
+    def proof_stats(self, enable=None):
+        """ola_gpu_proof_stats: switch the accounting (True / False / None = leave) and return the last proof's figures."""
+        out = (C.c_double * 8)()
+        self._chk(self.lib.ola_gpu_proof_stats(self.ctx, -1 if enable is None else int(bool(enable)), out))
+        return {"wall_ms": out[0], "sharded_ms_upto2": out[1], "sharded_ms_upto4": out[2], "sharded_ms_upto8": out[3],
+                "exchange_bytes": int(out[4]), "exchanges": int(out[5]), "peer_exchanges": int(out[6]), "peer_bytes_moved": int(out[7])}
 
     def _chk(self, rc):
         if rc != 0:

@@ -186,11 +186,14 @@ OlaBatch* batch_commit(DeviceCtx* ctx, NttTables& t, const uint64_t* const* cols
                 }
                 canonicalize(ctx, b->coeffs, (size_t)ncols * n);
             }
-            for (size_t c = 0; c < ((size_t)1 << rate_bits); c++) {
-                ntt_lde_leaf_order(t, b->coeffs, tmp, log_n, full_rate_bits, ncols, b->coset_first + c, 1);
-                launch_leaf_hash_colmajor(ctx, tmp, n, (int)ncols, n, b->heap + 4 * N + 4 * c * n);
+            {
+                WorkScope ws(ctx, (int)std::min(full_rate_bits, b->cap_height + shard_log_world));
+                for (size_t c = 0; c < ((size_t)1 << rate_bits); c++) {
+                    ntt_lde_leaf_order(t, b->coeffs, tmp, log_n, full_rate_bits, ncols, b->coset_first + c, 1);
+                    launch_leaf_hash_colmajor(ctx, tmp, n, (int)ncols, n, b->heap + 4 * N + 4 * c * n);
+                }
+                launch_merkle_build(ctx, b->heap, N, cap_height);
             }
-            launch_merkle_build(ctx, b->heap, N, cap_height);
             HIP_CHECK(hipStreamSynchronize(ctx->stream));
             ctx->free(tmp);
             if (stage) ctx->free(stage);
@@ -226,6 +229,7 @@ OlaBatch* batch_commit(DeviceCtx* ctx, NttTables& t, const uint64_t* const* cols
                     const uint32_t c1 = std::min(ncols, c0 + feed->chunk_cols);
                     feed->before_chunk(c0, c1);
                     ntt_interpolate(t, vals + (size_t)c0 * n, b->coeffs + (size_t)c0 * n, tmp, log_n, c1 - c0);
+                    WorkScope ws(ctx, (int)std::min(full_rate_bits, b->cap_height + shard_log_world));
                     ntt_lde_leaf_order(t, b->coeffs + (size_t)c0 * n, b->lde + (size_t)c0 * N, log_n, full_rate_bits, c1 - c0, b->coset_first,
                                        (size_t)1 << rate_bits);
                 }
@@ -245,6 +249,7 @@ OlaBatch* batch_commit(DeviceCtx* ctx, NttTables& t, const uint64_t* const* cols
         }
         // (OLA_TIMING scopes carry the reference's `timed!` names, fri/oracle.rs:56-90; "transpose LDEs" has no counterpart:
         // the LDE is produced in leaf order)
+        WorkScope ws(ctx, (int)std::min(full_rate_bits, b->cap_height + shard_log_world));   // from here on the rank's cosets only
         if (!lde_done) { PhaseTimer tp(ctx, "      FFT + blinding"); ntt_lde_leaf_order(t, b->coeffs, b->lde, log_n, full_rate_bits, ncols, b->coset_first, (size_t)1 << rate_bits); }
         {
             PhaseTimer tp(ctx, "      build Merkle tree");

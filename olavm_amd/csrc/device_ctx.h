@@ -51,8 +51,46 @@ struct ShardInfo {
     bool stream_ordered = false;
 };
 
+// Where a proof's device time goes with respect to the coset partition (ola_gpu_proof_stats): the prover brackets every piece
+// of work that the partition DIVIDES among the ranks with a WorkScope; the scopes are timed with events on the context's stream
+// (no synchronisation), and the bracketed time is summed per "largest world that still divides it" (a quotient that lives on
+// 2 cosets stops scaling at 2 GPUs).  Everything outside a scope -- interpolations, Z columns, FRI after the first layer, small
+// tables, launch gaps, host transcript -- is what every rank repeats.  exchange_bytes: the gathered payload of the exchanges a
+// sharded run performs (a rank receives (G-1)/G of it); counted on single-GPU runs too, so that one GPU can project G.
+struct WorkAcct {
+    bool on = false;
+    struct Span { hipEvent_t a, b; int maxlog; };
+    std::vector<Span> spans;
+    std::vector<hipEvent_t> spare;
+    double sharded_ms[4] = {0, 0, 0, 0};   // [k]: work that divides by min(G, 2^k), k = 1..3
+    double wall_ms = 0;
+    uint64_t exchange_bytes = 0;
+    uint32_t exchanges = 0;
+    bool shardable = false;                // the table being proven is large enough for the partition (ShardInfo::min_log_n)
+    hipEvent_t get() {
+        if (!spare.empty()) { hipEvent_t e = spare.back(); spare.pop_back(); return e; }
+        hipEvent_t e = nullptr;
+        if (hipEventCreate(&e) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        return e;
+    }
+    void begin_proof() { for (double& m : sharded_ms) m = 0; wall_ms = 0; exchange_bytes = 0; exchanges = 0; }
+    // after the stream has been synchronised
+    void collect() {
+        for (Span& s : spans) {
+            float ms = 0;
+            if (s.a && s.b && hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) sharded_ms[s.maxlog] += ms;
+            else (void)hipGetLastError();
+            if (s.a) spare.push_back(s.a);
+            if (s.b) spare.push_back(s.b);
+        }
+        spans.clear();
+    }
+    ~WorkAcct() { collect(); for (hipEvent_t e : spare) (void)hipEventDestroy(e); }
+};
+
 struct DeviceCtx {
     ShardInfo shard;
+    WorkAcct acct;
     int device = 0;
     hipStream_t stream = nullptr;
     bool owns_stream = false;
@@ -168,8 +206,34 @@ struct DeviceCtx {
     }
 };
 
+// Brackets work that the coset partition divides among up to 2^maxlog ranks (WorkAcct); active only while accounting is on and
+// the table being proven is on the partition.
+struct WorkScope {
+    DeviceCtx* ctx;
+    hipEvent_t a = nullptr;
+    int maxlog;
+    WorkScope(DeviceCtx* c, int maxlog_) : ctx(c), maxlog(maxlog_ < 1 ? 0 : (maxlog_ > 3 ? 3 : maxlog_)) {
+        if (!ctx->acct.on || !ctx->acct.shardable || maxlog == 0) { maxlog = 0; return; }
+        a = ctx->acct.get();
+        if (a && hipEventRecord(a, ctx->stream) != hipSuccess) { (void)hipGetLastError(); ctx->acct.spare.push_back(a); a = nullptr; }
+    }
+    ~WorkScope() {
+        if (!a) return;
+        hipEvent_t b = ctx->acct.get();
+        if (b && hipEventRecord(b, ctx->stream) != hipSuccess) { (void)hipGetLastError(); ctx->acct.spare.push_back(b); b = nullptr; }
+        ctx->acct.spans.push_back({a, b, maxlog});
+    }
+};
+// an exchange of the partition: `gathered_bytes` = payload of all ranks together
+inline void acct_exchange(DeviceCtx* ctx, size_t gathered_bytes) {
+    if (!ctx->acct.on) return;
+    ctx->acct.exchange_bytes += gathered_bytes;
+    ctx->acct.exchanges++;
+}
+
 // all-gather of device buffers through the host-supplied collective (ShardInfo)
 inline void shard_all_gather(DeviceCtx* ctx, const void* send_dev, void* recv_dev, size_t bytes) {
+    acct_exchange(ctx, bytes * ctx->shard.world);
     if (!ctx->shard.all_gather) throw OlaError(-1, "sharded proving needs ola_set_shard with an all_gather callback");
     if (!ctx->shard.stream_ordered) HIP_CHECK(hipStreamSynchronize(ctx->stream));
     const int32_t rc = ctx->shard.all_gather(ctx->shard.user, send_dev, recv_dev, bytes);

@@ -18,6 +18,8 @@
 //     commitment's Merkle leaves want, so the LDE never needs a bit-reversal pass.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+
 #include <algorithm>
 #include <map>
 #include <tuple>
@@ -311,10 +313,12 @@ static void launch_pass(const NttPassParams& p, size_t tiles, size_t cols, size_
     constexpr int NT = ntt_threads<R, LOGT>();
     const size_t lds_bytes = (size_t)(E + (E >> 4) + 1) * 8;
     auto kern = ntt_pass_kernel<R, LOGT, MODE>;
-    static bool attr_set = false;
-    if (!attr_set && lds_bytes > 48 * 1024) {
+    // the attribute is a property of the kernel ON ONE DEVICE: a context that spans several GPUs sets it once per device
+    static std::atomic<bool> attr_set[64];
+    int dev = 0;
+    if (lds_bytes > 48 * 1024 && hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64 && !attr_set[dev].load()) {
         HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        attr_set = true;
+        attr_set[dev].store(true);
     }
     dim3 grid((unsigned)tiles, (unsigned)cols, (unsigned)cosets);
     hipLaunchKernelGGL(kern, grid, dim3(NT), lds_bytes, stream, p);

@@ -4,8 +4,10 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <chrono>
 #include <cstring>
 #include <memory>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -14,6 +16,7 @@
 #include "gl.cuh"
 #include "poseidon_host.h"
 #include "lookup.h"
+#include "peer_group.h"
 
 // unity build: device code shares the __constant__ Poseidon tables
 #include "ntt.hip"
@@ -33,6 +36,18 @@ struct OlaCtx {
     NttTables* tables = nullptr;
     OlaGpuConfig cfg;
     std::vector<uint8_t> pending_proof;   // an AllProof that did not fit the caller's buffer (ola_take_pending_proof)
+    // A context that spans several GPUs (ola_gpu_init_multi): this object is rank 0, `peers` are ranks 1..n-1 (owned), `group`
+    // their meeting point (peer_group.h).  Empty / null for a single-device context.
+    std::vector<OlaCtx*> peers;
+    std::unique_ptr<PeerGroup> group;
+    ~OlaCtx() {
+        if (tables) ntt_tables_destroy(tables);
+        for (OlaCtx* p : peers) {
+            (void)hipSetDevice(p->dev.device);
+            (void)hipStreamSynchronize(p->dev.stream);
+            delete p;
+        }
+    }
 };
 
 // Kernel launches report configuration errors (grid / LDS limits, missing code object) only through the sticky "last
@@ -81,6 +96,90 @@ DeviceGuard::DeviceGuard(const OlaCtx* ctx) {
     if (prev != want) HIP_CHECK(hipSetDevice(want));
 }
 
+// the configuration a context runs with: the caller's, or StarkConfig::standard_fast_config, validated
+static OlaGpuConfig resolve_config(const OlaGpuConfig* cfg) {
+    OlaGpuConfig d = {};
+    d.device = -1; d.stream = nullptr; d.rate_bits = 3; d.cap_height = 4; d.proof_of_work_bits = 16;
+    d.fri_arity_bits = 4; d.fri_final_poly_bits = 5; d.num_query_rounds = 28; d.num_challenges = 2;
+    const OlaGpuConfig c = cfg ? *cfg : d;
+    // the structure parameters every later call relies on (a zero arity would loop forever in fri_arities, zero proof-of-work
+    // bits shift by 64 in the grinding kernel, ...)
+    require(c.rate_bits >= 1 && c.rate_bits <= 8, "rate_bits must be in 1..8");
+    require(c.cap_height <= 16, "cap_height must be at most 16");
+    require(c.proof_of_work_bits >= 1 && c.proof_of_work_bits <= 40, "proof_of_work_bits must be in 1..40");
+    require(c.fri_arity_bits >= 1 && c.fri_arity_bits <= 8, "fri_arity_bits must be in 1..8");
+    require(c.fri_final_poly_bits <= 16, "fri_final_poly_bits must be at most 16");
+    require(c.num_query_rounds >= 1 && c.num_query_rounds <= 1024, "num_query_rounds must be in 1..1024");
+    require(c.num_challenges == 2, "num_challenges must be 2 (circuits/src/stark/config.rs)");
+    require(c.hasher == OLA_HASH_POSEIDON || c.hasher == OLA_HASH_BLAKE3, "hasher must be OLA_HASH_POSEIDON or OLA_HASH_BLAKE3");
+    return c;
+}
+
+// one device's context: stream, Poseidon constants, transform tables (device < 0: the calling thread's current device)
+static std::unique_ptr<OlaCtx> create_device_ctx(const OlaGpuConfig& cfg, int device, void* stream) {
+    std::unique_ptr<OlaCtx> c(new OlaCtx());
+    c->cfg = cfg;
+    c->cfg.device = device;
+    c->cfg.stream = stream;
+    c->dev.hasher = (int)cfg.hasher;
+    if (device >= 0) HIP_CHECK(hipSetDevice(device));
+    HIP_CHECK(hipGetDevice(&c->dev.device));
+    if (stream) { c->dev.stream = (hipStream_t)stream; c->dev.owns_stream = false; }
+    else { HIP_CHECK(hipStreamCreateWithFlags(&c->dev.stream, hipStreamNonBlocking)); c->dev.owns_stream = true; }
+    { const char* t = getenv("OLA_TIMING"); c->dev.timing = t && *t && *t != '0'; }
+    poseidon_init(&c->dev);
+    c->tables = ntt_tables_create(&c->dev);
+    return c;
+}
+
+// prove_with_traces on a context that spans several GPUs: one worker thread per rank (the caller's thread is rank 0), every rank
+// runs the whole prover on the same traces with the coset partition switched on and the library's own xGMI all-gather
+// (peer_group.h) as its collective.  All ranks finish with the same AllProof bytes; rank 0's are returned.
+static void prove_with_traces_multi(OlaCtx* ctx, const u64* airset, size_t airset_words, const u64* const* traces, const uint32_t* log_n,
+                                    const u64* params, const u64* compress, std::vector<uint8_t>& bytes) {
+    const uint32_t world = (uint32_t)ctx->peers.size() + 1;
+    PeerGroup& g = *ctx->group;
+    g.reset();
+    struct Result { std::vector<uint8_t> bytes; int code = 0; std::string msg; };
+    std::vector<Result> res(world);
+    const auto t0 = std::chrono::steady_clock::now();
+    auto run = [&](uint32_t r) {
+        OlaCtx* c = r == 0 ? ctx : ctx->peers[r - 1];
+        try {
+            HIP_CHECK(hipSetDevice(c->dev.device));
+            (void)hipGetLastError();
+            ShardInfo sh;
+            sh.rank = r; sh.world = world;
+            while ((1u << sh.log_world) < world) sh.log_world++;
+            sh.all_gather = peer_all_gather; sh.user = &g.ranks[r]; sh.stream_ordered = true;
+            c->dev.shard = sh;
+            c->dev.acct.on = ctx->dev.acct.on;
+            c->dev.acct.begin_proof();
+            prove_with_traces(&c->dev, *c->tables, c->cfg, airset, airset_words, traces, log_n, params, compress, res[r].bytes);
+            HIP_CHECK(hipStreamSynchronize(c->dev.stream));
+            c->dev.acct.collect();
+            const hipError_t e = hipGetLastError();
+            if (e != hipSuccess && e != hipErrorNotReady) throw OlaError(OLA_E_HIP, std::string("kernel launch failed: ") + hipGetErrorString(e));
+        } catch (const OlaError& e) { res[r].code = e.code; res[r].msg = e.what(); g.fail(); }
+        catch (const std::bad_alloc&) { res[r].code = OLA_E_OOM; res[r].msg = "host out of memory"; g.fail(); }
+        catch (const std::exception& e) { res[r].code = OLA_E_INTERNAL; res[r].msg = e.what(); g.fail(); }
+        c->dev.shard = ShardInfo();
+    };
+    std::vector<std::thread> workers;
+    for (uint32_t r = 1; r < world; r++) workers.emplace_back(run, r);
+    run(0);
+    for (std::thread& t : workers) t.join();
+    ctx->dev.acct.wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    // the rank that failed first-hand explains more than the ones that were released from a barrier because of it
+    int bad = -1;
+    for (uint32_t r = 0; r < world; r++)
+        if (res[r].code != 0 && (bad < 0 || res[bad].msg.find("a peer rank") != std::string::npos)) bad = (int)r;
+    if (bad >= 0) throw OlaError(res[bad].code, "rank " + std::to_string(bad) + " (device " + std::to_string(g.ranks[bad].device) + "): " + res[bad].msg);
+    for (uint32_t r = 1; r < world; r++)
+        if (res[r].bytes != res[0].bytes) throw OlaError(OLA_E_INTERNAL, "ranks of the multi-device context produced different proofs (rank " + std::to_string(r) + ")");
+    bytes = std::move(res[0].bytes);
+}
+
 extern "C" {
 
 const char* ola_gpu_last_error(void) { return g_last_error.c_str(); }
@@ -91,41 +190,80 @@ int32_t ola_gpu_init(const OlaGpuConfig* cfg, OlaCtx** out_ctx) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
         throw OlaError(OLA_E_NO_DEVICE, "no HIP device visible (the backend has no CPU fallback)");
-    std::unique_ptr<OlaCtx> c(new OlaCtx());
-    OlaGpuConfig d = {};
-    d.device = -1; d.stream = nullptr; d.rate_bits = 3; d.cap_height = 4; d.proof_of_work_bits = 16;
-    d.fri_arity_bits = 4; d.fri_final_poly_bits = 5; d.num_query_rounds = 28; d.num_challenges = 2;
-    c->cfg = cfg ? *cfg : d;
-    // the structure parameters every later call relies on (a zero arity would loop forever in fri_arities, zero proof-of-work
-    // bits shift by 64 in the grinding kernel, ...)
-    require(c->cfg.rate_bits >= 1 && c->cfg.rate_bits <= 8, "rate_bits must be in 1..8");
-    require(c->cfg.cap_height <= 16, "cap_height must be at most 16");
-    require(c->cfg.proof_of_work_bits >= 1 && c->cfg.proof_of_work_bits <= 40, "proof_of_work_bits must be in 1..40");
-    require(c->cfg.fri_arity_bits >= 1 && c->cfg.fri_arity_bits <= 8, "fri_arity_bits must be in 1..8");
-    require(c->cfg.fri_final_poly_bits <= 16, "fri_final_poly_bits must be at most 16");
-    require(c->cfg.num_query_rounds >= 1 && c->cfg.num_query_rounds <= 1024, "num_query_rounds must be in 1..1024");
-    require(c->cfg.num_challenges == 2, "num_challenges must be 2 (circuits/src/stark/config.rs)");
-    require(c->cfg.hasher == OLA_HASH_POSEIDON || c->cfg.hasher == OLA_HASH_BLAKE3, "hasher must be OLA_HASH_POSEIDON or OLA_HASH_BLAKE3");
-    c->dev.hasher = (int)c->cfg.hasher;
-    require(c->cfg.device < ndev, "device index out of range");
-    if (c->cfg.device >= 0) HIP_CHECK(hipSetDevice(c->cfg.device));
-    HIP_CHECK(hipGetDevice(&c->dev.device));
-    if (c->cfg.stream) { c->dev.stream = (hipStream_t)c->cfg.stream; c->dev.owns_stream = false; }
-    else { HIP_CHECK(hipStreamCreateWithFlags(&c->dev.stream, hipStreamNonBlocking)); c->dev.owns_stream = true; }
-    { const char* t = getenv("OLA_TIMING"); c->dev.timing = t && *t && *t != '0'; }
-    poseidon_init(&c->dev);
-    c->tables = ntt_tables_create(&c->dev);
-    *out_ctx = c.release();
+    const OlaGpuConfig c = resolve_config(cfg);
+    require(c.device < ndev, "device index out of range");
+    *out_ctx = create_device_ctx(c, c.device, c.stream).release();
     g_live_contexts.fetch_add(1);
+    OLA_CATCH
+}
+
+int32_t ola_gpu_init_multi(const OlaGpuConfig* cfg, const int32_t* devices, uint32_t n_devices, OlaCtx** out_ctx) {
+    OLA_TRY
+    require(out_ctx != nullptr, "out_ctx is NULL");
+    require(n_devices == 1 || n_devices == 2 || n_devices == 4 || n_devices == 8, "a context spans 1, 2, 4 or 8 devices");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        throw OlaError(OLA_E_NO_DEVICE, "no HIP device visible (the backend has no CPU fallback)");
+    const OlaGpuConfig c = resolve_config(cfg);
+    require(n_devices <= (1u << c.rate_bits) && n_devices <= (1u << c.cap_height), "more devices than LDE cosets or Merkle cap entries");
+    std::vector<int> dv(n_devices);
+    for (uint32_t r = 0; r < n_devices; r++) {
+        dv[r] = devices ? devices[r] : (int)r;
+        require(dv[r] >= 0 && dv[r] < ndev, "device index out of range");
+    }
+    require(n_devices == 1 || c.stream == nullptr, "a multi-device context creates its own streams (cfg.stream must be NULL)");
+    int prev = -1;
+    if (hipGetDevice(&prev) != hipSuccess) { prev = -1; (void)hipGetLastError(); }
+    struct Restore { int d; ~Restore() { if (d >= 0) (void)hipSetDevice(d); } } restore{prev};
+    std::unique_ptr<OlaCtx> root = create_device_ctx(c, dv[0], c.stream);
+    if (n_devices > 1) {
+        for (uint32_t r = 1; r < n_devices; r++) root->peers.push_back(create_device_ctx(c, dv[r], nullptr).release());
+        // xGMI peer access between every pair of distinct devices (the all-gather pulls from the peers' memory)
+        for (uint32_t a = 0; a < n_devices; a++)
+            for (uint32_t b = 0; b < n_devices; b++) {
+                if (dv[a] == dv[b]) continue;
+                int can = 0;
+                HIP_CHECK(hipDeviceCanAccessPeer(&can, dv[a], dv[b]));
+                if (!can) throw OlaError(OLA_E_HIP, "device " + std::to_string(dv[a]) + " cannot access device " + std::to_string(dv[b]) + " (no peer access)");
+                HIP_CHECK(hipSetDevice(dv[a]));
+                const hipError_t e = hipDeviceEnablePeerAccess(dv[b], 0);
+                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) HIP_CHECK(e);
+                (void)hipGetLastError();
+            }
+        root->group.reset(new PeerGroup());
+        PeerGroup& g = *root->group;
+        g.world = n_devices;
+        g.ranks.resize(n_devices);
+        for (uint32_t r = 0; r < n_devices; r++) {
+            OlaCtx* rc = r == 0 ? root.get() : root->peers[r - 1];
+            PeerRank& pr = g.ranks[r];
+            pr.group = &g; pr.rank = r; pr.device = rc->dev.device; pr.stream = rc->dev.stream;
+            HIP_CHECK(hipSetDevice(pr.device));
+            HIP_CHECK(hipEventCreateWithFlags(&pr.ready, hipEventDisableTiming));
+            HIP_CHECK(hipEventCreateWithFlags(&pr.done, hipEventDisableTiming));
+        }
+    }
+    *out_ctx = root.release();
+    g_live_contexts.fetch_add(1);
+    OLA_CATCH
+}
+
+int32_t ola_gpu_device_count(OlaCtx* ctx, uint32_t* n_devices) {
+    OLA_TRY
+    require(ctx && n_devices, "null pointer");
+    *n_devices = (uint32_t)ctx->peers.size() + 1;
     OLA_CATCH
 }
 
 int32_t ola_gpu_free(OlaCtx* ctx) {
     OLA_TRY
     if (ctx) {
+        int prev = -1;
+        if (hipGetDevice(&prev) != hipSuccess) { prev = -1; (void)hipGetLastError(); }
+        (void)hipSetDevice(ctx->dev.device);
         (void)hipStreamSynchronize(ctx->dev.stream);
-        ntt_tables_destroy(ctx->tables);
         delete ctx;
+        if (prev >= 0) (void)hipSetDevice(prev);
         g_live_contexts.fetch_sub(1);
     }
     OLA_CATCH
@@ -136,6 +274,7 @@ int32_t ola_gpu_sync(OlaCtx* ctx) {
     OLA_ON_DEVICE(ctx);
     require(ctx, "ctx");
     HIP_CHECK(hipStreamSynchronize(ctx->dev.stream));
+    for (OlaCtx* p : ctx->peers) { HIP_CHECK(hipSetDevice(p->dev.device)); HIP_CHECK(hipStreamSynchronize(p->dev.stream)); }
     OLA_CATCH
 }
 
@@ -435,8 +574,17 @@ int32_t ola_prove_with_traces(OlaCtx* ctx, const uint64_t* airset, size_t airset
     OLA_ON_DEVICE(ctx);
     require(ctx && airset && traces && log_n && out_len, "null pointer");
     std::vector<uint8_t> bytes;
-    prove_with_traces(&ctx->dev, *ctx->tables, ctx->cfg, (const u64*)airset, airset_words, (const u64* const*)traces, log_n,
-                      (const u64*)params, (const u64*)compress_challenges, bytes);
+    if (ctx->peers.empty()) {
+        const auto t0 = std::chrono::steady_clock::now();
+        ctx->dev.acct.begin_proof();
+        prove_with_traces(&ctx->dev, *ctx->tables, ctx->cfg, (const u64*)airset, airset_words, (const u64* const*)traces, log_n,
+                          (const u64*)params, (const u64*)compress_challenges, bytes);
+        ctx->dev.acct.collect();
+        ctx->dev.acct.wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    } else {
+        prove_with_traces_multi(ctx, (const u64*)airset, airset_words, (const u64* const*)traces, log_n, (const u64*)params,
+                                (const u64*)compress_challenges, bytes);
+    }
     *out_len = bytes.size();
     if (bytes.size() > cap || !out) {
         ctx->pending_proof = std::move(bytes);          // the work is not lost: ola_take_pending_proof hands it over
@@ -571,6 +719,7 @@ int32_t ola_gpu_trim(OlaCtx* ctx) {
     OLA_ON_DEVICE(ctx);
     require(ctx, "ctx");
     ctx->dev.release_cache();
+    for (OlaCtx* p : ctx->peers) { HIP_CHECK(hipSetDevice(p->dev.device)); p->dev.release_cache(); }
     OLA_CATCH
 }
 
@@ -589,6 +738,19 @@ int32_t ola_gpu_memory_stats(OlaCtx* ctx, uint64_t out[4], int32_t reset) {
     DeviceCtx& d = ctx->dev;
     out[0] = d.live_bytes; out[1] = d.live_peak; out[2] = d.live_bytes + d.cached_bytes; out[3] = d.reserved_peak;
     if (reset) { d.live_peak = d.live_bytes; d.reserved_peak = d.live_bytes + d.cached_bytes; }
+    OLA_CATCH
+}
+
+int32_t ola_gpu_proof_stats(OlaCtx* ctx, int32_t enable, double out[8]) {
+    OLA_TRY
+    require(ctx, "ctx");
+    if (enable >= 0) ctx->dev.acct.on = enable != 0;
+    if (out) {
+        const WorkAcct& a = ctx->dev.acct;
+        out[0] = a.wall_ms; out[1] = a.sharded_ms[1]; out[2] = a.sharded_ms[2]; out[3] = a.sharded_ms[3];
+        out[4] = (double)a.exchange_bytes; out[5] = (double)a.exchanges;
+        out[6] = ctx->group ? (double)ctx->group->exchanges : 0; out[7] = ctx->group ? (double)ctx->group->bytes_moved : 0;
+    }
     OLA_CATCH
 }
 
@@ -620,6 +782,7 @@ int32_t ola_set_shard(OlaCtx* ctx, uint32_t rank, uint32_t world, ola_all_gather
     OLA_ON_DEVICE(ctx);
     require(ctx, "ctx");
     require(world >= 1 && world <= 8 && (world & (world - 1)) == 0 && rank < world, "world must be 1, 2, 4 or 8 and rank < world");
+    require(ctx->peers.empty(), "a multi-device context partitions the proof itself; ola_set_shard is for one-device contexts of multi-process hosts");
     require(world == 1 || all_gather, "a sharded context needs an all_gather callback");
     ShardInfo sh;
     if (world > 1) {

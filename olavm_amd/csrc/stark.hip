@@ -467,6 +467,7 @@ static OlaBatch* commit_shared(DeviceCtx* ctx, NttTables& t, const u64* dev_cols
     const size_t len_cap = (size_t)1 << cfg.cap_height;
     cap_full.assign(len_cap * 4, 0);
     if (!sharded) {
+        if (ctx->acct.shardable) acct_exchange(ctx, len_cap * 32);   // the cap slices a partitioned run gathers
         OlaBatch* b = batch_commit(ctx, t, nullptr, dev_cols, ncols, log_n, cfg.rate_bits, cfg.cap_height, from_values, 0, 0, feed, lean);
         try { batch_read_cap(ctx, *b, cap_full.data()); } catch (...) { batch_destroy(ctx, b); throw; }
         return b;
@@ -631,6 +632,7 @@ static void prove_single_table(DeviceCtx* ctx, NttTables& tables, const OlaGpuCo
         TwoLevel gt = get_two(tables, degree_bits, 0);
         const u64 n_inv = gl_inv(((u64)1 << degree_bits) % GL_P);
         hipLaunchKernelGGL(lagrange_coeffs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, lag_coef, n, n_inv, gt.lo, gt.hi, gt.h);
+        WorkScope ws(ctx, rate_bits);
         if (!lean) ntt_lde_leaf_order(tables, lag_coef, lag_lde, degree_bits, rate_bits, 2, coset_first, coset_count);
     }
     // descriptor for the kernel
@@ -723,6 +725,8 @@ static void prove_single_table(DeviceCtx* ctx, NttTables& tables, const OlaGpuCo
             HIP_CHECK(hipStreamSynchronize(ctx->stream));   // sd is a stack-lifetime staging buffer
         }
         u64* qv2 = (spec && crosscheck) ? mem.alloc(2 * plane) : nullptr;
+        WorkScope ws(ctx, qdb);   // the quotient lives on 2^qdb cosets: that many ranks share it
+        if (!sharded && ctx->acct.shardable) { acct_exchange(ctx, N * 8); acct_exchange(ctx, N * 8); }   // the two planes a partitioned run gathers
         for (size_t lc = 0; lc < lean_cosets; lc++) {
             u64* out = qloc;
             size_t points = sharded ? my_q_cosets * n : plane;
@@ -1130,6 +1134,8 @@ void prove_with_traces(DeviceCtx* ctx, NttTables& tables, const OlaGpuConfig& cf
     for (size_t t = 0; t < nt; t++) {
         PhaseTimer tt(ctx, "  table " + std::to_string(t) + " trace commitment (upload overlapped)");
         const size_t n_t = (size_t)1 << log_n[t];
+        ctx->acct.shardable = log_n[t] >= ctx->shard.min_log_n;
+        if (ctx->acct.shardable && !cpr[t]) acct_exchange(ctx, (size_t)set.tables[t].ncols * n_t * 8);   // the trace values a partitioned run gathers
         ColumnFeed feed;
         feed.chunk_cols = up.chunk_cols(t);
         feed.before_chunk = [&, t, n_t](uint32_t c0, uint32_t c1) {
@@ -1168,9 +1174,11 @@ void prove_with_traces(DeviceCtx* ctx, NttTables& tables, const OlaGpuConfig& cf
         if (!params && set.tables[t].n_params > 64) throw OlaError(OLA_E_INVALID_ARG, "params required");
         poff += set.tables[t].n_params;
         PhaseTimer tt(ctx, "  table " + std::to_string(t) + " prove_single_table");
+        ctx->acct.shardable = log_n[t] >= ctx->shard.min_log_n;
         prove_single_table(ctx, tables, cfg, set.tables[t], dev[t], *commits[t]->b, caps[t], jobs[t], pr, ch, bytes,
                            table_is_sharded(ctx, cfg, set.tables[t], log_n[t]));
     }
+    ctx->acct.shardable = false;
     // compress_challenges (prover.rs:307-320) -- produced by trace generation, carried through
     w.u32((uint32_t)nt);
     for (size_t t = 0; t < nt; t++) w.field(compress ? compress[t] : 0);

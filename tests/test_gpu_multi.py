@@ -1,0 +1,104 @@
+"""ONE context spanning several GPUs (ola_gpu_init_multi, SURVEY 8(b) Threading): one process, one ola_prove_with_traces
+call, the coset partition and its exchanges inside the library.  The test box has one GPU, so the logical ranks alias device 0:
+the worker threads, per-rank streams and pools, the event-ordered peer all-gather and the partition logic are all the real
+thing, only the copies are device-local instead of xGMI."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def small_instance():
+    from olavm_amd.air import ola_tables as T
+    from tests import tracegen
+    blob = T.ola_stark(range_bits=4, limb_bits=2).blob()
+    traces, params, compress = tracegen.empty_program_instance(log_n=12, live=np.random.default_rng(12))
+    return blob, traces, params, compress
+
+
+@pytest.mark.parametrize("hasher", ["poseidon", "blake3"])
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_multi_device_context_proof_equals_the_single_gpu_proof(world, hasher, small_instance, oracle):
+    from olavm_amd.backend import Backend
+    blob, traces, params, compress = small_instance
+    one = Backend(device=0, hasher=hasher)
+    single = one.prove_with_traces(blob, traces, params, compress)
+    one.close()
+    be = Backend(devices=[0] * world, hasher=hasher)
+    assert be.device_count() == world
+    be.proof_stats(enable=True)
+    multi = be.prove_with_traces(blob, traces, params, compress)
+    st = be.proof_stats()
+    again = be.prove_with_traces(blob, traces, params, compress)      # the context is reusable, events and pools included
+    be.close()
+    assert multi == single, "the multi-device context produced different proof bytes"
+    assert again == single
+    # three tables of the instance are on the partition (CPU, memory, Poseidon at 2^12 rows): 9 exchanges each, done by the
+    # library's own all-gather
+    assert st["peer_exchanges"] > 0 and st["peer_exchanges"] % 9 == 0, st
+    assert st["peer_bytes_moved"] > 0 and st["exchanges"] == st["peer_exchanges"], st
+    with oracle.hasher(hasher):
+        rc, why = oracle.verify_all_proof(blob, single, [int(x) for x in params])
+    assert rc == 0, why
+
+
+def test_multi_device_context_real_execution_8_ranks(oracle):
+    """An executed program against the full-size fixed tables, 8 logical ranks in one process: the program, range-check and bitwise
+    tables are on the partition too, with quotients that live on fewer cosets than there are ranks."""
+    from olavm_amd.air import miniexec as M, ola_tables as T
+    from olavm_amd.backend import Backend
+    blob = T.ola_stark().blob()
+    traces, params, compress = M.instance(M.memory_program(600), range_bits=16, limb_bits=8, max_steps=1 << 20)
+    one = Backend(device=0)
+    single = one.prove_with_traces(blob, traces, params, compress)
+    one.close()
+    be = Backend(devices=[0] * 8)
+    multi = be.prove_with_traces(blob, traces, params, compress)
+    be.close()
+    assert multi == single
+    rc, why = oracle.verify_all_proof(blob, single, [int(x) for x in params])
+    assert rc == 0, why
+
+
+def test_multi_device_context_large_transform_sizes():
+    """2^15-row tables (the three-launch transform kernels, 2^18-point LDEs) on 2 logical ranks."""
+    from olavm_amd.air import ola_tables as T
+    from olavm_amd.backend import Backend
+    from tests import tracegen
+    blob = T.ola_stark(range_bits=4, limb_bits=2).blob()
+    traces, params, compress = tracegen.empty_program_instance(log_n=15, live=np.random.default_rng(15))
+    one = Backend(device=0)
+    single = one.prove_with_traces(blob, traces, params, compress)
+    one.close()
+    be = Backend(devices=[0, 0])
+    assert be.prove_with_traces(blob, traces, params, compress) == single
+    be.close()
+
+
+def test_multi_device_context_other_entry_points_and_errors(small_instance):
+    """Outside ola_prove_with_traces a multi-device context behaves like a single-device one on devices[0]; a trace that violates
+    its AIR fails on every rank without hanging the others; bad arguments are refused."""
+    from olavm_amd.backend import Backend, OlaGpuError
+    from tests.oracle_lib import rand_field
+    blob, traces, params, compress = small_instance
+    be = Backend(devices=[0, 0])
+    vals = rand_field(np.random.default_rng(5), (4, 1 << 10))
+    one = Backend(device=0)
+    a, b = be.commit(vals), one.commit(vals)
+    assert np.array_equal(a.cap(), b.cap())
+    a.free(); b.free(); one.close()
+    bad = [np.array(t, copy=True) for t in traces]
+    bad[0][3, 5] ^= np.uint64(1)                      # one flipped cell of the CPU table
+    with pytest.raises(OlaGpuError) as ei:
+        be.prove_with_traces(blob, bad, params, compress)
+    assert ei.value.code in (-4, -1), ei.value      # quotient degree (or a non-binary filter), reported with the failing rank
+    assert be.prove_with_traces(blob, traces, params, compress)[:4] == (12).to_bytes(4, "little")   # still usable
+    from olavm_amd.backend import ALL_GATHER_FN
+    cb = ALL_GATHER_FN(lambda user, send, recv, nbytes: 1)
+    assert be.lib.ola_set_shard(be.ctx, 0, 2, cb, None) == -1      # the partition of a multi-device context is its own
+    be.close()
+    with pytest.raises(OlaGpuError):
+        Backend(devices=[0, 0, 0])                    # 1, 2, 4 or 8
+    with pytest.raises(OlaGpuError):
+        Backend(devices=[0, 99])

@@ -1,0 +1,29 @@
+#!/bin/bash
+# The GPU-box runs of a round, one named step per argument (gpurun -- 'bash tools/gpu.sh step1 step2 ...'); everything a step
+# prints or measures lands under gpurun_out/<step>/.  Replaces the one-off scripts of earlier rounds.
+R=${GRAFT_REPO_ROOT:-$(pwd)}; cd "$R"; export TMPDIR=/tmp
+for step in "$@"; do
+  O=gpurun_out/$step; mkdir -p "$O"
+  echo "=== $step"
+  case $step in
+    multi)       timeout 900 python -m pytest tests/test_gpu_multi.py -x -q 2>&1 | tail -15 | tee $O/pytest.log ;;
+    suite)       timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 | tee $O/pytest.log ;;
+    smoke)       timeout 600 python -c 'import __graft_entry__ as g; g.smoke()' 2>&1 | tail -5 | tee $O/smoke.log ;;
+    bench)       timeout 900 python bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err; tail -c 1500 $O/bench.json ;;
+    bench2)      timeout 900 python bench.py --gpus 2 --steps 10 --warmup 2 > $O/bench.json 2> $O/bench.err; tail -c 1500 $O/bench.json; tail -3 $O/bench.err ;;
+    stats)       timeout 600 python tools/proof_stats.py --out $O/proof_stats.json 2>&1 | tail -8 ;;
+    stats_real)  timeout 600 python tools/proof_stats.py --real --out $O/proof_stats_real.json 2>&1 | tail -8 ;;
+    stats_multi) timeout 600 python tools/proof_stats.py --log-n 20 --devices 0 0 0 0 0 0 0 0 --out $O/proof_stats.json 2>&1 | tail -8 ;;
+    phases)      OLA_TIMING=1 timeout 600 python tools/bench_prove.py 22 2 2> $O/phases.txt | tail -3; OLA_HASHER=blake3 OLA_TIMING=1 timeout 600 python tools/bench_prove.py 22 2 2> $O/phases_blake3.txt | tail -3 ;;
+    ntt_group)   # Infinity-Cache blocking of the transforms: working-set target in MB (0 = whole batch per launch)
+                 for mb in 0 32 64 96 128 192; do
+                   echo "-- OLA_NTT2_GROUP_MB=$mb"
+                   OLA_NTT2_GROUP_MB=$mb timeout 300 python bench.py --steps 20 --warmup 3 --no-prove --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('  ntt ms', d['ms_per_step'], 'frac', d['roofline']['frac'])"
+                   OLA_NTT2_GROUP_MB=$mb timeout 300 python tools/bench_ntt_matrix.py --log-n 22 --cols 94 --reps 3 --out $O/m_$mb.json 2>&1 | grep -E "lde|intt|ntt" | cut -c1-120
+                 done 2>&1 | tee $O/sweep.txt ;;
+    matrix)      timeout 1200 python tools/bench_ntt_matrix.py --out $O/ntt_matrix.json 2>&1 | tail -40 ;;
+    prof_bench)  cd /tmp; timeout 900 rocprofv3 --kernel-trace --stats -d $R/$O/prof -o p -- python $R/bench.py --steps 20 --warmup 5 > $R/$O/bench.json 2> $R/$O/err.txt; cd $R
+                 f=$(find $O/prof -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp "$f" $O/kernel_stats.csv && head -25 $O/kernel_stats.csv | cut -c1-160 ;;
+    *)           echo "unknown step $step" ;;
+  esac
+done
