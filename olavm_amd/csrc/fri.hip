@@ -354,6 +354,9 @@ static void query_leaves(DeviceCtx* ctx, NttTables& tables, const OlaBatch& b, c
 
 // all polynomials of a batch at one or two extension points -> host vectors
 // (two phases so that the evaluations of all oracles share one synchronisation: launch + async read-back, then collect)
+// Under the coset partition the COLUMNS of a batch are divided among the ranks (every rank holds all coefficients: the
+// interpolation is replicated): rank r evaluates columns [r * cpr, (r+1) * cpr), reduces its chunk partials on the device, and
+// the evaluations of all four jobs of a table travel in ONE all-gather of a few KB (proof.rs:198-233).
 struct EvalJob {
     std::vector<u64> part;
     unsigned nchunks = 0;
@@ -361,20 +364,50 @@ struct EvalJob {
     int npoints = 0;
     std::vector<Ext2>* out0 = nullptr;
     std::vector<Ext2>* out1 = nullptr;
+    // sharded form
+    uint32_t cpr = 0;           // columns per rank
+    size_t send_off = 0;        // this job's slot in a rank's record: [npoints][cpr][2] words
 };
+// partial[pt][chunk][col][2] -> out[pt][cpr][2] (columns beyond ncols_loc stay zero)
+__global__ __launch_bounds__(256) void eval_reduce_kernel(const u64* __restrict__ partial, unsigned nchunks, int ncols_loc, int npoints,
+                                                          int cpr, u64* __restrict__ out) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= npoints * cpr) return;
+    const int p = t / cpr, c = t % cpr;
+    u64 a = 0, b = 0;
+    if (c < ncols_loc)
+        for (unsigned ch = 0; ch < nchunks; ch++) {
+            const u64* v = partial + (((size_t)p * nchunks + ch) * ncols_loc + c) * 2;
+            a = gl_add(a, v[0]);
+            b = gl_add(b, v[1]);
+        }
+    out[((size_t)p * cpr + c) * 2] = a;
+    out[((size_t)p * cpr + c) * 2 + 1] = b;
+}
 static void eval_batch_launch(DevBuf& mem, const OlaBatch& b, int npoints, ExtPow p0, ExtPow p1, std::vector<Ext2>* out0,
-                              std::vector<Ext2>* out1, EvalJob& job) {
+                              std::vector<Ext2>* out1, EvalJob& job, u64* d_send = nullptr) {
     DeviceCtx* ctx = mem.ctx;
     const size_t n = b.n();
     const size_t chunk_len = std::max<size_t>(4096, (n + 255) / 256);
     const unsigned nchunks = (unsigned)((n + chunk_len - 1) / chunk_len);
+    job.nchunks = nchunks; job.ncols = b.ncols; job.npoints = npoints; job.out0 = out0; job.out1 = out1;
+    if (d_send) {           // this rank's columns only
+        const uint32_t cpr = job.cpr, c0 = std::min(b.ncols, ctx->shard.rank * cpr), c1 = std::min(b.ncols, c0 + cpr);
+        const uint32_t mine = c1 - c0;
+        u64* d_part = mem.alloc(std::max<size_t>(1, (size_t)npoints * nchunks * mine * 2));
+        if (mine)
+            hipLaunchKernelGGL(eval_points_kernel, dim3(nchunks, (mine + EVAL_CG - 1) / EVAL_CG), dim3(256), 0, ctx->stream, b.coeffs + (size_t)c0 * n, n,
+                               (int)mine, p0, p1, npoints, chunk_len, d_part);
+        hipLaunchKernelGGL(eval_reduce_kernel, dim3((unsigned)((npoints * cpr + 255) / 256)), dim3(256), 0, ctx->stream, d_part, nchunks, (int)mine,
+                           npoints, (int)cpr, d_send + job.send_off);
+        return;
+    }
     const unsigned groups = (b.ncols + EVAL_CG - 1) / EVAL_CG;
     const size_t pelems = (size_t)npoints * nchunks * b.ncols * 2;
     u64* d_part = mem.alloc(pelems);
     hipLaunchKernelGGL(eval_points_kernel, dim3(nchunks, groups), dim3(256), 0, ctx->stream, b.coeffs, n, (int)b.ncols, p0, p1,
                        npoints, chunk_len, d_part);
     job.part.resize(pelems);
-    job.nchunks = nchunks; job.ncols = b.ncols; job.npoints = npoints; job.out0 = out0; job.out1 = out1;
     HIP_CHECK(hipMemcpyAsync(job.part.data(), d_part, pelems * 8, hipMemcpyDeviceToHost, ctx->stream));
 }
 static void eval_batch_collect(const EvalJob& job) {
@@ -386,6 +419,17 @@ static void eval_batch_collect(const EvalJob& job) {
                 const u64* v = &job.part[(((size_t)p * job.nchunks + ch) * job.ncols + c) * 2];
                 o[c] = ext_add(o[c], ext_make(v[0], v[1]));
             }
+    }
+}
+// sharded: recv = [world][record], a record = the jobs' slots one after the other
+static void eval_batch_collect_sharded(const EvalJob& job, const u64* recv, size_t record_words) {
+    for (int p = 0; p < job.npoints; p++) {
+        std::vector<Ext2>& o = p == 0 ? *job.out0 : *job.out1;
+        o.assign(job.ncols, ext_make(0, 0));
+        for (uint32_t c = 0; c < job.ncols; c++) {
+            const u64* v = recv + (size_t)(c / job.cpr) * record_words + job.send_off + ((size_t)p * job.cpr + c % job.cpr) * 2;
+            o[c] = ext_make(v[0], v[1]);
+        }
     }
 }
 
@@ -435,6 +479,7 @@ struct FriLayer {
     size_t len;
     int arity_bits;
     std::vector<u64> cap;
+    size_t shard_leaves = 0;   // > 0: this rank holds leaves [rank * shard_leaves, (rank+1) * shard_leaves) only (first layer on the partition)
 };
 
 // ------------------------------------------------------------------------------------------------ the pipeline
@@ -465,12 +510,40 @@ void open_and_prove(DeviceCtx* ctx, NttTables& tables, const OlaGpuConfig& cfg, 
     std::vector<Ext2> local, next, zs_local, zs_next, q_local, zs_last_all, dummy;
     {
         EvalJob jobs[4];
-        eval_batch_launch(mem, trace, 2, pz, pzn, &local, &next, jobs[0]);
-        eval_batch_launch(mem, zs, 2, pz, pzn, &zs_local, &zs_next, jobs[1]);
-        eval_batch_launch(mem, quot, 1, pz, pz, &q_local, &dummy, jobs[2]);
-        eval_batch_launch(mem, zs, 1, pgi, pgi, &zs_last_all, &dummy, jobs[3]);
-        HIP_CHECK(hipStreamSynchronize(mem.ctx->stream));
-        for (auto& j : jobs) eval_batch_collect(j);
+        const OlaBatch* jb[4] = {&trace, &zs, &quot, &zs};
+        const int jp[4] = {2, 2, 1, 1};
+        const bool sharded = trace.is_shard() && ctx->shard.world > 1;
+        if (!sharded) {
+            {
+                WorkScope ws(ctx, 3);      // the partition divides the columns among the ranks
+                eval_batch_launch(mem, trace, 2, pz, pzn, &local, &next, jobs[0]);
+                eval_batch_launch(mem, zs, 2, pz, pzn, &zs_local, &zs_next, jobs[1]);
+                eval_batch_launch(mem, quot, 1, pz, pz, &q_local, &dummy, jobs[2]);
+                eval_batch_launch(mem, zs, 1, pgi, pgi, &zs_last_all, &dummy, jobs[3]);
+            }
+            if (ctx->acct.shardable) acct_exchange(ctx, (size_t)(2 * W + 3 * Z + Q) * 16);
+            HIP_CHECK(hipStreamSynchronize(mem.ctx->stream));
+            for (auto& j : jobs) eval_batch_collect(j);
+        } else {
+            const uint32_t world = ctx->shard.world;
+            size_t record = 0;
+            for (int i = 0; i < 4; i++) {
+                jobs[i].cpr = (jb[i]->ncols + world - 1) / world;
+                jobs[i].send_off = record;
+                record += (size_t)jp[i] * jobs[i].cpr * 2;
+            }
+            u64* d_send = mem.alloc(record);
+            u64* d_recv = mem.alloc(record * world);
+            eval_batch_launch(mem, trace, 2, pz, pzn, &local, &next, jobs[0], d_send);
+            eval_batch_launch(mem, zs, 2, pz, pzn, &zs_local, &zs_next, jobs[1], d_send);
+            eval_batch_launch(mem, quot, 1, pz, pz, &q_local, &dummy, jobs[2], d_send);
+            eval_batch_launch(mem, zs, 1, pgi, pgi, &zs_last_all, &dummy, jobs[3], d_send);
+            shard_all_gather(ctx, d_send, d_recv, record * 8);
+            std::vector<u64> recv(record * world);
+            HIP_CHECK(hipMemcpyAsync(recv.data(), d_recv, recv.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_CHECK(hipStreamSynchronize(ctx->stream));
+            for (auto& j : jobs) eval_batch_collect_sharded(j, recv.data(), record);
+        }
     }
     std::vector<u64> ctl_last;
     for (int i = (int)nperm; i < Z; i++) ctl_last.push_back(zs_last_all[i].a);
@@ -533,6 +606,11 @@ void open_and_prove(DeviceCtx* ctx, NttTables& tables, const OlaGpuConfig& cfg, 
     u64 shift = GL_GENERATOR;
     size_t len = N;
     u64* cur_coef = coef;  // planes [a | b] each `len`
+    // Under the coset partition the FIRST layer -- 15/16 of the commit phase's values and leaves -- is divided like a commitment
+    // (fri/prover.rs:72-121): its bit-reversed values are the leaf-order LDE of the n coefficients (the planes
+    // are zero beyond n), a rank extends and hashes its cosets only (n/arity leaves per coset), builds their sub-trees and the
+    // cap slices are all-gathered; the layers after the first fold (1/16 of the data, and shrinking) stay replicated.
+    const bool sharded = trace.is_shard() && ctx->shard.world > 1;
     for (size_t li = 0; li < arities.size(); li++) {
         const int ab = arities[li];
         const int arity = 1 << ab;
@@ -541,19 +619,42 @@ void open_and_prove(DeviceCtx* ctx, NttTables& tables, const OlaGpuConfig& cfg, 
         // values = coset_fft(coeffs, shift), kept bit-reversed (reverse_index_bits_in_place, prover.rs:88)
         FriLayer L;
         L.len = len; L.arity_bits = ab;
-        L.va = mem.alloc(2 * len);
-        L.vb = L.va + len;
-        {
-            std::unique_ptr<PhaseTimer> t_fft(li == 0 ? new PhaseTimer(ctx, "      perform final FFT " + std::to_string(len)) : nullptr);
-            ntt_coset_evaluate(tables, cur_coef, L.va, nullptr, cur_bits, 2, shift, false);
-        }
-        if (li == 0) t_fold.reset(new PhaseTimer(ctx, "      fold codewords in the commitment phase"));
         const size_t nleaves = len >> ab;
-        L.heap = mem.alloc(2 * nleaves * 4);
-        launch_leaf_hash_ext(ctx, L.va, L.vb, arity, nleaves, L.heap + 4 * nleaves);
-        launch_merkle_build(ctx, L.heap, nleaves, cfg.cap_height);
         L.cap.resize(len_cap * 4);
-        HIP_CHECK(hipMemcpyAsync(L.cap.data(), L.heap + 4 * len_cap, len_cap * 32, hipMemcpyDeviceToHost, ctx->stream));
+        const bool shard_layer = sharded && li == 0 && degree_bits >= ab;
+        if (shard_layer) {
+            const uint32_t lw = ctx->shard.log_world;
+            const size_t coset_count = ((size_t)1 << rate_bits) >> lw, coset_first = (size_t)ctx->shard.rank * coset_count;
+            const size_t len_loc = n * coset_count, nl_loc = len_loc >> ab, cap_loc = len_cap >> lw;
+            L.shard_leaves = nl_loc;
+            L.va = mem.alloc(2 * len_loc);
+            L.vb = L.va + len_loc;
+            {
+                std::unique_ptr<PhaseTimer> t_fft(new PhaseTimer(ctx, "      perform final FFT " + std::to_string(len) + " (this rank's cosets)"));
+                ntt_lde_leaf_order(tables, cur_coef, L.va, degree_bits, rate_bits, 2, coset_first, coset_count, len);
+            }
+            t_fold.reset(new PhaseTimer(ctx, "      fold codewords in the commitment phase"));
+            L.heap = mem.alloc(2 * nl_loc * 4);
+            launch_leaf_hash_ext(ctx, L.va, L.vb, arity, nl_loc, L.heap + 4 * nl_loc);
+            launch_merkle_build(ctx, L.heap, nl_loc, cfg.cap_height - lw);
+            u64* d_cap = mem.alloc(len_cap * 4);
+            shard_all_gather(ctx, L.heap + 4 * cap_loc, d_cap, cap_loc * 32);
+            HIP_CHECK(hipMemcpyAsync(L.cap.data(), d_cap, len_cap * 32, hipMemcpyDeviceToHost, ctx->stream));
+        } else {
+            WorkScope ws(ctx, (li == 0 && degree_bits >= ab) ? 3 : 0);
+            if (li == 0 && degree_bits >= ab && ctx->acct.shardable) acct_exchange(ctx, len_cap * 32);
+            L.va = mem.alloc(2 * len);
+            L.vb = L.va + len;
+            {
+                std::unique_ptr<PhaseTimer> t_fft(li == 0 ? new PhaseTimer(ctx, "      perform final FFT " + std::to_string(len)) : nullptr);
+                ntt_coset_evaluate(tables, cur_coef, L.va, nullptr, cur_bits, 2, shift, false);
+            }
+            if (li == 0) t_fold.reset(new PhaseTimer(ctx, "      fold codewords in the commitment phase"));
+            L.heap = mem.alloc(2 * nleaves * 4);
+            launch_leaf_hash_ext(ctx, L.va, L.vb, arity, nleaves, L.heap + 4 * nleaves);
+            launch_merkle_build(ctx, L.heap, nleaves, cfg.cap_height);
+            HIP_CHECK(hipMemcpyAsync(L.cap.data(), L.heap + 4 * len_cap, len_cap * 32, hipMemcpyDeviceToHost, ctx->stream));
+        }
         HIP_CHECK(hipStreamSynchronize(ctx->stream));
         challenger_observe_cap(ch, L.cap.data(), L.cap.size() / 4);
         const Ext2 beta = challenger_get_ext(ch);
@@ -603,6 +704,8 @@ void open_and_prove(DeviceCtx* ctx, NttTables& tables, const OlaGpuConfig& cfg, 
     {
         std::vector<size_t> cur = xs;
         std::vector<std::vector<unsigned long long>> h_idx_all(layers.size());   // staging buffers live until the one sync below
+        std::vector<u64> shard_recv;          // first layer on the partition: every rank's records [rank][rows nq*arity*2 | paths nq*depth*4]
+        size_t shard_record = 0;
         for (size_t li = 0; li < layers.size(); li++) {
             unsigned long long* d_idx = (unsigned long long*)mem.alloc(nq);
             FriLayer& L = layers[li];
@@ -614,19 +717,51 @@ void open_and_prove(DeviceCtx* ctx, NttTables& tables, const OlaGpuConfig& cfg, 
             std::vector<unsigned long long>& h_idx = h_idx_all[li];
             h_idx.resize(nq);
             for (int r = 0; r < nq; r++) { cur[r] >>= L.arity_bits; h_idx[r] = cur[r]; }
+            lrows[li].resize((size_t)nq * arity * 2);
+            if (ldepth[li] > 0) lpaths[li].resize((size_t)nq * ldepth[li] * 4);
+            if (L.shard_leaves) {
+                // every rank gathers all queries at the local index (meaningful on the owner only); the records are all-gathered
+                // and each query is read from its owner's copy below
+                for (int r = 0; r < nq; r++) h_idx[r] = cur[r] % L.shard_leaves;
+                HIP_CHECK(hipMemcpyAsync(d_idx, h_idx.data(), nq * 8, hipMemcpyHostToDevice, ctx->stream));
+                const size_t rows_w = (size_t)nq * arity * 2, paths_w = (size_t)nq * std::max(ldepth[li], 0) * 4;
+                shard_record = rows_w + paths_w;
+                u64* d_send = mem.alloc(shard_record);
+                u64* d_recv = mem.alloc(shard_record * ctx->shard.world);
+                hipLaunchKernelGGL(gather_ext_leaves_kernel, dim3((unsigned)nq), dim3(64), 0, ctx->stream, L.va, L.vb, arity, d_idx, d_send);
+                if (ldepth[li] > 0)
+                    hipLaunchKernelGGL(gather_paths_kernel, dim3((unsigned)nq), dim3(((ldepth[li] * 4 + 63) / 64) * 64), 0, ctx->stream, L.heap,
+                                       L.shard_leaves, ldepth[li], d_idx, d_send + rows_w);
+                shard_all_gather(ctx, d_send, d_recv, shard_record * 8);
+                shard_recv.resize(shard_record * ctx->shard.world);
+                HIP_CHECK(hipMemcpyAsync(shard_recv.data(), d_recv, shard_recv.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+                continue;
+            }
+            if (li == 0 && ctx->acct.shardable && ctx->shard.world <= 1) acct_exchange(ctx, ((size_t)nq * arity * 2 + (size_t)nq * std::max(ldepth[li], 0) * 4) * 8 * 8);
             HIP_CHECK(hipMemcpyAsync(d_idx, h_idx.data(), nq * 8, hipMemcpyHostToDevice, ctx->stream));
             u64* d_rows = mem.alloc((size_t)nq * arity * 2);
             hipLaunchKernelGGL(gather_ext_leaves_kernel, dim3((unsigned)nq), dim3(64), 0, ctx->stream, L.va, L.vb, arity, d_idx, d_rows);
-            lrows[li].resize((size_t)nq * arity * 2);
             HIP_CHECK(hipMemcpyAsync(lrows[li].data(), d_rows, lrows[li].size() * 8, hipMemcpyDeviceToHost, ctx->stream));
             if (ldepth[li] > 0) {
                 u64* d_paths = mem.alloc((size_t)nq * ldepth[li] * 4);
                 hipLaunchKernelGGL(gather_paths_kernel, dim3((unsigned)nq), dim3(((ldepth[li] * 4 + 63) / 64) * 64), 0, ctx->stream, L.heap,
                                    nleaves, ldepth[li], d_idx, d_paths);
-                lpaths[li].resize((size_t)nq * ldepth[li] * 4);
                 HIP_CHECK(hipMemcpyAsync(lpaths[li].data(), d_paths, lpaths[li].size() * 8, hipMemcpyDeviceToHost, ctx->stream));
             }
         }
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        if (!shard_recv.empty()) {
+            const FriLayer& L = layers[0];
+            const int arity = 1 << L.arity_bits, dep = std::max(ldepth[0], 0);
+            const size_t rows_w = (size_t)nq * arity * 2;
+            for (int r = 0; r < nq; r++) {
+                const size_t leaf = xs[r] >> L.arity_bits, owner = leaf / L.shard_leaves;
+                const u64* rec = shard_recv.data() + owner * shard_record;
+                std::copy(rec + (size_t)r * arity * 2, rec + (size_t)(r + 1) * arity * 2, lrows[0].begin() + (size_t)r * arity * 2);
+                if (dep) std::copy(rec + rows_w + (size_t)r * dep * 4, rec + rows_w + (size_t)(r + 1) * dep * 4, lpaths[0].begin() + (size_t)r * dep * 4);
+            }
+        }
+        (void)0;
         HIP_CHECK(hipStreamSynchronize(ctx->stream));
     }
 

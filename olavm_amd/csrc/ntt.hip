@@ -222,6 +222,8 @@ struct NttTables {
     std::map<std::pair<int, int>, TwoLevel> coset;   // (log_n, rate_bits) -> per-coset scale tables (blowup cosets)
     std::map<std::pair<int, u64>, TwoLevel> shift;   // (log_n, shift) -> s^k tables (single coset, arbitrary shift)
     std::map<std::tuple<int, int, int, u64>, const u64*> coset_steps;  // (log_n, rate_bits, e, shift) -> per-coset s^(2^e) (ntt2.hip)
+    // (log_n, rate_bits, lo/R/inverse, shift) -> per-coset pre-scale tables of a coset transform's first pass (ntt2.hip)
+    std::map<std::tuple<int, int, int, u64>, std::pair<const u64*, const u64*>> pre_tables;
 };
 
 static u64* upload(DeviceCtx* ctx, const std::vector<u64>& v) {
@@ -471,18 +473,20 @@ void ntt_evaluate(NttTables& t, const u64* coeffs, u64* values, u64* scratch, in
 // coefficients (natural, n per column) -> LDE on 7*<g>, in commitment leaf order: out[col][c*n + r] =
 // P(7 * g^bitrev(c) * w_n^bitrev_n(r)); equals natural LDE row bitrev_N(c*n + r).
 void ntt_lde_leaf_order(NttTables& t, const u64* coeffs, u64* lde, int L, int rate_bits, size_t cols, size_t coset_first,
-                        size_t coset_count) {
-    // cosets [coset_first, coset_first + coset_count) of the 2^rate_bits (leaf-order blocks of n); lde holds only those
+                        size_t coset_count, size_t in_col_stride = 0) {
+    // cosets [coset_first, coset_first + coset_count) of the 2^rate_bits (leaf-order blocks of n); lde holds only those.
+    // in_col_stride: distance between the coefficient columns (default n)
     const size_t n = (size_t)1 << L;
+    if (!in_col_stride) in_col_stride = n;
     if (L >= NTT2_MIN_LOG) {
-        ntt2_run(t, coeffs, n, lde, n * coset_count, nullptr, 0, L, cols, false, false, rate_bits, 0, coset_count, n, coset_first);
+        ntt2_run(t, coeffs, in_col_stride, lde, n * coset_count, nullptr, 0, L, cols, false, false, rate_bits, 0, coset_count, n, coset_first);
         return;
     }
     size_t stride = 0;
     TwoLevel sc = get_coset(t, L, rate_bits, &stride);
     sc.lo += coset_first * stride;
     sc.hi += coset_first * stride;
-    ntt_run(t, coeffs, n, lde, n * coset_count, nullptr, 0, L, cols, false, false, &sc, stride, coset_count, n, 1);
+    ntt_run(t, coeffs, in_col_stride, lde, n * coset_count, nullptr, 0, L, cols, false, false, &sc, stride, coset_count, n, 1);
 }
 void ntt_lde_leaf_order(NttTables& t, const u64* coeffs, u64* lde, int L, int rate_bits, size_t cols) {
     ntt_lde_leaf_order(t, coeffs, lde, L, rate_bits, cols, 0, (size_t)1 << rate_bits);

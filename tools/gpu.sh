@@ -7,6 +7,7 @@ for step in "$@"; do
   echo "=== $step"
   case $step in
     multi)       timeout 900 python -m pytest tests/test_gpu_multi.py -x -q 2>&1 | tail -15 | tee $O/pytest.log ;;
+    dist)        timeout 1200 python -m pytest tests/test_gpu_distributed.py tests/test_gpu_multi.py -x -q 2>&1 | tail -15 | tee $O/pytest.log ;;
     suite)       timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 | tee $O/pytest.log ;;
     smoke)       timeout 600 python -c 'import __graft_entry__ as g; g.smoke()' 2>&1 | tail -5 | tee $O/smoke.log ;;
     bench)       timeout 900 python bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err; tail -c 1500 $O/bench.json ;;
@@ -21,6 +22,18 @@ for step in "$@"; do
                    OLA_NTT2_GROUP_MB=$mb timeout 300 python bench.py --steps 20 --warmup 3 --no-prove --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('  ntt ms', d['ms_per_step'], 'frac', d['roofline']['frac'])"
                    OLA_NTT2_GROUP_MB=$mb timeout 300 python tools/bench_ntt_matrix.py --log-n 22 --cols 94 --reps 3 --out $O/m_$mb.json 2>&1 | grep -E "lde|intt|ntt" | cut -c1-120
                  done 2>&1 | tee $O/sweep.txt ;;
+    ntt_tests)   timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fullsize.py -x -q -k "ntt or lde or NTT or coset" 2>&1 | tail -8 | tee $O/pytest.log ;;
+    ntt_ab)      for lc in 1 4; do
+                   echo "-- OLA_NTT2_LAST_COLS=$lc"
+                   OLA_NTT2_LAST_COLS=$lc timeout 300 python bench.py --steps 20 --warmup 3 --no-prove --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('  ntt ms', d['ms_per_step'], 'frac', d['roofline']['frac'])"
+                   OLA_NTT2_LAST_COLS=$lc timeout 300 python tools/bench_ntt_matrix.py --log-n 20 22 --cols 94 --reps 5 --out $O/m_$lc.json 2>&1 | grep -E '"op"' | cut -c1-110
+                 done 2>&1 | tee $O/ab.txt ;;
+    lib_ab)      # same-box A/B of two builds of the library: ab_tmp/libola_<name>.so, alternating
+                 cp olavm_amd/lib/libola_gpu.so ab_tmp/libola_cur.so
+                 for v in ${AB_VARIANTS:-old new old new}; do cp ab_tmp/libola_$v.so olavm_amd/lib/libola_gpu.so; echo "-- $v"
+                   timeout 300 python bench.py --steps 30 --warmup 3 --no-prove --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('  ntt ms', d['ms_per_step'], 'frac', d['roofline']['frac'])"
+                   timeout 300 python tools/bench_ntt_matrix.py --log-n 22 --cols 94 --reps 5 --out $O/m_$v.json 2>&1 | grep -E '"op"' | cut -c1-110
+                 done 2>&1 | tee $O/ab.txt; cp ab_tmp/libola_cur.so olavm_amd/lib/libola_gpu.so ;;
     matrix)      timeout 1200 python tools/bench_ntt_matrix.py --out $O/ntt_matrix.json 2>&1 | tail -40 ;;
     prof_bench)  cd /tmp; timeout 900 rocprofv3 --kernel-trace --stats -d $R/$O/prof -o p -- python $R/bench.py --steps 20 --warmup 5 > $R/$O/bench.json 2> $R/$O/err.txt; cd $R
                  f=$(find $O/prof -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp "$f" $O/kernel_stats.csv && head -25 $O/kernel_stats.csv | cut -c1-160 ;;
