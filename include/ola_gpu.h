@@ -98,6 +98,25 @@ int32_t ola_gpu_memory_stats(OlaCtx* ctx, uint64_t out[4], int32_t reset);
  *           T(G) ~ out[0] - sum_k out[k] * (1 - 1/min(G, 2^k)) + out[4] * (G-1)/G / (xGMI rate) + out[5] * latency
  *   out[6], out[7]  multi-device context only: exchanges performed by the library's own all-gather and the bytes they moved. */
 int32_t ola_gpu_proof_stats(OlaCtx* ctx, int32_t enable, double out[8]);
+/* With the accounting on, the kernel families of the last proof one by one (Merkle leaves/s,
+ * permutations/s, FRI-fold bytes/s of a REAL proof): out[3*i .. 3*i+2] = device milliseconds and two unit counters of phase i.
+ *   OLA_PHASE_LEAF_HASH      hash invocations (sponge permutations / Blake3 compressions), bytes read + written
+ *   OLA_PHASE_MERKLE_LEVELS  inner nodes hashed (one permutation each under Poseidon), bytes read + written
+ *   OLA_PHASE_FRI_FOLD       bytes read + written, extension elements folded (fri/prover.rs:98-112)
+ *   OLA_PHASE_LDE            bytes read + written by the coset LDEs (8*n*(1 + cosets) per column), column-cosets
+ *   OLA_PHASE_INTT           bytes (16*n per column), columns
+ *   OLA_PHASE_QUOTIENT       LDE points evaluated, constraint-program length
+ *   OLA_PHASE_OPEN_EVAL      coefficient x point products, bytes read
+ * (hash/merkle_tree/mod.rs:180-266, fri/prover.rs:72-121, fri/oracle.rs:66-99).  On a multi-device context: rank 0's share. */
+#define OLA_PHASE_LEAF_HASH 0
+#define OLA_PHASE_MERKLE_LEVELS 1
+#define OLA_PHASE_FRI_FOLD 2
+#define OLA_PHASE_LDE 3
+#define OLA_PHASE_INTT 4
+#define OLA_PHASE_QUOTIENT 5
+#define OLA_PHASE_OPEN_EVAL 6
+#define OLA_PHASE_COUNT 7
+int32_t ola_gpu_phase_stats(OlaCtx* ctx, double* out /* 3 * n_phases */, uint32_t n_phases);
 /* Self-test of the device field arithmetic: the kernels' modular reduction is written with explicit carry chains in inline
  * assembly (olavm_amd/csrc/gl.cuh); this compares it with the plain C++ reduction on a table of edge values and on `pairs`
  * pseudo-random operand pairs and returns the number of disagreements (0 expected; about 10^9 pairs per 50 ms).  Meant to be

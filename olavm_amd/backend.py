@@ -64,6 +64,7 @@ def load_library():
     L.ola_gpu_init_multi.argtypes = [C.POINTER(OlaGpuConfig), C.POINTER(C.c_int32), C.c_uint32, C.POINTER(C.c_void_p)]
     L.ola_gpu_device_count.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
     L.ola_gpu_proof_stats.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_double)]
+    L.ola_gpu_phase_stats.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_uint32]
     L.ola_gpu_free.argtypes = [C.c_void_p]
     L.ola_gpu_sync.argtypes = [C.c_void_p]
     L.ola_ntt_batch.argtypes = [C.c_void_p, C.c_int32, U64P, U64P, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32]
@@ -127,7 +128,7 @@ EXPORTS = [
     "ola_air_kernels_available", "ola_commit_values_shard", "ola_commit_values_shard_dev", "ola_set_shard", "ola_gpu_trim", "ola_generate_poseidon_trace",
     "ola_permuted_cols", "ola_permuted_cols_dev", "ola_prove_single_table", "ola_take_pending_proof", "ola_gpu_memory_stats", "ola_gpu_selftest", "ola_gpu_reserve",
     "ola_table_shape", "ola_perm_z", "ola_ctl_z", "ola_quotient", "ola_set_shard_options", "ola_gpu_get_stream",
-    "ola_gpu_init_multi", "ola_gpu_device_count", "ola_gpu_proof_stats",
+    "ola_gpu_init_multi", "ola_gpu_device_count", "ola_gpu_proof_stats", "ola_gpu_phase_stats",
 ]
 
 
@@ -242,6 +243,15 @@ class Backend:
             self._chk(self.lib.ola_gpu_init_multi(C.byref(c), dv, len(devices), C.byref(self.ctx)))
         else:
             self._chk(self.lib.ola_gpu_init(C.byref(c), C.byref(self.ctx)))
+
+    PHASES = ("leaf_hash", "merkle_levels", "fri_fold", "lde", "intt", "quotient", "open_eval")
+
+    def phase_stats(self):
+        """ola_gpu_phase_stats of the last proof (accounting must be on): {phase: (ms, units0, units1)}."""
+        n = len(self.PHASES)
+        out = (C.c_double * (3 * n))()
+        self._chk(self.lib.ola_gpu_phase_stats(self.ctx, out, n))
+        return {name: (out[3 * i], out[3 * i + 1], out[3 * i + 2]) for i, name in enumerate(self.PHASES)}
 
     def device_count(self):
         n = C.c_uint32()

@@ -57,9 +57,13 @@ struct ShardInfo {
 // 2 cosets stops scaling at 2 GPUs).  Everything outside a scope -- interpolations, Z columns, FRI after the first layer, small
 // tables, launch gaps, host transcript -- is what every rank repeats.  exchange_bytes: the gathered payload of the exchanges a
 // sharded run performs (a rank receives (G-1)/G of it); counted on single-GPU runs too, so that one GPU can project G.
+// kernel families the accounting also times one by one (ola_gpu_phase_stats): device milliseconds + two unit counters each
+enum { PH_LEAF_HASH = 0, PH_MERKLE_LEVELS, PH_FRI_FOLD, PH_LDE, PH_INTT, PH_QUOTIENT, PH_OPEN_EVAL, PH_COUNT };
 struct WorkAcct {
     bool on = false;
-    struct Span { hipEvent_t a, b; int maxlog; };
+    struct Span { hipEvent_t a, b; int maxlog; };   // maxlog >= 100: a phase span, phase = maxlog - 100
+    double phase_ms[PH_COUNT] = {};
+    double phase_units[PH_COUNT][2] = {};
     std::vector<Span> spans;
     std::vector<hipEvent_t> spare;
     double sharded_ms[4] = {0, 0, 0, 0};   // [k]: work that divides by min(G, 2^k), k = 1..3
@@ -73,12 +77,16 @@ struct WorkAcct {
         if (hipEventCreate(&e) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
         return e;
     }
-    void begin_proof() { for (double& m : sharded_ms) m = 0; wall_ms = 0; exchange_bytes = 0; exchanges = 0; }
+    void begin_proof() {
+        for (double& m : sharded_ms) m = 0;
+        wall_ms = 0; exchange_bytes = 0; exchanges = 0;
+        for (int i = 0; i < PH_COUNT; i++) { phase_ms[i] = 0; phase_units[i][0] = phase_units[i][1] = 0; }
+    }
     // after the stream has been synchronised
     void collect() {
         for (Span& s : spans) {
             float ms = 0;
-            if (s.a && s.b && hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) sharded_ms[s.maxlog] += ms;
+            if (s.a && s.b && hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) { if (s.maxlog >= 100) phase_ms[s.maxlog - 100] += ms; else sharded_ms[s.maxlog] += ms; }
             else (void)hipGetLastError();
             if (s.a) spare.push_back(s.a);
             if (s.b) spare.push_back(s.b);
@@ -222,6 +230,25 @@ struct WorkScope {
         hipEvent_t b = ctx->acct.get();
         if (b && hipEventRecord(b, ctx->stream) != hipSuccess) { (void)hipGetLastError(); ctx->acct.spare.push_back(b); b = nullptr; }
         ctx->acct.spans.push_back({a, b, maxlog});
+    }
+};
+// Times one kernel family of a proof (WorkAcct::phase_ms) and counts what it processed; nests freely with WorkScope.
+struct PhaseScope {
+    DeviceCtx* ctx;
+    hipEvent_t a = nullptr;
+    int phase;
+    PhaseScope(DeviceCtx* c, int phase_, double units0, double units1 = 0) : ctx(c), phase(phase_) {
+        if (!ctx->acct.on) return;
+        ctx->acct.phase_units[phase][0] += units0;
+        ctx->acct.phase_units[phase][1] += units1;
+        a = ctx->acct.get();
+        if (a && hipEventRecord(a, ctx->stream) != hipSuccess) { (void)hipGetLastError(); ctx->acct.spare.push_back(a); a = nullptr; }
+    }
+    ~PhaseScope() {
+        if (!a) return;
+        hipEvent_t b = ctx->acct.get();
+        if (b && hipEventRecord(b, ctx->stream) != hipSuccess) { (void)hipGetLastError(); ctx->acct.spare.push_back(b); b = nullptr; }
+        ctx->acct.spans.push_back({a, b, 100 + phase});
     }
 };
 // an exchange of the partition: `gathered_bytes` = payload of all ranks together

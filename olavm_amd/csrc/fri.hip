@@ -516,6 +516,7 @@ void open_and_prove(DeviceCtx* ctx, NttTables& tables, const OlaGpuConfig& cfg, 
         if (!sharded) {
             {
                 WorkScope ws(ctx, 3);      // the partition divides the columns among the ranks
+                PhaseScope ph(ctx, PH_OPEN_EVAL, (double)n * (2 * W + 3 * Z + Q), (double)n * (W + 2 * Z + Q) * 8);
                 eval_batch_launch(mem, trace, 2, pz, pzn, &local, &next, jobs[0]);
                 eval_batch_launch(mem, zs, 2, pz, pzn, &zs_local, &zs_next, jobs[1]);
                 eval_batch_launch(mem, quot, 1, pz, pz, &q_local, &dummy, jobs[2]);
@@ -660,8 +661,11 @@ void open_and_prove(DeviceCtx* ctx, NttTables& tables, const OlaGpuConfig& cfg, 
         const Ext2 beta = challenger_get_ext(ch);
         const size_t out_len = len >> ab;
         u64* folded = mem.alloc(2 * out_len);
-        hipLaunchKernelGGL(fold_kernel, dim3((unsigned)((out_len + 255) / 256)), dim3(256), 0, ctx->stream, cur_coef, cur_coef + len, out_len,
-                           arity, beta, folded, folded + out_len);
+        {
+            PhaseScope ph(ctx, PH_FRI_FOLD, (double)(len + out_len) * 16, (double)len);
+            hipLaunchKernelGGL(fold_kernel, dim3((unsigned)((out_len + 255) / 256)), dim3(256), 0, ctx->stream, cur_coef, cur_coef + len, out_len,
+                               arity, beta, folded, folded + out_len);
+        }
         cur_coef = folded;
         len = out_len;
         shift = gl_pow(shift, (u64)arity);

@@ -331,8 +331,15 @@ static void require_leaf_width(size_t words) {
 // ---- host launchers ----
 void poseidon_init(DeviceCtx*) { poseidon_upload_constants(); }
 
+// hash invocations per leaf of `words` field elements: sponge permutations (rate 8), or Blake3 compressions (64-byte blocks,
+// plus the parent compressions of a multi-chunk leaf)
+static double leaf_hash_calls(const DeviceCtx* ctx, size_t words) {
+    if (ctx->hasher == 1) { const size_t blocks = (words * 8 + 63) / 64, chunks = (words * 8 + 1023) / 1024; return (double)(blocks + chunks - 1); }
+    return (double)((words + 7) / 8);
+}
 void launch_leaf_hash_colmajor(DeviceCtx* ctx, const u64* base, size_t col_stride, int ncols, size_t num_leaves,
                                u64* out) {
+    PhaseScope ph(ctx, PH_LEAF_HASH, (double)num_leaves * leaf_hash_calls(ctx, (size_t)ncols), (double)num_leaves * ((size_t)ncols * 8 + 32));
     if (is_b3(ctx)) {
         require_leaf_width((size_t)ncols);
         if (num_leaves) {
@@ -370,6 +377,7 @@ void launch_leaf_hash_rowmajor(DeviceCtx* ctx, const u64* rows, size_t row_len, 
     hipLaunchKernelGGL(leaf_hash_rowmajor_kernel, dim3(blocks), dim3(256), 0, ctx->stream, rows, row_len, num_leaves, out);
 }
 void launch_leaf_hash_ext(DeviceCtx* ctx, const u64* pa, const u64* pb, int arity, size_t num_leaves, u64* out) {
+    PhaseScope ph(ctx, PH_LEAF_HASH, (double)num_leaves * leaf_hash_calls(ctx, (size_t)(2 * arity)), (double)num_leaves * ((size_t)arity * 16 + 32));
     if (is_b3(ctx)) {
         require_leaf_width((size_t)(2 * arity));
         if (num_leaves) {
@@ -391,6 +399,7 @@ void launch_leaf_hash_ext(DeviceCtx* ctx, const u64* pa, const u64* pb, int arit
 // nothing above the cap is ever hashed
 void launch_merkle_build(DeviceCtx* ctx, u64* heap, size_t num_leaves, uint32_t cap_height) {
     const size_t last = (size_t)1 << cap_height, top = 256;   // levels of <= `top` nodes share one launch (1024 threads)
+    PhaseScope ph(ctx, PH_MERKLE_LEVELS, num_leaves > last ? (double)(num_leaves - last) : 0.0, num_leaves > last ? (double)(num_leaves - last) * 96 : 0.0);
     size_t level = num_leaves / 2;
     if (is_b3(ctx)) {
         for (; level >= last && level > top; level /= 2)

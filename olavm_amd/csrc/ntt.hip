@@ -461,6 +461,7 @@ static const int NTT2_MIN_LOG = 14;
 // values (natural) -> coefficients (natural), per column.  scratch must hold cols * 2^L elements when L > 13.
 void ntt_interpolate(NttTables& t, const u64* values, u64* coeffs, u64* scratch, int L, size_t cols) {
     const size_t n = (size_t)1 << L;
+    PhaseScope ph(t.ctx, PH_INTT, (double)cols * n * 16, (double)cols);
     if (L >= NTT2_MIN_LOG) { ntt2_run(t, values, n, coeffs, n, scratch, n, L, cols, true, true, -2, 0, 1, 0); return; }
     ntt_run(t, values, n, coeffs, n, scratch, n, L, cols, true, true, nullptr, 0, 1, 0, 1);
 }
@@ -478,6 +479,7 @@ void ntt_lde_leaf_order(NttTables& t, const u64* coeffs, u64* lde, int L, int ra
     // in_col_stride: distance between the coefficient columns (default n)
     const size_t n = (size_t)1 << L;
     if (!in_col_stride) in_col_stride = n;
+    PhaseScope ph(t.ctx, PH_LDE, (double)cols * n * 8 * (1 + coset_count), (double)cols * coset_count);
     if (L >= NTT2_MIN_LOG) {
         ntt2_run(t, coeffs, in_col_stride, lde, n * coset_count, nullptr, 0, L, cols, false, false, rate_bits, 0, coset_count, n, coset_first);
         return;

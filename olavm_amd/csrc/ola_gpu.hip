@@ -754,6 +754,18 @@ int32_t ola_gpu_proof_stats(OlaCtx* ctx, int32_t enable, double out[8]) {
     OLA_CATCH
 }
 
+int32_t ola_gpu_phase_stats(OlaCtx* ctx, double* out, uint32_t n_phases) {
+    OLA_TRY
+    require(ctx && out, "null pointer");
+    const WorkAcct& a = ctx->dev.acct;
+    for (uint32_t i = 0; i < n_phases; i++) {
+        out[3 * i] = i < PH_COUNT ? a.phase_ms[i] : 0;
+        out[3 * i + 1] = i < PH_COUNT ? a.phase_units[i][0] : 0;
+        out[3 * i + 2] = i < PH_COUNT ? a.phase_units[i][1] : 0;
+    }
+    OLA_CATCH
+}
+
 int32_t ola_set_shard_options(OlaCtx* ctx, uint32_t flags) {
     OLA_TRY
     require(ctx, "ctx");

@@ -13,7 +13,7 @@ from olavm_amd.backend import Backend  # noqa: E402
 blob = T.ola_stark().blob()
 traces, params, compress = tracegen.empty_program_instance(log_n=10, range_bits=16, limb_bits=8, log_n_cpu=log_n, log_n_mem=log_n)
 t0 = time.perf_counter()
-be = Backend(device=0)
+be = Backend(device=0, hasher=os.environ.get("OLA_HASHER", "poseidon"))
 print("[cold] ola_gpu_init %.3f s" % (time.perf_counter() - t0), file=sys.stderr, flush=True)
 for i in range(3):
     print("[cold] ---- proof %d ----" % i, file=sys.stderr, flush=True)

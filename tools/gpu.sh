@@ -34,6 +34,8 @@ for step in "$@"; do
                    timeout 300 python bench.py --steps 30 --warmup 3 --no-prove --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('  ntt ms', d['ms_per_step'], 'frac', d['roofline']['frac'])"
                    timeout 300 python tools/bench_ntt_matrix.py --log-n 22 --cols 94 --reps 5 --out $O/m_$v.json 2>&1 | grep -E '"op"' | cut -c1-110
                  done 2>&1 | tee $O/ab.txt; cp ab_tmp/libola_cur.so olavm_amd/lib/libola_gpu.so ;;
+    pmc)         bash tools/pmc_ntt.sh r03 2>&1 | tail -30 ;;
+    cold_b3)     OLA_HASHER=blake3 timeout 300 python tools/cold_phases.py 22 2> $O/cold_b3.txt >/dev/null; grep "\[cold\]" $O/cold_b3.txt ;;
     matrix)      timeout 1200 python tools/bench_ntt_matrix.py --out $O/ntt_matrix.json 2>&1 | tail -40 ;;
     prof_bench)  cd /tmp; timeout 900 rocprofv3 --kernel-trace --stats -d $R/$O/prof -o p -- python $R/bench.py --steps 20 --warmup 5 > $R/$O/bench.json 2> $R/$O/err.txt; cd $R
                  f=$(find $O/prof -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp "$f" $O/kernel_stats.csv && head -25 $O/kernel_stats.csv | cut -c1-160 ;;

@@ -20,11 +20,13 @@ def source_hash():
     return h.hexdigest()[:16]
 
 
-def main():
-    src, dst = sys.argv[1], sys.argv[2]
+COUNTERS = ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU", "TCC_HIT_sum", "TCC_MISS_sum")
+
+
+def collect(src, prefix=""):
     per = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
-    for ctr in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU"):
-        files = glob.glob(os.path.join(src, ctr, "**", "*counter_collection.csv"), recursive=True)
+    for ctr in COUNTERS:
+        files = glob.glob(os.path.join(src, prefix + ctr, "**", "*counter_collection.csv"), recursive=True)
         if not files:
             continue
         for r in csv.DictReader(open(files[0])):
@@ -36,12 +38,36 @@ def main():
     kernels = {}
     for k, c in per.items():
         kernels[k] = {ctr: {"dispatches": n, "per_dispatch": v / n} for ctr, (n, v) in c.items()}
+    return kernels
+
+
+def pass_totals(kernels, names):
+    """FETCH / WRITE (KiB) and L2 hits / misses summed over the NTT pass kernels, per 94 x 2^22 transform"""
+    passes = {k: v for k, v in kernels.items() if any(nm in k for nm in names) and "WRITE_SIZE" in v}
+    tot = {c: sum(v[c]["per_dispatch"] * v[c]["dispatches"] for v in passes.values() if c in v) for c in COUNTERS}
+    return passes, tot
+
+
+def main():
+    src, dst = sys.argv[1], sys.argv[2]
+    kernels = collect(src)
     n, cols = 1 << 22, 94
     elems = n * cols
     # the 2^22 natural-order transform is two strided 7-bit passes and the closing natural-order 8-bit pass
     names = ("ntt2_pass_kernel<7, 0, false, 4, false>", "ntt2_pass_kernel_w4<7, 0, false, 4>", "ntt2_pass_kernel<7, 0, false, 8, false>",
-             "ntt2_pass_kernel_w4<7, 0, false, 8>", "ntt2_pass_kernel<8, 2, false, 1, false>")
-    passes = {k: v for k, v in kernels.items() if any(nm in k for nm in names) and "WRITE_SIZE" in v}
+             "ntt2_pass_kernel_w4<7, 0, false, 8>", "ntt2_pass_kernel<8, 2, false, 1, false>", "ntt2_pass_kernel<8, 2, false, 4, false>")
+    passes, tot = pass_totals(kernels, names)
+    g_kernels = collect(src, "G96_")
+    g_passes, g_tot = pass_totals(g_kernels, names)
+    g_launches = sum(v["WRITE_SIZE"]["dispatches"] for v in g_passes.values())
+
+    def per_transform(t, transforms):
+        if not transforms:
+            return None
+        hit, miss = t.get("TCC_HIT_sum", 0), t.get("TCC_MISS_sum", 0)
+        return {"fetch_x2_plus_write_bytes": (2 * t["FETCH_SIZE"] + t["WRITE_SIZE"]) * 1024 / transforms,
+                "TCC_HIT_sum": hit / transforms, "TCC_MISS_sum": miss / transforms,
+                "l2_hit_rate": hit / (hit + miss) if hit + miss else None}
     launches = sum(v["WRITE_SIZE"]["dispatches"] for v in passes.values())
     fetch = sum(v["FETCH_SIZE"]["per_dispatch"] * v["FETCH_SIZE"]["dispatches"] for v in passes.values() if "FETCH_SIZE" in v)
     write = sum(v["WRITE_SIZE"]["per_dispatch"] * v["WRITE_SIZE"]["dispatches"] for v in passes.values())
@@ -59,6 +85,13 @@ def main():
             "algorithmic_bytes_per_launch": 16.0 * elems / 3,
             "valu_wave_insts_per_transform": valu / transforms if transforms else None,
             "valu_insts_per_element": valu * 64 / (transforms * elems) if transforms else None,
+        },
+        "infinity_cache_blocking_experiment": {
+            "what": "the same 3 transforms launched over the whole batch (group 0) and in column groups of 96 MB (OLA_NTT2_GROUP_MB=96: all three "
+                    "passes of a group back to back, so that a pass could read its predecessor's output from the 256 MiB Infinity Cache)",
+            "whole_batch_per_transform": per_transform(tot, transforms),
+            "groups_of_96MB_per_transform": per_transform(g_tot, 3.0 if g_launches else 0),
+            "groups_of_96MB_launches": g_launches,
         },
         "calibration": {
             "leaf_hash_colmajor_kernel": {"algorithmic_read_kib": 94 * (1 << 22) * 8 / 1024,
