@@ -33,6 +33,11 @@
 extern "C" {
 #endif
 
+/* ABI revision of this header.  3: OlaChallenger carries `hasher` + `reserved` (sizeof 240, was 232 in revision 1) and
+ * OlaGpuConfig.hasher occupies what was tail padding (sizeof unchanged, but the field must be set: zero-initialise the struct);
+ * multi-device contexts and the accounting entry points were added.  A host built against an older header must be rebuilt:
+ * ola_gpu_abi_version() lets it check at start-up that library and header agree (also on sizeof(OlaChallenger)). */
+#define OLA_GPU_ABI_VERSION 3
 #define OLA_OK 0
 #define OLA_E_INVALID_ARG (-1)
 #define OLA_E_NO_DEVICE (-2)
@@ -75,6 +80,9 @@ int32_t ola_gpu_init(const OlaGpuConfig* cfg, OlaCtx** out_ctx);
  * single-device context.  Entries of devices[] may repeat (logical ranks sharing a GPU: how the one-GPU test box exercises the
  * path).  cfg->device is ignored, cfg->stream must be NULL when n_devices > 1.  Needs peer access between the devices
  * (OLA_E_HIP otherwise). */
+/* OLA_GPU_ABI_VERSION of the library that was loaded; *challenger_size / *config_size (may be NULL) receive its sizeof(OlaChallenger)
+ * and sizeof(OlaGpuConfig). */
+int32_t ola_gpu_abi_version(size_t* challenger_size, size_t* config_size);
 int32_t ola_gpu_init_multi(const OlaGpuConfig* cfg, const int32_t* devices, uint32_t n_devices, OlaCtx** out_ctx);
 int32_t ola_gpu_device_count(OlaCtx* ctx, uint32_t* n_devices);
 int32_t ola_gpu_free(OlaCtx* ctx);

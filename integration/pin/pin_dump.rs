@@ -60,7 +60,38 @@ fn write_traces(path: &PathBuf, traces: &[Vec<PolynomialValues<F>>; NUM_TABLES],
     }
 }
 
+/// <name>.diag: what a first mismatch is diagnosed with in ONE run (compare_with_dump.py reads it): the reference's own
+/// cross-table-lookup challenges (get_challenges.rs:23-33) and the three Merkle caps of every table, hex of write_merkle_cap.
+fn write_diag(path: &PathBuf, proof: &crate::stark::proof::AllProof<F, C, D>, ola_stark: &OlaStark<F, D>, config: &StarkConfig) {
+    let ch = proof.get_challenges(ola_stark, config);
+    let mut s = String::from("OLADIAG01\n");
+    for c in ch.ctl_challenges.challenges.iter() {
+        s += &format!("ctl_challenge {} {}\n", c.beta.to_canonical_u64(), c.gamma.to_canonical_u64());
+    }
+    for (i, p) in proof.stark_proofs.iter().enumerate() {
+        for (name, cap) in [("trace_cap", &p.trace_cap), ("zs_cap", &p.permutation_ctl_zs_cap), ("quotient_cap", &p.quotient_polys_cap)] {
+            let mut b = Buffer::new(Vec::new());
+            b.write_merkle_cap(cap).unwrap();
+            let hex: String = b.bytes().iter().map(|x| format!("{:02x}", x)).collect();
+            s += &format!("table {} {} {}\n", i, name, hex);
+        }
+    }
+    File::create(path).unwrap().write_all(s.as_bytes()).unwrap();
+}
+
 fn dump_one(file_name: &str, call_data: Option<Vec<GoldilocksField>>) {
+    dump_named(file_name.trim_end_matches(".json"), file_name, call_data);
+}
+
+/// Runs `file_name` and returns the height (log2 rows) of the CPU table its execution fills, without proving.
+fn cpu_table_bits(file_name: &str, call_data: Option<Vec<GoldilocksField>>) -> usize {
+    std::env::set_var("OLA_PIN_HEIGHT_ONLY", "1");
+    let bits = dump_named("_probe", file_name, call_data);
+    std::env::remove_var("OLA_PIN_HEIGHT_ONLY");
+    bits
+}
+
+fn dump_named(stem: &str, file_name: &str, call_data: Option<Vec<GoldilocksField>>) -> usize {
     let out_dir = PathBuf::from(std::env::var("OLA_PIN_DIR").unwrap_or_else(|_| "/tmp/ola_pin".to_string()));
     std::fs::create_dir_all(&out_dir).unwrap();
     // ---- exactly ola_stark.rs::test_by_asm_json up to generate_traces ----
@@ -113,6 +144,10 @@ fn dump_one(file_name: &str, call_data: Option<Vec<GoldilocksField>>) {
 
     let mut ola_stark = OlaStark::default();
     let (traces, public_values) = generate_traces(program, &mut ola_stark, GenerationInputs::default());
+    let cpu_bits = traces[0][0].values.len().trailing_zeros() as usize;
+    if std::env::var("OLA_PIN_HEIGHT_ONLY").is_ok() {
+        return cpu_bits;
+    }
     let config = StarkConfig::standard_fast_config();
     // the traces as the prover receives them; the compress challenges are read back from the proof below
     let traces_copy: [Vec<PolynomialValues<F>>; NUM_TABLES] = traces.clone();
@@ -120,7 +155,7 @@ fn dump_one(file_name: &str, call_data: Option<Vec<GoldilocksField>>) {
         .expect("prove (Blake3GoldilocksConfig)");
     let proof = prove_with_traces::<F, C, D>(&ola_stark, &config, traces, public_values, &mut TimingTree::default()).expect("prove");
 
-    let stem = file_name.trim_end_matches(".json");
+    write_diag(&out_dir.join(format!("{stem}.diag")), &proof, &OlaStark::default(), &config);
     write_traces(&out_dir.join(format!("{stem}.traces")), &traces_copy, &proof.compress_challenges);
     let mut buf = Buffer::new(Vec::new());
     buf.write_all_proof(&proof).unwrap();
@@ -135,6 +170,7 @@ fn dump_one(file_name: &str, call_data: Option<Vec<GoldilocksField>>) {
     let degree_bits = proof.degree_bits(&config);
     verify_proof(OlaStark::default(), proof, &config).expect("the reference verifier must accept its own proof");
     println!("pin_dump: {stem}: table heights 2^{:?}, {} proof bytes", degree_bits, buf.len());
+    cpu_bits
 }
 
 #[test]
@@ -146,4 +182,13 @@ fn pin_dump() {
     dump_one("memory.json", None);
     dump_one("fib_asm.json", Some(words(&[10, 1, 2, 4185064725])));
     dump_one("sqrt_prophet_asm.json", Some(words(&[144, 10, 2, 3509365327])));
+    // BASELINE config 1: the Fibonacci program at a 2^12-row CPU table.  The loop count that fills 2^12 rows is found by running
+    // the executor (no proving) with doubling counts; the dump is then made at that count.
+    let mut loops = 16u64;
+    while cpu_table_bits("fib_asm.json", Some(words(&[loops, 1, 2, 4185064725]))) < 12 && loops < (1 << 20) {
+        loops *= 2;
+    }
+    assert_eq!(cpu_table_bits("fib_asm.json", Some(words(&[loops, 1, 2, 4185064725]))), 12, "no loop count gives a 2^12-row CPU table");
+    println!("pin_dump: fib_asm with {loops} iterations fills a 2^12-row CPU table");
+    dump_named("fib_asm_2p12", "fib_asm.json", Some(words(&[loops, 1, 2, 4185064725])));
 }

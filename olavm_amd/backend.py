@@ -61,6 +61,10 @@ def load_library():
     L = C.CDLL(p)
     L.ola_gpu_last_error.restype = C.c_char_p
     L.ola_gpu_init.argtypes = [C.POINTER(OlaGpuConfig), C.POINTER(C.c_void_p)]
+    L.ola_gpu_abi_version.argtypes = [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+    a, b = C.c_size_t(), C.c_size_t()
+    if L.ola_gpu_abi_version(C.byref(a), C.byref(b)) != 3 or a.value != C.sizeof(OlaChallenger) or b.value != C.sizeof(OlaGpuConfig):
+        raise OlaGpuError(-7, "libola_gpu.so and olavm_amd/backend.py disagree on the ABI revision or struct sizes: rebuild the library")
     L.ola_gpu_init_multi.argtypes = [C.POINTER(OlaGpuConfig), C.POINTER(C.c_int32), C.c_uint32, C.POINTER(C.c_void_p)]
     L.ola_gpu_device_count.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
     L.ola_gpu_proof_stats.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_double)]
@@ -128,7 +132,7 @@ EXPORTS = [
     "ola_air_kernels_available", "ola_commit_values_shard", "ola_commit_values_shard_dev", "ola_set_shard", "ola_gpu_trim", "ola_generate_poseidon_trace",
     "ola_permuted_cols", "ola_permuted_cols_dev", "ola_prove_single_table", "ola_take_pending_proof", "ola_gpu_memory_stats", "ola_gpu_selftest", "ola_gpu_reserve",
     "ola_table_shape", "ola_perm_z", "ola_ctl_z", "ola_quotient", "ola_set_shard_options", "ola_gpu_get_stream",
-    "ola_gpu_init_multi", "ola_gpu_device_count", "ola_gpu_proof_stats", "ola_gpu_phase_stats",
+    "ola_gpu_abi_version", "ola_gpu_init_multi", "ola_gpu_device_count", "ola_gpu_proof_stats", "ola_gpu_phase_stats",
 ]
 
 

@@ -81,8 +81,10 @@ GL_HD u64 gl_reduce128(u64 lo, u64 hi) { return gl_canon(gl_reduce128_weak(lo, h
 // wait states hipcc itself puts between a VALU write of an SGPR / VCC and a VALU read of it as carry or select mask on gfx950.
 // Measured (tests/gpu_glasm_selftest.cpp, 256 CUs): 2.63 T modular multiplications per second against 1.80 T for the C++ form;
 // 4 * 10^9 random and 45 k edge-case operand pairs agree.  The optimiser cannot see through them: keep the C++ form wherever it
-// can simplify.  OLA_GL_NO_ASM selects the C++ forms everywhere.
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(OLA_GL_NO_ASM)
+// can simplify.  OLA_GL_NO_ASM selects the C++ forms everywhere.  The chains assume wave64 lane masks in SGPR pairs, the gfx9 VOP3
+// carry encodings and gfx950's wait-state rules: they are compiled for gfx950 only (this library's one target); any other
+// --offload-arch gets the C++ forms, and ola_gpu_selftest compares the two on the device.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(OLA_GL_NO_ASM) && defined(__gfx950__)
 #define OLA_GL_ASM 1
 // t0 = lo - hh (mod p as a wrapped u64: p is added back when the subtraction borrowed), then t0 + hl * (2^32 - 1) as a
 // wrapped u64 plus its carry-out in `carry` (an SGPR lane mask).

