@@ -72,6 +72,15 @@ public:
         g.num_query_rounds = c.num_query_rounds; g.num_challenges = c.num_challenges; g.hasher = c.hasher;
         check(ola_gpu_init(&g, &ctx_));
     }
+    // One context spanning several GPUs of the node (ola_gpu_init_multi): prove_with_traces then runs on all of them in one call.
+    explicit Gpu(const std::vector<int32_t>& devices, const StarkConfig& c = StarkConfig::standard_fast_config()) : config(c) {
+        OlaGpuConfig g{};
+        g.device = -1; g.stream = nullptr; g.rate_bits = c.rate_bits; g.cap_height = c.cap_height;
+        g.proof_of_work_bits = c.proof_of_work_bits; g.fri_arity_bits = c.fri_arity_bits; g.fri_final_poly_bits = c.fri_final_poly_bits;
+        g.num_query_rounds = c.num_query_rounds; g.num_challenges = c.num_challenges; g.hasher = c.hasher;
+        check(ola_gpu_init_multi(&g, devices.data(), (uint32_t)devices.size(), &ctx_));
+    }
+    uint32_t device_count() const { uint32_t n = 0; check(ola_gpu_device_count(ctx_, &n)); return n; }
     ~Gpu() { if (ctx_) ola_gpu_free(ctx_); }
     Gpu(const Gpu&) = delete;
     Gpu& operator=(const Gpu&) = delete;

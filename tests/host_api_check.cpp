@@ -172,6 +172,11 @@ int main(int argc, char** argv) {
         bool threw = false;
         try { auto bad = airset; bad[0] ^= 1; (void)prove_with_traces(gpu, bad, traces, log_n, sec[3], sec[4]); } catch (const Error&) { threw = true; }
         EXPECT(threw);
+        {   // the same call on ONE context that spans two (logical) GPUs: same bytes (ola_gpu_init_multi, SURVEY 8(b) Threading)
+            Gpu two(std::vector<int32_t>{0, 0});
+            EXPECT(two.device_count() == 2);
+            EXPECT(prove_with_traces(two, airset, traces, log_n, sec[3], sec[4]) == proof);
+        }
 
         // the same proof with the reference's own orchestration (prover.rs:79-327): commit every trace, observe the caps, draw
         // the CTL challenges, prove table by table on the shared challenger, concatenate

@@ -15,6 +15,7 @@ for step in "$@"; do
     stats)       timeout 600 python tools/proof_stats.py --out $O/proof_stats.json 2>&1 | tail -8 ;;
     stats_real)  timeout 600 python tools/proof_stats.py --real --out $O/proof_stats_real.json 2>&1 | tail -8 ;;
     stats_multi) timeout 600 python tools/proof_stats.py --log-n 20 --devices 0 0 0 0 0 0 0 0 --out $O/proof_stats.json 2>&1 | tail -8 ;;
+    stats_multi22) timeout 900 python tools/proof_stats.py --log-n 22 --devices 0 0 0 0 0 0 0 0 --out $O/proof_stats.json 2>&1 | tail -8 ;;
     phases)      OLA_TIMING=1 timeout 600 python tools/bench_prove.py 22 2 2> $O/phases.txt | tail -3; OLA_HASHER=blake3 OLA_TIMING=1 timeout 600 python tools/bench_prove.py 22 2 2> $O/phases_blake3.txt | tail -3 ;;
     ntt_group)   # Infinity-Cache blocking of the transforms: working-set target in MB (0 = whole batch per launch)
                  for mb in 0 32 64 96 128 192; do
