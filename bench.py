@@ -54,6 +54,30 @@ def cpu_baseline(log_n, seconds_budget=20.0):
             "sample": f"{cols} columns x 2^{log_n} forward NTT (oracle evaluate_poly, OpenMP over columns) in {dt:.2f}s"}
 
 
+def cpu_baseline_prove(be, log_n=12):
+    """The CPU prove-time leg of the baseline: the oracle's prover (a port of circuits::stark::prover::prove_with_traces, NOT the
+    reference itself -- no Rust toolchain here) on the host cores, bounded to the 12-table instance with every large table at
+    2^log_n rows (BASELINE config 1's size; 10 - 20 s of CPU work), next to the GPU proving the identical instance; the bytes are
+    compared.  The oracle is timed here as the baseline and used as the checker, nothing it computes is shipped."""
+    import numpy as np
+    from olavm_amd.air import ola_tables as T
+    from tests import oracle_lib, tracegen
+    o = oracle_lib.load()
+    blob = T.ola_stark(range_bits=4, limb_bits=2).blob()
+    traces, params, compress = tracegen.empty_program_instance(log_n=log_n, live=np.random.default_rng(12))
+    t0 = time.perf_counter()
+    want = o.prove_with_traces(blob, traces, params, compress)
+    cpu_s = time.perf_counter() - t0
+    be.prove_with_traces(blob, traces, params, compress)
+    t0 = time.perf_counter()
+    got = be.prove_with_traces(blob, traces, params, compress)
+    gpu_s = time.perf_counter() - t0
+    return {"cpu_seconds": round(cpu_s, 2), "gpu_seconds": round(gpu_s, 4), "ratio": round(cpu_s / max(gpu_s, 1e-9), 1), "kind": "port",
+            "identical_bytes": bool(got == want), "proof_bytes": len(got),
+            "sample": f"prove_with_traces, 12 tables, heights 2^{[int(t.shape[1]).bit_length() - 1 for t in traces]} (miniature fixed tables), "
+                      "oracle prover (OpenMP) on the host cores vs one MI355X, same traces"}
+
+
 def pmc_record(log_n, cols):
     """HBM bytes per launch and VALU instructions per element of the NTT pass kernels from the rocprofv3 PMC record
     profiles/r03_ntt_pmc.json (tools/pmc_ntt.sh: FETCH_SIZE with the gfx950 x2 correction + WRITE_SIZE + SQ_INSTS_VALU, separate
@@ -758,6 +782,11 @@ def main():
                     res["prove_2p24_rows"] = {"error": repr(e)[:200]}
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(args.log_n)
+            if not args.no_prove:
+                try:
+                    res["cpu_baseline"]["prove"] = cpu_baseline_prove(be)
+                except Exception as e:      # noqa: BLE001 -- an extra: never at the price of the headline line
+                    res["cpu_baseline"]["prove"] = {"error": repr(e)[:200]}
         print(json.dumps(res), flush=True)
     if extras_hung:          # a collective of the extras never returned: the line is out, leave without touching NCCL again
         sys.stdout.flush()
