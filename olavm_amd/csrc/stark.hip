@@ -142,29 +142,48 @@ __device__ __forceinline__ u64 dev_lincol(const u64* __restrict__ d, u32& p, con
     return gl_add(s, d[p++]);
 }
 
-// CTL factor column: out[i] = filter(i) ? combine(i) : 1   (cross_table_lookup.rs:284-311)
-// One Z column per blockIdx.y: its descriptor starts at desc_all[offs[y]], its output at out_all + y*n.
+// CTL factor columns: out[i] = filter(i) ? combine(i) : 1   (cross_table_lookup.rs:284-311)
+// A table carries one Z column per (lookup side, challenge); the num_challenges columns of one side combine the SAME linear
+// combinations of trace columns with different (beta, gamma).  One blockIdx.y handles such a pair: descriptors at
+// desc_all[offs[pairs[2y]]] and desc_all[offs[pairs[2y+1]]] (equal indices: an unpaired column), outputs at out_all + index*n.
+// The trace cells and the linear combinations are read / evaluated once for both.
+__device__ __forceinline__ u64 dev_lincol_fast(const u64* __restrict__ d, u32& p, const u64* __restrict__ tab, size_t cs, size_t row) {
+    const u32 nt = (u32)d[p++];
+    u64 s = 0;
+    for (u32 i = 0; i < nt; i++) {
+        const u64 c = d[p++], f = d[p++];
+        const u64 v = gl_canon(tab[c * cs + row]);
+        s = gl_add(s, f == 1 ? v : gl_mul(v, f));          // the coefficient is uniform: no divergence; most are 1
+    }
+    return gl_add(s, d[p++]);
+}
 __global__ __launch_bounds__(256) void ctl_factor_kernel(const u64* __restrict__ trace, size_t n, const u64* __restrict__ desc_all,
-                                                         const u64* __restrict__ offs, u64* __restrict__ out_all,
+                                                         const u64* __restrict__ offs, const u64* __restrict__ pairs, u64* __restrict__ out_all,
                                                          unsigned* __restrict__ bad_filter) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const u64* __restrict__ desc = desc_all + offs[blockIdx.y];
-    u64* __restrict__ out = out_all + (size_t)blockIdx.y * n;
+    const u64 ya = pairs[2 * blockIdx.y], yb = pairs[2 * blockIdx.y + 1];
+    const u64* __restrict__ desc = desc_all + offs[ya];
+    const u64* __restrict__ descb = desc_all + offs[yb];
     u32 p = 0;
-    const u64 beta = desc[p++], gamma = desc[p++];
+    const u64 beta_a = desc[0], gamma_a = desc[1], beta_b = descb[0], gamma_b = descb[1];
+    p = 2;
     const u32 ncol = (u32)desc[p++];
     // combine = reduce_with_powers(evals, beta) + gamma = sum_k beta^k e_k + gamma
-    u64 acc = 0, bp = 1;
+    u64 acc_a = 0, acc_b = 0, bp_a = 1, bp_b = 1;
     for (u32 k = 0; k < ncol; k++) {
-        acc = gl_add(acc, gl_mul(bp, dev_lincol(desc, p, trace, n, i)));
-        bp = gl_mul(bp, beta);
+        const u64 e = dev_lincol_fast(desc, p, trace, n, i);
+        acc_a = gl_add(acc_a, k == 0 ? e : gl_mul(bp_a, e));
+        acc_b = gl_add(acc_b, k == 0 ? e : gl_mul(bp_b, e));
+        if (k + 1 < ncol) { bp_a = gl_mul(bp_a, beta_a); bp_b = gl_mul(bp_b, beta_b); }
     }
-    acc = gl_add(acc, gamma);
+    acc_a = gl_add(acc_a, gamma_a);
+    acc_b = gl_add(acc_b, gamma_b);
     u64 f = 1;
-    if (desc[p++]) f = dev_lincol(desc, p, trace, n, i);
+    if (desc[p++]) f = dev_lincol_fast(desc, p, trace, n, i);
     if (f > 1) atomicOr(bad_filter, 1u);  // cross_table_lookup.rs:303-305 panics "Non-binary filter?"
-    out[i] = (f == 1) ? acc : 1;
+    out_all[ya * n + i] = (f == 1) ? acc_a : 1;
+    if (yb != ya) out_all[yb * n + i] = (f == 1) ? acc_b : 1;
 }
 
 // permutation quotient column: out[i] = prod_inst (gamma + sum beta^k lhs_k) / prod_inst (gamma + sum beta^k rhs_k)
@@ -577,13 +596,28 @@ static void prove_single_table(DeviceCtx* ctx, NttTables& tables, const OlaGpuCo
     HIP_CHECK(hipMemsetAsync(d_bad_filter, 0, 8, ctx->stream));
     if (!ctl.empty() && !have_zs) {   // all CTL Z columns of the table in one launch per step
         std::vector<u64> offs(ctl_off.begin(), ctl_off.end());
-        u64* d_offs = mem.alloc(offs.size());
+        // the columns of one lookup side under the two challenges share their linear combinations: pair them (ctl_factor_kernel)
+        std::vector<u64> pairs;
+        {
+            std::vector<char> taken(ctl.size(), 0);
+            for (size_t a = 0; a < ctl.size(); a++) {
+                if (taken[a]) continue;
+                size_t b = a;
+                for (size_t c = a + 1; c < ctl.size(); c++)
+                    if (!taken[c] && ctl[c].twc == ctl[a].twc) { b = c; break; }
+                taken[a] = taken[b] = 1;
+                pairs.push_back(a); pairs.push_back(b);
+            }
+        }
+        u64* d_offs = mem.alloc(offs.size() + pairs.size());
+        u64* d_pairs = d_offs + offs.size();
         HIP_CHECK(hipMemcpyAsync(d_offs, offs.data(), offs.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+        HIP_CHECK(hipMemcpyAsync(d_pairs, pairs.data(), pairs.size() * 8, hipMemcpyHostToDevice, ctx->stream));
         u64* zc = zvals + (size_t)nperm * n;
-        hipLaunchKernelGGL(ctl_factor_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)ctl.size()), dim3(256), 0, ctx->stream, tv.vals, n, d_cd,
-                           d_offs, zc, d_bad_filter);
+        hipLaunchKernelGGL(ctl_factor_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)(pairs.size() / 2)), dim3(256), 0, ctx->stream, tv.vals, n, d_cd,
+                           d_offs, d_pairs, zc, d_bad_filter);
         product_scan_inclusive(ctx, zc, n, tot, ctl.size());
-        HIP_CHECK(hipStreamSynchronize(ctx->stream));   // offs is a stack-lifetime staging buffer
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));   // offs / pairs are stack-lifetime staging buffers
     }
     if (!ctl.empty() && !have_zs) {
         unsigned bad = 0;
