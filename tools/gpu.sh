@@ -38,6 +38,8 @@ for step in "$@"; do
     pmc)         bash tools/pmc_ntt.sh r03 2>&1 | tail -30 ;;
     cold_b3)     for w in ${WARM_ORDER:-1 0}; do echo "-- OLA_WARMUP=$w"; OLA_WARMUP=$w OLA_HASHER=blake3 timeout 300 python tools/cold_phases.py 22 2> $O/cold_b3_w$w.txt >/dev/null; grep "\[cold\]" $O/cold_b3_w$w.txt | head -4; done ;;
     lean24)      OLA_TIMING=1 timeout 600 python tools/bench_prove.py 24 2 2> $O/phases_2p24_lean.txt | tail -3 ;;
+    syncs)       timeout 1200 python -m pytest tests/test_gpu_stark.py tests/test_gpu_parity.py tests/test_gpu_multi.py tests/test_gpu_blake3.py tests/test_gpu_host_api.py -x -q 2>&1 | tail -3
+                 for i in 1 2; do OLA_HASHER=blake3 timeout 300 python tools/bench_prove.py 22 4 2>/dev/null | tail -2; timeout 300 python tools/bench_prove.py 10 6 2>/dev/null | tail -2; done ;;
     zcols)       timeout 900 python -m pytest tests/test_gpu_stark.py tests/test_gpu_multi.py -x -q 2>&1 | tail -3
                  OLA_HASHER=blake3 OLA_TIMING=1 timeout 300 python tools/bench_prove.py 22 2 2> $O/phases_b3.txt | tail -1; grep -E "permutation Z|prove_with_traces total" $O/phases_b3.txt | tail -14 | head -4 ;;
     matrix)      timeout 1200 python tools/bench_ntt_matrix.py --out $O/ntt_matrix.json 2>&1 | tail -40 ;;
