@@ -84,7 +84,7 @@ def pmc_record(log_n, cols):
     passes over the same 94 x 2^22 transform).  bench.py cannot run the profiler on itself; the record carries the hash of the
     kernel sources it was taken from and is used only while those sources are unchanged -- otherwise the fields are null."""
     import hashlib
-    path = os.path.join(ROOT, "profiles", "r02_ntt_pmc.json")
+    path = os.path.join(ROOT, "profiles", "r03_ntt_pmc.json")
     try:
         d = json.load(open(path))
         h = hashlib.sha256()
