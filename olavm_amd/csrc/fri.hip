@@ -318,7 +318,12 @@ static ExtPow make_ext_pow(DevBuf& mem, Ext2 z, int log_n) {
 // coset: every rank fills the records of its own queries, the records are all-gathered and each query is read from its
 // owner's copy (paths end at the owner's cap slice, which is a slice of the full cap).
 static void query_leaves(DeviceCtx* ctx, NttTables& tables, const OlaBatch& b, const size_t* xs, int nq, int depth, u64* rows_out, u64* paths_out) {
-    if (!b.is_shard()) { batch_get_leaves(ctx, b, xs, nq, rows_out, paths_out, &tables); return; }
+    if (!b.is_shard()) {
+        // what a partitioned run gathers here (records of nq queries from each of 8 ranks), counted for the one-GPU projection
+        if (ctx->acct.shardable && ctx->shard.world <= 1) acct_exchange(ctx, (size_t)nq * (b.ncols + (size_t)std::max(depth, 0) * 4) * 8 * 8);
+        batch_get_leaves(ctx, b, xs, nq, rows_out, paths_out, &tables);
+        return;
+    }
     const size_t n_loc = b.num_leaves(), first = (size_t)b.coset_first << b.log_n;
     const size_t dwords = (size_t)std::max(depth, 0) * 4, rec = b.ncols + dwords;
     const uint32_t world = ctx->shard.world;

@@ -28,6 +28,17 @@ def test_every_declared_symbol_is_exported(lib):
         assert hasattr(lib, name), name
 
 
+def test_abi_revision_and_struct_sizes(lib):
+    """ola_gpu_abi_version: the loaded library, the header and the ctypes structs agree (INTEGRATION.md "ABI revision")."""
+    from olavm_amd.backend import OlaChallenger, OlaGpuConfig
+    hdr = open(os.path.join(ROOT, "include", "ola_gpu.h")).read()
+    want = int(re.search(r"#define OLA_GPU_ABI_VERSION (\d+)", hdr).group(1))
+    a, b = C.c_size_t(), C.c_size_t()
+    assert lib.ola_gpu_abi_version(C.byref(a), C.byref(b)) == want == 3
+    assert a.value == C.sizeof(OlaChallenger) == 240 and b.value == C.sizeof(OlaGpuConfig)
+    assert lib.ola_gpu_abi_version(None, None) == want
+
+
 def test_no_cpu_fallback_without_device(lib):
     import torch
     if torch.cuda.is_available():

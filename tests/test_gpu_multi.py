@@ -104,3 +104,30 @@ def test_multi_device_context_other_entry_points_and_errors(small_instance):
         Backend(devices=[0, 0, 0])                    # 1, 2, 4 or 8
     with pytest.raises(OlaGpuError):
         Backend(devices=[0, 99])
+
+
+def test_partition_accounting_of_a_single_gpu_proof(small_instance):
+    """ola_gpu_proof_stats / ola_gpu_phase_stats on ONE GPU: the bracketed (dividable) kernel time is positive and below the wall
+    time, the exchanges a partitioned run would perform are counted (12 per table of 2^12 rows and more), the per-family counters add up to the instance (every leaf and node of every tree of the proof), and the
+    same proof on a 2-rank context reports exactly that many real exchanges."""
+    from olavm_amd.backend import Backend
+    blob, traces, params, compress = small_instance
+    be = Backend(device=0)
+    be.proof_stats(enable=True)
+    proof = be.prove_with_traces(blob, traces, params, compress)
+    st, ph = be.proof_stats(enable=False), be.phase_stats()
+    be.close()
+    sharded = st["sharded_ms_upto2"] + st["sharded_ms_upto4"] + st["sharded_ms_upto8"]
+    assert 0 < sharded < st["wall_ms"], st
+    on_partition = sum(1 for t in traces if t.shape[1] >= (1 << 12))
+    assert st["exchanges"] == 12 * on_partition and st["exchange_bytes"] > on_partition * (1 << 12) * 8, st
+    assert st["peer_exchanges"] == 0
+    ms, calls, byts = ph["leaf_hash"]
+    assert ms > 0 and calls > 0 and byts > 0
+    assert ph["merkle_levels"][1] > 0 and ph["lde"][0] > 0 and ph["quotient"][1] > 0 and ph["fri_fold"][0] > 0
+    two = Backend(devices=[0, 0])
+    two.proof_stats(enable=True)
+    assert two.prove_with_traces(blob, traces, params, compress) == proof
+    st2 = two.proof_stats()
+    two.close()
+    assert st2["peer_exchanges"] == st["exchanges"] == st2["exchanges"], (st, st2)

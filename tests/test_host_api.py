@@ -17,3 +17,15 @@ def test_host_layer_compiles_and_links_against_the_c_abi(tmp_path):
     # without its arguments it explains itself and exits before touching a device
     r = subprocess.run([exe], capture_output=True, text=True)
     assert r.returncode == 2 and "usage" in r.stdout
+
+
+def test_rank_barrier_of_the_multi_device_context(tmp_path):
+    """olavm_amd/csrc/peer_group.h on the host alone (tests/host_peer_group_check.cpp): 2 / 4 / 8 rank threads meet at the barrier
+    thousands of times without anybody running ahead; a rank that gives up releases the others with an error instead of a
+    deadlock, also when they arrive later; reset() makes the group usable again."""
+    here = os.path.dirname(os.path.abspath(__file__))
+    exe = os.path.join(str(tmp_path), "host_peer_group_check")
+    subprocess.check_call(["hipcc", "-O1", "-std=c++17", "-pthread", "-o", exe, os.path.join(here, "host_peer_group_check.cpp")],
+                          stderr=subprocess.DEVNULL)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "all ok" in r.stdout, r.stdout + r.stderr
