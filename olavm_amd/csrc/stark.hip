@@ -18,6 +18,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstdlib>
 #include <cstring>
@@ -1013,18 +1014,22 @@ class TraceUploader {
         th_ = std::thread([this] { run(); });
     }
     void wait(size_t t, uint32_t cols) {
+        const auto t0 = std::chrono::steady_clock::now();
         std::unique_lock<std::mutex> lk(mu_);
         cv_.wait(lk, [&] { return done_[t].load() >= cols || failed_; });
+        waited_ms_ += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         if (failed_) throw OlaError(OLA_E_HIP, "trace upload failed: " + error_);
     }
     void finish() {
         if (th_.joinable()) th_.join();
+        if (ctx_->timing) fprintf(stderr, "[ola-timing] trace upload: the proving thread waited %.3f ms for column groups; the uploader's first copy returned after %.3f ms\n", waited_ms_, first_copy_ms_);
         if (failed_) throw OlaError(OLA_E_HIP, "trace upload failed: " + error_);
     }
 
   private:
     struct Job { const u64* src; u64* dst; uint32_t ncols; size_t n; uint32_t chunk; };
     void run() {
+        const auto t_start = std::chrono::steady_clock::now();
         (void)hipSetDevice(ctx_->device);
         for (size_t t = 0; t < jobs_.size() && !cancel_.load(); t++) {
             const Job& j = jobs_[t];
@@ -1035,6 +1040,7 @@ class TraceUploader {
                 hipError_t e = hipMemcpyAsync(j.dst + (size_t)c0 * j.n, j.src + (size_t)c0 * j.n, (size_t)(c1 - c0) * j.n * 8,
                                               hipMemcpyDefault, stream_);
                 if (e == hipSuccess) e = hipStreamSynchronize(stream_);
+                if (first_copy_ms_ == 0) first_copy_ms_ = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
                 std::lock_guard<std::mutex> lk(mu_);
                 if (e != hipSuccess) { failed_ = true; error_ = hipGetErrorString(e); cv_.notify_all(); return; }
                 done_[t].store(c1);
@@ -1049,6 +1055,7 @@ class TraceUploader {
     std::mutex mu_;
     std::condition_variable cv_;
     std::atomic<bool> cancel_{false};
+    double waited_ms_ = 0, first_copy_ms_ = 0;      // OLA_TIMING: how long the prover waited for the upload / the first column group took
     bool failed_ = false;
     std::string error_;
     hipStream_t stream_ = nullptr;

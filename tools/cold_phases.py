@@ -15,7 +15,16 @@ blob = T.ola_stark().blob()
 t0 = time.perf_counter()
 be = Backend(device=0, hasher=os.environ.get("OLA_HASHER", "poseidon"))
 print("[cold] ola_gpu_init %.3f s" % (time.perf_counter() - t0), file=sys.stderr, flush=True)
+if os.environ.get("OLA_COLD_RESERVE"):
+    be.reserve(blob, [log_n, log_n, 18, 1, 16, 10, 10, 10, 10, 10, 10, 10])
 traces, params, compress = tracegen.empty_program_instance(log_n=10, range_bits=16, limb_bits=8, log_n_cpu=log_n, log_n_mem=log_n)
+if os.environ.get("OLA_COLD_PREHEAT"):
+    # is the first proof's excess the device coming out of idle?  keep it busy for a few hundred ms right before proof 0
+    t0, bad, calls = time.perf_counter(), 0, 0
+    while time.perf_counter() - t0 < 0.1 * int(os.environ["OLA_COLD_PREHEAT"]):
+        bad += be.selftest(1 << 30)
+        calls += 1
+    print("[cold] preheat: %d field self-tests, %d mismatches, %.3f s" % (calls, bad, time.perf_counter() - t0), file=sys.stderr, flush=True)
 for i in range(3):
     print("[cold] ---- proof %d ----" % i, file=sys.stderr, flush=True)
     t0 = time.perf_counter()

@@ -36,7 +36,9 @@ for step in "$@"; do
                    timeout 300 python tools/bench_ntt_matrix.py --log-n 22 --cols 94 --reps 5 --out $O/m_$v.json 2>&1 | grep -E '"op"' | cut -c1-110
                  done 2>&1 | tee $O/ab.txt; cp ab_tmp/libola_cur.so olavm_amd/lib/libola_gpu.so ;;
     pmc)         bash tools/pmc_ntt.sh r03 2>&1 | tail -30 ;;
-    cold_b3)     for w in ${WARM_ORDER:-1 0}; do echo "-- OLA_WARMUP=$w"; OLA_WARMUP=$w OLA_HASHER=blake3 timeout 300 python tools/cold_phases.py 22 2> $O/cold_b3_w$w.txt >/dev/null; grep "\[cold\]" $O/cold_b3_w$w.txt | head -4; done ;;
+    cold_preheat) OLA_COLD_PREHEAT=8 OLA_HASHER=blake3 timeout 300 python tools/cold_phases.py 22 2> $O/cold_b3_preheat.txt >/dev/null; grep "\[cold\]" $O/cold_b3_preheat.txt | head -8 ;;
+    cold_b3)     # one figure per call: only the first process on a fresh box sees a cold runtime (and, with luck, clean VRAM)
+                 OLA_HASHER=blake3 timeout 300 python tools/cold_phases.py 22 2> $O/cold_b3.txt >/dev/null; grep -E "\[cold\]|trace upload:" $O/cold_b3.txt | head -12 ;;
     lean24)      OLA_TIMING=1 timeout 600 python tools/bench_prove.py 24 2 2> $O/phases_2p24_lean.txt | tail -3 ;;
     syncs)       timeout 1200 python -m pytest tests/test_gpu_stark.py tests/test_gpu_parity.py tests/test_gpu_multi.py tests/test_gpu_blake3.py tests/test_gpu_host_api.py -x -q 2>&1 | tail -3
                  for i in 1 2; do OLA_HASHER=blake3 timeout 300 python tools/bench_prove.py 22 4 2>/dev/null | tail -2; timeout 300 python tools/bench_prove.py 10 6 2>/dev/null | tail -2; done ;;
