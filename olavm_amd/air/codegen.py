@@ -74,7 +74,7 @@ def num_emits(airset, t, num_challenges=2):
     return len(tab.emits) + 2 * tab.num_permutation_batches(num_challenges) + 2 * len(airset.ctl_jobs(t, num_challenges))
 
 
-SEGMENT_OPS = 96     # field operations between two code-motion barriers
+SEGMENT_OPS = 64     # field operations between two code-motion barriers
 
 
 def table_kernel(airset, t, name, num_challenges=2):

@@ -44,6 +44,27 @@ for step in "$@"; do
                  for i in 1 2; do OLA_HASHER=blake3 timeout 300 python tools/bench_prove.py 22 4 2>/dev/null | tail -2; timeout 300 python tools/bench_prove.py 10 6 2>/dev/null | tail -2; done ;;
     zcols)       timeout 900 python -m pytest tests/test_gpu_stark.py tests/test_gpu_multi.py -x -q 2>&1 | tail -3
                  OLA_HASHER=blake3 OLA_TIMING=1 timeout 300 python tools/bench_prove.py 22 2 2> $O/phases_b3.txt | tail -1; grep -E "permutation Z|prove_with_traces total" $O/phases_b3.txt | tail -14 | head -4 ;;
+    quot_ab)     # quotient-kernel variants (ab_tmp/libola_<v>.so): kernel-family block of the 2^22-row Blake3 proof
+                 cp olavm_amd/lib/libola_gpu.so ab_tmp/libola_cur.so
+                 for v in ${AB_VARIANTS:-seg96 seg48 seg160 seg256 seg96}; do cp ab_tmp/libola_$v.so olavm_amd/lib/libola_gpu.so; echo "-- $v"
+                   timeout 300 python - <<'PY'
+import sys, json
+sys.path.insert(0, ".")
+from olavm_amd.air import ola_tables as T, tracegen
+from olavm_amd.backend import Backend
+blob = T.ola_stark().blob()
+traces, params, compress = tracegen.empty_program_instance(log_n=10, range_bits=16, limb_bits=8, log_n_cpu=22, log_n_mem=22)
+be = Backend(device=0, hasher="blake3")
+be.proof_stats(enable=True)
+best = None
+for _ in range(4):
+    be.prove_with_traces(blob, traces, params, compress)
+    st, ph = be.proof_stats(), be.phase_stats()
+    if best is None or st["wall_ms"] < best[0]:
+        best = (st["wall_ms"], ph["quotient"][0])
+print("  wall %.1f ms, quotient kernels %.2f ms" % best)
+PY
+                 done 2>&1 | grep -v amdgpu | tee $O/ab.txt; cp ab_tmp/libola_cur.so olavm_amd/lib/libola_gpu.so ;;
     matrix)      timeout 1200 python tools/bench_ntt_matrix.py --out $O/ntt_matrix.json 2>&1 | tail -40 ;;
     prof_bench)  cd /tmp; timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof -o p -- python $R/bench.py --steps 20 --warmup 5 > $R/$O/bench.json 2> $R/$O/err.txt; cd $R
                  f=$(find $O/prof -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp "$f" $O/kernel_stats.csv && head -25 $O/kernel_stats.csv | cut -c1-160 ;;
