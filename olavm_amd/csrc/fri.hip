@@ -117,24 +117,30 @@ __global__ __launch_bounds__(256) void eval_points_kernel(const u64* __restrict_
             }
         }
     }
-    for (int p = 0; p < npoints; p++) {
+    // the accumulators are addressed with compile-time indices only (fully unrolled, the run-time conditions are uniform): a
+    // run-time index would put the whole array into scratch memory -- it did until round 3 (272 bytes per lane), and every
+    // accumulation of the loop above went through it
+#pragma unroll
+    for (int p = 0; p < 2; p++) {
+#pragma unroll
         for (int c = 0; c < EVAL_CG; c++) {
-            if (c0 + c >= ncols) break;
-            __syncthreads();
-            red[threadIdx.x] = acc[p][c].a;
-            red[256 + threadIdx.x] = acc[p][c].b;
-            __syncthreads();
-            for (int s = 128; s > 0; s >>= 1) {
-                if ((int)threadIdx.x < s) {
-                    red[threadIdx.x] = gl_add(red[threadIdx.x], red[threadIdx.x + s]);
-                    red[256 + threadIdx.x] = gl_add(red[256 + threadIdx.x], red[256 + threadIdx.x + s]);
-                }
+            if (p < npoints && c0 + c < ncols) {
                 __syncthreads();
-            }
-            if (threadIdx.x == 0) {
-                u64* o = partial + (((size_t)p * gridDim.x + blockIdx.x) * ncols + (c0 + c)) * 2;
-                o[0] = red[0];
-                o[1] = red[256];
+                red[threadIdx.x] = acc[p][c].a;
+                red[256 + threadIdx.x] = acc[p][c].b;
+                __syncthreads();
+                for (int s = 128; s > 0; s >>= 1) {
+                    if ((int)threadIdx.x < s) {
+                        red[threadIdx.x] = gl_add(red[threadIdx.x], red[threadIdx.x + s]);
+                        red[256 + threadIdx.x] = gl_add(red[256 + threadIdx.x], red[256 + threadIdx.x + s]);
+                    }
+                    __syncthreads();
+                }
+                if (threadIdx.x == 0) {
+                    u64* o = partial + (((size_t)p * gridDim.x + blockIdx.x) * ncols + (c0 + c)) * 2;
+                    o[0] = red[0];
+                    o[1] = red[256];
+                }
             }
         }
     }

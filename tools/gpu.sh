@@ -54,15 +54,16 @@ from olavm_amd.air import ola_tables as T, tracegen
 from olavm_amd.backend import Backend
 blob = T.ola_stark().blob()
 traces, params, compress = tracegen.empty_program_instance(log_n=10, range_bits=16, limb_bits=8, log_n_cpu=22, log_n_mem=22)
-be = Backend(device=0, hasher="blake3")
+import os
+be = Backend(device=0, hasher=os.environ.get("AB_HASHER", "blake3"))
 be.proof_stats(enable=True)
 best = None
 for _ in range(4):
     be.prove_with_traces(blob, traces, params, compress)
     st, ph = be.proof_stats(), be.phase_stats()
     if best is None or st["wall_ms"] < best[0]:
-        best = (st["wall_ms"], ph["quotient"][0])
-print("  wall %.1f ms, quotient kernels %.2f ms" % best)
+        best = (st["wall_ms"], ph["quotient"][0], ph["open_eval"][0], ph["merkle_levels"][0], ph["leaf_hash"][0])
+print("  wall %.1f ms, quotient kernels %.2f ms, opening evaluations %.2f ms, tree levels %.2f ms, leaves %.2f ms" % best)
 PY
                  done 2>&1 | grep -v amdgpu | tee $O/ab.txt; cp ab_tmp/libola_cur.so olavm_amd/lib/libola_gpu.so ;;
     matrix)      timeout 1200 python tools/bench_ntt_matrix.py --out $O/ntt_matrix.json 2>&1 | tail -40 ;;
