@@ -104,7 +104,8 @@ int32_t ola_gpu_memory_stats(OlaCtx* ctx, uint64_t out[4], int32_t reset);
  *   out[4], out[5]  bytes gathered by the partition's exchanges (all ranks' payload together; a rank receives (G-1)/G of it)
  *           and their number -- counted on a single-GPU run as well, which is what makes a projection from one GPU possible:
  *           T(G) ~ out[0] - sum_k out[k] * (1 - 1/min(G, 2^k)) + out[4] * (G-1)/G / (xGMI rate) + out[5] * latency
- *   out[6], out[7]  multi-device context only: exchanges performed by the library's own all-gather and the bytes they moved. */
+ *   out[6], out[7]  multi-device context only: exchanges performed by the library's own all-gather and the bytes they moved between
+ *           the ranks, both SINCE THE CONTEXT WAS CREATED (divide by the number of proofs). */
 int32_t ola_gpu_proof_stats(OlaCtx* ctx, int32_t enable, double out[8]);
 /* With the accounting on, the kernel families of the last proof one by one (Merkle leaves/s,
  * permutations/s, FRI-fold bytes/s of a REAL proof): out[3*i .. 3*i+2] = device milliseconds and two unit counters of phase i.
