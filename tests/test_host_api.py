@@ -29,3 +29,18 @@ def test_rank_barrier_of_the_multi_device_context(tmp_path):
                           stderr=subprocess.DEVNULL)
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and "all ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_header_is_valid_c_and_the_library_answers_its_revision(tmp_path):
+    """include/ola_gpu.h compiled as C99 (-Wall -Wextra -pedantic -Werror) in tests/host_c_abi_check.c, linked against libola_gpu.so
+    alone; run without arguments it compares the header's ABI revision and struct sizes with the library's and drives the host-only
+    challenger entry points -- no device needed."""
+    from olavm_amd.backend import lib_path, load_library
+    load_library()
+    here = os.path.dirname(os.path.abspath(__file__))
+    lib = os.path.dirname(lib_path())
+    exe = os.path.join(str(tmp_path), "host_c_abi_check")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", os.path.join(here, "host_c_abi_check.c"), "-o", exe,
+                           "-L" + lib, "-lola_gpu", "-Wl,-rpath," + lib])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and "c abi ok: revision 3" in r.stdout, r.stdout + r.stderr
