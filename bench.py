@@ -123,17 +123,19 @@ POSEIDON_VALU_PER_PERMUTATION = 15.5e3           # SQ_INSTS_VALU per permutation
 def partition_projection(st):
     """From ONE GPU's accounting (ola_gpu_proof_stats) to the coset partition over G GPUs: the bracketed kernel time divides by
     min(G, 2^k), everything else is repeated by every rank, the exchanges are added -- a rank receives (G-1)/G of the gathered
-    bytes over G-1 xGMI links at once (0.7 x 76.8 GB/s per link and direction assumed, 30 us per exchange)."""
-    link, lat = 0.7 * 76.8e9, 30e-6
+    bytes over G-1 xGMI links at once (0.7 x 76.8 GB/s per link and direction assumed); per exchange the latency the library's
+    all-gather showed on the one-GPU box with G ranks sharing the device (tests/gpu_peer_gather_check.cpp,
+    profiles/r03_peer_all_gather.txt: 31 / 59 / 158 us for 2 / 4 / 8 ranks -- an upper bound for ranks with a GPU each)."""
+    link, lat_by_g = 0.7 * 76.8e9, {2: 31e-6, 4: 59e-6, 8: 158e-6}
     sharded = st["sharded_ms_upto2"] + st["sharded_ms_upto4"] + st["sharded_ms_upto8"]
     out = {"wall_ms": round(st["wall_ms"], 2), "sharded_kernel_ms": round(sharded, 2), "replicated_ms": round(st["wall_ms"] - sharded, 2),
            "replicated_share": round(1.0 - sharded / max(st["wall_ms"], 1e-9), 4), "exchange_bytes": st["exchange_bytes"],
-           "exchanges": st["exchanges"], "assumed_xgmi_link_GBps_one_direction": round(link / 1e9, 1), "assumed_exchange_latency_us": 30}
+           "exchanges": st["exchanges"], "assumed_xgmi_link_GBps_one_direction": round(link / 1e9, 1), "assumed_exchange_latency_us": {"2": 31, "4": 59, "8": 158}}
     for g in (2, 4, 8):
         t = st["wall_ms"] * 1e-3
         for k, key in ((1, "sharded_ms_upto2"), (2, "sharded_ms_upto4"), (3, "sharded_ms_upto8")):
             t -= st[key] * 1e-3 * (1.0 - 1.0 / min(g, 1 << k))
-        t += st["exchange_bytes"] * (g - 1) / g / ((g - 1) * link) + st["exchanges"] * lat
+        t += st["exchange_bytes"] * (g - 1) / g / ((g - 1) * link) + st["exchanges"] * lat_by_g[g]
         out["projected_speedup_%d" % g] = round(st["wall_ms"] * 1e-3 / t, 2)
     return out
 

@@ -16,7 +16,9 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 # one xGMI link, one direction (MI355X: 7 links per GPU, 153.6 GB/s per link both directions together); a pull all-gather
 # over G GPUs uses G - 1 of a rank's links at once.  0.7 of the spec rate is what large peer copies reach on MI300-class parts.
 XGMI_LINK_BPS = 0.7 * 76.8e9
-EXCHANGE_LATENCY_S = 30e-6      # two thread barriers + G - 1 copy launches + event waits
+# two thread barriers + G - 1 copy launches + event waits: measured with G ranks sharing the one GPU of the test box
+# (tests/gpu_peer_gather_check.cpp, profiles/r03_peer_all_gather.txt) -- an upper bound for ranks that have a GPU each
+EXCHANGE_LATENCY_S = {2: 31e-6, 4: 59e-6, 8: 158e-6}
 
 
 def project(st, world):
@@ -27,7 +29,7 @@ def project(st, world):
     for k, key in ((1, "sharded_ms_upto2"), (2, "sharded_ms_upto4"), (3, "sharded_ms_upto8")):
         saved += st[key] * 1e-3 * (1.0 - 1.0 / min(world, 1 << k))
     recv = st["exchange_bytes"] * (world - 1) / world
-    xchg = recv / ((world - 1) * XGMI_LINK_BPS) + st["exchanges"] * EXCHANGE_LATENCY_S
+    xchg = recv / ((world - 1) * XGMI_LINK_BPS) + st["exchanges"] * EXCHANGE_LATENCY_S[world]
     return t - saved + xchg
 
 
@@ -73,7 +75,7 @@ def main():
     else:
         traces, params, compress = tracegen.empty_program_instance(log_n=10, range_bits=16, limb_bits=8, log_n_cpu=args.log_n, log_n_mem=args.log_n)
     res = {"heights": [int(t.shape[1]).bit_length() - 1 for t in traces], "real_execution": args.real,
-           "assumptions": {"xgmi_link_bytes_per_s_one_direction": XGMI_LINK_BPS, "exchange_latency_s": EXCHANGE_LATENCY_S}}
+           "assumptions": {"xgmi_link_bytes_per_s_one_direction": XGMI_LINK_BPS, "exchange_latency_s": {str(k): v for k, v in EXCHANGE_LATENCY_S.items()}}}
     for h in args.hashers:
         be = Backend(device=0, hasher=h)
         st = measure(be, blob, traces, params, compress)
