@@ -131,3 +131,20 @@ def test_partition_accounting_of_a_single_gpu_proof(small_instance):
     st2 = two.proof_stats()
     two.close()
     assert st2["peer_exchanges"] == st["exchanges"] == st2["exchanges"], (st, st2)
+
+
+def test_peer_all_gather_by_itself(tmp_path):
+    """tests/gpu_peer_gather_check.cpp: the library's all-gather (olavm_amd/csrc/peer_group.h) without the prover around it -- four rank
+    threads, blocks of 512 B ... 64 MB, every rank's result equal to the expected concatenation, also when the send block is
+    overwritten right after the exchange."""
+    import os
+    import shutil
+    import subprocess
+    if not shutil.which("hipcc"):
+        pytest.skip("no hipcc on this box")
+    here = os.path.dirname(os.path.abspath(__file__))
+    exe = os.path.join(str(tmp_path), "gpu_peer_gather_check")
+    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O2", "-std=c++17", "-pthread", "-o", exe, os.path.join(here, "gpu_peer_gather_check.cpp")],
+                          stderr=subprocess.DEVNULL)
+    r = subprocess.run([exe, "4"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "all ok" in r.stdout and "MISMATCH" not in r.stdout, r.stdout + r.stderr
