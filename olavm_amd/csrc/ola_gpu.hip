@@ -126,7 +126,7 @@ static std::unique_ptr<OlaCtx> create_device_ctx(const OlaGpuConfig& cfg, int de
     HIP_CHECK(hipGetDevice(&c->dev.device));
     if (stream) { c->dev.stream = (hipStream_t)stream; c->dev.owns_stream = false; }
     else { HIP_CHECK(hipStreamCreateWithFlags(&c->dev.stream, hipStreamNonBlocking)); c->dev.owns_stream = true; }
-    { const char* t = getenv("OLA_TIMING"); c->dev.timing = t && *t && *t != '0'; }
+    { const char* t = getenv("OLA_TIMING"); c->dev.timing = t && *t && *t != '0'; c->dev.acct.on = c->dev.timing; }   // OLA_TIMING also prints the partition accounting
     poseidon_init(&c->dev);
     c->tables = ntt_tables_create(&c->dev);
     return c;
@@ -587,6 +587,13 @@ int32_t ola_prove_with_traces(OlaCtx* ctx, const uint64_t* airset, size_t airset
                           (const u64*)params, (const u64*)compress_challenges, bytes);
         ctx->dev.acct.collect();
         ctx->dev.acct.wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        if (ctx->dev.timing && ctx->dev.acct.on) {
+            const WorkAcct& a = ctx->dev.acct;
+            const double sharded = a.sharded_ms[1] + a.sharded_ms[2] + a.sharded_ms[3];
+            fprintf(stderr, "[ola-timing] coset partition: sharded_kernel_ms %.2f (divides by up to 2 / 4 / 8 ranks: %.2f / %.2f / %.2f), replicated_ms %.2f of %.2f, "
+                            "exchange_bytes %llu in %u exchanges\n", sharded, a.sharded_ms[1], a.sharded_ms[2], a.sharded_ms[3], a.wall_ms - sharded, a.wall_ms,
+                    (unsigned long long)a.exchange_bytes, a.exchanges);
+        }
     } else {
         prove_with_traces_multi(ctx, (const u64*)airset, airset_words, (const u64* const*)traces, log_n, (const u64*)params,
                                 (const u64*)compress_challenges, bytes);
