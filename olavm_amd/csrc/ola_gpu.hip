@@ -166,7 +166,13 @@ static void prove_with_traces_multi(OlaCtx* ctx, const u64* airset, size_t airse
         c->dev.shard = ShardInfo();
     };
     std::vector<std::thread> workers;
-    for (uint32_t r = 1; r < world; r++) workers.emplace_back(run, r);
+    try {
+        for (uint32_t r = 1; r < world; r++) workers.emplace_back(run, r);
+    } catch (const std::exception& e) {          // the process cannot start another thread: release the ranks that did start
+        g.fail();
+        for (std::thread& t : workers) t.join();
+        throw OlaError(OLA_E_INTERNAL, std::string("could not start the rank threads of the multi-device context: ") + e.what());
+    }
     run(0);
     for (std::thread& t : workers) t.join();
     ctx->dev.acct.wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
