@@ -331,10 +331,12 @@ int32_t ola_permuted_cols_dev(OlaCtx* ctx, const uint64_t* inputs_dev, const uin
  * heavy work is divided.  For every table with at least 2^12 rows, rank r uploads 1/world of the columns (the values are
  * all-gathered device to device: xGMI instead of `world` copies over PCIe), extends and hashes cosets
  * [r*8/world, (r+1)*8/world) of all three commitments, and evaluates the quotient on those of its cosets that belong to the
- * quotient domain (the first 2^qdb cosets; all of them for the CPU, memory and Poseidon tables).  The exchanges go through
- * `all_gather` -- the trace values (8n bytes per column, once), Merkle cap slices (512 B per tree), the quotient values
- * (16 * 8n bytes per table) and the opened rows of the 28 queries -- and every rank ends up with the complete, identical
- * AllProof bytes.
+ * quotient domain (the first 2^qdb cosets; all of them for the CPU, memory and Poseidon tables); it evaluates its 1/world of the
+ * COLUMNS at the opening points, and extends / hashes its cosets of the first FRI layer.  The exchanges go through `all_gather`,
+ * twelve per table -- the trace values (8n bytes per column, once), Merkle cap slices of the three commitments and of the first
+ * FRI layer (512 B per tree), the two planes of quotient values (16 * 8n bytes per table), the opening values (a few KB), the
+ * opened rows and paths of the 28 queries in the three commitments and in the first FRI layer -- and every rank ends up with the
+ * complete, identical AllProof bytes.
  * all_gather(user, send_dev, recv_dev, bytes): gather `bytes` bytes of DEVICE memory from every rank into recv_dev in rank
  * order (world * bytes); return 0 when recv_dev is complete (or, with OLA_SHARD_STREAM_ORDERED, when the collective has been
  * enqueued on the context's stream).  world must be 1, 2, 4 or 8; world = 1 (or a NULL callback) restores single-GPU proving. */
