@@ -68,6 +68,8 @@ PY
                  done 2>&1 | grep -v amdgpu | tee $O/ab.txt; cp ab_tmp/libola_cur.so olavm_amd/lib/libola_gpu.so ;;
     peer_gather) hipcc --offload-arch=gfx950 -O2 -std=c++17 -pthread -o /tmp/gpu_peer_gather_check tests/gpu_peer_gather_check.cpp 2>/dev/null
                  for w in 2 4 8; do timeout 300 /tmp/gpu_peer_gather_check $w; done 2>&1 | grep -v amdgpu | tee $O/peer_gather.txt ;;
+    prof_b3)     cd /tmp; OLA_HASHER=blake3 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof -o p -- python $R/tools/bench_prove.py 22 5 > $R/$O/run.log 2> $R/$O/err.txt; cd $R
+                 f=$(find $O/prof -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp "$f" $O/kernel_stats.csv && head -16 $O/kernel_stats.csv | cut -c1-150; tail -3 $O/run.log ;;
     matrix)      timeout 1200 python tools/bench_ntt_matrix.py --out $O/ntt_matrix.json 2>&1 | tail -40 ;;
     prof_bench)  cd /tmp; timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof -o p -- python $R/bench.py --steps 20 --warmup 5 > $R/$O/bench.json 2> $R/$O/err.txt; cd $R
                  f=$(find $O/prof -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp "$f" $O/kernel_stats.csv && head -25 $O/kernel_stats.csv | cut -c1-160 ;;
