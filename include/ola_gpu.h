@@ -71,6 +71,9 @@ typedef struct OlaGpuConfig {
 
 /* ---- lifetime (replaces gpu_init / gpu_free, cfft/ntt/mod.rs:89-121 and core/src/storage/db.rs:248) ---- */
 int32_t ola_gpu_init(const OlaGpuConfig* cfg, OlaCtx** out_ctx);
+/* OLA_GPU_ABI_VERSION of the library that was loaded; *challenger_size / *config_size (may be NULL) receive its sizeof(OlaChallenger)
+ * and sizeof(OlaGpuConfig). */
+int32_t ola_gpu_abi_version(size_t* challenger_size, size_t* config_size);
 /* One context that spans n_devices GPUs of the node (1, 2, 4 or 8; devices = HIP ordinals, NULL = 0..n-1): the caller stays the
  * single process the reference's prover is (client/src/main.rs:174-214, one `prove` per process; the reference's own GPU state is
  * process-wide, cfft/ntt/mod.rs:14-17,48-50) and calls ola_prove_with_traces ONCE; inside, rank r is a worker thread on
@@ -80,9 +83,6 @@ int32_t ola_gpu_init(const OlaGpuConfig* cfg, OlaCtx** out_ctx);
  * single-device context.  Entries of devices[] may repeat (logical ranks sharing a GPU: how the one-GPU test box exercises the
  * path).  cfg->device is ignored, cfg->stream must be NULL when n_devices > 1.  Needs peer access between the devices
  * (OLA_E_HIP otherwise). */
-/* OLA_GPU_ABI_VERSION of the library that was loaded; *challenger_size / *config_size (may be NULL) receive its sizeof(OlaChallenger)
- * and sizeof(OlaGpuConfig). */
-int32_t ola_gpu_abi_version(size_t* challenger_size, size_t* config_size);
 int32_t ola_gpu_init_multi(const OlaGpuConfig* cfg, const int32_t* devices, uint32_t n_devices, OlaCtx** out_ctx);
 int32_t ola_gpu_device_count(OlaCtx* ctx, uint32_t* n_devices);
 int32_t ola_gpu_free(OlaCtx* ctx);

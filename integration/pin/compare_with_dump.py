@@ -167,7 +167,12 @@ def read_diag(path):
         if w[0] == "ctl_challenge":
             d["ctl_challenges"].append((int(w[1]), int(w[2])))
         elif w[0] == "table":
-            d["caps"][(int(w[1]), w[2])] = bytes.fromhex(w[3])
+            # pin_dump.rs writes a cap with Buffer::write_merkle_cap (serialization.rs:125-134): a u32 entry count, then the digests
+            raw = bytes.fromhex(w[3])
+            (n,) = struct.unpack_from("<I", raw, 0)
+            if len(raw) != 4 + 32 * n:
+                raise ValueError(f"{path}: cap of table {w[1]} ({w[2]}): {len(raw)} bytes do not hold a count and {n} digests")
+            d["caps"][(int(w[1]), w[2])] = raw[4:]
     return d
 
 

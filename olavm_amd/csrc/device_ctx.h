@@ -77,7 +77,24 @@ struct WorkAcct {
         if (hipEventCreate(&e) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
         return e;
     }
+    // Spans are only meaningful between begin_proof() and collect(): entry points that run a PhaseScope outside a proof (a host
+    // driving ola_commit_* / ola_ntt_* directly with the accounting on) would otherwise grow `spans` without bound and have their
+    // time charged to the next proof.  begin_proof() drops whatever is outstanding (events go back to `spare`), and outside a
+    // proof the list is capped: past the cap the oldest spans are recycled unread.
+    static constexpr size_t kMaxIdleSpans = 256;
+    void recycle_spans() {
+        for (Span& s : spans) { if (s.a) spare.push_back(s.a); if (s.b) spare.push_back(s.b); }
+        spans.clear();
+    }
+    void add_span(const Span& s) {
+        if (spans.size() >= (in_proof ? (size_t)1 << 16 : kMaxIdleSpans)) recycle_spans();   // in_proof stays set if a proof threw
+
+        spans.push_back(s);
+    }
+    bool in_proof = false;
     void begin_proof() {
+        recycle_spans();
+        in_proof = true;
         for (double& m : sharded_ms) m = 0;
         wall_ms = 0; exchange_bytes = 0; exchanges = 0;
         for (int i = 0; i < PH_COUNT; i++) { phase_ms[i] = 0; phase_units[i][0] = phase_units[i][1] = 0; }
@@ -92,6 +109,7 @@ struct WorkAcct {
             if (s.b) spare.push_back(s.b);
         }
         spans.clear();
+        in_proof = false;
     }
     ~WorkAcct() { collect(); for (hipEvent_t e : spare) (void)hipEventDestroy(e); }
 };
@@ -229,7 +247,7 @@ struct WorkScope {
         if (!a) return;
         hipEvent_t b = ctx->acct.get();
         if (b && hipEventRecord(b, ctx->stream) != hipSuccess) { (void)hipGetLastError(); ctx->acct.spare.push_back(b); b = nullptr; }
-        ctx->acct.spans.push_back({a, b, maxlog});
+        ctx->acct.add_span({a, b, maxlog});
     }
 };
 // Times one kernel family of a proof (WorkAcct::phase_ms) and counts what it processed; nests freely with WorkScope.
@@ -248,7 +266,7 @@ struct PhaseScope {
         if (!a) return;
         hipEvent_t b = ctx->acct.get();
         if (b && hipEventRecord(b, ctx->stream) != hipSuccess) { (void)hipGetLastError(); ctx->acct.spare.push_back(b); b = nullptr; }
-        ctx->acct.spans.push_back({a, b, 100 + phase});
+        ctx->acct.add_span({a, b, 100 + phase});
     }
 };
 // an exchange of the partition: `gathered_bytes` = payload of all ranks together

@@ -776,8 +776,6 @@ void open_and_prove(DeviceCtx* ctx, NttTables& tables, const OlaGpuConfig& cfg, 
                 if (dep) std::copy(rec + rows_w + (size_t)r * dep * 4, rec + rows_w + (size_t)(r + 1) * dep * 4, lpaths[0].begin() + (size_t)r * dep * 4);
             }
         }
-        (void)0;
-        HIP_CHECK(hipStreamSynchronize(ctx->stream));
     }
 
     // ---- serialise the FRI proof (serialization.rs:305-317) ----

@@ -85,7 +85,14 @@ static void require(bool ok, const char* what) {
 struct DeviceGuard {
     int prev = -1, want = -1;
     explicit DeviceGuard(const OlaCtx* ctx);
-    ~DeviceGuard() { if (prev >= 0 && prev != want) (void)hipSetDevice(prev); }
+    // Restores whatever the caller had, also when the body moved on to other devices (the peer loops of ola_gpu_sync /
+    // ola_gpu_trim on a multi-device context end on the last peer): compare with the device that is current NOW, not with `want`.
+    ~DeviceGuard() {
+        if (prev < 0) return;
+        int cur = -1;
+        if (hipGetDevice(&cur) != hipSuccess) { cur = -1; (void)hipGetLastError(); }
+        if (cur != prev) (void)hipSetDevice(prev);
+    }
 };
 #define OLA_ON_DEVICE(ctx) DeviceGuard ola_device_guard_(ctx)
 
