@@ -114,7 +114,7 @@ int32_t ola_gpu_proof_stats(OlaCtx* ctx, int32_t enable, double out[8]);
  *   OLA_PHASE_FRI_FOLD       bytes read + written, extension elements folded (fri/prover.rs:98-112)
  *   OLA_PHASE_LDE            bytes read + written by the coset LDEs (8*n*(1 + cosets) per column), column-cosets
  *   OLA_PHASE_INTT           bytes (16*n per column), columns
- *   OLA_PHASE_QUOTIENT       LDE points evaluated, constraint-program length
+ *   OLA_PHASE_QUOTIENT       LDE points evaluated, bytes a point streams (local + next row of the trace and Z batches, 16 written)
  *   OLA_PHASE_OPEN_EVAL      coefficient x point products, bytes read
  * (hash/merkle_tree/mod.rs:180-266, fri/prover.rs:72-121, fri/oracle.rs:66-99).  On a multi-device context: rank 0's share. */
 #define OLA_PHASE_LEAF_HASH 0

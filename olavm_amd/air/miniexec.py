@@ -696,6 +696,22 @@ def fibonacci(count, a_reg=1, b_reg=2):
     return p
 
 
+def fibonacci_loop(n=47, reps=1000):
+    """The shape of the reference's headline benchmark (circuits/benches/fibo_loop.rs:46, README.md:69: calldata [47, 1000] =
+    Fibonacci(47) computed 1000 times): an outer counter around the Fibonacci loop.  r1, r2 <- consecutive Fibonacci numbers
+    (F(47) = 2971215073 fits 32 bits), 6 instructions per inner step, 6 per repetition."""
+    p = Program()
+    p.add("MOV", dst=6, op1=("imm", 0))
+    outer = len(p.words()[0])
+    p.add("MOV", dst=1, op1=("imm", 0)).add("MOV", dst=2, op1=("imm", 1)).add("MOV", dst=3, op1=("imm", 0))
+    loop = len(p.words()[0])
+    p.add("ADD", dst=4, op0=1, op1=2).add("MOV", dst=1, op1=2).add("MOV", dst=2, op1=4)
+    p.add("ADD", dst=3, op0=3, op1=("imm", 1)).add("NEQ", dst=5, op0=3, op1=("imm", n)).add("CJMP", op0=5, op1=("imm", loop))
+    p.add("ADD", dst=6, op0=6, op1=("imm", 1)).add("NEQ", dst=5, op0=6, op1=("imm", reps)).add("CJMP", op0=5, op1=("imm", outer))
+    p.add("END")
+    return p
+
+
 def mixed_program():
     """Every supported instruction at least once, with values that fit the miniature fixed tables (< 2^8): arithmetic,
     comparisons, the three bitwise operations, a range check, a taken and a not-taken conditional jump and a jump."""

@@ -15,10 +15,10 @@
 
 #include "device_ctx.h"
 #include "gl.cuh"
+#include "ntt2t.cuh"   // Ntt2Params, the tile geometry helpers and the T-form pass kernels
 
 namespace ola {
 
-enum { N2_STRIDED = 0, N2_BITREV_LAST = 1, N2_NATURAL_LAST = 2 };
 #ifndef NTT2_DEFAULT_GROUP_MB
 #define NTT2_DEFAULT_GROUP_MB 0   // Infinity-Cache blocking of ntt2_run (see there); the environment overrides it
 #endif
@@ -31,34 +31,6 @@ enum { N2_STRIDED = 0, N2_BITREV_LAST = 1, N2_NATURAL_LAST = 2 };
 #ifndef NTT2_STRIDED_COLS
 #define NTT2_STRIDED_COLS 8   // columns per workgroup of a strided pass (see ntt2_pass_kernel): 8 against 4 is +1.4 % on the NTT, +3 % on the LDE
 #endif
-
-struct Ntt2Params {
-    const u64* in;
-    u64* out;
-    size_t in_col_stride, out_col_stride, in_coset_stride, out_coset_stride;
-    int log_n;  // L
-    size_t ncols;  // columns of the batch (a workgroup handles CB of them)
-    int lo;     // pass handles index bits [lo, lo+R)
-    const u64* tw_r;   // w_{2^R}^e, e < 2^R
-    const u64* tw_lo;  // two-level powers of w_{2^(lo+R)}
-    const u64* tw_hi;
-    int tw_h;
-    u64 post_scale;    // folded into the pass twiddle (STRIDED only)
-    const u64* sc_lo;  // optional pre-scale s^k (coset transforms), two-level per coset
-    const u64* sc_hi;
-    int sc_h;
-    size_t sc_coset_stride;
-    const u64* sc_step;  // NTT2_PRE_STYLE 0: per coset s^(2^(lo+R-4)) = ratio between consecutive register elements
-    const u64* sc_upow;  // per coset, 16 entries: u^j, u = s^(2^(lo+R-4)) = the pre-scale ratio between consecutive register elements
-    const u64* sc_tw;    // per coset, 2^R entries [q1][m_low]: w_{2^R}^(m_low*q1) * (s^(2^lo))^m_low -- the round twiddles with the
-                         // pre-scale's m_low factor folded in (R > 4)
-};
-
-__device__ __forceinline__ constexpr int rev_bits_c(int x, int bits) {
-    int r = 0;
-    for (int i = 0; i < bits; i++) r |= ((x >> i) & 1) << (bits - 1 - i);
-    return r;
-}
 
 // In-register decimation-in-frequency transform of 2^K values; output x[j] = X[bitrev_K(j)].
 // Twiddle of stage i for pair (j, j + 2^i): w_{2^(i+1)}^(j mod 2^i) = w_16^((j mod 2^i) << (3 - i)) = +-2^s.
@@ -77,17 +49,6 @@ __device__ __forceinline__ void dft_pow2(u64* x) {
             x[j + (1 << i)] = gl_mul_pow2_sw(d, t % 96);
         }
     }
-}
-
-__device__ __forceinline__ u64 two_level(const u64* __restrict__ lo, const u64* __restrict__ hi, int h, u64 e) {
-    return gl_mul(lo[e & (((u64)1 << h) - 1)], hi[e >> h]);
-}
-
-template <int R, int MODE>
-constexpr int ntt2_lds_elems() {
-    constexpr int K2 = R - 4;
-    if (MODE == N2_STRIDED) return 4096 + (K2 >= 1 ? 16 * (4096 >> (K2 + 4)) : 0);
-    return (1 << (8 - R)) * 16 * ((1 << R) + 1);
 }
 
 // CB = columns per workgroup.  Everything that depends only on the position inside the transform -- the pass twiddles and
@@ -354,6 +315,44 @@ static void ntt2_dispatch(int R, int mode, bool inv, const Ntt2Params& p, size_t
     else { if (inv) ntt2_dispatch_r<N2_NATURAL_LAST, true>(R, p, cols, cosets, s); else ntt2_dispatch_r<N2_NATURAL_LAST, false>(R, p, cols, cosets, s); }
 }
 
+// ---- T-form passes (ntt2t.cuh): same plan, same tiles, the load multiplier instead of the store-side twiddle
+// OLA_NTT2_TFORM=0 runs the canonical-arithmetic passes above instead (the A/B switch of the round-4 experiment).
+static bool ntt2_tform() {
+    static const bool v = [] { const char* e = getenv("OLA_NTT2_TFORM"); return !(e && atoi(e) == 0); }();
+    return v;
+}
+template <int R, int MODE, bool INV, int LM>
+static void ntt2t_launch(const Ntt2Params& p0, size_t cols, size_t cosets, hipStream_t stream) {
+    constexpr int CB = NTT2_STRIDED_COLS;   // every pass has sixteen load multipliers per thread to amortise
+    Ntt2Params p = p0;
+    p.ncols = cols;
+    const size_t lds_bytes = (size_t)ntt2_lds_elems<R, MODE>() * 8 + (R > 4 ? ((size_t)sizeof(TfTw) << R) : 0) + (LM == 1 ? ((size_t)8 << R) : 0);
+    dim3 grid((unsigned)(((size_t)1 << p.log_n) >> 12), (unsigned)((cols + CB - 1) / CB), (unsigned)cosets);
+    hipLaunchKernelGGL((ntt2t_pass_kernel<R, MODE, INV, CB, LM>), grid, dim3(256), lds_bytes, stream, p);
+}
+template <int MODE, bool INV, int LM>
+static void ntt2t_dispatch_r(int R, const Ntt2Params& p, size_t cols, size_t cosets, hipStream_t s) {
+    switch (R) {
+        case 4: ntt2t_launch<4, MODE, INV, LM>(p, cols, cosets, s); break;
+        case 5: ntt2t_launch<5, MODE, INV, LM>(p, cols, cosets, s); break;
+        case 6: ntt2t_launch<6, MODE, INV, LM>(p, cols, cosets, s); break;
+        case 7: ntt2t_launch<7, MODE, INV, LM>(p, cols, cosets, s); break;
+        default: ntt2t_launch<8, MODE, INV, LM>(p, cols, cosets, s); break;
+    }
+}
+template <bool INV>
+static void ntt2t_dispatch_inv(int R, int mode, int lm, const Ntt2Params& p, size_t cols, size_t cosets, hipStream_t s) {
+    if (mode == N2_STRIDED) {
+        if (lm == 0) ntt2t_dispatch_r<N2_STRIDED, INV, 0>(R, p, cols, cosets, s);
+        else ntt2t_dispatch_r<N2_STRIDED, INV, 1>(R, p, cols, cosets, s);
+    } else if (mode == N2_BITREV_LAST) ntt2t_dispatch_r<N2_BITREV_LAST, INV, 2>(R, p, cols, cosets, s);
+    else ntt2t_dispatch_r<N2_NATURAL_LAST, INV, 2>(R, p, cols, cosets, s);
+}
+static void ntt2t_dispatch(int R, int mode, bool inv, int lm, const Ntt2Params& p, size_t cols, size_t cosets, hipStream_t s) {
+    if (inv) ntt2t_dispatch_inv<true>(R, mode, lm, p, cols, cosets, s);
+    else ntt2t_dispatch_inv<false>(R, mode, lm, p, cols, cosets, s);
+}
+
 // round twiddles of a strided pass, [q1][m]: w_{2^R}^(m*q1), q1 < 16, m < 2^(R-4)
 static const u64* get_round_table(NttTables& t, int R, int inverse) {
     auto key = std::make_pair(200 + R, inverse);
@@ -386,6 +385,23 @@ static const u64* get_coset_steps(NttTables& t, int log_n, int rate_bits, int e,
             const u64 s = gl_mul(gl_pow(g, bitrev32((u32)c, rate_bits)), GL_GENERATOR);
             v.push_back(gl_pow(s, (u64)1 << e));
         }
+    }
+    return upload(t.ctx, v);  // small; lives in the persistent pool
+}
+
+// T-form passes of a coset transform: per coset c, (s_c^(2^lo))^m for m < 2^R -- the part of the pre-scale s^a that belongs to
+// the pass over index bits [lo, lo + R)
+static const u64* get_coset_pows(NttTables& t, int log_n, int rate_bits, int lo, int R, u64 single_shift) {
+    std::vector<u64> shifts;
+    if (rate_bits < 0) shifts.push_back(single_shift);
+    else {
+        const u64 g = gl_root_of_unity(log_n + rate_bits);
+        for (int c = 0; c < (1 << rate_bits); c++) shifts.push_back(gl_mul(gl_pow(g, bitrev32((u32)c, rate_bits)), GL_GENERATOR));
+    }
+    std::vector<u64> v;
+    for (u64 sc : shifts) {
+        const std::vector<u64> pw = powers(gl_pow(sc, (u64)1 << lo), (size_t)1 << R);
+        v.insert(v.end(), pw.begin(), pw.end());
     }
     return upload(t.ctx, v);  // small; lives in the persistent pool
 }
@@ -439,6 +455,42 @@ static void ntt2_run_group(NttTables& t, const u64* in, size_t in_col_stride, u6
     const u64* cur_in = in;
     size_t cur_in_stride = in_col_stride, cur_in_coset = 0;
     int lo = L;
+    if (ntt2_tform() && L <= 28) {   // (their lane offsets are 32-bit byte offsets)
+        // T-form passes (ntt2t.cuh): pass i multiplies what it LOADS by w_{2^(L-lo)}^(a_i * K) -- the inter-pass twiddles in the
+        // factorisation that depends on the pass's own index a_i only -- and, in a coset transform, by (s^(2^lo))^a_i; the closing
+        // pass also takes the final scale and writes canonical words
+        for (int i = 0; i < P; i++) {
+            const int R = Rs[i];
+            lo -= R;
+            const bool last = (i == P - 1);
+            Ntt2Params p = {};
+            p.log_n = L; p.lo = lo;
+            p.tw_r = get_round_table(t, R, inverse);
+            p.post_scale = last ? final_scale : 1;
+            p.in = cur_in; p.in_col_stride = cur_in_stride; p.in_coset_stride = cur_in_coset;
+            if (i > 0) {
+                TwoLevel tw = get_two(t, L - lo, inverse);
+                p.tw_lo = tw.lo; p.tw_hi = tw.hi; p.tw_h = tw.h;
+            }
+            if (sc_rate_bits != -2) {
+                const auto skey = std::make_tuple(L, sc_rate_bits, 1000 + lo * 16 + R, sc_rate_bits >= 0 ? (u64)0 : sc_shift);
+                auto st = t.coset_steps.find(skey);
+                if (st == t.coset_steps.end()) st = t.coset_steps.emplace(skey, get_coset_pows(t, L, sc_rate_bits, lo, R, sc_shift)).first;
+                p.sc_pow = st->second + (coset_first << R);
+            }
+            const int lm = last ? 2 : ((i > 0 || p.sc_pow) ? 1 : 0);
+            if (!last) {
+                p.out = work; p.out_col_stride = work_col_stride; p.out_coset_stride = work_coset_stride;
+                if (lo - 4 < 8 - R) throw OlaError(-7, "ntt2: pass split leaves a strided pass with lo + R < 12");
+                ntt2t_dispatch(R, N2_STRIDED, inverse, lm, p, cols, cosets, stream);
+                cur_in = work; cur_in_stride = work_col_stride; cur_in_coset = work_coset_stride;
+            } else {
+                p.out = out; p.out_col_stride = out_col_stride; p.out_coset_stride = out_coset_stride;
+                ntt2t_dispatch(R, natural_out ? N2_NATURAL_LAST : N2_BITREV_LAST, inverse, 2, p, cols, cosets, stream);
+            }
+        }
+        return;
+    }
     for (int i = 0; i < P; i++) {
         const int R = Rs[i];
         lo -= R;

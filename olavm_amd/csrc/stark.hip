@@ -761,7 +761,10 @@ static void prove_single_table(DeviceCtx* ctx, NttTables& tables, const OlaGpuCo
         }
         u64* qv2 = (spec && crosscheck) ? mem.alloc(2 * plane) : nullptr;
         WorkScope ws(ctx, qdb);   // the quotient lives on 2^qdb cosets: that many ranks share it
-        PhaseScope phq(ctx, PH_QUOTIENT, (double)(sharded ? my_q_cosets * n : size), (double)air.ops.size() / 2);
+        // units: LDE points evaluated; bytes a point streams -- local and next row of the trace and Z batches, two planes written
+        // (quotient row streaming is priced against HBM)
+        const double q_points = (double)(sharded ? my_q_cosets * n : size);
+        PhaseScope phq(ctx, PH_QUOTIENT, q_points, q_points * (8.0 * 2 * ((double)trace_c.ncols + (double)zs_c.b->ncols) + 16.0));
         if (!sharded && ctx->acct.shardable) { acct_exchange(ctx, N * 8); acct_exchange(ctx, N * 8); }   // the two planes a partitioned run gathers
         for (size_t lc = 0; lc < lean_cosets; lc++) {
             u64* out = qloc;

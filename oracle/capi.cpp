@@ -151,6 +151,15 @@ void oracle_batch_coeffs(void* h, u64* out) {  // column-major
     for (size_t c = 0; c < b->polynomials.size(); c++) memcpy(out + c * n, b->polynomials[c].data(), n * 8);
 }
 void oracle_batch_leaves(void* h, u64* out) { auto* b = (PolynomialBatch*)h; memcpy(out, b->merkle_tree.leaves.data(), b->merkle_tree.leaves.size() * 8); }
+// one leaf (a row of the LDE in commitment order) without copying all of them
+void oracle_batch_leaf(void* h, size_t leaf, u64* out) { auto* b = (PolynomialBatch*)h; memcpy(out, b->merkle_tree.get(leaf), b->merkle_tree.leaf_len * 8); }
+// the same leaves under the hasher that is selected NOW (set_hasher): the full-size tests extend a batch once and check the
+// Merkle tree of both hash configurations against it
+void oracle_batch_rehash(void* h) {
+    auto* b = (PolynomialBatch*)h;
+    MerkleTree& t = b->merkle_tree;
+    t = merkle_new_v2(std::move(t.leaves), t.num_leaves, t.leaf_len, t.cap_height);
+}
 int oracle_batch_prove(void* h, size_t leaf, u64* out) {
     auto* b = (PolynomialBatch*)h;
     std::vector<HashOut> s = b->merkle_tree.prove(leaf);

@@ -25,7 +25,11 @@ MerkleTree merkle_new_v2(std::vector<u64> leaves, size_t num_leaves, size_t leaf
     t.nodes.assign(2 * n > 0 ? 2 * n : 1, HashOut{0, 0, 0, 0});
 #pragma omp parallel for schedule(static)
     for (long i = 0; i < (long)n; i++) t.nodes[n + i] = merkle_two_to_one(t.leaf_hash[2 * i], t.leaf_hash[2 * i + 1]);
-    for (size_t i = n; i-- > 1;) t.nodes[i] = merkle_two_to_one(t.nodes[2 * i], t.nodes[2 * i + 1]);
+    // level by level from the leaves' parents up to the root at 1 (a level's nodes are independent)
+    for (size_t lvl = n / 2; lvl >= 1; lvl /= 2) {
+#pragma omp parallel for schedule(static) if (lvl >= 64)
+        for (long i = (long)lvl; i < (long)(2 * lvl); i++) t.nodes[i] = merkle_two_to_one(t.nodes[2 * i], t.nodes[2 * i + 1]);
+    }
     size_t len_cap = (size_t)1 << cap_height;
     t.cap.resize(len_cap);
     for (size_t i = 0; i < len_cap; i++) t.cap[i] = (len_cap == num_leaves) ? t.leaf_hash[i] : t.nodes[len_cap + i];

@@ -20,14 +20,28 @@ static inline u64 sbox7(u64 x) {
     return gl_mul(x3, x4);
 }
 
+// poseidon.rs:236-255 mds_layer, as the reference computes it: the state is split into 32-bit halves so that a row's twelve
+// products (coefficients below 2^6) accumulate in plain u64 words -- 13 * 2^32 * 2^6 < 2^42 -- and the two sums are joined and
+// reduced once per row.  Same value as the sum of 128-bit products reduced mod p (full-size commitments are checked against this
+// oracle: 10^8 permutations per batch).
 static void mds_layer(u64 s[12]) {
-    u64 out[12];
-    for (int r = 0; r < 12; r++) {
-        u128 acc = 0;  // 12 * 2^64 * 41 < 2^74
-        for (int i = 0; i < 12; i++) acc += (u128)s[(i + r) % 12] * OLA_POSEIDON_MDS_CIRC[i];
-        acc += (u128)s[r] * OLA_POSEIDON_MDS_DIAG[r];
-        out[r] = gl_reduce128(acc);          // same value as acc % p (a 128-bit division here made the oracle's grinding take seconds)
+    u64 lo[24], hi[24], out[12], al[12], ah[12];
+    for (int i = 0; i < 12; i++) {
+        lo[i] = lo[i + 12] = s[i] & 0xFFFFFFFFull;
+        hi[i] = hi[i + 12] = s[i] >> 32;
     }
+    for (int r = 0; r < 12; r++) {
+        al[r] = lo[r] * OLA_POSEIDON_MDS_DIAG[r];
+        ah[r] = hi[r] * OLA_POSEIDON_MDS_DIAG[r];
+    }
+    for (int i = 0; i < 12; i++) {          // row r takes s[(i + r) % 12] * circ[i]: twelve rows at a time
+        const u64 c = OLA_POSEIDON_MDS_CIRC[i];
+        for (int r = 0; r < 12; r++) {
+            al[r] += lo[i + r] * c;
+            ah[r] += hi[i + r] * c;
+        }
+    }
+    for (int r = 0; r < 12; r++) out[r] = gl_reduce128((u128)al[r] + ((u128)ah[r] << 32));
     for (int r = 0; r < 12; r++) s[r] = out[r];
 }
 

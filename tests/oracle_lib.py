@@ -53,6 +53,10 @@ class Oracle:
         L.oracle_batch_free.argtypes = [C.c_void_p]
         for f in ("oracle_batch_cap", "oracle_batch_coeffs", "oracle_batch_leaves"):
             getattr(L, f).argtypes = [C.c_void_p, U64P]
+        L.oracle_batch_leaf.argtypes = [C.c_void_p, C.c_size_t, U64P]
+        L.oracle_batch_leaf.restype = None
+        L.oracle_batch_rehash.argtypes = [C.c_void_p]
+        L.oracle_batch_rehash.restype = None
         L.oracle_batch_prove.argtypes = [C.c_void_p, C.c_size_t, U64P]
         L.oracle_batch_prove.restype = C.c_int
         L.oracle_challenger_new.restype = C.c_void_p
@@ -330,6 +334,15 @@ class Batch:
         out = np.empty((self.n << self.rate_bits, self.ncols), dtype=np.uint64)
         self.o.lib.oracle_batch_leaves(self.h, ptr(out))
         return out
+
+    def leaf(self, index):
+        out = np.empty(self.ncols, dtype=np.uint64)
+        self.o.lib.oracle_batch_leaf(self.h, index, ptr(out))
+        return out
+
+    def rehash(self):
+        """Rebuild the Merkle tree over the same leaves under the hasher selected now (`with oracle.hasher(...)`)."""
+        self.o.lib.oracle_batch_rehash(self.h)
 
     def prove(self, leaf):
         out = np.empty((64, 4), dtype=np.uint64)

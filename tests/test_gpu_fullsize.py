@@ -166,6 +166,113 @@ def test_config4_shape_poseidon_2p22_next_to_cpu_2p22(be, oracle):
     be.trim()
 
 
+def _sample_leaves(N):
+    """Eight leaves of an N-leaf commitment: both ends, both sides of a coset boundary, the middle of the last coset and three
+    scattered ones (a leaf is a row of the x8 LDE in commitment order; a block of N/8 leaves is one coset)."""
+    n = N // 8
+    return [0, 1, n - 1, n, 5 * n + 12345 % n, N // 2 + 0x155555 % n, 7 * n + n // 2, N - 1]
+
+
+def _check_leaves_and_paths(b, ob, N, label):
+    for j in _sample_leaves(N):
+        row, sib = b.leaf(j)
+        assert np.array_equal(row, ob.leaf(j)), (label, "leaf", j)
+        assert np.array_equal(sib, ob.prove(j)), (label, "path", j)
+
+
+def _trace_caps(proof):
+    """table -> the 16 x 4 words of its trace commitment's cap, cut out of AllProof bytes (serialization.rs:349-393)."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("compare_with_dump", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                                                    "integration", "pin", "compare_with_dump.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    caps = {}
+    for name, a, b in m.parse_all_proof(proof):
+        if name.endswith(": trace_cap"):
+            caps[int(name.split()[1].rstrip(":"))] = np.frombuffer(proof[a:b], dtype="<u8").reshape(-1, 4)
+    return caps
+
+
+def test_commitment_bytes_at_baseline_size_94_x_2p20(be, oracle):
+    """PolynomialBatch::from_values (fri/oracle.rs:45-99) + MerkleTree::new_v2 (hash/merkle_tree/mod.rs:180-266) at BASELINE config
+    3's size, BYTE FOR BYTE against the oracle: the CPU table of an executed program (94 columns x 2^20 rows, every column live)
+    is extended ONCE by the oracle; the GPU commitment's cap and eight sampled leaves with their sibling paths must equal it
+    under the Poseidon configuration and -- the same leaves re-hashed -- under the Blake3 configuration.  Covers the three-launch
+    transforms and the 2^23-leaf trees; then the trace cap inside a whole proof of that execution, with every LDE resident and
+    in memory-lean mode (OLA_LEAN=1: cosets streamed, nothing of the LDE kept), must be that same cap."""
+    import os
+    from olavm_amd.air import fastexec, miniexec as M
+    from olavm_amd.backend import Backend
+    blob = T.ola_stark().blob()
+    traces, params, compress = fastexec.instance(M.memory_program(70000), range_bits=16, limb_bits=8, max_steps=1 << 24)
+    vals = traces[0]
+    assert vals.shape == (94, 1 << 20)
+    N = 8 << 20
+    t0 = time.perf_counter()
+    ob = oracle.batch(vals)
+    t_oracle = time.perf_counter() - t0
+    want_cap = ob.cap()
+    b = be.commit(vals)
+    assert np.array_equal(b.cap(), want_cap), "Poseidon Merkle cap of the 94 x 2^20 commitment differs from the oracle's"
+    _check_leaves_and_paths(b, ob, N, "poseidon")
+    b.free()
+    # the cap inside a whole proof: resident, then memory-lean
+    proof = be.prove_with_traces(blob, traces, params, compress)
+    assert np.array_equal(_trace_caps(proof)[0], want_cap)
+    old = os.environ.get("OLA_LEAN")
+    os.environ["OLA_LEAN"] = "1"
+    try:
+        lean = be.prove_with_traces(blob, traces, params, compress)
+    finally:
+        if old is None:
+            del os.environ["OLA_LEAN"]
+        else:
+            os.environ["OLA_LEAN"] = old
+    assert lean == proof, "the memory-lean proof differs from the resident one at 2^20 rows"
+    be.trim()
+    # the same leaves under Blake3GoldilocksConfig
+    t0 = time.perf_counter()
+    with oracle.hasher("blake3"):
+        ob.rehash()
+        want3 = ob.cap()
+        b3 = Backend(device=0, hasher="blake3")
+        try:
+            g = b3.commit(vals)
+            assert np.array_equal(g.cap(), want3), "Blake3 Merkle cap of the 94 x 2^20 commitment differs from the oracle's"
+            _check_leaves_and_paths(g, ob, N, "blake3")
+            g.free()
+        finally:
+            b3.close()
+    print("94 x 2^20: oracle extension + Poseidon tree %.1f s, Blake3 re-hash + checks %.1f s" % (t_oracle, time.perf_counter() - t0))
+
+
+def test_commitment_bytes_at_baseline_size_29_x_2p22_blake3(oracle):
+    """The memory table's shape at BASELINE config 4's height (29 columns x 2^22 rows, 2^25 leaves) under the reference's Blake3
+    configuration, byte for byte against the oracle: cap, eight leaves, eight paths (Poseidon at this size would keep the CPU
+    oracle busy for minutes; the 94 x 2^20 test above covers the Poseidon tree, this one the 2^25-leaf transforms and heap)."""
+    import torch
+    from olavm_amd.backend import Backend
+    from tests.inputs import splitmix_columns
+    vals = splitmix_columns(torch, 29, 1 << 22).cpu().numpy().view(np.uint64) % np.uint64(P)
+    torch.cuda.empty_cache()
+    N = 8 << 22
+    b3 = Backend(device=0, hasher="blake3")
+    try:
+        with oracle.hasher("blake3"):
+            t0 = time.perf_counter()
+            ob = oracle.batch(vals)
+            t_oracle = time.perf_counter() - t0
+            g = b3.commit(vals)
+            assert np.array_equal(g.cap(), ob.cap()), "Blake3 Merkle cap of the 29 x 2^22 commitment differs from the oracle's"
+            _check_leaves_and_paths(g, ob, N, "blake3")
+            g.free()
+    finally:
+        b3.close()
+    print("29 x 2^22 (Blake3): oracle %.1f s" % t_oracle)
+
+
 def test_2p16_row_execution_bytes_equal_the_oracle_prover(be, oracle):
     """The largest instance the CPU port proves in test time (about 100 s on the GPU box's host cores): memory_program(3000),
     2^16 CPU rows, 2^17 program rows, full-size fixed tables -- AllProof bytes identical, byte for byte."""

@@ -189,3 +189,23 @@ def _replay(oracle, caps):
     for c in caps:
         ch.observe(c)
     return ch
+
+
+def test_batch_rehash_and_single_leaf(oracle):
+    """The helpers the full-size GPU tests lean on: one leaf without copying all of them, and the same leaves under the other
+    hash configuration == a batch built under that configuration from the start."""
+    rng = np.random.default_rng(5)
+    v = rand_field(rng, (7, 1 << 6))
+    b = oracle.batch(v)
+    leaves = b.leaves()
+    for j in (0, 1, 63, 64, 300, 511):
+        assert np.array_equal(b.leaf(j), leaves[j])
+    cap_p = b.cap().copy()
+    with oracle.hasher("blake3"):
+        want = oracle.batch(v)
+        b.rehash()
+        assert np.array_equal(b.cap(), want.cap()) and not np.array_equal(b.cap(), cap_p)
+        for j in (0, 77, 511):
+            assert np.array_equal(b.prove(j), want.prove(j))
+    b.rehash()
+    assert np.array_equal(b.cap(), cap_p)

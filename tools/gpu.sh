@@ -23,6 +23,15 @@ for step in "$@"; do
                    OLA_NTT2_GROUP_MB=$mb timeout 300 python bench.py --steps 20 --warmup 3 --no-prove --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('  ntt ms', d['ms_per_step'], 'frac', d['roofline']['frac'])"
                    OLA_NTT2_GROUP_MB=$mb timeout 300 python tools/bench_ntt_matrix.py --log-n 22 --cols 94 --reps 3 --out $O/m_$mb.json 2>&1 | grep -E "lde|intt|ntt" | cut -c1-120
                  done 2>&1 | tee $O/sweep.txt ;;
+    tform_ab)    # T-form passes against the canonical-arithmetic passes, same box, alternating (OLA_NTT2_TFORM=0/1)
+                 timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fullsize.py -x -q -k "ntt or lde or NTT or coset" 2>&1 | tail -8 | tee $O/pytest.log
+                 for v in 0 1 0 1; do echo "-- OLA_NTT2_TFORM=$v"
+                   OLA_NTT2_TFORM=$v timeout 300 python bench.py --steps 30 --warmup 3 --no-prove --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('  ntt ms', d['ms_per_step'], 'frac', d['roofline']['frac'])"
+                   OLA_NTT2_TFORM=$v timeout 300 python tools/bench_ntt_matrix.py --log-n 22 --cols 94 --reps 5 --out $O/m_$v.json 2>&1 | grep -E '"op"' | cut -c1-110
+                 done 2>&1 | tee $O/ab.txt ;;
+    tform_prof)  # per-kernel durations of the two pass families (NTT, iNTT and LDE of 94 x 2^22)
+                 for v in 0 1; do cd /tmp; OLA_NTT2_TFORM=$v timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof$v -o p -- python $R/tools/bench_ntt_matrix.py --log-n 22 --cols 94 --reps 5 --out $R/$O/m_$v.json > /dev/null 2> $R/$O/err$v.txt; cd $R
+                   f=$(find $O/prof$v -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp "$f" $O/kernel_stats_$v.csv && head -14 $O/kernel_stats_$v.csv | cut -c1-170; done ;;
     ntt_tests)   timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fullsize.py -x -q -k "ntt or lde or NTT or coset" 2>&1 | tail -8 | tee $O/pytest.log ;;
     ntt_ab)      for lc in 1 4; do
                    echo "-- OLA_NTT2_LAST_COLS=$lc"
@@ -35,7 +44,7 @@ for step in "$@"; do
                    timeout 300 python bench.py --steps 30 --warmup 3 --no-prove --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('  ntt ms', d['ms_per_step'], 'frac', d['roofline']['frac'])"
                    timeout 300 python tools/bench_ntt_matrix.py --log-n 22 --cols 94 --reps 5 --out $O/m_$v.json 2>&1 | grep -E '"op"' | cut -c1-110
                  done 2>&1 | tee $O/ab.txt; cp ab_tmp/libola_cur.so olavm_amd/lib/libola_gpu.so ;;
-    pmc)         bash tools/pmc_ntt.sh r03 2>&1 | tail -30 ;;
+    pmc)         bash tools/pmc_ntt.sh r04 2>&1 | tail -30 ;;
     cold_preheat) OLA_COLD_PREHEAT=8 OLA_HASHER=blake3 timeout 300 python tools/cold_phases.py 22 2> $O/cold_b3_preheat.txt >/dev/null; grep "\[cold\]" $O/cold_b3_preheat.txt | head -8 ;;
     cold_b3)     # one figure per call: only the first process on a fresh box sees a cold runtime (and, with luck, clean VRAM)
                  OLA_HASHER=blake3 timeout 300 python tools/cold_phases.py 22 2> $O/cold_b3.txt >/dev/null; grep -E "\[cold\]|trace upload:" $O/cold_b3.txt | head -12 ;;

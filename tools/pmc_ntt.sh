@@ -5,7 +5,7 @@
 # 94 x 2^20 commitment whose kernels have known byte counts: calibration).  Writes profiles/<tag>_ntt_pmc.json, which bench.py reads
 # (it carries the hash of the kernel sources; bench.py reports the figures only while the sources are unchanged).
 set -u
-tag=${1:-r03}
+tag=${1:-r04}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$R/gpurun_out/pmc_$tag
 mkdir -p $out
@@ -13,8 +13,9 @@ cd /tmp && export TMPDIR=/tmp
 for ctr in FETCH_SIZE WRITE_SIZE SQ_INSTS_VALU TCC_HIT_sum TCC_MISS_sum; do
   (cd $R && rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $out/$ctr -o p -- python tools/pmc_workload.py > $out/$ctr.log 2>&1)
 done
-# the Infinity-Cache blocking experiment (ntt2_run, OLA_NTT2_GROUP_MB): the same transforms in column groups of 96 MB
-for ctr in FETCH_SIZE WRITE_SIZE TCC_HIT_sum TCC_MISS_sum; do
+# the Infinity-Cache blocking experiment of round 3 (ntt2_run, OLA_NTT2_GROUP_MB): the same transforms in column groups of 96 MB;
+# only with OLA_PMC_G96=1 (it doubles the box time and its answer is on record in profiles/r03_ntt_pmc.json)
+[ "${OLA_PMC_G96:-0}" = 1 ] && for ctr in FETCH_SIZE WRITE_SIZE TCC_HIT_sum TCC_MISS_sum; do
   (cd $R && OLA_NTT2_GROUP_MB=96 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $out/G96_$ctr -o p -- python tools/pmc_workload.py > $out/G96_$ctr.log 2>&1)
 done
 cd $R && python3 tools/pmc_ntt_json.py $out profiles/${tag}_ntt_pmc.json

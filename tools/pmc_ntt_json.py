@@ -10,7 +10,7 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-NTT_SOURCES = ["olavm_amd/csrc/gl.cuh", "olavm_amd/csrc/ntt.hip", "olavm_amd/csrc/ntt2.hip"]
+NTT_SOURCES = ["olavm_amd/csrc/gl.cuh", "olavm_amd/csrc/ntt.hip", "olavm_amd/csrc/ntt2.hip", "olavm_amd/csrc/ntt2t.cuh"]
 
 
 def source_hash():
@@ -55,7 +55,9 @@ def main():
     elems = n * cols
     # the 2^22 natural-order transform is two strided 7-bit passes and the closing natural-order 8-bit pass
     names = ("ntt2_pass_kernel<7, 0, false, 4, false>", "ntt2_pass_kernel_w4<7, 0, false, 4>", "ntt2_pass_kernel<7, 0, false, 8, false>",
-             "ntt2_pass_kernel_w4<7, 0, false, 8>", "ntt2_pass_kernel<8, 2, false, 1, false>", "ntt2_pass_kernel<8, 2, false, 4, false>")
+             "ntt2_pass_kernel_w4<7, 0, false, 8>", "ntt2_pass_kernel<8, 2, false, 1, false>", "ntt2_pass_kernel<8, 2, false, 4, false>",
+             # round 4: the T-form passes (ntt2t.cuh): strided without / with load multipliers, closing natural-order pass
+             "ntt2t_pass_kernel<7, 0, false, 8, 0>", "ntt2t_pass_kernel<7, 0, false, 8, 1>", "ntt2t_pass_kernel<8, 2, false, 8, 2>")
     passes, tot = pass_totals(kernels, names)
     g_kernels = collect(src, "G96_")
     g_passes, g_tot = pass_totals(g_kernels, names)
