@@ -37,7 +37,7 @@ extern "C" {
  * OlaGpuConfig.hasher occupies what was tail padding (sizeof unchanged, but the field must be set: zero-initialise the struct);
  * multi-device contexts and the accounting entry points were added.  A host built against an older header must be rebuilt:
  * ola_gpu_abi_version() lets it check at start-up that library and header agree (also on sizeof(OlaChallenger)). */
-#define OLA_GPU_ABI_VERSION 3
+#define OLA_GPU_ABI_VERSION 4
 #define OLA_OK 0
 #define OLA_E_INVALID_ARG (-1)
 #define OLA_E_NO_DEVICE (-2)
@@ -85,6 +85,22 @@ int32_t ola_gpu_abi_version(size_t* challenger_size, size_t* config_size);
  * (OLA_E_HIP otherwise). */
 int32_t ola_gpu_init_multi(const OlaGpuConfig* cfg, const int32_t* devices, uint32_t n_devices, OlaCtx** out_ctx);
 int32_t ola_gpu_device_count(OlaCtx* ctx, uint32_t* n_devices);
+/* Who carries the exchanges of a multi-device context (SURVEY 8(b),(e): "RCCL-over-xGMI all-gather of Merkle caps and FRI
+ * commitments").  OLA_COLLECTIVE = peer (default) | rccl, read by ola_gpu_init_multi: with rccl the library dlopen()s librccl.so,
+ * creates one communicator per device (ncclCommInitAll over the context's devices) and every exchange is an ncclAllGather on the
+ * rank's stream; with peer it is the library's own event-ordered pulls (hipMemcpyPeerAsync).  RCCL is never a link dependency.
+ * When RCCL cannot carry the context -- library absent, or logical ranks aliased onto one physical GPU -- the context keeps the
+ * peer carrier and `note` says why.  *carrier: OLA_COLLECTIVE_*, *ranks: ranks the carrier spans; note (may be NULL) receives a
+ * NUL-terminated explanation (RCCL version when active, the refusal otherwise). */
+#define OLA_COLLECTIVE_NONE 0u /* single-device context: no exchanges */
+#define OLA_COLLECTIVE_PEER 1u
+#define OLA_COLLECTIVE_RCCL 2u
+int32_t ola_gpu_collective(OlaCtx* ctx, uint32_t* carrier, uint32_t* ranks, char* note, size_t note_cap);
+/* The context's all-gather by itself (what bench.py times for the 512-byte cap exchange and the trace exchange, and what the
+ * tests check): every rank contributes bytes_per_rank bytes of its own pattern, `reps` gathers run back to back on the ranks'
+ * streams through `carrier` (OLA_COLLECTIVE_PEER / _RCCL; the latter needs a context created under OLA_COLLECTIVE=rccl, also a
+ * single-device one: a 1-rank communicator).  *ms_per_gather: slowest rank's mean; *mismatches: wrong bytes over all ranks (0). */
+int32_t ola_gpu_all_gather_check(OlaCtx* ctx, uint32_t carrier, size_t bytes_per_rank, uint32_t reps, double* ms_per_gather, uint64_t* mismatches);
 int32_t ola_gpu_free(OlaCtx* ctx);
 const char* ola_gpu_last_error(void);
 int32_t ola_gpu_sync(OlaCtx* ctx);

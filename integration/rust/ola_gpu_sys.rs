@@ -1,4 +1,4 @@
-//! Raw bindings of `libola_gpu.so` (`include/ola_gpu.h`, ABI revision 3) for the reference's `circuits` crate.
+//! Raw bindings of `libola_gpu.so` (`include/ola_gpu.h`, ABI revision 4) for the reference's `circuits` crate.
 //!
 //! Drop into `circuits/src/stark/ola_gpu_sys.rs` (integration/patches/0001-feature-hip.patch adds the `mod` line and the
 //! feature).  Replaces the reference's dead CUDA FFI -- `gpu_init` / `gpu_method` / `gpu_free`,
@@ -11,7 +11,7 @@
 #![allow(non_camel_case_types, dead_code)]
 use std::os::raw::{c_char, c_void};
 
-pub const OLA_GPU_ABI_VERSION: i32 = 3;
+pub const OLA_GPU_ABI_VERSION: i32 = 4;
 pub const OLA_OK: i32 = 0;
 pub const OLA_E_INVALID_ARG: i32 = -1;
 pub const OLA_E_NO_DEVICE: i32 = -2;
@@ -32,6 +32,10 @@ pub const OLA_NTT_COSET_LDE: i32 = 2;
 pub const OLA_NTT_COSET_INTERPOLATE: i32 = 3;
 pub const OLA_NTT_COSET_LDE_LEAF_ORDER: i32 = 4;
 pub const OLA_SHARD_STREAM_ORDERED: u32 = 1;
+/// ola_gpu_collective: who carries a multi-device context's exchanges
+pub const OLA_COLLECTIVE_NONE: u32 = 0;
+pub const OLA_COLLECTIVE_PEER: u32 = 1;
+pub const OLA_COLLECTIVE_RCCL: u32 = 2;
 pub const OLA_PHASE_COUNT: u32 = 7;
 
 #[repr(C)]
@@ -78,6 +82,9 @@ extern "C" {
     pub fn ola_gpu_abi_version(challenger_size: *mut usize, config_size: *mut usize) -> i32;
     pub fn ola_gpu_init_multi(cfg: *const OlaGpuConfig, devices: *const i32, n_devices: u32, out_ctx: *mut *mut OlaCtx) -> i32;
     pub fn ola_gpu_device_count(ctx: *mut OlaCtx, n_devices: *mut u32) -> i32;
+    pub fn ola_gpu_collective(ctx: *mut OlaCtx, carrier: *mut u32, ranks: *mut u32, note: *mut c_char, note_cap: usize) -> i32;
+    pub fn ola_gpu_all_gather_check(ctx: *mut OlaCtx, carrier: u32, bytes_per_rank: usize, reps: u32, ms_per_gather: *mut f64,
+        mismatches: *mut u64) -> i32;
     pub fn ola_gpu_free(ctx: *mut OlaCtx) -> i32;
     pub fn ola_gpu_last_error() -> *const c_char;
     pub fn ola_gpu_sync(ctx: *mut OlaCtx) -> i32;

@@ -63,10 +63,12 @@ def load_library():
     L.ola_gpu_init.argtypes = [C.POINTER(OlaGpuConfig), C.POINTER(C.c_void_p)]
     L.ola_gpu_abi_version.argtypes = [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
     a, b = C.c_size_t(), C.c_size_t()
-    if L.ola_gpu_abi_version(C.byref(a), C.byref(b)) != 3 or a.value != C.sizeof(OlaChallenger) or b.value != C.sizeof(OlaGpuConfig):
+    if L.ola_gpu_abi_version(C.byref(a), C.byref(b)) != 4 or a.value != C.sizeof(OlaChallenger) or b.value != C.sizeof(OlaGpuConfig):
         raise OlaGpuError(-7, "libola_gpu.so and olavm_amd/backend.py disagree on the ABI revision or struct sizes: rebuild the library")
     L.ola_gpu_init_multi.argtypes = [C.POINTER(OlaGpuConfig), C.POINTER(C.c_int32), C.c_uint32, C.POINTER(C.c_void_p)]
     L.ola_gpu_device_count.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
+    L.ola_gpu_collective.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_char_p, C.c_size_t]
+    L.ola_gpu_all_gather_check.argtypes = [C.c_void_p, C.c_uint32, C.c_size_t, C.c_uint32, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     L.ola_gpu_proof_stats.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_double)]
     L.ola_gpu_phase_stats.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_uint32]
     L.ola_gpu_free.argtypes = [C.c_void_p]
@@ -133,6 +135,7 @@ EXPORTS = [
     "ola_permuted_cols", "ola_permuted_cols_dev", "ola_prove_single_table", "ola_take_pending_proof", "ola_gpu_memory_stats", "ola_gpu_selftest", "ola_gpu_reserve",
     "ola_table_shape", "ola_perm_z", "ola_ctl_z", "ola_quotient", "ola_set_shard_options", "ola_gpu_get_stream",
     "ola_gpu_abi_version", "ola_gpu_init_multi", "ola_gpu_device_count", "ola_gpu_proof_stats", "ola_gpu_phase_stats",
+    "ola_gpu_collective", "ola_gpu_all_gather_check",
 ]
 
 
@@ -244,7 +247,18 @@ class Backend:
         self.ctx = C.c_void_p()
         if devices is not None:
             dv = (C.c_int32 * len(devices))(*[int(d) for d in devices])
-            self._chk(self.lib.ola_gpu_init_multi(C.byref(c), dv, len(devices), C.byref(self.ctx)))
+            # collective="rccl" | "peer": the library reads OLA_COLLECTIVE when the context is created (ola_gpu_collective tells what it got)
+            want, old = cfg.get("collective"), os.environ.get("OLA_COLLECTIVE")
+            if want is not None:
+                os.environ["OLA_COLLECTIVE"] = want
+            try:
+                self._chk(self.lib.ola_gpu_init_multi(C.byref(c), dv, len(devices), C.byref(self.ctx)))
+            finally:
+                if want is not None:
+                    if old is None:
+                        del os.environ["OLA_COLLECTIVE"]
+                    else:
+                        os.environ["OLA_COLLECTIVE"] = old
         else:
             self._chk(self.lib.ola_gpu_init(C.byref(c), C.byref(self.ctx)))
 
@@ -261,6 +275,19 @@ class Backend:
         n = C.c_uint32()
         self._chk(self.lib.ola_gpu_device_count(self.ctx, C.byref(n)))
         return n.value
+
+    def collective(self):
+        """ola_gpu_collective: who carries this context's exchanges -> {"carrier": "none" | "peer" | "rccl", "ranks": n, "note": str}"""
+        carrier, ranks = C.c_uint32(), C.c_uint32()
+        note = C.create_string_buffer(512)
+        self._chk(self.lib.ola_gpu_collective(self.ctx, C.byref(carrier), C.byref(ranks), note, 512))
+        return {"carrier": ("none", "peer", "rccl")[carrier.value], "ranks": ranks.value, "note": note.value.decode()}
+
+    def all_gather_check(self, carrier, bytes_per_rank, reps=10):
+        """ola_gpu_all_gather_check through "peer" or "rccl": -> (ms per gather on the slowest rank, wrong bytes over all ranks)"""
+        ms, bad = C.c_double(), C.c_uint64()
+        self._chk(self.lib.ola_gpu_all_gather_check(self.ctx, {"peer": 1, "rccl": 2}[carrier], bytes_per_rank, reps, C.byref(ms), C.byref(bad)))
+        return ms.value, bad.value
 
     def proof_stats(self, enable=None):
         """ola_gpu_proof_stats: switch the accounting (True / False / None = leave) and return the last proof's figures."""

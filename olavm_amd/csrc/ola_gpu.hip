@@ -17,6 +17,7 @@
 #include "poseidon_host.h"
 #include "lookup.h"
 #include "peer_group.h"
+#include "rccl_carrier.h"
 
 // unity build: device code shares the __constant__ Poseidon tables
 #include "ntt.hip"
@@ -40,6 +41,10 @@ struct OlaCtx {
     // their meeting point (peer_group.h).  Empty / null for a single-device context.
     std::vector<OlaCtx*> peers;
     std::unique_ptr<PeerGroup> group;
+    // who moves the bytes of the partition's exchanges (ola_gpu_collective): the library's peer pulls, or RCCL when OLA_COLLECTIVE=rccl
+    // asked for it at ola_gpu_init_multi and RCCL could be set up over the context's devices (rccl_carrier.h); else the reason why not
+    std::unique_ptr<RcclGroup> rccl;
+    std::string collective_note;
     ~OlaCtx() {
         if (tables) ntt_tables_destroy(tables);
         for (OlaCtx* p : peers) {
@@ -158,7 +163,9 @@ static void prove_with_traces_multi(OlaCtx* ctx, const u64* airset, size_t airse
             ShardInfo sh;
             sh.rank = r; sh.world = world;
             while ((1u << sh.log_world) < world) sh.log_world++;
-            sh.all_gather = peer_all_gather; sh.user = &g.ranks[r]; sh.stream_ordered = true;
+            if (ctx->rccl) { sh.all_gather = rccl_all_gather; sh.user = &ctx->rccl->ranks[r]; }
+            else { sh.all_gather = peer_all_gather; sh.user = &g.ranks[r]; }
+            sh.stream_ordered = true;
             c->dev.shard = sh;
             c->dev.acct.on = ctx->dev.acct.on;
             c->dev.acct.begin_proof();
@@ -256,8 +263,100 @@ int32_t ola_gpu_init_multi(const OlaGpuConfig* cfg, const int32_t* devices, uint
             HIP_CHECK(hipEventCreateWithFlags(&pr.done, hipEventDisableTiming));
         }
     }
+    // OLA_COLLECTIVE = peer (default) | rccl: the carrier of this context's exchanges.  RCCL is loaded on request only; when it
+    // cannot carry the context (library absent, ranks aliased onto one GPU) the context keeps the peer carrier and records why.
+    {
+        const char* e = getenv("OLA_COLLECTIVE");
+        const std::string want = e ? e : "peer";
+        if (want == "rccl") {
+            std::vector<hipStream_t> streams(n_devices);
+            for (uint32_t r = 0; r < n_devices; r++) streams[r] = r == 0 ? root->dev.stream : root->peers[r - 1]->dev.stream;
+            std::string why;
+            root->rccl = rccl_group_create(dv, streams, root->group.get(), why);
+            if (root->rccl) root->collective_note = "RCCL " + std::to_string(root->rccl->version) + ": ncclAllGather on " + std::to_string(n_devices) + " communicator(s) of one ncclCommInitAll";
+            else root->collective_note = "OLA_COLLECTIVE=rccl refused, peer carrier kept: " + why;
+        } else if (want != "peer") {
+            throw OlaError(OLA_E_INVALID_ARG, "OLA_COLLECTIVE must be peer or rccl");
+        }
+    }
     *out_ctx = root.release();
     g_live_contexts.fetch_add(1);
+    OLA_CATCH
+}
+
+int32_t ola_gpu_collective(OlaCtx* ctx, uint32_t* carrier, uint32_t* ranks, char* note, size_t note_cap) {
+    OLA_TRY
+    require(ctx != nullptr, "ctx");
+    if (carrier) *carrier = ctx->rccl ? OLA_COLLECTIVE_RCCL : (ctx->group ? OLA_COLLECTIVE_PEER : OLA_COLLECTIVE_NONE);
+    if (ranks) *ranks = ctx->rccl ? (uint32_t)ctx->rccl->comms.size() : (uint32_t)ctx->peers.size() + 1;
+    if (note && note_cap) { snprintf(note, note_cap, "%s", ctx->collective_note.c_str()); }
+    OLA_CATCH
+}
+
+// The context's all-gather by itself, on every rank of the context: each rank fills a block of `bytes_per_rank` bytes with its
+// own pattern, `reps` gathers run back to back on the ranks' streams, every byte of every rank's result is compared.
+int32_t ola_gpu_all_gather_check(OlaCtx* ctx, uint32_t carrier, size_t bytes_per_rank, uint32_t reps, double* ms_per_gather, uint64_t* mismatches) {
+    OLA_TRY
+    OLA_ON_DEVICE(ctx);
+    require(ctx && mismatches, "null pointer");
+    require(bytes_per_rank > 0 && bytes_per_rank % 8 == 0 && reps >= 1, "bytes_per_rank must be a positive multiple of 8, reps >= 1");
+    require(carrier == OLA_COLLECTIVE_PEER || carrier == OLA_COLLECTIVE_RCCL, "carrier must be OLA_COLLECTIVE_PEER or OLA_COLLECTIVE_RCCL");
+    if (carrier == OLA_COLLECTIVE_RCCL && !ctx->rccl)
+        throw OlaError(OLA_E_INVALID_ARG, "this context has no RCCL carrier" + (ctx->collective_note.empty() ? std::string(" (create it with OLA_COLLECTIVE=rccl)") : ": " + ctx->collective_note));
+    if (carrier == OLA_COLLECTIVE_PEER && !ctx->group) throw OlaError(OLA_E_INVALID_ARG, "a single-device context has no peers to gather from");
+    const uint32_t world = carrier == OLA_COLLECTIVE_RCCL ? (uint32_t)ctx->rccl->comms.size() : (uint32_t)ctx->peers.size() + 1;
+    if (ctx->group) ctx->group->reset();
+    std::vector<uint64_t> bad(world, 0);
+    std::vector<double> ms(world, 0.0);
+    std::vector<int> code(world, 0);
+    std::vector<std::string> msg(world);
+    auto run = [&](uint32_t r) {
+        OlaCtx* c = r == 0 ? ctx : ctx->peers[r - 1];
+        DeviceCtx* d = &c->dev;
+        void *send = nullptr, *recv = nullptr;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        try {
+            HIP_CHECK(hipSetDevice(d->device));
+            send = d->alloc(bytes_per_rank);
+            recv = d->alloc(bytes_per_rank * world);
+            HIP_CHECK(hipMemsetAsync(send, (int)(0x11 * (r + 1)), bytes_per_rank, d->stream));
+            HIP_CHECK(hipMemsetAsync(recv, 0, bytes_per_rank * world, d->stream));
+            HIP_CHECK(hipEventCreate(&e0));
+            HIP_CHECK(hipEventCreate(&e1));
+            void* user = carrier == OLA_COLLECTIVE_RCCL ? (void*)&ctx->rccl->ranks[r] : (void*)&ctx->group->ranks[r];
+            auto gather = carrier == OLA_COLLECTIVE_RCCL ? rccl_all_gather : peer_all_gather;
+            if (gather(user, send, recv, bytes_per_rank) != 0) throw OlaError(OLA_E_INTERNAL, "all-gather failed (warm-up)");
+            HIP_CHECK(hipEventRecord(e0, d->stream));
+            for (uint32_t i = 0; i < reps; i++)
+                if (gather(user, send, recv, bytes_per_rank) != 0) throw OlaError(OLA_E_INTERNAL, "all-gather failed");
+            HIP_CHECK(hipEventRecord(e1, d->stream));
+            HIP_CHECK(hipStreamSynchronize(d->stream));
+            float t = 0;
+            HIP_CHECK(hipEventElapsedTime(&t, e0, e1));
+            ms[r] = t / reps;
+            std::vector<unsigned char> host(bytes_per_rank * world);
+            HIP_CHECK(hipMemcpy(host.data(), recv, host.size(), hipMemcpyDeviceToHost));
+            for (uint32_t j = 0; j < world; j++)
+                for (size_t k = 0; k < bytes_per_rank; k++) bad[r] += host[(size_t)j * bytes_per_rank + k] != (unsigned char)(0x11 * (j + 1));
+        } catch (const OlaError& e) { code[r] = e.code; msg[r] = e.what(); if (ctx->group) ctx->group->fail(); }
+        catch (const std::exception& e) { code[r] = OLA_E_INTERNAL; msg[r] = e.what(); if (ctx->group) ctx->group->fail(); }
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+        (void)hipStreamSynchronize(d->stream);
+        d->free(send);
+        d->free(recv);
+    };
+    std::vector<std::thread> workers;
+    for (uint32_t r = 1; r < world; r++) workers.emplace_back(run, r);
+    run(0);
+    for (std::thread& t : workers) t.join();
+    for (uint32_t r = 0; r < world; r++)
+        if (code[r] != 0) throw OlaError(code[r], "rank " + std::to_string(r) + ": " + msg[r]);
+    uint64_t total = 0;
+    double worst = 0;
+    for (uint32_t r = 0; r < world; r++) { total += bad[r]; worst = std::max(worst, ms[r]); }
+    *mismatches = total;
+    if (ms_per_gather) *ms_per_gather = worst;
     OLA_CATCH
 }
 

@@ -148,3 +148,85 @@ def test_peer_all_gather_by_itself(tmp_path):
                           stderr=subprocess.DEVNULL)
     r = subprocess.run([exe, "4"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "all ok" in r.stdout and "MISMATCH" not in r.stdout, r.stdout + r.stderr
+
+
+def test_rccl_carrier_one_rank_communicator_round_trips():
+    """OLA_COLLECTIVE=rccl: librccl.so is loaded on request (never linked), ncclCommInitAll over the context's devices, every
+    exchange an ncclAllGather on the rank's stream (olavm_amd/csrc/rccl_carrier.h).  What one GPU can exercise: a 1-device
+    context gets a 1-rank communicator and its gather returns the rank's own block, for a 512-byte cap block and a 64 MB one."""
+    from olavm_amd.backend import Backend, OlaGpuError
+    be = Backend(devices=[0], collective="rccl")
+    try:
+        c = be.collective()
+        assert c["carrier"] == "rccl" and c["ranks"] == 1 and c["note"].startswith("RCCL "), c
+        for size in (512, 64 << 20):
+            ms, bad = be.all_gather_check("rccl", size, reps=3)
+            assert bad == 0 and ms >= 0, (size, ms, bad)
+        with pytest.raises(OlaGpuError):
+            be.all_gather_check("peer", 512)          # a single-device context has no peers
+    finally:
+        be.close()
+    plain = Backend(device=0)
+    assert plain.collective()["carrier"] == "none"
+    with pytest.raises(OlaGpuError) as e:
+        plain.all_gather_check("rccl", 512)
+    assert "OLA_COLLECTIVE=rccl" in str(e.value)
+    plain.close()
+
+
+def test_rccl_refused_on_aliased_devices_with_a_clear_reason(small_instance):
+    """Logical ranks sharing one physical GPU cannot form an RCCL communicator: the context says so, keeps the library's peer
+    carrier, and proves the same bytes."""
+    from olavm_amd.backend import Backend, OlaGpuError
+    blob, traces, params, compress = small_instance
+    one = Backend(device=0)
+    single = one.prove_with_traces(blob, traces, params, compress)
+    one.close()
+    be = Backend(devices=[0, 0], collective="rccl")
+    try:
+        c = be.collective()
+        assert c["carrier"] == "peer" and c["ranks"] == 2, c
+        assert "refused" in c["note"] and "share device 0" in c["note"], c
+        assert be.prove_with_traces(blob, traces, params, compress) == single
+        ms, bad = be.all_gather_check("peer", 512, reps=5)
+        assert bad == 0
+        with pytest.raises(OlaGpuError) as e:
+            be.all_gather_check("rccl", 512)
+        assert "share device 0" in str(e.value)
+    finally:
+        be.close()
+    with pytest.raises(OlaGpuError):
+        Backend(devices=[0, 0], collective="mpi")
+
+
+def test_two_physical_gpus_both_carriers_and_the_callers_device():
+    """Needs two GPUs (skipped on the one-GPU test box): distinct ordinals, so hipMemcpyPeerAsync / hipDeviceEnablePeerAccess /
+    cross-device event waits and -- under OLA_COLLECTIVE=rccl -- a 2-rank communicator really run; the caller's current HIP device
+    must be what it was after prove / sync / trim / free."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one GPU on this box")
+    from olavm_amd.air import ola_tables as T
+    from olavm_amd.backend import Backend
+    from tests import tracegen
+    blob = T.ola_stark(range_bits=4, limb_bits=2).blob()
+    traces, params, compress = tracegen.empty_program_instance(log_n=12, live=np.random.default_rng(12))
+    torch.cuda.set_device(0)
+    one = Backend(device=0)
+    single = one.prove_with_traces(blob, traces, params, compress)
+    one.close()
+    for carrier in ("peer", "rccl"):
+        be = Backend(devices=[0, 1], collective=carrier)
+        assert be.collective()["carrier"] == carrier, be.collective()
+        assert torch.cuda.current_device() == 0
+        assert be.prove_with_traces(blob, traces, params, compress) == single
+        assert torch.cuda.current_device() == 0
+        be.sync()
+        assert torch.cuda.current_device() == 0
+        be.trim()
+        assert torch.cuda.current_device() == 0
+        for size in (512, 64 << 20):
+            ms, bad = be.all_gather_check(carrier, size, reps=5)
+            assert bad == 0, (carrier, size)
+        be.close()
+        assert torch.cuda.current_device() == 0

@@ -19,3 +19,4 @@ done
   (cd $R && OLA_NTT2_GROUP_MB=96 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $out/G96_$ctr -o p -- python tools/pmc_workload.py > $out/G96_$ctr.log 2>&1)
 done
 cd $R && python3 tools/pmc_ntt_json.py $out profiles/${tag}_ntt_pmc.json
+cp profiles/${tag}_ntt_pmc.json $out/ 2>/dev/null || true
