@@ -491,7 +491,10 @@ def sharded_prove_time(be, rank, world, log_n, coll_dev, reps=2, real=False):
     dist.barrier()
     single = sharding.max_over_ranks([single], device=coll_dev)[0]
     res["single_gpu_seconds_same_box"] = round(single, 4)
-    res["speedup_over_one_gpu"] = round(single / t, 3) if t > 0 else None
+    aliased = world > torch.cuda.device_count()          # a dry run with ranks sharing GPUs measures no speed-up
+    res["speedup_over_one_gpu"] = round(single / t, 3) if t > 0 and not aliased else None
+    if aliased:
+        res["devices_aliased"] = True
     return res
 
 
@@ -571,16 +574,46 @@ def single_process_multi(args):
            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
                         "traffic": None, "algorithmic_bytes_per_launch": 16.0 * n * cols / passes, "kernel": "ntt2t_pass_kernel", "launches_per_step": passes,
                         "avg_launch_ms": round(launch_ms, 4), "note": "per GPU, slowest rank" + ("; ranks share physical GPUs" if aliased else "")}}
+    try:
+        res["collective"] = collective_report(Backend, devices, aliased, args.log_n, cols)
+    except Exception as e:              # noqa: BLE001 -- an extra: never at the price of the headline line
+        res["collective"] = {"error": repr(e)[:300]}
     if not args.no_prove:
+        carrier = os.environ.get("OLA_COLLECTIVE", "peer")
         try:
-            res["prove_sharded"] = multi_context_prove(Backend, devices, args.log_n, real=False)
-            res["prove_real_execution_sharded"] = multi_context_prove(Backend, devices, args.log_n, real=True)
+            res["prove_sharded"] = multi_context_prove(Backend, devices, args.log_n, real=False, aliased=aliased, collective=carrier)
+            res["prove_real_execution_sharded"] = multi_context_prove(Backend, devices, args.log_n, real=True, aliased=aliased, collective=carrier)
         except Exception as e:          # noqa: BLE001 -- an extra: never at the price of the headline line
             res.setdefault("prove_sharded", {"error": repr(e)[:300]})
     print(json.dumps(res), flush=True)
 
 
-def multi_context_prove(Backend, devices, log_n, real, reps=2):
+def collective_report(Backend, devices, aliased, log_n, cols):
+    """Which carrier a multi-device context over `devices` gets for each setting of OLA_COLLECTIVE (ola_gpu_collective: did RCCL
+    see N ranks, or why not), and -- on distinct physical GPUs -- both carriers timed by themselves for the two exchanges that
+    matter: the 512-byte Merkle-cap gather (latency) and the trace gather of a 2^log_n-row, `cols`-column table (bandwidth)."""
+    N = len(devices)
+    out = {"requested_by_default": os.environ.get("OLA_COLLECTIVE", "peer")}
+    trace_block = (cols * (8 << log_n) // N + 7) // 8 * 8
+    for carrier in ("peer", "rccl"):
+        be = Backend(devices=devices, collective=carrier)
+        try:
+            c = be.collective()
+            entry = {"got": c["carrier"], "ranks": c["ranks"], "note": c["note"]}
+            if c["carrier"] == carrier and not aliased:
+                for name, size, reps in (("cap_gather_512B", 512, 50), ("trace_gather", trace_block, 5)):
+                    ms, bad = be.all_gather_check(carrier, size, reps=reps)
+                    entry[name] = {"bytes_per_rank": size, "ms": round(ms, 4), "wrong_bytes": int(bad),
+                                   "GBps_received_per_rank": round(size * (N - 1) / (ms * 1e-3) / 1e9, 2) if ms > 0 else None}
+            out[carrier] = entry
+        finally:
+            be.close()
+    if aliased:
+        out["note"] = "ranks share physical GPUs on this box: RCCL cannot form a communicator over them and nothing is timed"
+    return out
+
+
+def multi_context_prove(Backend, devices, log_n, real, reps=2, aliased=False, collective="peer"):
     """STRONG scaling of the whole proof: ONE ola_prove_with_traces call on a context that spans `devices`, against the same
     call on a single-device context of the same box; bytes compared, oracle-verified."""
     from olavm_amd.air import ola_tables as T
@@ -592,7 +625,8 @@ def multi_context_prove(Backend, devices, log_n, real, reps=2):
         traces, params, compress = fastexec.instance(miniexec.memory_program(count), range_bits=16, limb_bits=8, max_steps=1 << (log_n + 1))
     else:
         traces, params, compress = tracegen.empty_program_instance(log_n=10, range_bits=16, limb_bits=8, log_n_cpu=log_n, log_n_mem=log_n)
-    mb = Backend(devices=devices)
+    mb = Backend(devices=devices, collective=collective)
+    carrier = mb.collective()
     mb.proof_stats(enable=True)
     ts, proof = [], b""
     for _ in range(reps + 1):
@@ -608,10 +642,14 @@ def multi_context_prove(Backend, devices, log_n, real, reps=2):
     t1 = time.perf_counter() - t0
     one.close()
     t = min(ts[1:])
+    # a speed-up is only a speed-up on distinct physical GPUs; with aliased ranks one device does all ranks' work
+    speed = {"speedup_over_one_gpu": round(t1 / t, 3)} if not aliased else {"speedup_over_one_gpu": None, "devices_aliased": True}
     return {"seconds": round(t, 4), "first_call_seconds": round(ts[0], 4), "proof_bytes": len(proof), "scaling": "strong",
             "exchanges_per_proof": st["peer_exchanges"] // (reps + 1), "bytes_moved_between_gpus_per_proof": st["peer_bytes_moved"] // (reps + 1),
-            "single_gpu_seconds_same_box": round(t1, 4), "speedup_over_one_gpu": round(t1 / t, 3),
-            "collective": "library all-gather: peer-to-peer pulls over xGMI ordered by stream events (olavm_amd/csrc/peer_group.h)",
+            "single_gpu_seconds_same_box": round(t1, 4), **speed,
+            "collective": ("RCCL: ncclAllGather on one communicator per device (olavm_amd/csrc/rccl_carrier.h)" if carrier["carrier"] == "rccl" else
+                           "library all-gather: peer-to-peer pulls over xGMI ordered by stream events (olavm_amd/csrc/peer_group.h)"),
+            "collective_ranks": carrier["ranks"], "collective_note": carrier["note"],
             "workload": f"ONE ola_prove_with_traces call on a context spanning {len(devices)} GPUs (devices {devices}), 12 tables, heights 2^{[int(x.shape[1]).bit_length() - 1 for x in traces]}"
                         + (", executed program" if real else ""),
             **verify_proofs(blob, [proof, single], params)}
