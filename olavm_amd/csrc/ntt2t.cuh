@@ -510,7 +510,8 @@ __device__ __forceinline__ void ntt2t_pass_body(const Ntt2Params& p) {
 
 // Strided passes are held to 128 VGPRs = four waves per SIMD (they sit at 124 - 130 by themselves; at most two spilled words):
 // with their multipliers in LDS the pass is a balance of load latency and issue time, and the fourth wave is what hides the loads.
-// Closing passes carry sixteen 64-bit multipliers per thread and would spill 30 - 70 words under the same cap: left alone.
+// Closing passes carry sixteen 64-bit multipliers per thread (142 - 156 VGPRs, three waves); held to 128 they spill 16 - 32 words
+// and the x8 LDE of 94 x 2^22 goes from 32.7 to 35.2 ms (same-box alternation, round 4): left alone.
 template <int R, int MODE, bool INV, int CB, int LM>
 __global__ __launch_bounds__(256, (MODE == N2_STRIDED ? 4 : 1)) void ntt2t_pass_kernel(Ntt2Params p) { ntt2t_pass_body<R, MODE, INV, CB, LM>(p); }
 
