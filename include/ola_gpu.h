@@ -108,7 +108,8 @@ int32_t ola_gpu_sync(OlaCtx* ctx);
  * the cached blocks to the driver.  Live OlaBatch objects are not affected. */
 int32_t ola_gpu_trim(OlaCtx* ctx);
 /* Device memory of the context's buffer pool, in bytes: out[0] handed out now, out[1] the most ever handed out at once,
- * out[2] handed out + cached now, out[3] the most ever held (the high-water mark of a proof; reset = 1 restarts the marks). */
+ * out[2] handed out + cached now, out[3] the most ever held (the high-water mark of a proof; reset = 1 restarts the marks).
+ * On a multi-device context every rank has its own pool: each figure is the largest over the ranks (what one GPU must hold). */
 int32_t ola_gpu_memory_stats(OlaCtx* ctx, uint64_t out[4], int32_t reset);
 /* Where the device time of a proof goes with respect to the coset partition.  enable: 1 / 0 switches the accounting on / off for
  * the proofs that follow (a few hundred event records per proof, no synchronisation), -1 leaves it as it is.  out (may be NULL)

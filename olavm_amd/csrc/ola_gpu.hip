@@ -860,9 +860,16 @@ int32_t ola_gpu_memory_stats(OlaCtx* ctx, uint64_t out[4], int32_t reset) {
     OLA_TRY
     OLA_ON_DEVICE(ctx);
     require(ctx && out, "null pointer");
-    DeviceCtx& d = ctx->dev;
-    out[0] = d.live_bytes; out[1] = d.live_peak; out[2] = d.live_bytes + d.cached_bytes; out[3] = d.reserved_peak;
-    if (reset) { d.live_peak = d.live_bytes; d.reserved_peak = d.live_bytes + d.cached_bytes; }
+    // a multi-device context: every rank has its own pool (also when ranks share a GPU); the figures are the LARGEST over the ranks,
+    // i.e. what one GPU of the node has to hold
+    for (int i = 0; i < 4; i++) out[i] = 0;
+    for (size_t r = 0; r <= ctx->peers.size(); r++) {
+        DeviceCtx& d = r == 0 ? ctx->dev : ctx->peers[r - 1]->dev;
+        std::lock_guard<std::mutex> lk(d.mu);
+        const uint64_t v[4] = {d.live_bytes, d.live_peak, d.live_bytes + d.cached_bytes, d.reserved_peak};
+        for (int i = 0; i < 4; i++) out[i] = std::max<uint64_t>(out[i], v[i]);
+        if (reset) { d.live_peak = d.live_bytes; d.reserved_peak = d.live_bytes + d.cached_bytes; }
+    }
     OLA_CATCH
 }
 

@@ -16,6 +16,9 @@ for step in "$@"; do
     stats_real)  timeout 600 python tools/proof_stats.py --real --out $O/proof_stats_real.json 2>&1 | tail -8 ;;
     stats_multi) timeout 600 python tools/proof_stats.py --log-n 20 --devices 0 0 0 0 0 0 0 0 --out $O/proof_stats.json 2>&1 | tail -8 ;;
     stats_multi22) timeout 900 python tools/proof_stats.py --log-n 22 --devices 0 0 0 0 0 0 0 0 --out $O/proof_stats.json 2>&1 | tail -8 ;;
+    stats_multi23) # dry run towards config 5 on ONE GPU: per-rank pool high-water marks (8 aliased ranks at 2^23 rows do not fit 288 GB: OLA_E_OOM, clean)
+                 timeout 900 python tools/proof_stats.py --log-n 22 --hashers blake3 --devices 0 0 0 0 0 0 0 0 --out $O/proof_stats_8x2p22.json 2>&1 | tail -3
+                 timeout 900 python tools/proof_stats.py --log-n 23 --hashers blake3 --devices 0 0 0 0 --out $O/proof_stats_4x2p23.json 2>&1 | tail -3 ;;
     phases)      OLA_TIMING=1 timeout 600 python tools/bench_prove.py 22 2 2> $O/phases.txt | tail -3; OLA_HASHER=blake3 OLA_TIMING=1 timeout 600 python tools/bench_prove.py 22 2 2> $O/phases_blake3.txt | tail -3 ;;
     ntt_group)   # Infinity-Cache blocking of the transforms: working-set target in MB (0 = whole batch per launch)
                  for mb in 0 32 64 96 128 192; do

@@ -85,6 +85,7 @@ def main():
         be.close()
         if args.devices:
             mb = Backend(devices=args.devices, hasher=h)
+            mb.memory_stats(reset=True)
             mb.prove_with_traces(blob, traces, params, compress)
             ts = []
             for _ in range(3):
@@ -93,7 +94,9 @@ def main():
                 ts.append(time.perf_counter() - t0)
             st = mb.proof_stats()
             res[h]["multi_device_context"] = {"devices": args.devices, "seconds": round(min(ts), 4), "identical_to_single_gpu_proof": p == single,
-                                              "peer_exchanges": st["peer_exchanges"], "peer_bytes_moved": st["peer_bytes_moved"]}
+                                              "peer_exchanges": st["peer_exchanges"], "peer_bytes_moved": st["peer_bytes_moved"],
+                                              # each rank's own pool (ranks may share a GPU here): the largest high-water mark over the ranks
+                                              "pool_high_water_gb_largest_rank": round(mb.memory_stats()["reserved_peak"] / 1e9, 2)}
             print(h, "multi", json.dumps(res[h]["multi_device_context"]), flush=True)
             mb.close()
     os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
