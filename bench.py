@@ -704,6 +704,16 @@ def main():
     torch.cuda.set_stream(stream)
     be = Backend(device=local_rank, stream=stream.cuda_stream)
 
+    # The first proof of a fresh process (what `ola prove` sees), measured FIRST: before this process has allocated anything large.
+    # VRAM that a still-living process has freed is handed out dirty and is scrubbed inside the next owner's hipMalloc (about 30 ms
+    # per GB), which would be charged to whichever child runs first (docs/EXPERIMENTS.md, cold start).
+    cold = cold_b3 = None
+    if world == 1 and rank == 0 and not args.no_prove:
+        cold = {"cold_process": cold_process_prove(args.log_n, local_rank, reserve=True),
+                "cold_process_without_reserve": cold_process_prove(args.log_n, local_rank, reserve=False)}
+        cold_b3 = {"cold_process": cold_process_prove(args.log_n, local_rank, reserve=True, hasher="blake3"),
+                   "cold_process_without_reserve": cold_process_prove(args.log_n, local_rank, reserve=False, hasher="blake3")}
+
     n = 1 << args.log_n
     cols = args.cols
     # synthetic trace columns: uniform 64-bit words reduced mod p on the fly by the kernels (inputs may be non-canonical)
@@ -812,13 +822,6 @@ def main():
             except Exception as e:      # noqa: BLE001 -- an extra: never at the price of the headline line
                 res["roofline_lde"] = {"error": repr(e)[:200]}
         if world == 1 and not args.no_prove:
-            # The first proof of a fresh process, measured before this process has cycled hundreds of GB through the driver:
-            # VRAM that a still-living process has freed is handed out dirty and is scrubbed inside the next owner's hipMalloc
-            # (about 30 ms per GB), which would be charged to whichever child runs first (cold start).
-            cold = {"cold_process": cold_process_prove(args.log_n, local_rank, reserve=True),
-                    "cold_process_without_reserve": cold_process_prove(args.log_n, local_rank, reserve=False)}
-            cold_b3 = {"cold_process": cold_process_prove(args.log_n, local_rank, reserve=True, hasher="blake3"),
-                       "cold_process_without_reserve": cold_process_prove(args.log_n, local_rank, reserve=False, hasher="blake3")}
             try:
                 be_b3 = Backend(device=local_rank, stream=stream.cuda_stream, hasher="blake3")
             except Exception:
