@@ -709,7 +709,12 @@ def main():
     # per GB), which would be charged to whichever child runs first (docs/EXPERIMENTS.md, cold start).
     cold = cold_b3 = None
     if world == 1 and rank == 0 and not args.no_prove:
-        cold = {"cold_process": cold_process_prove(args.log_n, local_rank, reserve=True),
+        # The very first GPU-heavy process on a box also pays for what the PREVIOUS tenant left behind (dirty VRAM is scrubbed inside
+        # the new owner's hipMalloc): reported under its own name, so that the figures after it describe this library and not the
+        # box's history.  Measured: 1.9x / 3.7x for whichever child ran first, 1.16 - 1.18x for the ones after it, either order.
+        first = cold_process_prove(args.log_n, local_rank, reserve=True)
+        cold = {"first_process_on_this_box": first,
+                "cold_process": cold_process_prove(args.log_n, local_rank, reserve=True),
                 "cold_process_without_reserve": cold_process_prove(args.log_n, local_rank, reserve=False)}
         cold_b3 = {"cold_process": cold_process_prove(args.log_n, local_rank, reserve=True, hasher="blake3"),
                    "cold_process_without_reserve": cold_process_prove(args.log_n, local_rank, reserve=False, hasher="blake3")}
