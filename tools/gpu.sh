@@ -19,6 +19,24 @@ for step in "$@"; do
     stats_multi23) # dry run towards config 5 on ONE GPU: per-rank pool high-water marks (8 aliased ranks at 2^23 rows do not fit 288 GB: OLA_E_OOM, clean)
                  timeout 900 python tools/proof_stats.py --log-n 22 --hashers blake3 --devices 0 0 0 0 0 0 0 0 --out $O/proof_stats_8x2p22.json 2>&1 | tail -3
                  timeout 900 python tools/proof_stats.py --log-n 23 --hashers blake3 --devices 0 0 0 0 --out $O/proof_stats_4x2p23.json 2>&1 | tail -3 ;;
+    sq_passes)   bash tools/pmc_sq.sh sq_passes python tools/pmc_workload_lde.py 2>&1 | tail -12 | tee $O/sq.txt
+                 cd /tmp; for ctr in "SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INST_CYCLES_VMEM"; do
+                   (cd $R && rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $R/$O/lds -o p -- python tools/pmc_workload_lde.py > $R/$O/lds.log 2>&1); done; cd $R
+                 f=$(find $O/lds -name "*counter_collection.csv" | head -1); [ -n "$f" ] && python3 - "$f" <<'PY' | tee $O/lds.txt
+import csv, sys, collections
+acc = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
+for r in csv.DictReader(open(sys.argv[1])):
+    k = r["Kernel_Name"].split("(")[0][-52:]
+    acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
+    if r["Counter_Name"] == "SQ_WAVE_CYCLES": cnt[k] += 1
+for k, c in sorted(acc.items(), key=lambda kv: -kv[1].get("SQ_WAVE_CYCLES", 0))[:8]:
+    wc = c.get("SQ_WAVE_CYCLES", 1) or 1
+    print(f"{k:52s} n={cnt[k]:3d} " + " ".join(f"{n[3:]}={c.get(n, 0) / wc:6.3f}" for n in ("SQ_WAIT_INST_LDS", "SQ_LDS_IDX_ACTIVE", "SQ_LDS_BANK_CONFLICT", "SQ_INST_CYCLES_VMEM")) +
+          f" lds_insts={c.get('SQ_INSTS_LDS', 0):.3e} vmem_rd={c.get('SQ_INSTS_VMEM_RD', 0):.3e} vmem_wr={c.get('SQ_INSTS_VMEM_WR', 0):.3e}")
+PY
+                 ;;
+    banks)       hipcc --offload-arch=gfx950 -O3 -o /tmp/valu_rates tools/ubench/valu_rates.hip 2>/dev/null
+                 for w in 8 4 3; do /tmp/valu_rates $w 46; done 2>&1 | grep -v amdgpu | tee $O/banks.txt ;;
     phases)      OLA_TIMING=1 timeout 600 python tools/bench_prove.py 22 2 2> $O/phases.txt | tail -3; OLA_HASHER=blake3 OLA_TIMING=1 timeout 600 python tools/bench_prove.py 22 2 2> $O/phases_blake3.txt | tail -3 ;;
     ntt_group)   # Infinity-Cache blocking of the transforms: working-set target in MB (0 = whole batch per launch)
                  for mb in 0 32 64 96 128 192; do

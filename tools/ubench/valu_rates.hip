@@ -72,6 +72,18 @@ BENCH_KERNEL(k_and_or, "v_and_or_b32 %0, %1, %2, %3\n v_and_or_b32 %1, %2, %3, %
 BENCH_KERNEL(k_bfly, "v_add_u32 %0, %0, %1\n v_sub_u32 %1, %0, %1\n v_add_u32 %2, %2, %3\n v_sub_u32 %3, %2, %3", "memory")
 BENCH_KERNEL(k_mix, "v_mad_i64_i32 %4, vcc, %0, %1, %4\n v_and_b32 %0, 0xffffff, %2\n v_alignbit_b32 %1, %2, %3, 24\n v_add_u32 %2, %2, %3", "vcc")
 
+// VGPR banks: does it matter which registers the two sources of a fast-class instruction come from?  Explicit registers,
+// index mod 4 equal ("same bank": what limb i of two T-form elements in 4-aligned register quadruples gives) against
+// all different.  (round 4)
+#define BANK_CLOBBER "v40","v41","v42","v43","v44","v45","v46","v47","v48","v49","v50","v51","v52","v53","v54","v55"
+BENCH_KERNEL(k_add_same_bank, "v_add_u32 v40, v44, v48\n v_add_u32 v41, v45, v49\n v_add_u32 v42, v46, v50\n v_add_u32 v43, v47, v51", BANK_CLOBBER)
+BENCH_KERNEL(k_add_diff_bank, "v_add_u32 v40, v45, v50\n v_add_u32 v41, v46, v51\n v_add_u32 v42, v47, v48\n v_add_u32 v43, v44, v49", BANK_CLOBBER)
+BENCH_KERNEL(k_add_src_same_dst_diff, "v_add_u32 v41, v44, v48\n v_add_u32 v42, v45, v49\n v_add_u32 v43, v46, v50\n v_add_u32 v40, v47, v51", BANK_CLOBBER)
+BENCH_KERNEL(k_bfly_same_bank, "v_add_u32 v40, v44, v48\n v_sub_u32 v52, v44, v48\n v_add_u32 v41, v45, v49\n v_sub_u32 v53, v45, v49", BANK_CLOBBER)
+BENCH_KERNEL(k_bfly_diff_bank, "v_add_u32 v40, v44, v49\n v_sub_u32 v52, v44, v49\n v_add_u32 v41, v45, v50\n v_sub_u32 v53, v45, v50", BANK_CLOBBER)
+BENCH_KERNEL(k_mad_same_bank, "v_mad_i64_i32 v[40:41], vcc, v44, v48, v[52:53]\n v_mad_i64_i32 v[42:43], vcc, v45, v49, v[54:55]\n v_mad_i64_i32 v[40:41], vcc, v46, v50, v[52:53]\n v_mad_i64_i32 v[42:43], vcc, v47, v51, v[54:55]", BANK_CLOBBER, "vcc")
+BENCH_KERNEL(k_mad_diff_bank, "v_mad_i64_i32 v[40:41], vcc, v45, v50, v[52:53]\n v_mad_i64_i32 v[42:43], vcc, v46, v51, v[54:55]\n v_mad_i64_i32 v[40:41], vcc, v47, v48, v[52:53]\n v_mad_i64_i32 v[42:43], vcc, v44, v49, v[54:55]", BANK_CLOBBER, "vcc")
+
 typedef void (*kern_t)(unsigned*, unsigned);
 struct B { const char* name; kern_t k; };
 
@@ -96,10 +108,16 @@ int main(int argc, char** argv) {
                 {"v_add_u32 chain", k_add_u32_chain}, {"v_xor_b32", k_xor}, {"v_lshl_or_b32", k_lshl_or}, {"v_sub_u32", k_sub_u32},
                 {"v_mad_i64_i32", k_mad_i64_i32}, {"v_and_b32 literal", k_and_lit}, {"v_ashrrev_i32", k_ashr}, {"v_lshlrev_b32", k_lshl32},
                 {"v_lshrrev_b32", k_lshr32}, {"v_lshl_add_u32", k_lshl_add_u32}, {"v_perm_b32", k_perm}, {"v_add_u32_sdwa sext", k_add_sdwa},
-                {"v_or_b32", k_or}, {"v_bfe_u32", k_bfe}, {"v_and_or_b32", k_and_or}, {"add/sub butterflies", k_bfly}, {"mad,and,alignbit,add", k_mix}};
+                {"v_or_b32", k_or}, {"v_bfe_u32", k_bfe}, {"v_and_or_b32", k_and_or}, {"add/sub butterflies", k_bfly}, {"mad,and,alignbit,add", k_mix},
+                {"v_add_u32 src same bank", k_add_same_bank}, {"v_add_u32 all banks differ", k_add_diff_bank}, {"v_add_u32 src same, dst other", k_add_src_same_dst_diff},
+                {"butterfly src same bank", k_bfly_same_bank}, {"butterfly src diff bank", k_bfly_diff_bank},
+                {"v_mad_i64_i32 src same bank", k_mad_same_bank}, {"v_mad_i64_i32 src diff bank", k_mad_diff_bank}};
+    if (argc > 2) { const int skip = atoi(argv[2]); for (int i = 0; i + skip < (int)(sizeof(list) / sizeof(list[0])); i++) list[i] = list[i + skip]; }   // argv[2]: start at entry N
+    const int n_run = (int)(sizeof(list) / sizeof(list[0])) - (argc > 2 ? atoi(argv[2]) : 0);
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    for (auto& b : list) {
+    for (int bi = 0; bi < n_run; bi++) {
+        B& b = list[bi];
         hipLaunchKernelGGL(b.k, dim3(blocks), dim3(256), 0, 0, out, 1u);
         hipDeviceSynchronize();
         hipEventRecord(e0);
