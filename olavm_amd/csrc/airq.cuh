@@ -33,10 +33,26 @@ struct Acc160 { u64 lo, hi; u32 top; };   // sum of < 2^32 products of two u64
 __device__ __forceinline__ void acc_mad(Acc160& a, u64 x, u64 w) {
     u64 plo, phi;
     mul_wide(x, w, plo, phi);
+#if defined(OLA_GL_ASM) && !defined(OLA_ACC_NO_ASM)
+    // the 160-bit addition as ONE carry chain through VCC (hipcc re-derives each carry with a 64-bit compare and a select:
+    // 8 instructions for these 5); consecutive VCC producers / consumers need no wait states
+    u32 l0 = (u32)a.lo, l1 = (u32)(a.lo >> 32), h0 = (u32)a.hi, h1 = (u32)(a.hi >> 32);
+    asm("v_add_co_u32 %0, vcc, %0, %5\n\t"
+        "v_addc_co_u32 %1, vcc, %1, %6, vcc\n\t"
+        "v_addc_co_u32 %2, vcc, %2, %7, vcc\n\t"
+        "v_addc_co_u32 %3, vcc, %3, %8, vcc\n\t"
+        "v_addc_co_u32 %4, vcc, 0, %4, vcc"
+        : "+v"(l0), "+v"(l1), "+v"(h0), "+v"(h1), "+v"(a.top)
+        : "v"((u32)plo), "v"((u32)(plo >> 32)), "v"((u32)phi), "v"((u32)(phi >> 32))
+        : "vcc");
+    a.lo = ((u64)l1 << 32) | l0;
+    a.hi = ((u64)h1 << 32) | h0;
+#else
     a.lo += plo;
     phi += (a.lo < plo) ? 1ull : 0ull;     // phi <= 2^64 - 2, cannot wrap
     a.hi += phi;
     a.top += (a.hi < phi) ? 1u : 0u;
+#endif
 }
 // lo + hi*2^64 + top*2^128 mod p, with 2^128 = -2^32 (mod p) and top*2^32 <= p - 1
 __device__ __forceinline__ u64 acc_reduce(const Acc160& a) { return gl_sub(gl_reduce128_cc(a.lo, a.hi), (u64)a.top << 32); }

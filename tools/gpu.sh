@@ -37,6 +37,25 @@ PY
                  ;;
     banks)       hipcc --offload-arch=gfx950 -O3 -o /tmp/valu_rates tools/ubench/valu_rates.hip 2>/dev/null
                  for w in 8 4 3; do /tmp/valu_rates $w 46; done 2>&1 | grep -v amdgpu | tee $O/banks.txt ;;
+    quot_check)  timeout 1200 python -m pytest tests/test_gpu_stark.py tests/test_gpu_blake3.py -x -q 2>&1 | tail -3 | tee $O/pytest.log
+                 for h in blake3 poseidon; do AB_HASHER=$h timeout 300 python - <<'PY'
+import os, sys
+sys.path.insert(0, ".")
+from olavm_amd.air import ola_tables as T, tracegen
+from olavm_amd.backend import Backend
+blob = T.ola_stark().blob()
+traces, params, compress = tracegen.empty_program_instance(log_n=10, range_bits=16, limb_bits=8, log_n_cpu=22, log_n_mem=22)
+be = Backend(device=0, hasher=os.environ["AB_HASHER"])
+be.proof_stats(enable=True)
+best = None
+for _ in range(4):
+    be.prove_with_traces(blob, traces, params, compress)
+    st, ph = be.proof_stats(), be.phase_stats()
+    if best is None or st["wall_ms"] < best[0]:
+        best = (st["wall_ms"], ph["quotient"][0], ph["open_eval"][0], ph["lde"][0], ph["leaf_hash"][0])
+print(os.environ["AB_HASHER"], "wall %.1f ms, quotient kernels %.2f ms, opening evaluations %.2f ms, LDE %.2f ms, leaves %.2f ms" % best)
+PY
+                 done 2>&1 | grep -v amdgpu | tee $O/quot.txt ;;
     phases)      OLA_TIMING=1 timeout 600 python tools/bench_prove.py 22 2 2> $O/phases.txt | tail -3; OLA_HASHER=blake3 OLA_TIMING=1 timeout 600 python tools/bench_prove.py 22 2 2> $O/phases_blake3.txt | tail -3 ;;
     ntt_group)   # Infinity-Cache blocking of the transforms: working-set target in MB (0 = whole batch per launch)
                  for mb in 0 32 64 96 128 192; do
