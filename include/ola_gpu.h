@@ -145,8 +145,10 @@ int32_t ola_gpu_proof_stats(OlaCtx* ctx, int32_t enable, double out[8]);
 int32_t ola_gpu_phase_stats(OlaCtx* ctx, double* out /* 3 * n_phases */, uint32_t n_phases);
 /* Self-test of the device field arithmetic: the kernels' modular reduction is written with explicit carry chains in inline
  * assembly (olavm_amd/csrc/gl.cuh); this compares it with the plain C++ reduction on a table of edge values and on `pairs`
- * pseudo-random operand pairs and returns the number of disagreements (0 expected; about 10^9 pairs per 50 ms).  Meant to be
- * run once after ola_gpu_init on a new driver or compiler. */
+ * pseudo-random operand pairs and returns the number of disagreements (0 expected; about 10^9 pairs per 50 ms).  It also runs
+ * the limb arithmetic of the transform passes (olavm_amd/csrc/ntt2t.cuh: fold to u64 with its carry fixes, carry step, product
+ * cut into limbs, table multiplication, the sixteen shifts of a radix-16 block) against canonical arithmetic on pairs / 16 limb
+ * vectors that sit on the magnitude bounds.  Meant to be run once after ola_gpu_init on a new driver or compiler. */
 int32_t ola_gpu_selftest(OlaCtx* ctx, uint64_t pairs, uint64_t* mismatches);
 /* Start allocating, on a helper thread, the large device buffers that ola_prove_with_traces will need for this AIR set and these
  * table heights (log2 rows per table); returns at once.  The driver scrubs previously used VRAM inside hipMalloc (about 30 ms per
