@@ -223,7 +223,6 @@ struct NttTables {
     std::map<std::pair<int, u64>, TwoLevel> shift;   // (log_n, shift) -> s^k tables (single coset, arbitrary shift)
     std::map<std::tuple<int, int, int, u64>, const u64*> coset_steps;  // (log_n, rate_bits, e, shift) -> per-coset s^(2^e) (ntt2.hip)
     // (log_n, rate_bits, lo/R/inverse, shift) -> per-coset pre-scale tables of a coset transform's first pass (ntt2.hip)
-    std::map<std::tuple<int, int, int, u64>, std::pair<const u64*, const u64*>> pre_tables;
 };
 
 static u64* upload(DeviceCtx* ctx, const std::vector<u64>& v) {

@@ -22,12 +22,6 @@ namespace ola {
 #ifndef NTT2_DEFAULT_GROUP_MB
 #define NTT2_DEFAULT_GROUP_MB 0   // Infinity-Cache blocking of ntt2_run (see there); the environment overrides it
 #endif
-#ifndef NTT2_PRE_STYLE
-#define NTT2_PRE_STYLE 0   // how a coset transform's first pass applies the pre-scale s^k (ntt2_pass_body): 0 = weights in registers, 1 = factored
-#endif
-#ifndef NTT2_LAST_COLS
-#define NTT2_LAST_COLS 1
-#endif
 #ifndef NTT2_STRIDED_COLS
 #define NTT2_STRIDED_COLS 8   // columns per workgroup of a strided pass (see ntt2_pass_kernel): 8 against 4 is +1.4 % on the NTT, +3 % on the LDE
 #endif
@@ -72,7 +66,7 @@ __device__ __forceinline__ void ntt2_pass_body(const Ntt2Params& p) {
     const int L = p.log_n, lo = p.lo;
 
     if (R > 4) {
-        if (tid < (1 << R)) tw1[tid] = (PRE && NTT2_PRE_STYLE == 1) ? p.sc_tw[(coset << R) + tid] : p.tw_r[tid];   // [q1][m_low] for the strided pass
+        if (tid < (1 << R)) tw1[tid] = p.tw_r[tid];   // [q1][m_low] for the strided pass
     }
 
     auto pad1 = [](int e) -> int { return K2 >= 1 ? e + ((e >> (K2 + 4)) << 4) : e; };
@@ -120,22 +114,10 @@ __device__ __forceinline__ void ntt2_pass_body(const Ntt2Params& p) {
     const int uB = tid & 15, m_hi = tid >> 4;
 
     // ---- column-independent multipliers
-    // Coset pre-scale (first pass of a coset transform, lo + R = L): element k = k_lo + 2^lo * (m_low + 2^K2 * j) is scaled by
-    //   s^k = s^k_lo * t^m_low * u^j,   t = s^(2^lo), u = t^(2^K2).
-    // Only u^j has to meet the data before the first round: 16 values per coset, the same for every thread.  t^m_low is common to a thread's radix-16 group and rides on the round twiddle (sc_tw), s^k_lo is common
-    // to a tile position's whole 2^R-point group and rides on the pass twiddle below.
+    // Coset pre-scale (first pass of a coset transform, lo + R = L): the full weight s^k of each of the thread's 16 elements in
+    // registers, built once per workgroup from a two-level lookup and the per-coset ratio, reused for its CB columns (194 VGPRs;
+    // a factored form at 108 VGPRs was measured 4 % slower in round 3 and is gone: docs/EXPERIMENTS.md)
     constexpr bool prescale = PRE;
-    constexpr bool factored = PRE && NTT2_PRE_STYLE == 1;
-#if NTT2_PRE_STYLE == 1
-    u64 up[PRE ? 16 : 1];
-    if (prescale) {
-#pragma unroll
-        for (int j = 0; j < 16; j++) up[j] = p.sc_upow[(coset << 4) + j];   // uniform: scalar loads
-    }
-#else
-    // Style 0 (the default -- measured 4 % faster on the x8 LDE than the factored form although it needs 194 VGPRs against 108:
-    // the pass is bound by VALU issue, not by occupancy): the full weight s^k of each of the thread's 16 elements in registers,
-    // built once per workgroup from a two-level lookup and the per-coset ratio, reused for its CB columns.
     u64 up[PRE ? 16 : 1];
     if (prescale) {
         const u64 sb = two_level(p.sc_lo + coset * p.sc_coset_stride, p.sc_hi + coset * p.sc_coset_stride, p.sc_h, a0);
@@ -147,7 +129,6 @@ __device__ __forceinline__ void ntt2_pass_body(const Ntt2Params& p) {
             if (j < 15) w = gl_mul(w, st);
         }
     }
-#endif
     u64 wt[16];   // pass twiddle w_B^(low*q) (times the final scale) of the 16 phase-B elements, in store order
     if (MODE == N2_STRIDED) {
         // q = rev_R(m) = rev_K2(j2)*16 + rev4(m_hi):  base * step^rev_K2(j2)
@@ -157,7 +138,6 @@ __device__ __forceinline__ void ntt2_pass_body(const Ntt2Params& p) {
             const u32 ntile = (blk << D) + t;
             const u64 low = ((u64)(ntile & (lowblks - 1)) << 4) + uB;
             u64 base = gl_mul(two_level(p.tw_lo, p.tw_hi, p.tw_h, low * (u64)rev_bits_c(m_hi & 15, 4)), p.post_scale);
-            if (factored) base = gl_mul(base, two_level(p.sc_lo + coset * p.sc_coset_stride, p.sc_hi + coset * p.sc_coset_stride, p.sc_h, low));
             const u64 step = (K2 >= 1) ? two_level(p.tw_lo, p.tw_hi, p.tw_h, low << 4) : 1;
             u64 w = base;
 #pragma unroll
@@ -193,7 +173,7 @@ __device__ __forceinline__ void ntt2_pass_body(const Ntt2Params& p) {
             }
             if (prescale) {
 #pragma unroll
-                for (int j = (NTT2_PRE_STYLE == 1 ? 1 : 0); j < 16; j++) x[j] = gl_mul(x[j], up[j]);
+                for (int j = 0; j < 16; j++) x[j] = gl_mul(x[j], up[j]);
             }
             dft_pow2<4, INV>(x);
             if (R > 4 && cc == 0) __syncthreads();  // tw1 visible
@@ -205,7 +185,7 @@ __device__ __forceinline__ void ntt2_pass_body(const Ntt2Params& p) {
                 // pass reads it from a [q1][m_low] table: one LDS read at a compile-time row, no data-dependent skipping (a wave
                 // mixes all m_low, so skipping the unit entries saves nothing and costs registers: 134 -> 108 VGPRs without it)
                 if (MODE == N2_STRIDED) {
-                    if (R > 4 && (factored || q1 != 0)) v = gl_mul(v, tw1[(q1 << K2) + m_low]);
+                    if (R > 4 && q1 != 0) v = gl_mul(v, tw1[(q1 << K2) + m_low]);
                 } else if (R > 4 && q1 != 0) {
                     const int idx = m_low * q1;  // < 2^R
                     if (idx) v = gl_mul(v, tw1[idx]);
@@ -278,12 +258,6 @@ __device__ __forceinline__ void ntt2_pass_body(const Ntt2Params& p) {
 template <int R, int MODE, bool INV, int CB, bool PRE>
 __global__ __launch_bounds__(256) void ntt2_pass_kernel(Ntt2Params p) { ntt2_pass_body<R, MODE, INV, CB, PRE>(p); }
 // ------------------------------------------------------------------------------------------------ host side
-// columns per workgroup of a closing pass (it has no pass twiddles to share; what a wider workgroup saves is the reload of the
-// round-twiddle table and a launch slot per column): OLA_NTT2_LAST_COLS = 1 or 4
-static int ntt2_last_cols() {
-    static const int v = [] { const char* e = getenv("OLA_NTT2_LAST_COLS"); return (e && atoi(e) == 4) ? 4 : ((e && atoi(e) == 1) ? 1 : NTT2_LAST_COLS); }();
-    return v;
-}
 template <int R, int MODE, bool INV, int CB>
 static void ntt2_launch_cb(const Ntt2Params& p0, size_t cols, size_t cosets, hipStream_t stream) {
     Ntt2Params p = p0;
@@ -295,9 +269,8 @@ static void ntt2_launch_cb(const Ntt2Params& p0, size_t cols, size_t cosets, hip
 }
 template <int R, int MODE, bool INV>
 static void ntt2_launch(const Ntt2Params& p, size_t cols, size_t cosets, hipStream_t stream) {
-    if (MODE == N2_STRIDED) ntt2_launch_cb<R, MODE, INV, NTT2_STRIDED_COLS>(p, cols, cosets, stream);
-    else if (ntt2_last_cols() == 4) ntt2_launch_cb<R, MODE, INV, (MODE == N2_STRIDED ? NTT2_STRIDED_COLS : 4)>(p, cols, cosets, stream);
-    else ntt2_launch_cb<R, MODE, INV, (MODE == N2_STRIDED ? NTT2_STRIDED_COLS : 1)>(p, cols, cosets, stream);
+    // a closing pass has no pass twiddles to share among columns: one column per workgroup
+    ntt2_launch_cb<R, MODE, INV, (MODE == N2_STRIDED ? NTT2_STRIDED_COLS : 1)>(p, cols, cosets, stream);
 }
 template <int MODE, bool INV>
 static void ntt2_dispatch_r(int R, const Ntt2Params& p, size_t cols, size_t cosets, hipStream_t s) {
@@ -374,7 +347,7 @@ static const u64* get_full_small(NttTables& t, int R, int inverse) {
     return t.small[key] = upload(t.ctx, v);
 }
 
-// per-coset ratio s_c^(2^e) for the pre-scale recurrence (NTT2_PRE_STYLE 0)
+// per-coset ratio s_c^(2^e) for the pre-scale recurrence
 static const u64* get_coset_steps(NttTables& t, int log_n, int rate_bits, int e, u64 single_shift) {
     std::vector<u64> v;
     if (rate_bits < 0) {
@@ -404,37 +377,6 @@ static const u64* get_coset_pows(NttTables& t, int log_n, int rate_bits, int lo,
         v.insert(v.end(), pw.begin(), pw.end());
     }
     return upload(t.ctx, v);  // small; lives in the persistent pool
-}
-
-// Pre-scale tables of the first pass of a coset transform (ntt2_pass_body): for every coset c with shift s_c
-//   upow[c][j]            = u^j,  u = s_c^(2^(lo+R-4)),  j < 16
-//   tw[c][(q1<<K2) + m]   = w_{2^R}^(m*q1) * (s_c^(2^lo))^m,  q1 < 16, m < 2^(R-4)      (R > 4)
-// The cosets are the LDE family 7*g^bitrev(c) (rate_bits >= 0) or the single shift `single_shift` (rate_bits < 0).
-struct PreTables { const u64* upow; const u64* tw; };
-static PreTables make_pre_tables(NttTables& t, int log_n, int rate_bits, u64 single_shift, int lo, int R, int inverse) {
-    std::vector<u64> shifts;
-    if (rate_bits < 0) shifts.push_back(single_shift);
-    else {
-        const u64 g = gl_root_of_unity(log_n + rate_bits);
-        for (int c = 0; c < (1 << rate_bits); c++) shifts.push_back(gl_mul(gl_pow(g, bitrev32((u32)c, rate_bits)), GL_GENERATOR));
-    }
-    const int K2 = R - 4;
-    std::vector<u64> upow, tw;
-    const u64 w = root_for(R, inverse);
-    for (u64 sc : shifts) {
-        const u64 tt = gl_pow(sc, (u64)1 << lo), u = gl_pow(tt, (u64)1 << K2);
-        const std::vector<u64> up = powers(u, 16);
-        upow.insert(upow.end(), up.begin(), up.end());
-        if (K2 >= 1) {
-            const std::vector<u64> tp = powers(tt, (size_t)1 << K2);
-            for (int q1 = 0; q1 < 16; q1++)
-                for (int m = 0; m < (1 << K2); m++) tw.push_back(gl_mul(gl_pow(w, (u64)m * q1), tp[m]));
-        }
-    }
-    PreTables r;
-    r.upow = upload(t.ctx, upow);          // small; live in the context's persistent pool
-    r.tw = tw.empty() ? nullptr : upload(t.ctx, tw);
-    return r;
 }
 
 // Same contract as ntt_run (ntt.hip) for L >= 14.  prescale: rate_bits >= 0 selects the LDE coset family
@@ -512,20 +454,12 @@ static void ntt2_run_group(NttTables& t, const u64* in, size_t in_col_stride, u6
                 else sc = get_shift(t, L, sc_shift);
                 // a coset sub-range (one GPU's share of the LDE) starts `coset_first` entries into the per-coset tables
                 p.sc_lo = sc.lo + coset_first * stride; p.sc_hi = sc.hi + coset_first * stride; p.sc_h = sc.h; p.sc_coset_stride = stride;
-                const auto key = std::make_tuple(L, sc_rate_bits, lo * 64 + R * 2 + (inverse ? 1 : 0), sc_rate_bits >= 0 ? (u64)0 : sc_shift);
-                auto it = t.pre_tables.find(key);   // cached per context: the device tables die with it
-                if (it == t.pre_tables.end()) {
-                    const PreTables pt = make_pre_tables(t, L, sc_rate_bits, sc_shift, lo, R, inverse ? 1 : 0);
-                    it = t.pre_tables.emplace(key, std::make_pair(pt.upow, pt.tw)).first;
-                }
                 {
                     const auto skey = std::make_tuple(L, sc_rate_bits, lo + R - 4, sc_rate_bits >= 0 ? (u64)0 : sc_shift);
                     auto st = t.coset_steps.find(skey);
                     if (st == t.coset_steps.end()) st = t.coset_steps.emplace(skey, get_coset_steps(t, L, sc_rate_bits, lo + R - 4, sc_shift)).first;
                     p.sc_step = st->second + coset_first;
                 }
-                p.sc_upow = it->second.first + coset_first * 16;
-                p.sc_tw = it->second.second ? it->second.second + (coset_first << R) : nullptr;
             }
             // the strided kernel addresses a workgroup's 2^(8-R) tiles as one uniform base + lane offsets
             if (lo - 4 < 8 - R) throw OlaError(-7, "ntt2: pass split leaves a strided pass with lo + R < 12");

@@ -53,10 +53,7 @@ struct Ntt2Params {
     const u64* sc_hi;
     int sc_h;
     size_t sc_coset_stride;
-    const u64* sc_step;  // NTT2_PRE_STYLE 0: per coset s^(2^(lo+R-4)) = ratio between consecutive register elements
-    const u64* sc_upow;  // per coset, 16 entries: u^j, u = s^(2^(lo+R-4)) = the pre-scale ratio between consecutive register elements
-    const u64* sc_tw;    // per coset, 2^R entries [q1][m_low]: w_{2^R}^(m_low*q1) * (s^(2^lo))^m_low -- the round twiddles with the
-                         // pre-scale's m_low factor folded in (R > 4)
+    const u64* sc_step;  // canonical passes: per coset s^(2^(lo+R-4)) = ratio between consecutive register elements
     const u64* sc_pow;   // T-form passes of a coset transform: per coset, 2^R entries (s^(2^lo))^m
 };
 

@@ -63,6 +63,8 @@ PY
                    OLA_NTT2_GROUP_MB=$mb timeout 300 python bench.py --steps 20 --warmup 3 --no-prove --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('  ntt ms', d['ms_per_step'], 'frac', d['roofline']['frac'])"
                    OLA_NTT2_GROUP_MB=$mb timeout 300 python tools/bench_ntt_matrix.py --log-n 22 --cols 94 --reps 3 --out $O/m_$mb.json 2>&1 | grep -E "lde|intt|ntt" | cut -c1-120
                  done 2>&1 | tee $O/sweep.txt ;;
+    canon_passes) # the canonical-arithmetic passes (OLA_NTT2_TFORM=0: the A/B control, and the path of transforms beyond 2^28) against the oracle
+                 OLA_NTT2_TFORM=0 timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fullsize.py -x -q -k "ntt or lde or NTT or coset or commit" 2>&1 | tail -4 | tee $O/pytest.log ;;
     tform_ab)    # T-form passes against the canonical-arithmetic passes, same box, alternating (OLA_NTT2_TFORM=0/1)
                  timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fullsize.py -x -q -k "ntt or lde or NTT or coset" 2>&1 | tail -8 | tee $O/pytest.log
                  for v in 0 1 0 1; do echo "-- OLA_NTT2_TFORM=$v"
@@ -73,12 +75,7 @@ PY
                  for v in 0 1; do cd /tmp; OLA_NTT2_TFORM=$v timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof$v -o p -- python $R/tools/bench_ntt_matrix.py --log-n 22 --cols 94 --reps 5 --out $R/$O/m_$v.json > /dev/null 2> $R/$O/err$v.txt; cd $R
                    f=$(find $O/prof$v -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp "$f" $O/kernel_stats_$v.csv && head -14 $O/kernel_stats_$v.csv | cut -c1-170; done ;;
     ntt_tests)   timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fullsize.py -x -q -k "ntt or lde or NTT or coset" 2>&1 | tail -8 | tee $O/pytest.log ;;
-    ntt_ab)      for lc in 1 4; do
-                   echo "-- OLA_NTT2_LAST_COLS=$lc"
-                   OLA_NTT2_LAST_COLS=$lc timeout 300 python bench.py --steps 20 --warmup 3 --no-prove --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('  ntt ms', d['ms_per_step'], 'frac', d['roofline']['frac'])"
-                   OLA_NTT2_LAST_COLS=$lc timeout 300 python tools/bench_ntt_matrix.py --log-n 20 22 --cols 94 --reps 5 --out $O/m_$lc.json 2>&1 | grep -E '"op"' | cut -c1-110
-                 done 2>&1 | tee $O/ab.txt ;;
-    lib_ab)      # same-box A/B of two builds of the library: ab_tmp/libola_<name>.so, alternating
+    lib_ab)      # same-box A/B of two builds of the library: ab_tmp/libola_<name>.so, alternating (take ab_tmp/ out of .gpurunignore for the call)
                  cp olavm_amd/lib/libola_gpu.so ab_tmp/libola_cur.so
                  for v in ${AB_VARIANTS:-old new old new}; do cp ab_tmp/libola_$v.so olavm_amd/lib/libola_gpu.so; echo "-- $v"
                    timeout 300 python bench.py --steps 30 --warmup 3 --no-prove --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('  ntt ms', d['ms_per_step'], 'frac', d['roofline']['frac'])"
