@@ -44,3 +44,16 @@ def test_header_is_valid_c_and_the_library_answers_its_revision(tmp_path):
                            "-L" + lib, "-lola_gpu", "-Wl,-rpath," + lib])
     r = subprocess.run([exe], capture_output=True, text=True, timeout=60)
     assert r.returncode == 0 and "c abi ok: revision 4" in r.stdout, r.stdout + r.stderr
+
+
+def test_tform_arithmetic_on_the_host(tmp_path):
+    """olavm_amd/csrc/tform.cuh -- the limb arithmetic of the transform passes -- is host + device code: tests/host_tform_check.cpp
+    runs every primitive against canonical arithmetic on bound-sitting limb vectors (values AND magnitudes), checks that the
+    blocks' powers of two are the reference's roots of unity, and the radix-16 / 8 / 4 / 2 blocks against a naive DFT in the
+    reference's decimation-in-frequency order, forward and inverse."""
+    here = os.path.dirname(os.path.abspath(__file__))
+    exe = os.path.join(str(tmp_path), "host_tform_check")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Wextra", "-Werror", "-Wno-unknown-pragmas", "-I" + os.path.join(os.path.dirname(here), "olavm_amd", "csrc"),
+                           os.path.join(here, "host_tform_check.cpp"), "-o", exe])
+    r = subprocess.run([exe, "300000"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "tform ok" in r.stdout, r.stdout + r.stderr

@@ -10,7 +10,7 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-NTT_SOURCES = ["olavm_amd/csrc/gl.cuh", "olavm_amd/csrc/ntt.hip", "olavm_amd/csrc/ntt2.hip", "olavm_amd/csrc/ntt2t.cuh"]
+NTT_SOURCES = ["olavm_amd/csrc/gl.cuh", "olavm_amd/csrc/ntt.hip", "olavm_amd/csrc/ntt2.hip", "olavm_amd/csrc/ntt2t.cuh", "olavm_amd/csrc/tform.cuh"]
 
 
 def source_hash():
