@@ -12,6 +12,9 @@ for step in "$@"; do
     smoke)       timeout 600 python -c 'import __graft_entry__ as g; g.smoke()' 2>&1 | tail -5 | tee $O/smoke.log ;;
     bench)       timeout 900 python bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err; tail -c 1500 $O/bench.json ;;
     bench2)      timeout 900 python bench.py --gpus 2 --steps 10 --warmup 2 > $O/bench.json 2> $O/bench.err; tail -c 1500 $O/bench.json; tail -3 $O/bench.err ;;
+    torchrun2)   # the launcher path of `bench.py --gpus N` (what the driver's scaling run uses), dry: two ranks share the one GPU, gloo carries the collectives
+                 OLA_BENCH_BACKEND=gloo timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 10 --warmup 2 > $O/bench.json 2> $O/bench.err
+                 tail -c 2500 $O/bench.json; tail -3 $O/bench.err ;;
     stats)       timeout 600 python tools/proof_stats.py --out $O/proof_stats.json 2>&1 | tail -8 ;;
     stats_real)  timeout 600 python tools/proof_stats.py --real --out $O/proof_stats_real.json 2>&1 | tail -8 ;;
     stats_multi) timeout 600 python tools/proof_stats.py --log-n 20 --devices 0 0 0 0 0 0 0 0 --out $O/proof_stats.json 2>&1 | tail -8 ;;
