@@ -105,7 +105,11 @@ int32_t ola_gpu_free(OlaCtx* ctx);
 const char* ola_gpu_last_error(void);
 int32_t ola_gpu_sync(OlaCtx* ctx);
 /* Scratch and commitment buffers are recycled through a per-context cache (tens of GB after a 2^22-row proof); this returns
- * the cached blocks to the driver.  Live OlaBatch objects are not affected. */
+ * the cached blocks to the driver.  Live OlaBatch objects are not affected.
+ * Single-device contexts of one process that sit on the same GPU hand cached blocks to each other: a context that needs a
+ * block takes a fitting one from a sibling that is idle (no call running on it, its stream drained) before it asks the
+ * driver -- a host that keeps a Poseidon and a Blake3 context pays for one pool, and the second context's first proof does
+ * not wait for the driver to scrub recycled VRAM.  OLA_POOL_SHARE=0 (read at ola_gpu_init) keeps a context out of it. */
 int32_t ola_gpu_trim(OlaCtx* ctx);
 /* Device memory of the context's buffer pool, in bytes: out[0] handed out now, out[1] the most ever handed out at once,
  * out[2] handed out + cached now, out[3] the most ever held (the high-water mark of a proof; reset = 1 restarts the marks).

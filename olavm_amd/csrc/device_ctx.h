@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <cstdio>
@@ -114,6 +115,14 @@ struct WorkAcct {
     ~WorkAcct() { collect(); for (hipEvent_t e : spare) (void)hipEventDestroy(e); }
 };
 
+struct DeviceCtx;
+// The contexts of this process, for the hand-over of cached blocks between the ones that share a GPU (DeviceCtx::adopt).
+struct PoolRegistry {
+    std::mutex mu;
+    std::vector<DeviceCtx*> all;
+    static PoolRegistry& get() { static PoolRegistry* r = new PoolRegistry(); return *r; }   // never destroyed: contexts may outlive static teardown
+};
+
 struct DeviceCtx {
     ShardInfo shard;
     WorkAcct acct;
@@ -134,6 +143,74 @@ struct DeviceCtx {
     std::condition_variable cv;
     std::multiset<size_t> pending;             // sizes the helper has not delivered yet
     std::thread reserver;
+    // Hand-over between the contexts of one process that share a GPU (a host that keeps a Poseidon and a Blake3 context, say): a
+    // context that misses in its own cache takes a fitting block out of the cache of an IDLE sibling instead of going to hipMalloc
+    // (which scrubs recycled VRAM at about 30 ms per GB and would make the two pools add up).  A sibling lends only when
+    //   - it takes part (`lends`: single-device contexts; OLA_POOL_SHARE=0 switches the hand-over off),
+    //   - none of the C-ABI calls is running on it (`calls`: its upload / peer streams and helper threads live inside calls),
+    //   - its stream has drained (hipStreamQuery) -- or is the borrower's own stream, where stream order does the job --
+    // all checked under the sibling's `mu`: whatever is in its cache then was freed by finished calls whose work has completed.
+    std::atomic<int> calls{0};
+    bool lends = false;
+    size_t adopted_bytes = 0, adopted_blocks = 0;
+    void join_pool_registry() {
+        const char* e = getenv("OLA_POOL_SHARE");
+        lends = !(e && *e == '0');
+        PoolRegistry& R = PoolRegistry::get();
+        std::lock_guard<std::mutex> lk(R.mu);
+        R.all.push_back(this);
+    }
+    void leave_pool_registry() {
+        PoolRegistry& R = PoolRegistry::get();
+        std::lock_guard<std::mutex> lk(R.mu);
+        for (size_t i = 0; i < R.all.size(); i++)
+            if (R.all[i] == this) { R.all.erase(R.all.begin() + (long)i); break; }
+    }
+    // true when `o` (locked by the caller) may hand blocks of its cache to this context right now
+    bool sibling_is_idle(DeviceCtx* o) {
+        if (o->calls.load() != 0) return false;
+        if (o->stream == stream) return true;
+        const hipError_t q = hipStreamQuery(o->stream);
+        if (q != hipSuccess) { (void)hipGetLastError(); return false; }
+        return true;
+    }
+    void* adopt(size_t want, size_t& got) {
+        if (!lends) return nullptr;
+        PoolRegistry& R = PoolRegistry::get();
+        std::lock_guard<std::mutex> rk(R.mu);
+        for (DeviceCtx* o : R.all) {
+            if (o == this || !o->lends || o->device != device) continue;
+            std::unique_lock<std::mutex> lk(o->mu, std::try_to_lock);
+            if (!lk.owns_lock()) continue;
+            auto it = o->cache.lower_bound(want);
+            if (it == o->cache.end() || it->first > want + want / 4) continue;
+            if (!sibling_is_idle(o)) continue;
+            void* p = it->second;
+            got = it->first;
+            o->cached_bytes -= got;
+            o->cache.erase(it);
+            return p;
+        }
+        return nullptr;
+    }
+    // out of memory: the cached blocks of idle siblings on this device go back to the driver
+    size_t release_idle_siblings() {
+        if (!lends) return 0;
+        size_t freed = 0;
+        PoolRegistry& R = PoolRegistry::get();
+        std::lock_guard<std::mutex> rk(R.mu);
+        for (DeviceCtx* o : R.all) {
+            if (o == this || !o->lends || o->device != device) continue;
+            std::unique_lock<std::mutex> lk(o->mu, std::try_to_lock);
+            if (!lk.owns_lock() || o->cache.empty() || !sibling_is_idle(o)) continue;
+            for (auto& kv : o->cache) (void)hipFree(kv.second);
+            freed += o->cached_bytes;
+            o->cache.clear();
+            o->cached_bytes = 0;
+        }
+        if (freed && timing) fprintf(stderr, "[ola-timing] device allocator: out of memory, released %.1f GB cached by idle contexts on this GPU\n", freed / 1e9);
+        return freed;
+    }
     void reserve_async(std::vector<size_t> sizes) {
         join_reserver();
         {
@@ -200,10 +277,26 @@ struct DeviceCtx {
             }
         }
         void* p = nullptr;
+        {
+            size_t got = 0;
+            p = adopt(want, got);
+            if (p) {
+                std::lock_guard<std::mutex> lk(mu);
+                live[p] = got;
+                note_alloc(got);
+                adopted_bytes += got;
+                adopted_blocks++;
+                return p;
+            }
+        }
         hipError_t e = hipMalloc(&p, want);
         if (e != hipSuccess) {
             (void)hipGetLastError();
             release_cache();
+            e = hipMalloc(&p, want);
+        }
+        if (e != hipSuccess && release_idle_siblings() > 0) {
+            (void)hipGetLastError();
             e = hipMalloc(&p, want);
         }
         if (e != hipSuccess) throw OlaError(-3, std::string("hipMalloc(") + std::to_string(want) + "): " + hipGetErrorString(e));
@@ -223,6 +316,7 @@ struct DeviceCtx {
         live.erase(it);
     }
     ~DeviceCtx() {
+        leave_pool_registry();
         join_reserver();
         if (stream) (void)hipStreamSynchronize(stream);
         for (auto& kv : cache) (void)hipFree(kv.second);

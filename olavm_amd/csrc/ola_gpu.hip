@@ -89,10 +89,12 @@ static void require(bool ok, const char* what) {
 // right GPU when the host drives several contexts or calls from a thread that never called hipSetDevice.
 struct DeviceGuard {
     int prev = -1, want = -1;
-    explicit DeviceGuard(const OlaCtx* ctx);
+    std::atomic<int>* calls = nullptr;   // the context's count of running C-ABI calls (DeviceCtx::calls: no block hand-over out of a busy context)
+    explicit DeviceGuard(OlaCtx* ctx);
     // Restores whatever the caller had, also when the body moved on to other devices (the peer loops of ola_gpu_sync /
     // ola_gpu_trim on a multi-device context end on the last peer): compare with the device that is current NOW, not with `want`.
     ~DeviceGuard() {
+        if (calls) calls->fetch_sub(1);
         if (prev < 0) return;
         int cur = -1;
         if (hipGetDevice(&cur) != hipSuccess) { cur = -1; (void)hipGetLastError(); }
@@ -101,11 +103,13 @@ struct DeviceGuard {
 };
 #define OLA_ON_DEVICE(ctx) DeviceGuard ola_device_guard_(ctx)
 
-DeviceGuard::DeviceGuard(const OlaCtx* ctx) {
+DeviceGuard::DeviceGuard(OlaCtx* ctx) {
     if (!ctx) return;
     want = ctx->dev.device;
     if (hipGetDevice(&prev) != hipSuccess) { prev = -1; (void)hipGetLastError(); }
     if (prev != want) HIP_CHECK(hipSetDevice(want));
+    calls = &ctx->dev.calls;          // last: a constructor that threw has no destructor to undo it
+    calls->fetch_add(1);
 }
 
 // the configuration a context runs with: the caller's, or StarkConfig::standard_fast_config, validated
@@ -213,6 +217,7 @@ int32_t ola_gpu_init(const OlaGpuConfig* cfg, OlaCtx** out_ctx) {
     const OlaGpuConfig c = resolve_config(cfg);
     require(c.device < ndev, "device index out of range");
     *out_ctx = create_device_ctx(c, c.device, c.stream).release();
+    (*out_ctx)->dev.join_pool_registry();
     g_live_contexts.fetch_add(1);
     OLA_CATCH
 }
@@ -280,6 +285,7 @@ int32_t ola_gpu_init_multi(const OlaGpuConfig* cfg, const int32_t* devices, uint
         }
     }
     *out_ctx = root.release();
+    if (n_devices == 1) (*out_ctx)->dev.join_pool_registry();     // the ranks of a multi-device context keep their pools to themselves
     g_live_contexts.fetch_add(1);
     OLA_CATCH
 }

@@ -1228,6 +1228,10 @@ void prove_with_traces(DeviceCtx* ctx, NttTables& tables, const OlaGpuConfig& cf
     // compress_challenges (prover.rs:307-320) -- produced by trace generation, carried through
     w.u32((uint32_t)nt);
     for (size_t t = 0; t < nt; t++) w.field(compress ? compress[t] : 0);
+    if (ctx->timing && ctx->adopted_blocks) {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        fprintf(stderr, "[ola-timing] device allocator: %zu block(s), %.1f GB, taken over from idle contexts on this GPU so far\n", ctx->adopted_blocks, ctx->adopted_bytes / 1e9);
+    }
 }
 
 // ola_air_kernels_available

@@ -12,6 +12,26 @@ for step in "$@"; do
     smoke)       timeout 600 python -c 'import __graft_entry__ as g; g.smoke()' 2>&1 | tail -5 | tee $O/smoke.log ;;
     bench)       timeout 900 python bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err; tail -c 1500 $O/bench.json ;;
     bench2)      timeout 900 python bench.py --gpus 2 --steps 10 --warmup 2 > $O/bench.json 2> $O/bench.err; tail -c 1500 $O/bench.json; tail -3 $O/bench.err ;;
+    pool)        OLA_TIMING=0 timeout 600 python -m pytest tests/test_gpu_pool.py tests/test_gpu_host_api.py -x -q 2>&1 | tail -8 | tee $O/pytest.log
+                 timeout 600 python - <<'PY' 2>&1 | grep -v amdgpu | tee $O/handover.txt
+import sys, time
+sys.path.insert(0, ".")
+from olavm_amd.air import ola_tables as T, tracegen
+from olavm_amd.backend import Backend
+blob = T.ola_stark().blob()
+traces, params, compress = tracegen.empty_program_instance(log_n=10, range_bits=16, limb_bits=8, log_n_cpu=22, log_n_mem=22)
+import os
+for share in ("1", "0"):
+    os.environ["OLA_POOL_SHARE"] = share
+    a = Backend(device=0); b = Backend(device=0, hasher="blake3")
+    ts = []
+    for be in (a, a, b, b, a, b):
+        t0 = time.perf_counter(); be.prove_with_traces(blob, traces, params, compress); ts.append(time.perf_counter() - t0)
+    print("OLA_POOL_SHARE=%s  poseidon first %.3f warm %.3f | blake3 first %.3f warm %.3f | back to poseidon %.3f, to blake3 %.3f | pools %.1f + %.1f GB"
+          % (share, ts[0], ts[1], ts[2], ts[3], ts[4], ts[5], a.memory_stats()["reserved"] / 1e9, b.memory_stats()["reserved"] / 1e9))
+    a.close(); b.close()
+PY
+                 ;;
     torchrun2)   # the launcher path of `bench.py --gpus N` (what the driver's scaling run uses), dry: two ranks share the one GPU, gloo carries the collectives
                  OLA_BENCH_BACKEND=gloo timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 10 --warmup 2 > $O/bench.json 2> $O/bench.err
                  tail -c 2500 $O/bench.json; tail -3 $O/bench.err ;;
