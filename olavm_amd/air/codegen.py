@@ -47,11 +47,11 @@ class _Emitter:
             self.add("AIRQ_EMIT_ALL(%d, gl_mul(%s, lag_last));" % (i, expr))
 
 
-def _lincol(col, row):
+def _lincol(col, row, cell=None):
     """C expression of a Col (linear combination of trace columns) on the local ('L') or next ('N') row."""
     acc = None
     for c, f in col.terms:
-        v = "%sC(%d)" % (row, c)
+        v = cell(row, c) if cell else "%sC(%d)" % (row, c)
         if f == 1:
             term, neg = v, False
         elif f == P - 1:
@@ -75,10 +75,34 @@ def num_emits(airset, t, num_challenges=2):
 
 
 SEGMENT_OPS = 64     # field operations between two code-motion barriers
+# Re-loads of trace cells are what the large tables' kernels wait for (the CPU table: 1 247 cell loads in the source for 331
+# distinct cells, none of them answered by a cache -- profiles/r04_proof_pmc_*.txt).  Two places a cell can stay instead:
+CTL_REG_CELLS = 12   # cells most lookups of the table read (clk, the selectors, ...): in registers for the whole lookup section
+CTL_REG_MIN_USES = 6
+LDS_SLOTS = 20       # lane-private LDS slots per thread (20 x 2 KB per workgroup: four workgroups per CU still fit in 160 KB)
+LDS_MIN_USES = 3
 
 
 def table_kernel(airset, t, name, num_challenges=2):
-    """-> (source text of the kernel, K).
+    """-> (source text of the kernel, K).  Printed twice: the first print counts how often each trace cell is loaded, the second
+    keeps the most re-loaded ones in registers (lookup section) or in LDS (AIRQ_CACHE_*, whole kernel)."""
+    uses = {}
+    _table_kernel(airset, t, name, num_challenges, uses=uses)
+    ctl = sorted(((n, k) for k, n in uses.get("ctl", {}).items() if n >= CTL_REG_MIN_USES), key=lambda x: (-x[0], x[1]))[:CTL_REG_CELLS]
+    regs = [k for _, k in ctl]
+    rest = {}
+    for section, cnt in uses.items():
+        for k, n in cnt.items():
+            if not (section == "ctl" and k in regs):
+                rest[k] = rest.get(k, 0) + n
+    for k in regs:                     # a register cell is loaded once at the head of the lookup section: that load may come from LDS
+        rest[k] = rest.get(k, 0) + 1
+    lds = sorted(((n, k) for k, n in rest.items() if n >= LDS_MIN_USES), key=lambda x: (-x[0], x[1]))[:LDS_SLOTS]
+    return _table_kernel(airset, t, name, num_challenges, ctl_regs=regs, lds_cells=[k for _, k in lds])
+
+
+def _table_kernel(airset, t, name, num_challenges=2, uses=None, ctl_regs=(), lds_cells=()):
+    """One print of the kernel.  uses: dict to fill with {section: {(row, col): loads}} (counting print).
 
     Register pressure is what limits these kernels (the CPU table keeps ~90 trace cells and ~65 shared subexpressions
     alive if every value is computed once), so the code is cut into segments separated by compiler barriers: trace
@@ -96,6 +120,27 @@ def table_kernel(airset, t, name, num_challenges=2):
     e.add("AIRQ_PROLOGUE(%d)" % K)
     nodes = tab.nodes
     LEAF = (OP_LOCAL, OP_NEXT, OP_CONST, OP_PARAM)
+    lds_slot = {k: i for i, k in enumerate(lds_cells)}
+    section = {"name": "program"}
+    BARRIER = "AIRQ_SEGMENT_BARRIER_C;" if lds_slot else "AIRQ_SEGMENT_BARRIER;"
+
+    def cell(row, c):
+        """Expression of trace cell (row 'L' / 'N', column c) at this place of the kernel."""
+        k = (row, c)
+        if uses is not None:
+            sec = uses.setdefault(section["name"], {})
+            sec[k] = sec.get(k, 0) + 1
+        if section["name"] == "ctl" and k in ctl_regs:
+            return "h%s%d" % (row, c)
+        if k in lds_slot:
+            return "CL(%d)" % lds_slot[k]
+        return "%sC(%d)" % (row, c)
+
+    if lds_slot:
+        e.add("AIRQ_CACHE_DECL(%d);" % len(lds_slot))
+        for k, i in lds_slot.items():
+            e.add("AIRQ_CACHE_PUT(%d, %sC(%d));" % (i, k[0], k[1]))
+        e.add(BARRIER)
 
     def is_cheap(j):
         op, a, b = nodes[j]
@@ -106,7 +151,7 @@ def table_kernel(airset, t, name, num_challenges=2):
     state = {"seg": 0, "ops": 0, "local": {}}
 
     def barrier():
-        e.add("AIRQ_SEGMENT_BARRIER;")
+        e.add(BARRIER)
         state["seg"] += 1
         state["ops"] = 0
         state["local"] = {}
@@ -114,9 +159,9 @@ def table_kernel(airset, t, name, num_challenges=2):
     def leaf_expr(j):
         op, a, _ = nodes[j]
         if op == OP_LOCAL:
-            return "LC(%d)" % a
+            return cell("L", a)
         if op == OP_NEXT:
-            return "NC(%d)" % a
+            return cell("N", a)
         if op == OP_CONST:
             return _lit(a)
         return "D[%d]" % (d_params + a)
@@ -165,6 +210,7 @@ def table_kernel(airset, t, name, num_challenges=2):
         state["ops"] += 1
     barrier()
     # ---- permutation checks (permutation.rs:302-360) ----
+    section["name"] = "perm"
     for b in range(nperm):
         e.emit(KIND_FIRST, "gl_sub(ZL(%d), 1)" % b)
     total = len(tab.permutation_pairs) * num_challenges
@@ -178,8 +224,8 @@ def table_kernel(airset, t, name, num_challenges=2):
             pair = tab.permutation_pairs[inst // num_challenges]
             slot = d_perm + 2 * (b * bs + i)
             e.add("    { const u64 beta = D[%d], gamma = D[%d];" % (slot, slot + 1))
-            ls = ["LC(%d)" % l for l, _ in pair]
-            rs = ["LC(%d)" % r for _, r in pair]
+            ls = [cell("L", l) for l, _ in pair]
+            rs = [cell("L", r) for _, r in pair]
             e.add("      u64 l = %s, r = %s;" % (ls[-1], rs[-1]))
             for k in range(len(pair) - 2, -1, -1):
                 e.add("      l = gl_add(gl_mul(l, beta), %s); r = gl_add(gl_mul(r, beta), %s);" % (ls[k], rs[k]))
@@ -187,7 +233,7 @@ def table_kernel(airset, t, name, num_challenges=2):
             inst += 1
         e.emit(KIND_ALL, "gl_sub(gl_mul(ZN(%d), pr), gl_mul(ZL(%d), pl))" % (b, b))
         e.add("}")
-        e.add("AIRQ_SEGMENT_BARRIER;")
+        e.add(BARRIER)
     # ---- cross-table lookup checks (cross_table_lookup.rs:380-421) ----
     # Emits are indexed, so evaluation order is free: the Z columns that look at the same columns (one per challenge)
     # are evaluated together, streaming the column values through one Horner step per challenge.
@@ -201,19 +247,23 @@ def table_kernel(airset, t, name, num_challenges=2):
     for i, twc in enumerate(jobs):
         d_job[i] = off
         off += 1 + len(twc.columns)
+    section["name"] = "ctl_head"
+    if ctl_regs:
+        e.add("const u64 " + ", ".join("h%s%d = %s" % (r, c, cell(r, c)) for r, c in ctl_regs) + ";")
+    section["name"] = "ctl"
     for twc, idxs in groups.values():
         e.add("{")
-        e.add("  const u64 el0 = %s, en0 = %s;" % (_lincol(twc.columns[0], "L"), _lincol(twc.columns[0], "N")))   # beta^0 term
+        e.add("  const u64 el0 = %s, en0 = %s;" % (_lincol(twc.columns[0], "L", cell), _lincol(twc.columns[0], "N", cell)))   # beta^0 term
         e.add("  Acc160 " + ", ".join("al%d = {el0, 0, 0}, an%d = {en0, 0, 0}" % (i, i) for i in idxs) + ";")
         for k, col in enumerate(twc.columns):
             if k == 0:
                 continue
-            e.add("  { const u64 el = %s, en = %s;" % (_lincol(col, "L"), _lincol(col, "N")))
+            e.add("  { const u64 el = %s, en = %s;" % (_lincol(col, "L", cell), _lincol(col, "N", cell)))
             for i in idxs:
                 e.add("    acc_mad(al%d, el, D[%d]); acc_mad(an%d, en, D[%d]);" % (i, d_job[i] + 1 + k, i, d_job[i] + 1 + k))
             e.add("  }")
         if twc.filter_column is not None:
-            e.add("  const u64 fl = %s, fn = %s;" % (_lincol(twc.filter_column, "L"), _lincol(twc.filter_column, "N")))
+            e.add("  const u64 fl = %s, fn = %s;" % (_lincol(twc.filter_column, "L", cell), _lincol(twc.filter_column, "N", cell)))
         for i in idxs:
             e.add("  { u64 cl = gl_add(acc_reduce(al%d), D[%d]), cn = gl_add(acc_reduce(an%d), D[%d]);" % (i, d_job[i], i, d_job[i]))
             if twc.filter_column is not None:   # select(f, x) = f*x + 1 - f
@@ -224,7 +274,7 @@ def table_kernel(airset, t, name, num_challenges=2):
             e.emit(KIND_TRANSITION, "gl_sub(zn, gl_mul(zl, cn))")
             e.add("  }")
         e.add("}")
-        e.add("AIRQ_SEGMENT_BARRIER;")
+        e.add(BARRIER)
     e.idx = first_idx + 2 * len(jobs)
     assert e.idx == K, (e.idx, K)
     e.add("AIRQ_EPILOGUE")

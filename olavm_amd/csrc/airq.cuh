@@ -86,10 +86,19 @@ typedef const u64 __attribute__((address_space(4)))* airq_cptr;
     constexpr int AIRQ_K = (K_);                                                                                           \
     Acc160 accA0 = {0, 0, 0}, accA1 = {0, 0, 0}, accT0 = {0, 0, 0}, accT1 = {0, 0, 0};
 // LDE values are canonical (the NTT writes canonical words)
+#ifdef AIRQ_TIMING_ONLY_L2_LOADS
+// Timing experiment (wrong results): every workgroup reads the first 2048 points of each column, so all cell loads hit L2 --
+// the instruction stream is unchanged, the HBM traffic is gone.  What the kernel would cost if its loads were free.
+#define LC(c) (T_ + ((size_t)(c) * N + (jb_ & 0x700)))[lane_]
+#define NC(c) (T_ + ((size_t)(c) * N + (nb_ & 0x700)))[noff_]
+#define ZL(c) (Z_ + ((size_t)(c) * N + (jb_ & 0x700)))[lane_]
+#define ZN(c) (Z_ + ((size_t)(c) * N + (nb_ & 0x700)))[noff_]
+#else
 #define LC(c) (T_ + ((size_t)(c) * N + jb_))[lane_]
 #define NC(c) (T_ + ((size_t)(c) * N + nb_))[noff_]
 #define ZL(c) (Z_ + ((size_t)(c) * N + jb_))[lane_]
 #define ZN(c) (Z_ + ((size_t)(c) * N + nb_))[noff_]
+#endif
 #define AIRQ_EMIT_ALL(i, v) { const u64 v_ = (v); acc_mad(accA0, v_, D[8 + (i)]); acc_mad(accA1, v_, D[8 + AIRQ_K + (i)]); }
 #define AIRQ_EMIT_TRANS(i, v) { const u64 v_ = (v); acc_mad(accT0, v_, D[8 + (i)]); acc_mad(accT1, v_, D[8 + AIRQ_K + (i)]); }
 // Segment boundary: the base pointers and the running accumulators pass through one opaque (empty) volatile asm.  The
@@ -99,6 +108,16 @@ typedef const u64 __attribute__((address_space(4)))* airq_cptr;
 // invariant and all ~300 of them were hoisted to the top of the kernel.)  The pointers keep their address spaces
 // (global for the trace / Z tables, constant for the descriptor, which is read with scalar loads).
 #define AIRQ_SEGMENT_BARRIER asm volatile("" : "+s"(T_), "+s"(Z_), "+s"(D), "+v"(accA0.lo), "+v"(accT0.lo))
+// Cells that many segments read (round 4: the CPU table's kernel fetched 3.2 x its algorithmic bytes, every re-load of a segment
+// going out to HBM -- the points in flight touch far more than the L2 holds -- and with its loads served from L2 it ran in
+// 44 ms instead of 70).  The most re-read cells are therefore loaded once per point and parked in LDS: AIRQ_CACHE_DECL(S)
+// reserves S lane-private 8-byte slots per thread ([slot][lane]: conflict-free, no synchronisation -- a lane only reads what it
+// wrote), AIRQ_CACHE_PUT fills one, CL(s) reads it back.  The lane's byte offset passes through the segment barrier like the
+// table pointers, so that the LDS reads, too, stay inside their segment.
+#define AIRQ_CACHE_DECL(S_) __shared__ u64 cache_[(S_) * AIRQ_THREADS]; u32 coff_ = lane_ * 8u
+#define AIRQ_CACHE_PUT(s, v) (*(u64*)((char*)cache_ + coff_ + (s) * (AIRQ_THREADS * 8)) = (v))
+#define CL(s) (*(const u64*)((const char*)cache_ + coff_ + (s) * (AIRQ_THREADS * 8)))
+#define AIRQ_SEGMENT_BARRIER_C asm volatile("" : "+s"(T_), "+s"(Z_), "+s"(D), "+v"(accA0.lo), "+v"(accT0.lo), "+v"(coff_))
 #define AIRQ_EPILOGUE                                                                                                      \
     {                                                                                                                      \
         const u64 zh_inv = D[c_];                                                                                          \

@@ -840,7 +840,9 @@ static void prove_single_table(DeviceCtx* ctx, NttTables& tables, const OlaGpuCo
         unsigned flag = 0;
         HIP_CHECK(hipMemcpyAsync(&flag, d_flag, 4, hipMemcpyDeviceToHost, ctx->stream));
         HIP_CHECK(hipStreamSynchronize(ctx->stream));
+#ifndef AIRQ_TIMING_ONLY_L2_LOADS      // (timing builds of airq.cuh's experiment produce garbage on purpose)
         if (flag) throw OlaError(OLA_E_QUOTIENT_DEGREE, "Quotient has failed, the vanishing polynomial is not divisible by Z_H");
+#endif
     }
     // chunks of n coefficients: [challenge][k] -> column challenge*q + k
     ph.reset();
