@@ -171,7 +171,9 @@ def phase_block(be, hasher="poseidon"):
     ms, pts, byts = ph["quotient"]
     if ms > 0:      # quotient row streaming is HBM-class -- bytes = the LDE cells a point reads (local and next row of the trace and Z batches) + 16 written
         out["quotient"] = {"ms": round(ms, 2), "points_per_s_G": round(pts / (ms * 1e-3) / 1e9, 3), "bytes": int(byts),
-                           "GBps": round(byts / (ms * 1e-3) / 1e9, 1), "frac": round(byts / (ms * 1e-3) / (HBM_PEAK_GBPS * 1e9), 4), "bound": "hbm (contract); integer ALU / load latency (measured)"}
+                           "GBps": round(byts / (ms * 1e-3) / 1e9, 1), "frac": round(byts / (ms * 1e-3) / (HBM_PEAK_GBPS * 1e9), 4), "bound": "hbm (contract); measured: re-loads of trace cells on top of 48 k VALU instructions per point -- "
+                                    "the CPU table's kernel fetches 221 GB per launch for 93 GB algorithmic (profiles/r04_proof_pmc_blake3.txt), "
+                                    "and runs in 44 ms instead of 61 when its loads hit L2 (profiles/r04_quotient_cell_cache.txt)"}
     ms, prods, byts = ph["open_eval"]
     if ms > 0:      # every coefficient of every committed polynomial read once per point pair
         out["open_eval"] = {"ms": round(ms, 2), "coefficient_point_products_per_s_G": round(prods / (ms * 1e-3) / 1e9, 2), "bytes": int(byts),
