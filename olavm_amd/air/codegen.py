@@ -80,29 +80,42 @@ SEGMENT_OPS = 64     # field operations between two code-motion barriers
 CTL_REG_CELLS = 12   # cells most lookups of the table read (clk, the selectors, ...): in registers for the whole lookup section
 CTL_REG_MIN_USES = 6
 LDS_SLOTS = 20       # lane-private LDS slots per thread (20 x 2 KB per workgroup: four workgroups per CU still fit in 160 KB)
-LDS_MIN_USES = 3
+LDS_MIN_USES = 2
 
 
 def table_kernel(airset, t, name, num_challenges=2):
-    """-> (source text of the kernel, K).  Printed twice: the first print counts how often each trace cell is loaded, the second
-    keeps the most re-loaded ones in registers (lookup section) or in LDS (AIRQ_CACHE_*, whole kernel)."""
-    uses = {}
-    _table_kernel(airset, t, name, num_challenges, uses=uses)
-    ctl = sorted(((n, k) for k, n in uses.get("ctl", {}).items() if n >= CTL_REG_MIN_USES), key=lambda x: (-x[0], x[1]))[:CTL_REG_CELLS]
-    regs = [k for _, k in ctl]
-    rest = {}
-    for section, cnt in uses.items():
-        for k, n in cnt.items():
-            if not (section == "ctl" and k in regs):
-                rest[k] = rest.get(k, 0) + n
-    for k in regs:                     # a register cell is loaded once at the head of the lookup section: that load may come from LDS
-        rest[k] = rest.get(k, 0) + 1
-    lds = sorted(((n, k) for k, n in rest.items() if n >= LDS_MIN_USES), key=lambda x: (-x[0], x[1]))[:LDS_SLOTS]
-    return _table_kernel(airset, t, name, num_challenges, ctl_regs=regs, lds_cells=[k for _, k in lds])
+    """-> (source text of the kernel, K).  Printed twice per candidate phase length: the first print counts how often each
+    trace cell is loaded in each phase of the kernel, the second keeps the most re-loaded ones in registers (lookup section)
+    or in LDS (AIRQ_CACHE_*; the slots are re-assigned at every phase boundary).  The phase length with the fewest loads from
+    global memory wins (small tables: one phase for the whole constraint program)."""
+    import re
+    best = None
+    for phase_segments in PHASE_SEGMENT_CHOICES:
+        uses = {"phase": {}, "ctl": {}}
+        _table_kernel(airset, t, name, num_challenges, uses=uses, phase_segments=phase_segments)
+        ctl = sorted(((n, k) for k, n in uses["ctl"].items() if n >= CTL_REG_MIN_USES), key=lambda x: (-x[0], x[1]))[:CTL_REG_CELLS]
+        regs = [k for _, k in ctl]
+        lds_sets = {}
+        for phase, cnt in uses["phase"].items():
+            cnt = dict(cnt)
+            if phase == "tail":        # a register cell is loaded once, at the head of the lookup section: that load may come from LDS
+                for k in regs:
+                    cnt[k] = cnt.get(k, 0) - uses["ctl"][k] + 1
+            top = sorted(((n, k) for k, n in cnt.items() if n >= LDS_MIN_USES), key=lambda x: (-x[0], x[1]))[:LDS_SLOTS]
+            lds_sets[phase] = [k for _, k in top]
+        src, K = _table_kernel(airset, t, name, num_challenges, ctl_regs=regs, lds_sets=lds_sets, phase_segments=phase_segments)
+        loads = len(re.findall(r"\b[LN]C\(\d+\)", src))
+        if best is None or loads < best[0]:
+            best = (loads, src, K)
+    return best[1], best[2]
 
 
-def _table_kernel(airset, t, name, num_challenges=2, uses=None, ctl_regs=(), lds_cells=()):
-    """One print of the kernel.  uses: dict to fill with {section: {(row, col): loads}} (counting print).
+PHASE_SEGMENT_CHOICES = (7, 1 << 30)   # the constraint program is cut into phases of this many segments; each phase (and the
+                                       # permutation + lookup tail) parks ITS most re-loaded cells in the LDS slots
+
+
+def _table_kernel(airset, t, name, num_challenges=2, uses=None, ctl_regs=(), lds_sets=None, phase_segments=7):
+    """One print of the kernel.  uses: dict to fill with the loads per phase and cell (counting print); lds_sets: {phase: cells}.
 
     Register pressure is what limits these kernels (the CPU table keeps ~90 trace cells and ~65 shared subexpressions
     alive if every value is computed once), so the code is cut into segments separated by compiler barriers: trace
@@ -120,27 +133,43 @@ def _table_kernel(airset, t, name, num_challenges=2, uses=None, ctl_regs=(), lds
     e.add("AIRQ_PROLOGUE(%d)" % K)
     nodes = tab.nodes
     LEAF = (OP_LOCAL, OP_NEXT, OP_CONST, OP_PARAM)
-    lds_slot = {k: i for i, k in enumerate(lds_cells)}
-    section = {"name": "program"}
-    BARRIER = "AIRQ_SEGMENT_BARRIER_C;" if lds_slot else "AIRQ_SEGMENT_BARRIER;"
+    lds_sets = lds_sets or {}
+    use_lds = any(lds_sets.values())
+    lds_slot = {}                        # cell -> slot, for the phase being printed
+    section = {"name": "program", "phase": None}
+    BARRIER = "AIRQ_SEGMENT_BARRIER_C;" if use_lds else "AIRQ_SEGMENT_BARRIER;"
 
     def cell(row, c):
         """Expression of trace cell (row 'L' / 'N', column c) at this place of the kernel."""
         k = (row, c)
         if uses is not None:
-            sec = uses.setdefault(section["name"], {})
-            sec[k] = sec.get(k, 0) + 1
+            ph = uses["phase"].setdefault(section["phase"], {})
+            ph[k] = ph.get(k, 0) + 1
+            if section["name"] == "ctl":
+                uses["ctl"][k] = uses["ctl"].get(k, 0) + 1
         if section["name"] == "ctl" and k in ctl_regs:
             return "h%s%d" % (row, c)
         if k in lds_slot:
             return "CL(%d)" % lds_slot[k]
         return "%sC(%d)" % (row, c)
 
-    if lds_slot:
-        e.add("AIRQ_CACHE_DECL(%d);" % len(lds_slot))
-        for k, i in lds_slot.items():
-            e.add("AIRQ_CACHE_PUT(%d, %sC(%d));" % (i, k[0], k[1]))
-        e.add(BARRIER)
+    def phase_begin(name):
+        """The LDS slots change hands: cells that stay keep their slot, the others are loaded into the freed ones."""
+        section["phase"] = name
+        want = lds_sets.get(name, [])
+        for k in [k for k in lds_slot if k not in want]:
+            del lds_slot[k]
+        free = [i for i in range(LDS_SLOTS) if i not in lds_slot.values()]
+        fresh = [k for k in want if k not in lds_slot]
+        for k in fresh:
+            lds_slot[k] = free.pop(0)
+            e.add("AIRQ_CACHE_PUT(%d, %sC(%d));" % (lds_slot[k], k[0], k[1]))
+        if fresh:
+            e.add(BARRIER)
+
+    if use_lds:
+        e.add("AIRQ_CACHE_DECL(%d);" % LDS_SLOTS)
+    phase_begin("p0")
 
     def is_cheap(j):
         op, a, b = nodes[j]
@@ -155,6 +184,8 @@ def _table_kernel(airset, t, name, num_challenges=2, uses=None, ctl_regs=(), lds
         state["seg"] += 1
         state["ops"] = 0
         state["local"] = {}
+        if section["name"] == "program" and state["seg"] % phase_segments == 0:
+            phase_begin("p%d" % (state["seg"] // phase_segments))
 
     def leaf_expr(j):
         op, a, _ = nodes[j]
@@ -211,6 +242,7 @@ def _table_kernel(airset, t, name, num_challenges=2, uses=None, ctl_regs=(), lds
     barrier()
     # ---- permutation checks (permutation.rs:302-360) ----
     section["name"] = "perm"
+    phase_begin("tail")
     for b in range(nperm):
         e.emit(KIND_FIRST, "gl_sub(ZL(%d), 1)" % b)
     total = len(tab.permutation_pairs) * num_challenges

@@ -105,6 +105,9 @@ PY
                    timeout 300 python tools/bench_ntt_matrix.py --log-n 22 --cols 94 --reps 5 --out $O/m_$v.json 2>&1 | grep -E '"op"' | cut -c1-110
                  done 2>&1 | tee $O/ab.txt; cp ab_tmp/libola_cur.so olavm_amd/lib/libola_gpu.so ;;
     pmc)         bash tools/pmc_ntt.sh r04 2>&1 | tail -30 ;;
+    quot_final)  # after a change to the quotient kernels: the proof tests, the full-size and multi-rank ones, smoke
+                 timeout 1500 python -m pytest tests/test_gpu_fullsize.py tests/test_gpu_multi.py tests/test_gpu_pool.py tests/test_gpu_host_api.py -x -q > $O/pytest_full.log 2>&1; grep -E ' passed| failed| error' $O/pytest_full.log | tee $O/pytest.log
+                 ;;
     sq_proof)    # SQ issue / stall counters of every kernel of one 2^22-row proof (Blake3 configuration)
                  OLA_HASHER=blake3 bash tools/pmc_sq.sh sq_proof python tools/bench_prove.py 22 1 2>&1 | tail -10 | tee $O/sq.txt ;;
     pmc_proof)   bash tools/pmc_proof.sh r04 blake3 2>&1 | tail -34; bash tools/pmc_proof.sh r04 poseidon 2>&1 | tail -34 ;;
