@@ -181,12 +181,59 @@ def phase_block(be, hasher="poseidon"):
     return out
 
 
+def replicated_breakdown(st, scopes, upload, heights, min_log_n=12):
+    """What every rank of the coset partition repeats (`replicated_ms` = wall - bracketed kernel time), split by where it sits:
+    the reference's `timed!` scopes with device times (ola_gpu_scope_times), each minus the divided work that began inside it.
+    Scopes of tables below the partition threshold are summed into one figure; the trace-commitment line of the large tables
+    contains the GPU's idle time while it waits for column groups (reported next to it from the host's clock)."""
+    large = {t for t, h in enumerate(heights) if h >= min_log_n}
+    out, small = {}, 0.0
+    names = {"compute permutation Z(x) polys": "z_columns", "compute CTL Z(x) polys": "z_columns", "compute Zs commitment": "zs_commitment_interpolation",
+             "compute quotient polys": "quotient_interpolation_and_split", "split quotient polys": "quotient_interpolation_and_split",
+             "compute quotient commitment": "quotient_commitment", "compute openings proof": "openings_composition_fri_tail_pow_queries"}
+    total = 0.0
+    for s in scopes:
+        if s["name"] == "prove_with_traces total":
+            total = s["ms"]
+        rep = s["ms"] - s["sharded_ms"]
+        if s["name"].endswith("trace commitment (upload overlapped)") or s["name"].endswith("prove_single_table"):
+            if s["table"] not in large:
+                small += rep
+            elif s["name"].endswith("trace commitment (upload overlapped)"):
+                out["trace_commitments_interpolation_and_upload_stalls"] = out.get("trace_commitments_interpolation_and_upload_stalls", 0.0) + rep
+        elif s["table"] in large and s["depth"] == 2 and s["name"] in names:
+            out[names[s["name"]]] = out.get(names[s["name"]], 0.0) + rep
+    out["tables_below_the_partition_threshold"] = small
+    out = {k: round(v, 2) for k, v in out.items()}
+    out["host_side_and_launch_gaps"] = round(st["wall_ms"] - total, 2)
+    out["upload_wait_of_the_proving_thread_host_clock"] = round(upload["waited_ms"], 2)
+    out["sum_check"] = {"replicated_ms": round(st["wall_ms"] - (st["sharded_ms_upto2"] + st["sharded_ms_upto4"] + st["sharded_ms_upto8"]), 2),
+                        "sum_of_lines": round(sum(v for k, v in out.items() if k != "upload_wait_of_the_proving_thread_host_clock" and not isinstance(v, dict)), 2)}
+    return out
+
+
 def accounted_proof(be, blob, traces, params, compress, hasher="poseidon"):
-    """One more proof with the library's accounting on: the partition projection and the per-kernel-family block."""
+    """One more proof with the library's accounting on: the partition projection, the breakdown of the replicated share by
+    `timed!` scope, and the per-kernel-family block."""
     be.proof_stats(enable=True)
-    be.prove_with_traces(blob, traces, params, compress)
-    st = be.proof_stats(enable=False)
-    return {"partition": partition_projection(st), "kernels": phase_block(be, hasher)}
+    be.scope_times(enable=True)
+    try:
+        be.prove_with_traces(blob, traces, params, compress)
+        scopes = be.scope_times()
+    finally:
+        be.scope_times(enable=False)
+        st = be.proof_stats(enable=False)
+    heights = [int(t.shape[1]).bit_length() - 1 for t in traces]
+    part = partition_projection(st)
+    part["replicated_breakdown_ms"] = replicated_breakdown(st, scopes, be.upload_stats(), heights)
+    return {"partition": part, "kernels": phase_block(be, hasher)}
+
+
+def scattered_columns(traces):
+    """The traces as the reference's caller holds them (prover.rs:79-83: per table a Vec of PolynomialValues, every column its own
+    Vec<F>): one allocation per column, every word written."""
+    import numpy as np
+    return [[np.array(t[c], dtype=np.uint64, copy=True) for c in range(t.shape[0])] for t in traces]
 
 
 def verify_proofs(blob, proofs, params, hasher="poseidon"):
@@ -279,6 +326,27 @@ def timed_proofs(be, blob, traces, params, compress, reps, hasher="poseidon"):
     times = sorted(times[1:])
     res = {"seconds": round(times[len(times) // 2], 4), "min_seconds": round(times[0], 4), "reps": reps, "proof_bytes": len(proofs[-1]),
            "first_call_seconds": round(first, 4), **verify_proofs(blob, proofs, params, hasher)}
+    try:
+        up = be.upload_stats()
+        res["upload"] = {"path": up["mode"], "copier_threads": up["threads"], "GB": round(up["bytes"] / 1e9, 2), "ms": round(up["total_ms"], 1),
+                         "GBps": round(up["bytes"] / 1e6 / max(up["total_ms"], 1e-9), 1), "upload_wait_ms": round(up["waited_ms"], 1),
+                         "first_group_ms": round(up["first_group_ms"], 2)}
+        # the same proof from the reference's own trace type: every column a separate allocation (ola_prove_with_traces_cols)
+        cols = scattered_columns(traces)
+        ts, same = [], True
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            same &= be.prove_with_traces(blob, cols, params, compress) == proofs[-1]
+            ts.append(time.perf_counter() - t0)
+        up = be.upload_stats()
+        ts.sort()
+        res["host_columns_scattered"] = {"seconds": round(ts[len(ts) // 2], 4), "min_seconds": round(ts[0], 4), "identical_to_contiguous_table_proof": bool(same),
+                                         "over_contiguous": round(ts[len(ts) // 2] / max(res["seconds"], 1e-9), 3), "upload_wait_ms": round(up["waited_ms"], 1),
+                                         "upload_GBps": round(up["bytes"] / 1e6 / max(up["total_ms"], 1e-9), 1), "columns": sum(len(c) for c in cols),
+                                         "entry_point": "ola_prove_with_traces_cols"}
+        del cols
+    except Exception as e:              # noqa: BLE001 -- an extra
+        res["host_columns_scattered"] = {"error": repr(e)[:200]}
     try:
         res.update(accounted_proof(be, blob, traces, params, compress, hasher))
     except Exception as e:              # noqa: BLE001 -- an extra

@@ -36,8 +36,11 @@ extern "C" {
 /* ABI revision of this header.  3: OlaChallenger carries `hasher` + `reserved` (sizeof 240, was 232 in revision 1) and
  * OlaGpuConfig.hasher occupies what was tail padding (sizeof unchanged, but the field must be set: zero-initialise the struct);
  * multi-device contexts and the accounting entry points were added.  A host built against an older header must be rebuilt:
- * ola_gpu_abi_version() lets it check at start-up that library and header agree (also on sizeof(OlaChallenger)). */
-#define OLA_GPU_ABI_VERSION 4
+ * ola_gpu_abi_version() lets it check at start-up that library and header agree (also on sizeof(OlaChallenger)).
+ * 5: ola_prove_with_traces_cols (one pointer per column: the reference's [Vec<PolynomialValues<F>>; NUM_TABLES] as it is),
+ * ola_gpu_scope_times (the `timed!` scopes with device times, for the caller's TimingTree), ola_gpu_upload_stats; no struct of
+ * revision 4 changed. */
+#define OLA_GPU_ABI_VERSION 5
 #define OLA_OK 0
 #define OLA_E_INVALID_ARG (-1)
 #define OLA_E_NO_DEVICE (-2)
@@ -147,6 +150,32 @@ int32_t ola_gpu_proof_stats(OlaCtx* ctx, int32_t enable, double out[8]);
 #define OLA_PHASE_OPEN_EVAL 6
 #define OLA_PHASE_COUNT 7
 int32_t ola_gpu_phase_stats(OlaCtx* ctx, double* out /* 3 * n_phases */, uint32_t n_phases);
+/* The reference's `timed!` scopes of the LAST whole proof with device times, for the caller's TimingTree (prover.rs:84
+ * `timing: &mut TimingTree`; plonky2/plonky2/src/util/timing.rs:7-194; scope names prover.rs:111-553, fri/oracle.rs:56-90,221-225,
+ * fri/prover.rs:41-58).  enable: 1 / 0 switches the recording on / off for the proofs that follow (two event records per scope on
+ * the context's stream, no synchronisation inside the proof), -1 leaves it.  out (may be NULL; cap entries): the scopes in the
+ * order they were entered; *n_out (may be NULL) their number (returns OLA_E_INVALID_ARG when cap is too small; *n_out is set).
+ *   name                the reference's scope name ("compute Zs commitment", "IFFT", "perform final FFT 33554432", ...) or one of
+ *                       this library's grouping scopes ("table 3 prove_single_table", "prove_with_traces total")
+ *   is_reference_scope  1 when the reference has a `timed!` of that name at that place
+ *   depth / ref_depth   open scopes around it: all of them / only the reference's (the reference's tree is flat across tables)
+ *   table               index of the table being proven, -1 outside
+ *   start_ms, ms        when the GPU entered the scope (since the proof's first enqueue) and how long it stayed
+ *   sharded_ms          part of `ms` that the coset partition divides among ranks (needs ola_gpu_proof_stats switched on)
+ * "transpose LDEs" (fri/oracle.rs:84) never appears: the LDE is produced in leaf order, there is no transpose. */
+typedef struct OlaScopeTime {
+    char name[64];
+    uint32_t depth, ref_depth;
+    int32_t table;
+    uint32_t is_reference_scope;
+    double start_ms, ms, sharded_ms;
+} OlaScopeTime;
+int32_t ola_gpu_scope_times(OlaCtx* ctx, int32_t enable, OlaScopeTime* out, uint32_t cap, uint32_t* n_out);
+/* The trace upload of the last whole proof: out[0] milliseconds the proving thread was blocked waiting for column groups,
+ * out[1] milliseconds from the first byte asked for to the last byte on the device, out[2] until the first column group was
+ * complete, out[3] bytes, out[4] path (0 pinned staging ring, 1 pageable hipMemcpyAsync, 2 hipHostRegister: env OLA_UPLOAD),
+ * out[5] copier threads.  On a multi-device context: rank 0's share. */
+int32_t ola_gpu_upload_stats(OlaCtx* ctx, double out[6]);
 /* Self-test of the device field arithmetic: the kernels' modular reduction is written with explicit carry chains in inline
  * assembly (olavm_amd/csrc/gl.cuh); this compares it with the plain C++ reduction on a table of edge values and on `pairs`
  * pseudo-random operand pairs and returns the number of disagreements (0 expected; about 10^9 pairs per 50 ms).  It also runs
@@ -312,6 +341,18 @@ int32_t ola_pow(OlaCtx* ctx, const uint64_t h[4], uint32_t bits, uint64_t* witne
 int32_t ola_prove_with_traces(OlaCtx* ctx, const uint64_t* airset, size_t airset_words, const uint64_t* const* traces,
                               const uint32_t* log_n, const uint64_t* params, const uint64_t* compress_challenges,
                               uint8_t* out, size_t cap, size_t* out_len);
+
+/* The same proof from the reference's own trace type: prove_with_traces takes `&[Vec<PolynomialValues<F>>; NUM_TABLES]`
+ * (circuits/src/stark/prover.rs:79-83) -- per table a Vec of columns, every column its own Vec<F>
+ * (plonky2/field/src/polynomial/mod.rs:24-26), F = GoldilocksField = repr(transparent) u64 (goldilocks_field.rs:24-26).
+ * cols[t][c]: pointer to the 2^log_n[t] values of column c of table t, wherever the caller's allocator put it; the Rust shim
+ * passes `c.values.as_ptr() as *const u64` and copies nothing (precedent for per-column pointers: cfft/ntt/mod.rs:123-147).
+ * ola_prove_with_traces is the special case cols[t][c] = traces[t] + c 2^log_n[t].  Everything else as above; host columns are
+ * staged through the context's pinned ring by a few copier threads (OLA_UPLOAD_THREADS, default 6; olavm_amd/csrc/upload.h),
+ * a table whose FIRST column is device memory is taken as resident on this GPU column by column. */
+int32_t ola_prove_with_traces_cols(OlaCtx* ctx, const uint64_t* airset, size_t airset_words, const uint64_t* const* const* cols,
+                                   const uint32_t* log_n, const uint64_t* params, const uint64_t* compress_challenges,
+                                   uint8_t* out, size_t cap, size_t* out_len);
 
 /* Copies out (and forgets) the proof a preceding ola_prove_with_traces could not return because its buffer was too small. */
 int32_t ola_take_pending_proof(OlaCtx* ctx, uint8_t* out, size_t cap, size_t* out_len);

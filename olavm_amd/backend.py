@@ -26,6 +26,12 @@ class OlaGpuConfig(C.Structure):
                 ("num_query_rounds", C.c_uint32), ("num_challenges", C.c_uint32), ("hasher", C.c_uint32)]
 
 
+class OlaScopeTime(C.Structure):
+    """include/ola_gpu.h OlaScopeTime: one `timed!` scope of the last proof with device times."""
+    _fields_ = [("name", C.c_char * 64), ("depth", C.c_uint32), ("ref_depth", C.c_uint32), ("table", C.c_int32),
+                ("is_reference_scope", C.c_uint32), ("start_ms", C.c_double), ("ms", C.c_double), ("sharded_ms", C.c_double)]
+
+
 class OlaChallenger(C.Structure):
     _fields_ = [("sponge_state", C.c_uint64 * 12), ("input_buffer", C.c_uint64 * 8), ("output_buffer", C.c_uint64 * 8),
                 ("input_len", C.c_uint32), ("output_len", C.c_uint32), ("hasher", C.c_uint32), ("reserved", C.c_uint32)]
@@ -63,7 +69,7 @@ def load_library():
     L.ola_gpu_init.argtypes = [C.POINTER(OlaGpuConfig), C.POINTER(C.c_void_p)]
     L.ola_gpu_abi_version.argtypes = [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
     a, b = C.c_size_t(), C.c_size_t()
-    if L.ola_gpu_abi_version(C.byref(a), C.byref(b)) != 4 or a.value != C.sizeof(OlaChallenger) or b.value != C.sizeof(OlaGpuConfig):
+    if L.ola_gpu_abi_version(C.byref(a), C.byref(b)) != 5 or a.value != C.sizeof(OlaChallenger) or b.value != C.sizeof(OlaGpuConfig):
         raise OlaGpuError(-7, "libola_gpu.so and olavm_amd/backend.py disagree on the ABI revision or struct sizes: rebuild the library")
     L.ola_gpu_init_multi.argtypes = [C.POINTER(OlaGpuConfig), C.POINTER(C.c_int32), C.c_uint32, C.POINTER(C.c_void_p)]
     L.ola_gpu_device_count.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
@@ -100,6 +106,10 @@ def load_library():
                                      C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
     L.ola_prove_with_traces.argtypes = [C.c_void_p, U64P, C.c_size_t, C.POINTER(U64P), C.POINTER(C.c_uint32), U64P, U64P,
                                         C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.ola_prove_with_traces_cols.argtypes = [C.c_void_p, U64P, C.c_size_t, C.POINTER(C.POINTER(U64P)), C.POINTER(C.c_uint32), U64P, U64P,
+                                             C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.ola_gpu_scope_times.argtypes = [C.c_void_p, C.c_int32, C.POINTER(OlaScopeTime), C.c_uint32, C.POINTER(C.c_uint32)]
+    L.ola_gpu_upload_stats.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
     L.ola_commit_values_shard.argtypes = [C.c_void_p, C.POINTER(U64P), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                           C.POINTER(C.c_void_p), U64P]
     L.ola_commit_values_shard_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
@@ -135,7 +145,7 @@ EXPORTS = [
     "ola_permuted_cols", "ola_permuted_cols_dev", "ola_prove_single_table", "ola_take_pending_proof", "ola_gpu_memory_stats", "ola_gpu_selftest", "ola_gpu_reserve",
     "ola_table_shape", "ola_perm_z", "ola_ctl_z", "ola_quotient", "ola_set_shard_options", "ola_gpu_get_stream",
     "ola_gpu_abi_version", "ola_gpu_init_multi", "ola_gpu_device_count", "ola_gpu_proof_stats", "ola_gpu_phase_stats",
-    "ola_gpu_collective", "ola_gpu_all_gather_check",
+    "ola_gpu_collective", "ola_gpu_all_gather_check", "ola_prove_with_traces_cols", "ola_gpu_scope_times", "ola_gpu_upload_stats",
 ]
 
 
@@ -295,6 +305,24 @@ class Backend:
         self._chk(self.lib.ola_gpu_proof_stats(self.ctx, -1 if enable is None else int(bool(enable)), out))
         return {"wall_ms": out[0], "sharded_ms_upto2": out[1], "sharded_ms_upto4": out[2], "sharded_ms_upto8": out[3],
                 "exchange_bytes": int(out[4]), "exchanges": int(out[5]), "peer_exchanges": int(out[6]), "peer_bytes_moved": int(out[7])}
+
+    def scope_times(self, enable=None):
+        """ola_gpu_scope_times: switch the recording (True / False / None = leave); -> the last proof's `timed!` scopes as dicts."""
+        n = C.c_uint32()
+        self._chk(self.lib.ola_gpu_scope_times(self.ctx, -1 if enable is None else int(bool(enable)), None, 0, C.byref(n)))
+        if n.value == 0:
+            return []
+        out = (OlaScopeTime * n.value)()
+        self._chk(self.lib.ola_gpu_scope_times(self.ctx, -1, out, n.value, C.byref(n)))
+        return [{"name": o.name.decode(), "depth": o.depth, "ref_depth": o.ref_depth, "table": o.table, "reference": bool(o.is_reference_scope),
+                 "start_ms": o.start_ms, "ms": o.ms, "sharded_ms": o.sharded_ms} for o in out]
+
+    def upload_stats(self):
+        """ola_gpu_upload_stats of the last whole proof."""
+        out = (C.c_double * 6)()
+        self._chk(self.lib.ola_gpu_upload_stats(self.ctx, out))
+        return {"waited_ms": out[0], "total_ms": out[1], "first_group_ms": out[2], "bytes": int(out[3]),
+                "mode": ("staged", "pageable", "register")[int(out[4])], "threads": int(out[5])}
 
     def _chk(self, rc):
         if rc != 0:
@@ -509,22 +537,51 @@ class Backend:
         self._chk(self.lib.ola_set_shard_options(self.ctx, 1 if on_device else 0))
 
     def prove_with_traces(self, airset_blob, traces, params=None, compress=None, cap=8 << 20):
-        """AllProof bytes for the multi-table STARK described by `airset_blob` (olavm_amd.air.AirSet.blob())."""
+        """AllProof bytes for the multi-table STARK described by `airset_blob` (olavm_amd.air.AirSet.blob()).
+
+        A table is a 2-d numpy array (host, one column-major block), a contiguous 64-bit torch tensor resident on this GPU, or a
+        LIST of 1-d uint64 arrays -- every column its own allocation, the reference's Vec<PolynomialValues<F>> (prover.rs:79-83).
+        As soon as one table is a list the call goes through ola_prove_with_traces_cols (blocks become their column pointers)."""
         blob = np.ascontiguousarray(airset_blob, dtype=np.uint64)
-        # a table is a numpy array (host) or anything with data_ptr() and a shape -- a contiguous int64 / uint64 torch tensor
-        # resident on this GPU -- table by table
-        tr = [t if hasattr(t, "data_ptr") else np.ascontiguousarray(t, dtype=np.uint64) for t in traces]
-        for t in tr:
-            if hasattr(t, "data_ptr") and not (t.is_contiguous() and t.element_size() == 8):
-                raise ValueError("device-resident tables must be contiguous 64-bit tensors")
-        ptrs = (U64P * len(tr))(*[C.cast(C.c_void_p(t.data_ptr()), U64P) if hasattr(t, "data_ptr") else _p(t) for t in tr])
-        logs = (C.c_uint32 * len(tr))(*[int(t.shape[1]).bit_length() - 1 for t in tr])
         pr = None if params is None else np.ascontiguousarray(params, dtype=np.uint64)
         cc = None if compress is None else np.ascontiguousarray(compress, dtype=np.uint64)
         need = C.c_size_t(0)
         buf = C.create_string_buffer(cap)
-        rc = self.lib.ola_prove_with_traces(self.ctx, _p(blob), blob.size, ptrs, logs, None if pr is None else _p(pr),
-                                            None if cc is None else _p(cc), buf, cap, C.byref(need))
+        if any(isinstance(t, (list, tuple)) for t in traces):
+            keep, tabs, logs = [], [], []
+            for t in traces:
+                if isinstance(t, (list, tuple)):
+                    cols = [np.ascontiguousarray(c, dtype=np.uint64).reshape(-1) for c in t]
+                    n = cols[0].size
+                    if any(c.size != n for c in cols):
+                        raise ValueError("columns of one table differ in length")
+                    addrs = [c.ctypes.data for c in cols]
+                elif hasattr(t, "data_ptr"):
+                    if not (t.is_contiguous() and t.element_size() == 8):
+                        raise ValueError("device-resident tables must be contiguous 64-bit tensors")
+                    cols, n = t, int(t.shape[1])
+                    addrs = [t.data_ptr() + 8 * n * c for c in range(int(t.shape[0]))]
+                else:
+                    cols = np.ascontiguousarray(t, dtype=np.uint64)
+                    n = cols.shape[1]
+                    addrs = [cols.ctypes.data + 8 * n * c for c in range(cols.shape[0])]
+                arr = (U64P * len(addrs))(*[C.cast(C.c_void_p(a), U64P) for a in addrs])
+                keep.append((cols, arr))
+                tabs.append(arr)
+                logs.append(n.bit_length() - 1)
+            ptrs = (C.POINTER(U64P) * len(tabs))(*[C.cast(a, C.POINTER(U64P)) for a in tabs])
+            logs = (C.c_uint32 * len(logs))(*logs)
+            rc = self.lib.ola_prove_with_traces_cols(self.ctx, _p(blob), blob.size, ptrs, logs, None if pr is None else _p(pr),
+                                                     None if cc is None else _p(cc), buf, cap, C.byref(need))
+        else:
+            tr = [t if hasattr(t, "data_ptr") else np.ascontiguousarray(t, dtype=np.uint64) for t in traces]
+            for t in tr:
+                if hasattr(t, "data_ptr") and not (t.is_contiguous() and t.element_size() == 8):
+                    raise ValueError("device-resident tables must be contiguous 64-bit tensors")
+            ptrs = (U64P * len(tr))(*[C.cast(C.c_void_p(t.data_ptr()), U64P) if hasattr(t, "data_ptr") else _p(t) for t in tr])
+            logs = (C.c_uint32 * len(tr))(*[int(t.shape[1]).bit_length() - 1 for t in tr])
+            rc = self.lib.ola_prove_with_traces(self.ctx, _p(blob), blob.size, ptrs, logs, None if pr is None else _p(pr),
+                                                None if cc is None else _p(cc), buf, cap, C.byref(need))
         if rc != 0 and need.value > cap:            # the proof is kept in the context: fetch it, do not prove again
             buf = C.create_string_buffer(need.value)
             rc = self.lib.ola_take_pending_proof(self.ctx, buf, need.value, C.byref(need))

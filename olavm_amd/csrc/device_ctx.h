@@ -58,11 +58,36 @@ struct ShardInfo {
 // 2 cosets stops scaling at 2 GPUs).  Everything outside a scope -- interpolations, Z columns, FRI after the first layer, small
 // tables, launch gaps, host transcript -- is what every rank repeats.  exchange_bytes: the gathered payload of the exchanges a
 // sharded run performs (a rank receives (G-1)/G of it); counted on single-GPU runs too, so that one GPU can project G.
+// The reference's `timed!` scopes (prover.rs:111-553, fri/oracle.rs:56-90,221-225, fri/prover.rs:41-58) with DEVICE times: when
+// switched on (ola_gpu_scope_times), every PhaseTimer brackets its scope with two events on the context's stream -- no
+// synchronisation, the host keeps running ahead -- and after the proof's final synchronisation the list holds, per scope, its
+// nesting depth, when the GPU entered it (ms since the proof began on the stream), how long the GPU stayed in it, and how much
+// of that was work the coset partition divides (WorkScope spans that began inside it).  The Rust shim replays the list into
+// the caller's TimingTree (integration/rust/hip_prover.rs); bench.py turns it into the breakdown of the replicated share.
+struct ScopeLog {
+    struct Rec { std::string name; uint32_t depth, ref_depth; int parent, table; bool ref; hipEvent_t a, b; double start_ms, ms, sharded_ms; };
+    bool on = false;
+    std::vector<Rec> recs;
+    int open = -1;                 // innermost open scope
+    uint32_t depth = 0, ref_depth = 0;
+    int table = -1;                // set by prove_with_traces around each table's scopes
+    hipEvent_t origin = nullptr;
+    // a scope the reference has under the same name (the others are this library's grouping: "table 3 prove_single_table", ...)
+    static bool is_reference_scope(const std::string& n) {
+        static const char* names[] = {"compute trace commitments", "compute permutation Z(x) polys", "compute Zs commitment", "compute quotient polys",
+                                      "split quotient polys", "compute quotient commitment", "compute openings proof", "IFFT", "FFT + blinding",
+                                      "build Merkle tree", "fold codewords in the commitment phase", "find proof-of-work witness"};
+        for (const char* s : names) if (n == s) return true;
+        // format!("perform final FFT {}", len), fri/oracle.rs:223 -- not the partitioned variant, which carries a suffix
+        return n.rfind("perform final FFT ", 0) == 0 && n.find('(') == std::string::npos;
+    }
+};
+
 // kernel families the accounting also times one by one (ola_gpu_phase_stats): device milliseconds + two unit counters each
 enum { PH_LEAF_HASH = 0, PH_MERKLE_LEVELS, PH_FRI_FOLD, PH_LDE, PH_INTT, PH_QUOTIENT, PH_OPEN_EVAL, PH_COUNT };
 struct WorkAcct {
     bool on = false;
-    struct Span { hipEvent_t a, b; int maxlog; };   // maxlog >= 100: a phase span, phase = maxlog - 100
+    struct Span { hipEvent_t a, b; int maxlog; int scope; };   // maxlog >= 100: a phase span, phase = maxlog - 100; scope: ScopeLog index or -1
     double phase_ms[PH_COUNT] = {};
     double phase_units[PH_COUNT][2] = {};
     std::vector<Span> spans;
@@ -101,10 +126,16 @@ struct WorkAcct {
         for (int i = 0; i < PH_COUNT; i++) { phase_ms[i] = 0; phase_units[i][0] = phase_units[i][1] = 0; }
     }
     // after the stream has been synchronised
-    void collect() {
+    void collect(ScopeLog* log = nullptr) {
         for (Span& s : spans) {
             float ms = 0;
-            if (s.a && s.b && hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) { if (s.maxlog >= 100) phase_ms[s.maxlog - 100] += ms; else sharded_ms[s.maxlog] += ms; }
+            if (s.a && s.b && hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) {
+                if (s.maxlog >= 100) phase_ms[s.maxlog - 100] += ms;
+                else {
+                    sharded_ms[s.maxlog] += ms;
+                    if (log) for (int i = s.scope; i >= 0 && i < (int)log->recs.size(); i = log->recs[(size_t)i].parent) log->recs[(size_t)i].sharded_ms += ms;
+                }
+            }
             else (void)hipGetLastError();
             if (s.a) spare.push_back(s.a);
             if (s.b) spare.push_back(s.b);
@@ -113,6 +144,16 @@ struct WorkAcct {
         in_proof = false;
     }
     ~WorkAcct() { collect(); for (hipEvent_t e : spare) (void)hipEventDestroy(e); }
+};
+
+// what the last upload did (ola_gpu_upload_stats)
+struct UploadStats {
+    double waited_ms = 0;       // the proving thread blocked this long for column groups
+    double total_ms = 0;        // first byte asked for -> last byte on the device
+    double first_ms = 0;        // until the first column group was complete
+    double bytes = 0;
+    uint32_t mode = 0;          // 0 staged, 1 pageable, 2 registered
+    uint32_t threads = 0;
 };
 
 struct DeviceCtx;
@@ -148,11 +189,37 @@ struct DeviceCtx {
     // (which scrubs recycled VRAM at about 30 ms per GB and would make the two pools add up).  A sibling lends only when
     //   - it takes part (`lends`: single-device contexts; OLA_POOL_SHARE=0 switches the hand-over off),
     //   - none of the C-ABI calls is running on it (`calls`: its upload / peer streams and helper threads live inside calls),
-    //   - its stream has drained (hipStreamQuery) -- or is the borrower's own stream, where stream order does the job --
+    //   - its stream has drained (hipStreamQuery; also asked when both share a stream -- the borrower's upload stream is not
+    //     ordered behind it),
     // all checked under the sibling's `mu`: whatever is in its cache then was freed by finished calls whose work has completed.
     std::atomic<int> calls{0};
     bool lends = false;
+    // pinned staging ring of the trace upload (upload.h), kept from proof to proof: hipHostMalloc costs milliseconds per 100 MB
+    void* staging = nullptr;
+    size_t staging_bytes = 0;
+    UploadStats upload;
+    ScopeLog scopes;
     size_t adopted_bytes = 0, adopted_blocks = 0;
+    // scopes of one proof: begin on the stream, resolve after the final synchronisation
+    void scopes_begin() {
+        ScopeLog& L = scopes;
+        for (ScopeLog::Rec& r : L.recs) { if (r.a) acct.spare.push_back(r.a); if (r.b) acct.spare.push_back(r.b); r.a = r.b = nullptr; }
+        L.recs.clear(); L.open = -1; L.depth = L.ref_depth = 0; L.table = -1;
+        if (!L.on) return;
+        if (!L.origin) L.origin = acct.get();
+        if (L.origin && hipEventRecord(L.origin, stream) != hipSuccess) (void)hipGetLastError();
+    }
+    void scopes_collect() {
+        ScopeLog& L = scopes;
+        for (ScopeLog::Rec& r : L.recs) {
+            float s = 0, m = 0;
+            if (L.origin && r.a && r.b && hipEventElapsedTime(&s, L.origin, r.a) == hipSuccess && hipEventElapsedTime(&m, r.a, r.b) == hipSuccess) { r.start_ms = s; r.ms = m; }
+            else (void)hipGetLastError();
+            if (r.a) acct.spare.push_back(r.a);
+            if (r.b) acct.spare.push_back(r.b);
+            r.a = r.b = nullptr;
+        }
+    }
     void join_pool_registry() {
         const char* e = getenv("OLA_POOL_SHARE");
         lends = !(e && *e == '0');
@@ -169,7 +236,8 @@ struct DeviceCtx {
     // true when `o` (locked by the caller) may hand blocks of its cache to this context right now
     bool sibling_is_idle(DeviceCtx* o) {
         if (o->calls.load() != 0) return false;
-        if (o->stream == stream) return true;
+        // also when the lender runs on the borrower's own stream: the borrower's upload stream writes into fresh blocks without
+        // being ordered behind that stream's pending kernels (an asynchronous entry point frees scratch with work in flight)
         const hipError_t q = hipStreamQuery(o->stream);
         if (q != hipSuccess) { (void)hipGetLastError(); return false; }
         return true;
@@ -316,12 +384,15 @@ struct DeviceCtx {
         live.erase(it);
     }
     ~DeviceCtx() {
+        for (ScopeLog::Rec& r : scopes.recs) { if (r.a) acct.spare.push_back(r.a); if (r.b) acct.spare.push_back(r.b); }
+        if (scopes.origin) acct.spare.push_back(scopes.origin);      // ~WorkAcct destroys the pool of events
         leave_pool_registry();
         join_reserver();
         if (stream) (void)hipStreamSynchronize(stream);
         for (auto& kv : cache) (void)hipFree(kv.second);
         for (auto& kv : live) (void)hipFree(kv.first);
         for (void* p : persistent) (void)hipFree(p);
+        if (staging) (void)hipHostFree(staging);
         if (owns_stream && stream) (void)hipStreamDestroy(stream);
     }
 };
@@ -331,9 +402,10 @@ struct DeviceCtx {
 struct WorkScope {
     DeviceCtx* ctx;
     hipEvent_t a = nullptr;
-    int maxlog;
+    int maxlog, scope = -1;
     WorkScope(DeviceCtx* c, int maxlog_) : ctx(c), maxlog(maxlog_ < 1 ? 0 : (maxlog_ > 3 ? 3 : maxlog_)) {
         if (!ctx->acct.on || !ctx->acct.shardable || maxlog == 0) { maxlog = 0; return; }
+        if (ctx->scopes.on) scope = ctx->scopes.open;
         a = ctx->acct.get();
         if (a && hipEventRecord(a, ctx->stream) != hipSuccess) { (void)hipGetLastError(); ctx->acct.spare.push_back(a); a = nullptr; }
     }
@@ -341,7 +413,7 @@ struct WorkScope {
         if (!a) return;
         hipEvent_t b = ctx->acct.get();
         if (b && hipEventRecord(b, ctx->stream) != hipSuccess) { (void)hipGetLastError(); ctx->acct.spare.push_back(b); b = nullptr; }
-        ctx->acct.add_span({a, b, maxlog});
+        ctx->acct.add_span({a, b, maxlog, scope});
     }
 };
 // Times one kernel family of a proof (WorkAcct::phase_ms) and counts what it processed; nests freely with WorkScope.
@@ -360,7 +432,7 @@ struct PhaseScope {
         if (!a) return;
         hipEvent_t b = ctx->acct.get();
         if (b && hipEventRecord(b, ctx->stream) != hipSuccess) { (void)hipGetLastError(); ctx->acct.spare.push_back(b); b = nullptr; }
-        ctx->acct.add_span({a, b, 100 + phase});
+        ctx->acct.add_span({a, b, 100 + phase, -1});
     }
 };
 // an exchange of the partition: `gathered_bytes` = payload of all ranks together
@@ -384,10 +456,27 @@ struct PhaseTimer {
     DeviceCtx* ctx;
     std::string name;
     std::chrono::steady_clock::time_point t0;
+    int rec = -1;
     PhaseTimer(DeviceCtx* c, const std::string& n) : ctx(c), name(n) {
+        if (ctx->scopes.on) {
+            ScopeLog& L = ctx->scopes;
+            const std::string bare = n.substr(std::min(n.size(), n.find_first_not_of(' ')));
+            ScopeLog::Rec r{bare, L.depth, L.ref_depth, L.open, L.table, ScopeLog::is_reference_scope(bare), ctx->acct.get(), nullptr, 0, 0, 0};
+            if (r.a && hipEventRecord(r.a, ctx->stream) != hipSuccess) { (void)hipGetLastError(); ctx->acct.spare.push_back(r.a); r.a = nullptr; }
+            rec = (int)L.recs.size();
+            L.recs.push_back(r);
+            L.open = rec; L.depth++; if (r.ref) L.ref_depth++;
+        }
         if (ctx->timing) { (void)hipStreamSynchronize(ctx->stream); t0 = std::chrono::steady_clock::now(); }
     }
     ~PhaseTimer() {
+        if (rec >= 0 && rec < (int)ctx->scopes.recs.size()) {
+            ScopeLog& L = ctx->scopes;
+            ScopeLog::Rec& r = L.recs[(size_t)rec];
+            r.b = ctx->acct.get();
+            if (r.b && hipEventRecord(r.b, ctx->stream) != hipSuccess) { (void)hipGetLastError(); ctx->acct.spare.push_back(r.b); r.b = nullptr; }
+            L.open = r.parent; L.depth = r.depth; L.ref_depth = r.ref_depth;
+        }
         if (!ctx->timing) return;
         (void)hipStreamSynchronize(ctx->stream);
         const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();

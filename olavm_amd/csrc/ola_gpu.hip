@@ -151,7 +151,7 @@ static std::unique_ptr<OlaCtx> create_device_ctx(const OlaGpuConfig& cfg, int de
 // prove_with_traces on a context that spans several GPUs: one worker thread per rank (the caller's thread is rank 0), every rank
 // runs the whole prover on the same traces with the coset partition switched on and the library's own xGMI all-gather
 // (peer_group.h) as its collective.  All ranks finish with the same AllProof bytes; rank 0's are returned.
-static void prove_with_traces_multi(OlaCtx* ctx, const u64* airset, size_t airset_words, const u64* const* traces, const uint32_t* log_n,
+static void prove_with_traces_multi(OlaCtx* ctx, const u64* airset, size_t airset_words, const TraceSource* traces, const uint32_t* log_n,
                                     const u64* params, const u64* compress, std::vector<uint8_t>& bytes) {
     const uint32_t world = (uint32_t)ctx->peers.size() + 1;
     PeerGroup& g = *ctx->group;
@@ -173,9 +173,12 @@ static void prove_with_traces_multi(OlaCtx* ctx, const u64* airset, size_t airse
             c->dev.shard = sh;
             c->dev.acct.on = ctx->dev.acct.on;
             c->dev.acct.begin_proof();
+            c->dev.scopes.on = ctx->dev.scopes.on && r == 0;
+            c->dev.scopes_begin();
             prove_with_traces(&c->dev, *c->tables, c->cfg, airset, airset_words, traces, log_n, params, compress, res[r].bytes);
             HIP_CHECK(hipStreamSynchronize(c->dev.stream));
-            c->dev.acct.collect();
+            c->dev.scopes_collect();
+            c->dev.acct.collect(&c->dev.scopes);
             const hipError_t e = hipGetLastError();
             if (e != hipSuccess && e != hipErrorNotReady) throw OlaError(OLA_E_HIP, std::string("kernel launch failed: ") + hipGetErrorString(e));
         } catch (const OlaError& e) { res[r].code = e.code; res[r].msg = e.what(); g.fail(); }
@@ -691,19 +694,18 @@ int32_t ola_open_and_prove(OlaCtx* ctx, const OlaBatch* trace, const OlaBatch* z
     OLA_CATCH
 }
 
-int32_t ola_prove_with_traces(OlaCtx* ctx, const uint64_t* airset, size_t airset_words, const uint64_t* const* traces,
-                              const uint32_t* log_n, const uint64_t* params, const uint64_t* compress_challenges, uint8_t* out,
-                              size_t cap, size_t* out_len) {
-    OLA_TRY
-    OLA_ON_DEVICE(ctx);
-    require(ctx && airset && traces && log_n && out_len, "null pointer");
+// the body of both whole-proof entry points: `src[t]` says where table t's columns are
+static void prove_all(OlaCtx* ctx, const uint64_t* airset, size_t airset_words, const std::vector<TraceSource>& src, const uint32_t* log_n,
+                      const uint64_t* params, const uint64_t* compress_challenges, uint8_t* out, size_t cap, size_t* out_len) {
     std::vector<uint8_t> bytes;
     if (ctx->peers.empty()) {
         const auto t0 = std::chrono::steady_clock::now();
         ctx->dev.acct.begin_proof();
-        prove_with_traces(&ctx->dev, *ctx->tables, ctx->cfg, (const u64*)airset, airset_words, (const u64* const*)traces, log_n,
+        ctx->dev.scopes_begin();
+        prove_with_traces(&ctx->dev, *ctx->tables, ctx->cfg, (const u64*)airset, airset_words, src.data(), log_n,
                           (const u64*)params, (const u64*)compress_challenges, bytes);
-        ctx->dev.acct.collect();
+        if (ctx->dev.scopes.on) { HIP_CHECK(hipStreamSynchronize(ctx->dev.stream)); ctx->dev.scopes_collect(); }
+        ctx->dev.acct.collect(&ctx->dev.scopes);
         ctx->dev.acct.wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         if (ctx->dev.timing && ctx->dev.acct.on) {
             const WorkAcct& a = ctx->dev.acct;
@@ -713,7 +715,7 @@ int32_t ola_prove_with_traces(OlaCtx* ctx, const uint64_t* airset, size_t airset
                     (unsigned long long)a.exchange_bytes, a.exchanges);
         }
     } else {
-        prove_with_traces_multi(ctx, (const u64*)airset, airset_words, (const u64* const*)traces, log_n, (const u64*)params,
+        prove_with_traces_multi(ctx, (const u64*)airset, airset_words, src.data(), log_n, (const u64*)params,
                                 (const u64*)compress_challenges, bytes);
     }
     *out_len = bytes.size();
@@ -723,6 +725,36 @@ int32_t ola_prove_with_traces(OlaCtx* ctx, const uint64_t* airset, size_t airset
     }
     ctx->pending_proof.clear();
     memcpy(out, bytes.data(), bytes.size());
+}
+
+int32_t ola_prove_with_traces(OlaCtx* ctx, const uint64_t* airset, size_t airset_words, const uint64_t* const* traces,
+                              const uint32_t* log_n, const uint64_t* params, const uint64_t* compress_challenges, uint8_t* out,
+                              size_t cap, size_t* out_len) {
+    OLA_TRY
+    OLA_ON_DEVICE(ctx);
+    require(ctx && airset && traces && log_n && out_len, "null pointer");
+    const size_t nt = airset_widths((const u64*)airset, airset_words).size();
+    std::vector<TraceSource> src(nt);
+    for (size_t t = 0; t < nt; t++) { require(traces[t] != nullptr, "traces[t] is NULL"); src[t].base = (const u64*)traces[t]; }
+    prove_all(ctx, airset, airset_words, src, log_n, params, compress_challenges, out, cap, out_len);
+    OLA_CATCH
+}
+
+int32_t ola_prove_with_traces_cols(OlaCtx* ctx, const uint64_t* airset, size_t airset_words, const uint64_t* const* const* cols,
+                                   const uint32_t* log_n, const uint64_t* params, const uint64_t* compress_challenges, uint8_t* out,
+                                   size_t cap, size_t* out_len) {
+    OLA_TRY
+    OLA_ON_DEVICE(ctx);
+    require(ctx && airset && cols && log_n && out_len, "null pointer");
+    const std::vector<size_t> widths = airset_widths((const u64*)airset, airset_words);
+    const size_t nt = widths.size();
+    std::vector<TraceSource> src(nt);
+    for (size_t t = 0; t < nt; t++) {
+        require(cols[t] != nullptr, "cols[t] is NULL");
+        for (size_t c = 0; c < widths[t]; c++) require(cols[t][c] != nullptr, "cols[t][c] is NULL");
+        src[t].cols = (const u64* const*)cols[t];
+    }
+    prove_all(ctx, airset, airset_words, src, log_n, params, compress_challenges, out, cap, out_len);
     OLA_CATCH
 }
 
@@ -900,6 +932,34 @@ int32_t ola_gpu_phase_stats(OlaCtx* ctx, double* out, uint32_t n_phases) {
         out[3 * i] = i < PH_COUNT ? a.phase_ms[i] : 0;
         out[3 * i + 1] = i < PH_COUNT ? a.phase_units[i][0] : 0;
         out[3 * i + 2] = i < PH_COUNT ? a.phase_units[i][1] : 0;
+    }
+    OLA_CATCH
+}
+
+int32_t ola_gpu_upload_stats(OlaCtx* ctx, double out[6]) {
+    OLA_TRY
+    require(ctx && out, "null pointer");
+    const UploadStats& u = ctx->dev.upload;
+    out[0] = u.waited_ms; out[1] = u.total_ms; out[2] = u.first_ms; out[3] = u.bytes; out[4] = (double)u.mode; out[5] = (double)u.threads;
+    OLA_CATCH
+}
+
+int32_t ola_gpu_scope_times(OlaCtx* ctx, int32_t enable, OlaScopeTime* out, uint32_t cap, uint32_t* n_out) {
+    OLA_TRY
+    require(ctx, "ctx");
+    if (enable >= 0) ctx->dev.scopes.on = enable != 0;
+    const std::vector<ScopeLog::Rec>& recs = ctx->dev.scopes.recs;
+    if (n_out) *n_out = (uint32_t)recs.size();
+    if (out) {
+        for (size_t i = 0; i < recs.size() && i < cap; i++) {
+            const ScopeLog::Rec& r = recs[i];
+            OlaScopeTime& o = out[i];
+            memset(&o, 0, sizeof o);
+            snprintf(o.name, sizeof o.name, "%s", r.name.c_str());
+            o.depth = r.depth; o.ref_depth = r.ref_depth; o.table = r.table; o.is_reference_scope = r.ref ? 1 : 0;
+            o.start_ms = r.start_ms; o.ms = r.ms; o.sharded_ms = r.sharded_ms;
+        }
+        require(recs.size() <= cap, "scope buffer too small (*n_out holds the count)");
     }
     OLA_CATCH
 }

@@ -32,6 +32,7 @@
 #include "device_ctx.h"
 #include "gl.cuh"
 #include "airq.cuh"
+#include "upload.h"
 
 namespace ola {
 
@@ -549,7 +550,9 @@ static void prove_single_table(DeviceCtx* ctx, NttTables& tables, const OlaGpuCo
     const int nz = nperm + (int)ctl.size();
     if (nz == 0) throw OlaError(OLA_E_INVALID_ARG, "No CTL?");
     // OLA_TIMING scopes carry the reference's `timed!` names (prover.rs:374-544)
-    std::unique_ptr<PhaseTimer> ph(new PhaseTimer(ctx, "    compute permutation Z(x) polys"));
+    // (the reference times only the permutation Z's, and only for tables that have permutation arguments, prover.rs:371-377; its
+    // CTL Z's are computed untimed in cross_table_lookup_data, cross_table_lookup.rs:224-311 -- here both happen in this scope)
+    std::unique_ptr<PhaseTimer> ph(new PhaseTimer(ctx, nperm > 0 ? "    compute permutation Z(x) polys" : "    compute CTL Z(x) polys"));
     u64* zvals = mem.alloc((size_t)nz * n);
     u64* tot = mem.alloc(pscan_tot_stride(n) * std::max<size_t>(1, ctl.size()));
     u64* tmpcol = mem.alloc(n);
@@ -1000,72 +1003,6 @@ void phase_quotient_host(DeviceCtx* ctx, NttTables& tables, const OlaGpuConfig& 
     prove_single_table(ctx, tables, cfg, air, tv, trace_c, cap, jobs[table], params ? params : zero_params.data(), ch, bytes, false, &tap);
 }
 
-// Transfer of the trace tables (host memory, or device memory of the same GPU) into the prover's buffers on a helper thread and a
-// dedicated stream, in groups of columns of about 64 MB; wait(t, c) blocks until columns [0, c) of table t are on the device.
-class TraceUploader {
-  public:
-    TraceUploader(DeviceCtx* ctx, size_t ntables) : ctx_(ctx), jobs_(ntables), done_(ntables) {
-        for (auto& d : done_) d.store(0);
-    }
-    ~TraceUploader() { cancel_.store(true); if (th_.joinable()) th_.join(); if (stream_) (void)hipStreamDestroy(stream_); }
-    void add(size_t t, const u64* src, u64* dst, uint32_t ncols, size_t n) {
-        const size_t target = (size_t)64 << 20;
-        uint32_t cc = (uint32_t)std::max<size_t>(1, target / (n * 8));
-        jobs_[t] = {src, dst, ncols, n, std::max(1u, std::min(cc, ncols))};      // ncols may be 0: a rank without columns of its own
-    }
-    uint32_t chunk_cols(size_t t) const { return jobs_[t].chunk; }
-    void start() {
-        HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
-        th_ = std::thread([this] { run(); });
-    }
-    void wait(size_t t, uint32_t cols) {
-        const auto t0 = std::chrono::steady_clock::now();
-        std::unique_lock<std::mutex> lk(mu_);
-        cv_.wait(lk, [&] { return done_[t].load() >= cols || failed_; });
-        waited_ms_ += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-        if (failed_) throw OlaError(OLA_E_HIP, "trace upload failed: " + error_);
-    }
-    void finish() {
-        if (th_.joinable()) th_.join();
-        if (ctx_->timing) fprintf(stderr, "[ola-timing] trace upload: the proving thread waited %.3f ms for column groups; the uploader's first copy returned after %.3f ms\n", waited_ms_, first_copy_ms_);
-        if (failed_) throw OlaError(OLA_E_HIP, "trace upload failed: " + error_);
-    }
-
-  private:
-    struct Job { const u64* src; u64* dst; uint32_t ncols; size_t n; uint32_t chunk; };
-    void run() {
-        const auto t_start = std::chrono::steady_clock::now();
-        (void)hipSetDevice(ctx_->device);
-        for (size_t t = 0; t < jobs_.size() && !cancel_.load(); t++) {
-            const Job& j = jobs_[t];
-            for (uint32_t c0 = 0; c0 < j.ncols && !cancel_.load(); c0 += j.chunk) {
-                const uint32_t c1 = std::min(j.ncols, c0 + j.chunk);
-                // hipMemcpyDefault: a table may already be resident in HBM (generated there, or kept from an earlier step) -- the
-                // copy is then device to device (the prover canonicalises and works in its own buffer)
-                hipError_t e = hipMemcpyAsync(j.dst + (size_t)c0 * j.n, j.src + (size_t)c0 * j.n, (size_t)(c1 - c0) * j.n * 8,
-                                              hipMemcpyDefault, stream_);
-                if (e == hipSuccess) e = hipStreamSynchronize(stream_);
-                if (first_copy_ms_ == 0) first_copy_ms_ = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
-                std::lock_guard<std::mutex> lk(mu_);
-                if (e != hipSuccess) { failed_ = true; error_ = hipGetErrorString(e); cv_.notify_all(); return; }
-                done_[t].store(c1);
-                cv_.notify_all();
-            }
-        }
-    }
-    DeviceCtx* ctx_;
-    std::vector<Job> jobs_;
-    std::vector<std::atomic<uint32_t>> done_;
-    std::thread th_;
-    std::mutex mu_;
-    std::condition_variable cv_;
-    std::atomic<bool> cancel_{false};
-    double waited_ms_ = 0, first_copy_ms_ = 0;      // OLA_TIMING: how long the prover waited for the upload / the first column group took
-    bool failed_ = false;
-    std::string error_;
-    hipStream_t stream_ = nullptr;
-};
-
 // Memory-lean tables (OLA_LEAN=1 forces, =0 forbids, default: when keeping every LDE resident would not fit): the LDEs of the
 // large tables are streamed coset by coset instead of kept (batch_commit lean) -- a 2^24-row CPU table then proves on one GPU
 // (fri/oracle.rs:66-99 holds all of it; the reference's GPU shim was sized for 2^24, cfft/ntt/mod.rs:13).
@@ -1135,9 +1072,10 @@ void reserve_for_proof(DeviceCtx* ctx, const OlaGpuConfig& cfg, const u64* airse
     ctx->reserve_async(sizes);
 }
 
-// prove_with_traces (prover.rs:79-327).  traces[t]: host pointer to a column-major ncols x 2^log_n[t] table.
+// prove_with_traces (prover.rs:79-327).  traces[t]: where table t's columns are -- one column-major ncols x 2^log_n[t] block, or one
+// pointer per column (the reference's Vec<PolynomialValues<F>>, prover.rs:79-83) -- see upload.h.
 void prove_with_traces(DeviceCtx* ctx, NttTables& tables, const OlaGpuConfig& cfg, const u64* airset, size_t airset_words,
-                       const u64* const* traces, const uint32_t* log_n, const u64* params, const u64* compress,
+                       const TraceSource* traces, const uint32_t* log_n, const u64* params, const u64* compress,
                        std::vector<uint8_t>& bytes) {
     HAirSet set = parse_airset(airset, airset_words);
     const size_t nt = set.tables.size();
@@ -1161,8 +1099,8 @@ void prove_with_traces(DeviceCtx* ctx, NttTables& tables, const OlaGpuConfig& cf
         if (table_is_sharded(ctx, cfg, set.tables[t], log_n[t])) cpr[t] = (w + world - 1) / world;
         dev[t].vals = mem.alloc((size_t)(cpr[t] ? cpr[t] * world : w) << log_n[t]);
     }
-    // The traces are pageable host memory: a helper thread pushes them to the device in column groups on its own stream
-    // while this thread already interpolates / extends / hashes what has arrived (H2D of a 2^22-row instance is ~75 ms).
+    // The traces are pageable host memory: the uploader's threads push them to the device through a pinned staging ring on
+    // their own stream while this thread already interpolates / extends / hashes what has arrived (upload.h).
     const std::vector<char> lean = plan_lean_tables(ctx, cfg, set, log_n);
     TraceUploader up(ctx, nt);
     std::vector<uint32_t> own_cols(nt, 0);
@@ -1172,14 +1110,15 @@ void prove_with_traces(DeviceCtx* ctx, NttTables& tables, const OlaGpuConfig& cf
         if (cpr[t]) {
             const uint32_t c0 = std::min(w, rank * cpr[t]), c1 = std::min(w, (rank + 1) * cpr[t]);
             own_cols[t] = c1 - c0;
-            up.add(t, traces[t] + (size_t)c0 * n_t, dev[t].vals + (size_t)c0 * n_t, own_cols[t], n_t);
+            up.add(t, traces[t], c0, dev[t].vals + (size_t)c0 * n_t, own_cols[t], n_t);
         } else {
-            up.add(t, traces[t], dev[t].vals, w, n_t);
+            up.add(t, traces[t], 0, dev[t].vals, w, n_t);
         }
     }
     up.start();
     std::unique_ptr<PhaseTimer> t_commit(new PhaseTimer(ctx, "compute trace commitments"));
     for (size_t t = 0; t < nt; t++) {
+        ctx->scopes.table = (int)t;
         PhaseTimer tt(ctx, "  table " + std::to_string(t) + " trace commitment (upload overlapped)");
         const size_t n_t = (size_t)1 << log_n[t];
         ctx->acct.shardable = log_n[t] >= ctx->shard.min_log_n;
@@ -1207,6 +1146,7 @@ void prove_with_traces(DeviceCtx* ctx, NttTables& tables, const OlaGpuConfig& cf
                                       table_is_sharded(ctx, cfg, set.tables[t], log_n[t]), &feed, caps[t], lean[t] != 0);
     }
     up.finish();
+    ctx->scopes.table = -1;
     t_commit.reset();
     for (size_t t = 0; t < nt; t++) challenger_observe_cap(ch, caps[t].data(), caps[t].size() / 4);
     // CTL challenges and per-table job lists, in cross_table_lookup_data order
@@ -1221,6 +1161,7 @@ void prove_with_traces(DeviceCtx* ctx, NttTables& tables, const OlaGpuConfig& cf
         const u64* pr = params ? params + poff : zero_params.data();
         if (!params && set.tables[t].n_params > 64) throw OlaError(OLA_E_INVALID_ARG, "params required");
         poff += set.tables[t].n_params;
+        ctx->scopes.table = (int)t;
         PhaseTimer tt(ctx, "  table " + std::to_string(t) + " prove_single_table");
         ctx->acct.shardable = log_n[t] >= ctx->shard.min_log_n;
         prove_single_table(ctx, tables, cfg, set.tables[t], dev[t], *commits[t]->b, caps[t], jobs[t], pr, ch, bytes,
@@ -1234,6 +1175,14 @@ void prove_with_traces(DeviceCtx* ctx, NttTables& tables, const OlaGpuConfig& cf
         std::lock_guard<std::mutex> lk(ctx->mu);
         fprintf(stderr, "[ola-timing] device allocator: %zu block(s), %.1f GB, taken over from idle contexts on this GPU so far\n", ctx->adopted_blocks, ctx->adopted_bytes / 1e9);
     }
+}
+
+// column counts of the tables of an AIR set (the whole-proof entry points validate their pointer arrays with it)
+std::vector<size_t> airset_widths(const u64* airset, size_t airset_words) {
+    HAirSet set = parse_airset(airset, airset_words);
+    std::vector<size_t> w;
+    for (const HTable& t : set.tables) w.push_back((size_t)t.ncols);
+    return w;
 }
 
 // ola_air_kernels_available

@@ -1,0 +1,301 @@
+// Trace upload of prove_with_traces: the caller's tables -- [Vec<PolynomialValues<F>>; NUM_TABLES] in the reference
+// (circuits/src/stark/prover.rs:79-83; one Vec<F> per column, plonky2/field/src/polynomial/mod.rs:24-26; GoldilocksField is
+// repr(transparent) u64, goldilocks_field.rs:24-26) -- go to the prover's column-major device buffers while the proving thread
+// already interpolates / extends / hashes the column groups that have arrived.
+//
+// A column is wherever the caller's allocator put it (TraceSource::cols) or part of one contiguous block (TraceSource::base).
+// Host memory is pageable; hipMemcpyAsync from pageable memory is staged by the runtime on the calling thread, one chunk in
+// flight (round 4: 40 GB/s, the proving thread waited 62 - 82 ms of a 261 ms proof).  Here the staging is the library's own:
+// a ring of pinned slots kept by the context, filled by a few copier threads (a core copies 8 - 12 GB/s, the link wants
+// 50+), every filled slot sent with hipMemcpyAsync on the upload stream right away -- copies queue back to back on the DMA
+// engine -- and one thread that retires slots in order and publishes "columns [0, c) of table t have arrived".
+//   OLA_UPLOAD=staged (default) | pageable (round 4's path, kept as the A/B control) | register (hipHostRegister the caller's
+//   columns and copy from them directly; measured)
+//   OLA_UPLOAD_THREADS (default 6), OLA_UPLOAD_PIECE_MB (4), OLA_UPLOAD_SLOTS (32)
+// Tables that are already in device memory are copied device to device without staging.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "device_ctx.h"
+
+namespace ola {
+
+typedef unsigned long long u64;   // as in gl.cuh
+
+// where one table's columns are: `cols[c]` (each its own allocation) or `base + c n` (one block)
+struct TraceSource {
+    const u64* base = nullptr;
+    const u64* const* cols = nullptr;
+    const u64* col(uint32_t c, size_t n) const { return cols ? cols[c] : base + (size_t)c * n; }
+};
+
+class TraceUploader {
+  public:
+    enum Mode { STAGED = 0, PAGEABLE = 1, REGISTER = 2 };
+    TraceUploader(DeviceCtx* ctx, size_t ntables) : ctx_(ctx), jobs_(ntables), done_(ntables) {
+        for (auto& d : done_) d.store(0);
+        const char* m = getenv("OLA_UPLOAD");
+        mode_ = (m && !strcmp(m, "pageable")) ? PAGEABLE : (m && !strcmp(m, "register")) ? REGISTER : STAGED;
+        piece_bytes_ = (size_t)env_int("OLA_UPLOAD_PIECE_MB", 4, 1, 256) << 20;
+        slots_ = (size_t)env_int("OLA_UPLOAD_SLOTS", 32, 2, 1024);
+        const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+        // the ranks of a multi-device context upload side by side: keep the copier threads of all of them within the machine
+        const unsigned share = std::max(1u, hw / std::max(1u, ctx->shard.world));
+        nthreads_ = (unsigned)env_int("OLA_UPLOAD_THREADS", (int)std::min(6u, std::max(1u, share - 1)), 1, 64);
+    }
+    ~TraceUploader() {
+        cancel_.store(true);
+        { std::lock_guard<std::mutex> lk(mu_); cv_.notify_all(); }
+        join_all();
+        for (void* p : registered_) (void)hipHostUnregister(p);
+        for (hipEvent_t e : events_) if (e) (void)hipEventDestroy(e);
+        if (start_ev_) (void)hipEventDestroy(start_ev_);
+        if (stream_) (void)hipStreamDestroy(stream_);
+    }
+    // columns [first, first + ncols) of `src` -> dst (column c of the job at dst + c n)
+    void add(size_t t, const TraceSource& src, uint32_t first, u64* dst, uint32_t ncols, size_t n) {
+        const size_t target = (size_t)64 << 20;
+        uint32_t cc = (uint32_t)std::max<size_t>(1, target / (n * 8));
+        jobs_[t] = {src, first, dst, ncols, n, std::max(1u, std::min(cc, ncols))};      // ncols may be 0: a rank without columns of its own
+    }
+    // granularity the proving thread should ask in (about 64 MB of columns)
+    uint32_t chunk_cols(size_t t) const { return jobs_[t].chunk; }
+    void start() {
+        HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+        // the destination buffers come out of the context's cache: whatever was enqueued on the context's stream before this call
+        // (an asynchronous entry point that freed its scratch with kernels still pending) must have finished with them first
+        HIP_CHECK(hipEventCreateWithFlags(&start_ev_, hipEventDisableTiming));
+        HIP_CHECK(hipEventRecord(start_ev_, ctx_->stream));
+        HIP_CHECK(hipStreamWaitEvent(stream_, start_ev_, 0));
+        plan();
+        t_start_ = std::chrono::steady_clock::now();
+        if (mode_ == STAGED && !pieces_.empty()) {
+            ensure_ring();
+            events_.assign(slots_, nullptr);
+            for (auto& e : events_) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            issued_.reset(new std::atomic<char>[pieces_.size()]);
+            for (size_t i = 0; i < pieces_.size(); i++) issued_[i].store(0);
+            for (unsigned k = 0; k < nthreads_; k++) copiers_.emplace_back([this] { copier(); });
+            th_ = std::thread([this] { retire(); });
+        } else {
+            th_ = std::thread([this] { run_direct(); });
+        }
+    }
+    void wait(size_t t, uint32_t cols) {
+        const auto t0 = std::chrono::steady_clock::now();
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [&] { return done_[t].load() >= cols || failed_; });
+        waited_ms_ += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        if (failed_) throw OlaError(-5, "trace upload failed: " + error_);
+    }
+    void finish() {
+        join_all();
+        UploadStats& s = ctx_->upload;
+        s.waited_ms = waited_ms_; s.total_ms = total_ms_; s.first_ms = first_ms_; s.bytes = (double)bytes_; s.mode = (uint32_t)mode_;
+        s.threads = mode_ == STAGED ? nthreads_ : 1;
+        if (ctx_->timing)
+            fprintf(stderr, "[ola-timing] trace upload (%s, %u copier thread(s)): %.2f GB in %.3f ms = %.1f GB/s; the proving thread waited %.3f ms for column groups; first group complete after %.3f ms\n",
+                    mode_ == STAGED ? "pinned staging ring" : mode_ == PAGEABLE ? "pageable hipMemcpyAsync" : "hipHostRegister", s.threads, bytes_ / 1e9, total_ms_,
+                    total_ms_ > 0 ? bytes_ / 1e6 / total_ms_ : 0.0, waited_ms_, first_ms_);
+        if (failed_) throw OlaError(-5, "trace upload failed: " + error_);
+    }
+
+  private:
+    struct Job { TraceSource src; uint32_t first; u64* dst; uint32_t ncols; size_t n; uint32_t chunk; };
+    // one staging slot's worth: whole columns [c0, c1) of a table, or rows [row0, row0 + rows) of the single column c0
+    struct Piece { uint32_t table, c0, c1; size_t row0, rows; uint32_t cols_done; bool device_src; };
+
+    static int env_int(const char* name, int dflt, int lo, int hi) {
+        const char* e = getenv(name);
+        if (!e || !*e) return dflt;
+        return std::max(lo, std::min(hi, atoi(e)));
+    }
+    static bool is_device_pointer(const void* p) {
+        hipPointerAttribute_t a;
+        if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }   // plain malloc memory: "invalid value"
+        return a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged;
+    }
+    void plan() {
+        for (size_t t = 0; t < jobs_.size(); t++) {
+            const Job& j = jobs_[t];
+            if (!j.ncols) continue;
+            const size_t col_bytes = j.n * 8;
+            bytes_ += col_bytes * j.ncols;
+            const bool dev = is_device_pointer(j.src.col(j.first, j.n));
+            // only the staging ring cuts columns: the other paths copy whole column groups, as round 4 did
+            const bool whole = dev || mode_ != STAGED;
+            if (col_bytes >= piece_bytes_ && !whole) {
+                const size_t rows_per = piece_bytes_ / 8;
+                for (uint32_t c = 0; c < j.ncols; c++)
+                    for (size_t r = 0; r < j.n; r += rows_per)
+                        pieces_.push_back({(uint32_t)t, c, c + 1, r, std::min(rows_per, j.n - r), r + rows_per >= j.n ? c + 1 : c, false});
+            } else {
+                // small columns travel together; device-resident tables go column group by column group
+                const uint32_t per = whole ? j.chunk : (uint32_t)std::max<size_t>(1, piece_bytes_ / col_bytes);
+                for (uint32_t c = 0; c < j.ncols; c += per) {
+                    const uint32_t c1 = std::min(j.ncols, c + per);
+                    pieces_.push_back({(uint32_t)t, c, c1, 0, j.n, c1, dev});
+                }
+            }
+        }
+    }
+    const u64* src_of(const Piece& p, uint32_t c) const { const Job& j = jobs_[p.table]; return j.src.col(j.first + c, j.n) + p.row0; }
+    u64* dst_of(const Piece& p) const { const Job& j = jobs_[p.table]; return j.dst + (size_t)p.c0 * j.n + p.row0; }
+    size_t bytes_of(const Piece& p) const { return (size_t)(p.c1 - p.c0) * p.rows * 8; }
+    // the source columns [c0, c1) of a piece are one run of memory (always true for a contiguous table)
+    bool contiguous(const Piece& p) const {
+        for (uint32_t c = p.c0 + 1; c < p.c1; c++) if (src_of(p, c) != src_of(p, c - 1) + p.rows) return false;
+        return true;
+    }
+    void ensure_ring() {
+        const size_t want = piece_bytes_ * slots_;
+        if (ctx_->staging && ctx_->staging_bytes >= want) return;
+        if (ctx_->staging) { (void)hipHostFree(ctx_->staging); ctx_->staging = nullptr; ctx_->staging_bytes = 0; }
+        HIP_CHECK(hipHostMalloc(&ctx_->staging, want, hipHostMallocDefault));
+        ctx_->staging_bytes = want;
+    }
+    void fail(hipError_t e) {
+        std::lock_guard<std::mutex> lk(mu_);
+        if (!failed_) { failed_ = true; error_ = hipGetErrorString(e); }
+        cv_.notify_all();
+    }
+    void publish(const Piece& p, size_t completed) {
+        std::lock_guard<std::mutex> lk(mu_);
+        completed_ = completed;
+        if (p.cols_done > done_[p.table].load()) {
+            done_[p.table].store(p.cols_done);
+            if (first_ms_ == 0) first_ms_ = since_start();
+        }
+        cv_.notify_all();
+    }
+    double since_start() const { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start_).count(); }
+
+    // STAGED: copier threads take pieces in order, fill the piece's slot (free once the piece `slots_` earlier has retired) and
+    // send it; retire() waits for the copies in order.
+    void copier() {
+        (void)hipSetDevice(ctx_->device);
+        for (;;) {
+            const size_t i = next_.fetch_add(1);
+            if (i >= pieces_.size() || cancel_.load()) return;
+            const Piece& p = pieces_[i];
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [&] { return completed_ + slots_ > i || failed_ || cancel_.load(); });
+                if (failed_ || cancel_.load()) { issued_[i].store(2); cv_.notify_all(); return; }
+            }
+            hipError_t e = hipSuccess;
+            if (p.device_src) {
+                for (uint32_t c = p.c0; c < p.c1 && e == hipSuccess; c++) {
+                    std::lock_guard<std::mutex> lk(issue_mu_);
+                    e = hipMemcpyAsync(dst_of(p) + (size_t)(c - p.c0) * p.rows, src_of(p, c), p.rows * 8, hipMemcpyDeviceToDevice, stream_);
+                }
+                std::lock_guard<std::mutex> lk(issue_mu_);
+                if (e == hipSuccess) e = hipEventRecord(events_[i % slots_], stream_);
+            } else {
+                char* slot = (char*)ctx_->staging + (i % slots_) * piece_bytes_;
+                for (uint32_t c = p.c0; c < p.c1; c++) memcpy(slot + (size_t)(c - p.c0) * p.rows * 8, src_of(p, c), p.rows * 8);
+                std::lock_guard<std::mutex> lk(issue_mu_);
+                e = hipMemcpyAsync(dst_of(p), slot, bytes_of(p), hipMemcpyHostToDevice, stream_);
+                if (e == hipSuccess) e = hipEventRecord(events_[i % slots_], stream_);
+            }
+            if (e != hipSuccess) fail(e);
+            issued_[i].store(e == hipSuccess ? 1 : 2);
+            { std::lock_guard<std::mutex> lk(mu_); cv_.notify_all(); }
+            if (e != hipSuccess) return;
+        }
+    }
+    void retire() {
+        (void)hipSetDevice(ctx_->device);
+        for (size_t i = 0; i < pieces_.size(); i++) {
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [&] { return issued_[i].load() != 0 || failed_ || cancel_.load(); });
+                if (issued_[i].load() != 1) return;
+            }
+            const hipError_t e = hipEventSynchronize(events_[i % slots_]);
+            if (e != hipSuccess) { fail(e); return; }
+            publish(pieces_[i], i + 1);
+        }
+        total_ms_ = since_start();
+    }
+    // PAGEABLE / REGISTER (and nothing to stage): one thread, one copy per piece
+    void run_direct() {
+        (void)hipSetDevice(ctx_->device);
+        if (mode_ == REGISTER) {
+            for (size_t t = 0; t < jobs_.size() && !cancel_.load(); t++) {
+                const Job& j = jobs_[t];
+                if (!j.ncols || is_device_pointer(j.src.col(j.first, j.n))) continue;
+                if (j.src.cols) {
+                    for (uint32_t c = 0; c < j.ncols; c++) reg((void*)j.src.col(j.first + c, j.n), j.n * 8);
+                } else {
+                    reg((void*)j.src.col(j.first, j.n), (size_t)j.ncols * j.n * 8);
+                }
+            }
+            register_ms_ = since_start();
+            if (ctx_->timing) fprintf(stderr, "[ola-timing] trace upload: hipHostRegister of %zu range(s) took %.3f ms\n", registered_.size(), register_ms_);
+        }
+        for (size_t i = 0; i < pieces_.size() && !cancel_.load(); i++) {
+            const Piece& p = pieces_[i];
+            hipError_t e = hipSuccess;
+            if (p.c1 - p.c0 > 1 && contiguous(p)) {
+                e = hipMemcpyAsync(dst_of(p), src_of(p, p.c0), bytes_of(p), hipMemcpyDefault, stream_);
+            } else {
+                for (uint32_t c = p.c0; c < p.c1 && e == hipSuccess; c++)
+                    e = hipMemcpyAsync(dst_of(p) + (size_t)(c - p.c0) * p.rows, src_of(p, c), p.rows * 8, hipMemcpyDefault, stream_);
+            }
+            // group boundary (or every piece from pageable memory, where the call itself is the copy): wait and publish
+            const bool last_of_group = p.cols_done != p.c0 && (p.cols_done % jobs_[p.table].chunk == 0 || p.cols_done == jobs_[p.table].ncols);
+            if (e == hipSuccess && (last_of_group || p.device_src)) e = hipStreamSynchronize(stream_);
+            if (e != hipSuccess) { fail(e); return; }
+            if (last_of_group || p.device_src) publish(p, i + 1);
+        }
+        total_ms_ = since_start();
+    }
+    void reg(void* p, size_t bytes) {
+        // registration wants page-aligned ranges; neighbouring columns of one allocation may share a page, hence "already registered" is fine
+        const uintptr_t a = (uintptr_t)p & ~(uintptr_t)4095, b = ((uintptr_t)p + bytes + 4095) & ~(uintptr_t)4095;
+        const hipError_t e = hipHostRegister((void*)a, b - a, hipHostRegisterDefault);
+        if (e == hipSuccess) registered_.push_back((void*)a);
+        else (void)hipGetLastError();                   // not fatal: the copy then goes through the runtime's own staging
+    }
+    void join_all() {
+        for (std::thread& t : copiers_) if (t.joinable()) t.join();
+        if (th_.joinable()) th_.join();
+    }
+
+    DeviceCtx* ctx_;
+    std::vector<Job> jobs_;
+    std::vector<Piece> pieces_;
+    std::vector<std::atomic<uint32_t>> done_;
+    std::unique_ptr<std::atomic<char>[]> issued_;     // per piece: 0 not yet, 1 sent, 2 given up
+    std::vector<hipEvent_t> events_;                  // per slot
+    std::vector<std::thread> copiers_;
+    std::vector<void*> registered_;
+    std::thread th_;
+    std::mutex mu_, issue_mu_;
+    std::condition_variable cv_;
+    std::atomic<size_t> next_{0};
+    size_t completed_ = 0;                            // pieces retired (guarded by mu_)
+    std::atomic<bool> cancel_{false};
+    Mode mode_ = STAGED;
+    size_t piece_bytes_ = 0, slots_ = 0, bytes_ = 0;
+    unsigned nthreads_ = 1;
+    std::chrono::steady_clock::time_point t_start_;
+    double waited_ms_ = 0, first_ms_ = 0, total_ms_ = 0, register_ms_ = 0;
+    bool failed_ = false;
+    std::string error_;
+    hipStream_t stream_ = nullptr;
+    hipEvent_t start_ev_ = nullptr;
+};
+
+}  // namespace ola

@@ -42,3 +42,25 @@ def test_cpp_host_layer_passes_the_reference_style_checks_and_proves_the_same_by
     assert proof == oracle.prove_with_traces(blob, traces, params, compress)
     rc, why = oracle.verify_all_proof(blob, proof, params)
     assert rc == 0, why
+
+
+def test_c99_program_proves_from_separately_allocated_columns(tmp_path, oracle):
+    """tests/host_c_abi_check.c (C99, linked against libola_gpu.so alone) holds the traces the way the reference does -- every column its
+    own malloc (prover.rs:79-83, polynomial/mod.rs:24-26) -- and proves through ola_prove_with_traces_cols, then through
+    ola_prove_with_traces from the contiguous tables: the program compares the two, this test compares with the oracle prover."""
+    from olavm_amd.air import miniexec as M
+    from olavm_amd.backend import lib_path
+    s = T.ola_stark(range_bits=4, limb_bits=2)
+    blob = s.blob()
+    traces, params, compress = M.instance(M.mixed_program())
+    logs = [int(t.shape[1]).bit_length() - 1 for t in traces]
+    fixture, proof_path = tmp_path / "fixture.bin", tmp_path / "proof.bin"
+    write_fixture(fixture, [[0], blob, logs, params, compress, [t.n_params for t in s.tables]] + list(traces))
+    lib = os.path.dirname(lib_path())
+    exe = os.path.join(str(tmp_path), "host_c_abi_check")
+    subprocess.check_call(["gcc", "-std=c99", "-O1", "-Wall", "-Wextra", "-pedantic", "-Werror", os.path.join(HERE, "host_c_abi_check.c"), "-o", exe,
+                           "-L" + lib, "-lola_gpu", "-Wl,-rpath," + lib, "-Wl,-rpath-link,/opt/rocm/lib"])
+    r = subprocess.run([exe, str(fixture), str(proof_path)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "per-column == contiguous" in r.stdout, r.stdout + r.stderr
+    proof = open(proof_path, "rb").read()
+    assert proof == oracle.prove_with_traces(blob, traces, params, compress)

@@ -6,6 +6,11 @@ for step in "$@"; do
   O=gpurun_out/$step; mkdir -p "$O"
   echo "=== $step"
   case $step in
+    upload)      # trace upload: the box's H2D ceilings, the tests of the per-column entry point, the paths alternated inside the 2^22-row proof
+                 hipcc --offload-arch=gfx950 -O3 -pthread -o /tmp/h2d_rates tools/ubench/h2d_rates.hip 2>/dev/null && timeout 300 /tmp/h2d_rates 4 2>&1 | grep -v amdgpu | tee $O/h2d_rates.txt
+                 timeout 900 python -m pytest tests/test_gpu_upload.py tests/test_gpu_host_api.py -x -q 2>&1 | tail -15 | tee $O/pytest.log
+                 timeout 900 python tools/bench_upload.py 22 blake3 3 2>&1 | grep -v amdgpu | tee $O/ab_blake3.txt
+                 OLA_HASHER=blake3 OLA_TIMING=1 timeout 300 python tools/bench_prove.py 22 2 2> $O/phases_blake3.txt | tail -2 ;;
     multi)       timeout 900 python -m pytest tests/test_gpu_multi.py -x -q 2>&1 | tail -15 | tee $O/pytest.log ;;
     dist)        timeout 1200 python -m pytest tests/test_gpu_distributed.py tests/test_gpu_multi.py -x -q 2>&1 | tail -15 | tee $O/pytest.log ;;
     suite)       timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 | tee $O/pytest.log ;;
