@@ -165,10 +165,13 @@ int32_t ola_gpu_phase_stats(OlaCtx* ctx, double* out /* 3 * n_phases */, uint32_
  * "transpose LDEs" (fri/oracle.rs:84) never appears: the LDE is produced in leaf order, there is no transpose. */
 typedef struct OlaScopeTime {
     char name[64];
-    uint32_t depth, ref_depth;
+    uint32_t depth;
+    uint32_t ref_depth;
     int32_t table;
     uint32_t is_reference_scope;
-    double start_ms, ms, sharded_ms;
+    double start_ms;
+    double ms;
+    double sharded_ms;
 } OlaScopeTime;
 int32_t ola_gpu_scope_times(OlaCtx* ctx, int32_t enable, OlaScopeTime* out, uint32_t cap, uint32_t* n_out);
 /* The trace upload of the last whole proof: out[0] milliseconds the proving thread was blocked waiting for column groups,

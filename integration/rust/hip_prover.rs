@@ -1,19 +1,27 @@
 //! `prove_with_traces` on the MI355X backend: the body the `hip` feature substitutes for the CPU prover's
 //! (circuits/src/stark/prover.rs:79-327).  Drop into `circuits/src/stark/hip_prover.rs`.
 //!
-//! One call crosses the boundary: the twelve column-major traces go in as host pointers, the `AllProof` comes back in the
-//! reference's own wire format (`Buffer::write_all_proof`, serialization.rs:377-393) and is decoded with `Buffer::read_all_proof`
-//! (:394-412).  The executor / client path above (`client/src/main.rs:174-214`, `circuits/benches/fibo_loop.rs:72-91`) does not
-//! change.  The hash configuration is the caller's `C`: `PoseidonGoldilocksConfig` or `Blake3GoldilocksConfig`.
+//! One call crosses the boundary.  The twelve traces go in as they are -- `[Vec<PolynomialValues<F>>; NUM_TABLES]`, every column
+//! its own `Vec<F>` (plonky2/field/src/polynomial/mod.rs:24-26), `F = GoldilocksField` = `repr(transparent) u64`
+//! (goldilocks_field.rs:24-26): the shim hands the library one pointer per column (`ola_prove_with_traces_cols`) and copies
+//! nothing.  The `AllProof` comes back in the reference's own wire format (`Buffer::write_all_proof`, serialization.rs:377-393)
+//! and is decoded with `Buffer::read_all_proof` (:394-412).  The `timed!` scopes of the CPU prover come back with the GPU's
+//! times and are replayed into the caller's `TimingTree`.  The executor / client path above (`client/src/main.rs:174-214`,
+//! `circuits/benches/fibo_loop.rs:72-91`) does not change.  The hash configuration is the caller's `C`:
+//! `PoseidonGoldilocksConfig` or `Blake3GoldilocksConfig`.
 use std::any::type_name;
-use std::sync::OnceLock;
+use std::ffi::CStr;
+use std::sync::{Mutex, OnceLock};
+use std::time::{Duration, Instant};
 
-use anyhow::{ensure, Result};
+use anyhow::{bail, ensure, Result};
 use plonky2::field::extension::Extendable;
 use plonky2::field::polynomial::PolynomialValues;
 use plonky2::field::types::PrimeField64;
+use plonky2::fri::reduction_strategies::FriReductionStrategy;
 use plonky2::hash::hash_types::RichField;
 use plonky2::plonk::config::GenericConfig;
+use plonky2::util::timing::TimingTree;
 
 use super::config::StarkConfig;
 use super::ola_gpu_sys::*;
@@ -32,32 +40,70 @@ fn airset() -> &'static [u64] {
 
 struct SendPtr(*mut OlaCtx);
 unsafe impl Send for SendPtr {}
-unsafe impl Sync for SendPtr {}
 
-/// One context per hash configuration for the life of the process (the reference's own GPU state is process-wide:
-/// cfft/ntt/mod.rs:14-17,48-50).  `OLA_GPUS` = 1, 2, 4 or 8: the context spans that many devices and the partition and its
-/// exchanges happen inside the library (`OLA_COLLECTIVE` = peer | rccl selects who moves the bytes).
-fn ctx(hasher: u32, fri: &plonky2::fri::FriConfig) -> Result<*mut OlaCtx> {
-    static CTX: [OnceLock<SendPtr>; 2] = [OnceLock::new(), OnceLock::new()];
-    let slot = &CTX[hasher as usize];
-    if let Some(c) = slot.get() {
-        return Ok(c.0);
+/// One context per hash configuration for the life of the process, and ONE proof at a time on the GPU: a context is
+/// thread-compatible, not re-entrant (the reference's own GPU state is process-wide behind a mutex as well:
+/// cfft/ntt/mod.rs:14-17,48-50).  The slot is filled under its lock, so two threads that arrive together create one context,
+/// not two (a second context would hold tens of GB of pooled HBM for nothing).  `OLA_GPUS` = 1, 2, 4 or 8: the context spans
+/// that many devices and the partition and its exchanges happen inside the library (`OLA_COLLECTIVE` = peer | rccl selects who
+/// moves the bytes).  The guard is held for the whole proof.
+fn with_ctx<R>(hasher: u32, config: &StarkConfig, body: impl FnOnce(*mut OlaCtx) -> Result<R>) -> Result<R> {
+    static CTX: [OnceLock<Mutex<Option<SendPtr>>>; 2] = [OnceLock::new(), OnceLock::new()];
+    let mut slot = CTX[hasher as usize].get_or_init(|| Mutex::new(None)).lock().unwrap_or_else(|e| e.into_inner());
+    if slot.is_none() {
+        check_abi()?;
+        let fri = &config.fri_config;
+        // the library folds with one arity; StarkConfig::standard_fast_config is ConstantArityBits(4, 5) (config.rs:18-30)
+        let (arity_bits, final_poly_bits) = match fri.reduction_strategy {
+            FriReductionStrategy::ConstantArityBits(a, f) => (a as u32, f as u32),
+            ref other => bail!("the hip backend folds with FriReductionStrategy::ConstantArityBits only, the config asks for {other:?}"),
+        };
+        let n: u32 = std::env::var("OLA_GPUS").ok().and_then(|v| v.parse().ok()).unwrap_or(1);
+        let mut cfg: OlaGpuConfig = unsafe { std::mem::zeroed() };
+        cfg.device = -1;
+        cfg.rate_bits = fri.rate_bits as u32;
+        cfg.cap_height = fri.cap_height as u32;
+        cfg.proof_of_work_bits = fri.proof_of_work_bits;
+        cfg.fri_arity_bits = arity_bits;
+        cfg.fri_final_poly_bits = final_poly_bits;
+        cfg.num_query_rounds = fri.num_query_rounds as u32;
+        cfg.num_challenges = config.num_challenges as u32;
+        cfg.hasher = hasher;
+        let mut c = std::ptr::null_mut();
+        check(unsafe { ola_gpu_init_multi(&cfg, std::ptr::null(), n, &mut c) })?;
+        *slot = Some(SendPtr(c));
     }
-    check_abi()?;
-    let n: u32 = std::env::var("OLA_GPUS").ok().and_then(|v| v.parse().ok()).unwrap_or(1);
-    let mut cfg: OlaGpuConfig = unsafe { std::mem::zeroed() };
-    cfg.device = -1;
-    cfg.rate_bits = fri.rate_bits as u32;
-    cfg.cap_height = fri.cap_height as u32;
-    cfg.proof_of_work_bits = fri.proof_of_work_bits;
-    cfg.fri_arity_bits = 4; // FriReductionStrategy::ConstantArityBits(4, 5), config.rs:18-30
-    cfg.fri_final_poly_bits = 5;
-    cfg.num_query_rounds = fri.num_query_rounds as u32;
-    cfg.num_challenges = 2;
-    cfg.hasher = hasher;
-    let mut c = std::ptr::null_mut();
-    check(unsafe { ola_gpu_init_multi(&cfg, std::ptr::null(), n, &mut c) })?;
-    Ok(slot.get_or_init(|| SendPtr(c)).0)
+    body(slot.as_ref().unwrap().0)
+}
+
+/// The `timed!` scopes of the proof that has just run, with the GPU's times (`ola_gpu_scope_times`), replayed into the
+/// caller's tree under the names the CPU prover uses -- "compute trace commitments", "compute Zs commitment", "IFFT",
+/// "FFT + blinding", "build Merkle tree", "compute quotient polys", "compute openings proof", "perform final FFT {n}",
+/// "fold codewords in the commitment phase", "find proof-of-work witness" (prover.rs:111-553, fri/oracle.rs:56-90,221-225,
+/// fri/prover.rs:41-58) -- so that `timing.print()` reads as it does for the CPU prover, one line per scope.  Only the
+/// reference's scopes are replayed (the library's own grouping scopes, "table 3 prove_single_table", are skipped), at the depth
+/// they have among themselves; `t0` is the host's clock when the call was made.  `TimingTree::record` is the one method the
+/// patch adds to plonky2/plonky2/src/util/timing.rs (the tree's fields are private).
+fn replay_scopes(c: *mut OlaCtx, timing: &mut TimingTree, t0: Instant) -> Result<()> {
+    let mut n = 0u32;
+    check(unsafe { ola_gpu_scope_times(c, -1, std::ptr::null_mut(), 0, &mut n) })?;
+    if n == 0 {
+        return Ok(());
+    }
+    let mut scopes: Vec<OlaScopeTime> = Vec::with_capacity(n as usize);
+    check(unsafe { ola_gpu_scope_times(c, -1, scopes.as_mut_ptr(), n, &mut n) })?;
+    unsafe { scopes.set_len(n as usize) };
+    for s in scopes.iter().filter(|s| s.is_reference_scope != 0) {
+        let name = unsafe { CStr::from_ptr(s.name.as_ptr()) }.to_string_lossy();
+        timing.record(
+            s.ref_depth as usize,
+            &name,
+            log::Level::Debug,
+            t0 + Duration::from_secs_f64(s.start_ms * 1e-3),
+            Duration::from_secs_f64(s.ms * 1e-3),
+        );
+    }
+    Ok(())
 }
 
 /// `C::Hasher` -> OLA_HASH_*: the two configurations the reference instantiates the prover with
@@ -78,18 +124,20 @@ pub fn prove_with_traces_hip<F, C, const D: usize>(
     config: &StarkConfig,
     trace_poly_values: &[Vec<PolynomialValues<F>>; NUM_TABLES],
     public_values: PublicValues,
+    timing: &mut TimingTree,
 ) -> Result<AllProof<F, C, D>>
 where
     F: RichField + Extendable<D>,
     C: GenericConfig<D, F = F>,
 {
     ensure!(D == 2, "the backend proves over the quadratic extension");
-    // column-major u64 copies of the twelve tables (values may be any representative; the library canonicalises)
-    let flat: Vec<Vec<u64>> = trace_poly_values
-        .iter()
-        .map(|t| t.iter().flat_map(|c| c.values.iter().map(|x| x.to_noncanonical_u64())).collect())
-        .collect();
-    let ptrs: Vec<*const u64> = flat.iter().map(|t| t.as_ptr()).collect();
+    ensure!(std::mem::size_of::<F>() == 8, "the backend reads columns as u64 words (GoldilocksField is repr(transparent) u64)");
+    // one pointer per column, no copy: values may be any representative, the library canonicalises on the device
+    let cols: Vec<Vec<*const u64>> = trace_poly_values.iter().map(|t| t.iter().map(|c| c.values.as_ptr() as *const u64).collect()).collect();
+    let tables: Vec<*const *const u64> = cols.iter().map(|t| t.as_ptr()).collect();
+    for t in trace_poly_values.iter() {
+        ensure!(!t.is_empty() && t.iter().all(|c| c.len() == t[0].len() && c.len().is_power_of_two()), "ragged trace table");
+    }
     let log_n: Vec<u32> = trace_poly_values.iter().map(|t| t[0].len().trailing_zeros()).collect();
     // prover.rs:307-320: the two compress challenges come from trace generation, not from this transcript
     let bitwise = ola_stark.bitwise_stark.get_compress_challenge().unwrap().to_canonical_u64();
@@ -99,22 +147,31 @@ where
     compress[Table::Bitwise as usize] = bitwise;
     compress[Table::Program as usize] = program;
 
-    let c = ctx(hasher_of::<F, C, D>()?, &config.fri_config)?;
     let words = airset();
-    let mut out = vec![0u8; 8 << 20];
-    let mut len = 0usize;
-    let rc = unsafe {
-        ola_prove_with_traces(c, words.as_ptr(), words.len(), ptrs.as_ptr(), log_n.as_ptr(), params.as_ptr(), compress.as_ptr(),
-                              out.as_mut_ptr(), out.len(), &mut len)
-    };
-    if rc == OLA_E_INVALID_ARG && len > out.len() {
-        // the proof is larger than the buffer: it was kept, fetch it without proving again
-        out.resize(len, 0);
-        check(unsafe { ola_take_pending_proof(c, out.as_mut_ptr(), out.len(), &mut len) })?;
-    } else {
-        check(rc)?;
-    }
-    out.truncate(len);
+    let out = with_ctx(hasher_of::<F, C, D>()?, config, |c| {
+        // scope times cost two event records per scope; ask for them when somebody will read the tree (TimingTree logs at Debug)
+        let want_scopes = log::log_enabled!(log::Level::Debug);
+        check(unsafe { ola_gpu_scope_times(c, want_scopes as i32, std::ptr::null_mut(), 0, std::ptr::null_mut()) })?;
+        let mut out = vec![0u8; 8 << 20];
+        let mut len = 0usize;
+        let t0 = Instant::now();
+        let rc = unsafe {
+            ola_prove_with_traces_cols(c, words.as_ptr(), words.len(), tables.as_ptr(), log_n.as_ptr(), params.as_ptr(), compress.as_ptr(),
+                                       out.as_mut_ptr(), out.len(), &mut len)
+        };
+        if rc == OLA_E_INVALID_ARG && len > out.len() {
+            // the proof is larger than the buffer: it was kept, fetch it without proving again
+            out.resize(len, 0);
+            check(unsafe { ola_take_pending_proof(c, out.as_mut_ptr(), out.len(), &mut len) })?;
+        } else {
+            check(rc)?;
+        }
+        out.truncate(len);
+        if want_scopes {
+            replay_scopes(c, timing, t0)?;
+        }
+        Ok(out)
+    })?;
     let mut proof: AllProof<F, C, D> = Buffer::new(out).read_all_proof()?;
     proof.public_values = public_values; // not part of the wire format (serialization.rs:391)
     Ok(proof)

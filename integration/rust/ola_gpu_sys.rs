@@ -1,4 +1,4 @@
-//! Raw bindings of `libola_gpu.so` (`include/ola_gpu.h`, ABI revision 4) for the reference's `circuits` crate.
+//! Raw bindings of `libola_gpu.so` (`include/ola_gpu.h`, ABI revision 5) for the reference's `circuits` crate.
 //!
 //! Drop into `circuits/src/stark/ola_gpu_sys.rs` (integration/patches/0001-feature-hip.patch adds the `mod` line and the
 //! feature).  Replaces the reference's dead CUDA FFI -- `gpu_init` / `gpu_method` / `gpu_free`,
@@ -11,7 +11,7 @@
 #![allow(non_camel_case_types, dead_code)]
 use std::os::raw::{c_char, c_void};
 
-pub const OLA_GPU_ABI_VERSION: i32 = 4;
+pub const OLA_GPU_ABI_VERSION: i32 = 5;
 pub const OLA_OK: i32 = 0;
 pub const OLA_E_INVALID_ARG: i32 = -1;
 pub const OLA_E_NO_DEVICE: i32 = -2;
@@ -73,6 +73,20 @@ pub struct OlaChallenger {
     pub hasher: u32,
     pub reserved: u32,
 }
+/// One `timed!` scope of the last proof with device times (`ola_gpu_scope_times`), for the caller's `TimingTree`
+/// (plonky2/plonky2/src/util/timing.rs:7-194).
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct OlaScopeTime {
+    pub name: [c_char; 64],
+    pub depth: u32,
+    pub ref_depth: u32,
+    pub table: i32,
+    pub is_reference_scope: u32,
+    pub start_ms: f64,
+    pub ms: f64,
+    pub sharded_ms: f64,
+}
 /// `ola_all_gather_fn`: gather `bytes` bytes of device memory from every rank into `recv_dev` (rank order), 0 = done
 pub type OlaAllGatherFn = Option<unsafe extern "C" fn(user: *mut c_void, send_dev: *const c_void, recv_dev: *mut c_void, bytes: usize) -> i32>;
 
@@ -92,6 +106,8 @@ extern "C" {
     pub fn ola_gpu_memory_stats(ctx: *mut OlaCtx, out: *mut u64, reset: i32) -> i32;
     pub fn ola_gpu_proof_stats(ctx: *mut OlaCtx, enable: i32, out: *mut f64) -> i32;
     pub fn ola_gpu_phase_stats(ctx: *mut OlaCtx, out: *mut f64, n_phases: u32) -> i32;
+    pub fn ola_gpu_scope_times(ctx: *mut OlaCtx, enable: i32, out: *mut OlaScopeTime, cap: u32, n_out: *mut u32) -> i32;
+    pub fn ola_gpu_upload_stats(ctx: *mut OlaCtx, out: *mut f64) -> i32;
     pub fn ola_gpu_selftest(ctx: *mut OlaCtx, pairs: u64, mismatches: *mut u64) -> i32;
     pub fn ola_gpu_reserve(ctx: *mut OlaCtx, airset: *const u64, airset_words: usize, log_n: *const u32) -> i32;
     pub fn ola_table_shape(ctx: *mut OlaCtx, airset: *const u64, airset_words: usize, table: u32, out: *mut u32) -> i32;
@@ -140,6 +156,9 @@ extern "C" {
         openings_len: *mut usize) -> i32;
     pub fn ola_pow(ctx: *mut OlaCtx, h: *const u64, bits: u32, witness: *mut u64) -> i32;
     pub fn ola_prove_with_traces(ctx: *mut OlaCtx, airset: *const u64, airset_words: usize, traces: *const *const u64,
+        log_n: *const u32, params: *const u64, compress_challenges: *const u64, out: *mut u8, cap: usize,
+        out_len: *mut usize) -> i32;
+    pub fn ola_prove_with_traces_cols(ctx: *mut OlaCtx, airset: *const u64, airset_words: usize, cols: *const *const *const u64,
         log_n: *const u32, params: *const u64, compress_challenges: *const u64, out: *mut u8, cap: usize,
         out_len: *mut usize) -> i32;
     pub fn ola_take_pending_proof(ctx: *mut OlaCtx, out: *mut u8, cap: usize, out_len: *mut usize) -> i32;

@@ -1115,9 +1115,26 @@ void prove_with_traces(DeviceCtx* ctx, NttTables& tables, const OlaGpuConfig& cf
             up.add(t, traces[t], 0, dev[t].vals, w, n_t);
         }
     }
+    // Order of upload and commitment (the caps enter the transcript in table order afterwards, prover.rs:139-142): the tables
+    // below 64 MB first -- their commitments then run in the shadow of the large upload instead of after it --, then the large
+    // ones from the largest down: what is left to do when the last byte arrives is one column group and the Merkle tree of
+    // the smallest large table, and the largest tree (190 ms for the CPU table under Poseidon) overlaps the rest of the upload.
+    std::vector<size_t> order(nt);
+    for (size_t t = 0; t < nt; t++) order[t] = t;
+    {
+        auto bytes_of = [&](size_t t) { return ((size_t)set.tables[t].ncols << log_n[t]) * 8; };
+        const size_t big = (size_t)64 << 20;
+        std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) {
+            const bool la = bytes_of(a) >= big, lb = bytes_of(b) >= big;
+            if (la != lb) return lb;                       // small ones first
+            return la && bytes_of(a) > bytes_of(b);        // large: descending; small: as numbered
+        });
+    }
+    up.set_order(order);
     up.start();
     std::unique_ptr<PhaseTimer> t_commit(new PhaseTimer(ctx, "compute trace commitments"));
-    for (size_t t = 0; t < nt; t++) {
+    commits.resize(nt);
+    for (size_t t : order) {
         ctx->scopes.table = (int)t;
         PhaseTimer tt(ctx, "  table " + std::to_string(t) + " trace commitment (upload overlapped)");
         const size_t n_t = (size_t)1 << log_n[t];
@@ -1129,7 +1146,7 @@ void prove_with_traces(DeviceCtx* ctx, NttTables& tables, const OlaGpuConfig& cf
             up.wait(t, c1);
             canonicalize(ctx, dev[t].vals + (size_t)c0 * n_t, (size_t)(c1 - c0) * n_t);
         };
-        commits.emplace_back(new BatchHolder(ctx));
+        commits[t].reset(new BatchHolder(ctx));
         if (cpr[t]) {
             // this rank's columns have to be on the device, then every rank receives everybody's
             up.wait(t, own_cols[t]);

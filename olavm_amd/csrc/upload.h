@@ -6,13 +6,18 @@
 // A column is wherever the caller's allocator put it (TraceSource::cols) or part of one contiguous block (TraceSource::base).
 // Host memory is pageable; hipMemcpyAsync from pageable memory is staged by the runtime on the calling thread, one chunk in
 // flight (round 4: 40 GB/s, the proving thread waited 62 - 82 ms of a 261 ms proof).  Here the staging is the library's own:
-// a ring of pinned slots kept by the context, filled by a few copier threads (a core copies 8 - 12 GB/s, the link wants
-// 50+), every filled slot sent with hipMemcpyAsync on the upload stream right away -- copies queue back to back on the DMA
-// engine -- and one thread that retires slots in order and publishes "columns [0, c) of table t have arrived".
-//   OLA_UPLOAD=staged (default) | pageable (round 4's path, kept as the A/B control) | register (hipHostRegister the caller's
-//   columns and copy from them directly; measured)
-//   OLA_UPLOAD_THREADS (default 6), OLA_UPLOAD_PIECE_MB (4), OLA_UPLOAD_SLOTS (32)
+// a ring of pinned slots kept by the context, filled by a few copier threads (one core copies 29 GB/s on the test box, the
+// link carries 56.8), every filled slot sent with hipMemcpyAsync right away on one of two upload streams in turn -- the
+// next copy is already queued on the other DMA engine when one ends; with one stream the gap between copies costs 18 us per
+// piece, 45 instead of 56 GB/s at 4 MB pieces -- and one thread that retires slots in order and publishes "columns [0, c) of
+// table t have arrived".  Tables are sent in the order the caller gives (prove_with_traces: small tables first, then the large
+// ones in descending size, so that what is left to do after the last byte is the smallest large table's Merkle tree).
+//   OLA_UPLOAD=staged (default) | pageable (round 4's path: hipMemcpyAsync from the caller's memory, kept as the A/B control)
+//   OLA_UPLOAD_THREADS (default 4), OLA_UPLOAD_PIECE_MB (16), OLA_UPLOAD_SLOTS (8), OLA_UPLOAD_STREAMS (2)
 // Tables that are already in device memory are copied device to device without staging.
+// Not built: hipHostRegister of the caller's columns -- pinning 4.29 GB took 212.8 ms on the test box (50 ms per GB, three
+// times the transfer itself; tools/ubench/h2d_rates.hip, profiles/r05_h2d_rates.txt), and page-rounded registrations take in
+// neighbouring heap objects, after which the runtime refuses copies that straddle the registration's edge.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -41,26 +46,26 @@ struct TraceSource {
 
 class TraceUploader {
   public:
-    enum Mode { STAGED = 0, PAGEABLE = 1, REGISTER = 2 };
+    enum Mode { STAGED = 0, PAGEABLE = 1 };
     TraceUploader(DeviceCtx* ctx, size_t ntables) : ctx_(ctx), jobs_(ntables), done_(ntables) {
         for (auto& d : done_) d.store(0);
         const char* m = getenv("OLA_UPLOAD");
-        mode_ = (m && !strcmp(m, "pageable")) ? PAGEABLE : (m && !strcmp(m, "register")) ? REGISTER : STAGED;
-        piece_bytes_ = (size_t)env_int("OLA_UPLOAD_PIECE_MB", 4, 1, 256) << 20;
-        slots_ = (size_t)env_int("OLA_UPLOAD_SLOTS", 32, 2, 1024);
+        mode_ = (m && !strcmp(m, "pageable")) ? PAGEABLE : STAGED;
+        piece_bytes_ = (size_t)env_int("OLA_UPLOAD_PIECE_MB", 16, 1, 256) << 20;
+        slots_ = (size_t)env_int("OLA_UPLOAD_SLOTS", 8, 2, 1024);
+        nstreams_ = (size_t)env_int("OLA_UPLOAD_STREAMS", 2, 1, 4);
         const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
         // the ranks of a multi-device context upload side by side: keep the copier threads of all of them within the machine
         const unsigned share = std::max(1u, hw / std::max(1u, ctx->shard.world));
-        nthreads_ = (unsigned)env_int("OLA_UPLOAD_THREADS", (int)std::min(6u, std::max(1u, share - 1)), 1, 64);
+        nthreads_ = (unsigned)env_int("OLA_UPLOAD_THREADS", (int)std::min(4u, std::max(1u, share - 1)), 1, 64);
     }
     ~TraceUploader() {
         cancel_.store(true);
         { std::lock_guard<std::mutex> lk(mu_); cv_.notify_all(); }
         join_all();
-        for (void* p : registered_) (void)hipHostUnregister(p);
         for (hipEvent_t e : events_) if (e) (void)hipEventDestroy(e);
         if (start_ev_) (void)hipEventDestroy(start_ev_);
-        if (stream_) (void)hipStreamDestroy(stream_);
+        for (hipStream_t st : streams_) if (st) (void)hipStreamDestroy(st);
     }
     // columns [first, first + ncols) of `src` -> dst (column c of the job at dst + c n)
     void add(size_t t, const TraceSource& src, uint32_t first, u64* dst, uint32_t ncols, size_t n) {
@@ -70,13 +75,16 @@ class TraceUploader {
     }
     // granularity the proving thread should ask in (about 64 MB of columns)
     uint32_t chunk_cols(size_t t) const { return jobs_[t].chunk; }
+    // tables are sent in this order (default: as numbered)
+    void set_order(const std::vector<size_t>& order) { order_ = order; }
     void start() {
-        HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+        streams_.assign(mode_ == STAGED ? nstreams_ : 1, nullptr);
+        for (hipStream_t& st : streams_) HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
         // the destination buffers come out of the context's cache: whatever was enqueued on the context's stream before this call
         // (an asynchronous entry point that freed its scratch with kernels still pending) must have finished with them first
         HIP_CHECK(hipEventCreateWithFlags(&start_ev_, hipEventDisableTiming));
         HIP_CHECK(hipEventRecord(start_ev_, ctx_->stream));
-        HIP_CHECK(hipStreamWaitEvent(stream_, start_ev_, 0));
+        for (hipStream_t st : streams_) HIP_CHECK(hipStreamWaitEvent(st, start_ev_, 0));
         plan();
         t_start_ = std::chrono::steady_clock::now();
         if (mode_ == STAGED && !pieces_.empty()) {
@@ -105,7 +113,7 @@ class TraceUploader {
         s.threads = mode_ == STAGED ? nthreads_ : 1;
         if (ctx_->timing)
             fprintf(stderr, "[ola-timing] trace upload (%s, %u copier thread(s)): %.2f GB in %.3f ms = %.1f GB/s; the proving thread waited %.3f ms for column groups; first group complete after %.3f ms\n",
-                    mode_ == STAGED ? "pinned staging ring" : mode_ == PAGEABLE ? "pageable hipMemcpyAsync" : "hipHostRegister", s.threads, bytes_ / 1e9, total_ms_,
+                    mode_ == STAGED ? "pinned staging ring" : "pageable hipMemcpyAsync", s.threads, bytes_ / 1e9, total_ms_,
                     total_ms_ > 0 ? bytes_ / 1e6 / total_ms_ : 0.0, waited_ms_, first_ms_);
         if (failed_) throw OlaError(-5, "trace upload failed: " + error_);
     }
@@ -126,7 +134,8 @@ class TraceUploader {
         return a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged;
     }
     void plan() {
-        for (size_t t = 0; t < jobs_.size(); t++) {
+        if (order_.size() != jobs_.size()) { order_.resize(jobs_.size()); for (size_t t = 0; t < jobs_.size(); t++) order_[t] = t; }
+        for (size_t t : order_) {
             const Job& j = jobs_[t];
             if (!j.ncols) continue;
             const size_t col_bytes = j.n * 8;
@@ -194,19 +203,18 @@ class TraceUploader {
                 if (failed_ || cancel_.load()) { issued_[i].store(2); cv_.notify_all(); return; }
             }
             hipError_t e = hipSuccess;
+            hipStream_t st = streams_[i % streams_.size()];
             if (p.device_src) {
-                for (uint32_t c = p.c0; c < p.c1 && e == hipSuccess; c++) {
-                    std::lock_guard<std::mutex> lk(issue_mu_);
-                    e = hipMemcpyAsync(dst_of(p) + (size_t)(c - p.c0) * p.rows, src_of(p, c), p.rows * 8, hipMemcpyDeviceToDevice, stream_);
-                }
                 std::lock_guard<std::mutex> lk(issue_mu_);
-                if (e == hipSuccess) e = hipEventRecord(events_[i % slots_], stream_);
+                for (uint32_t c = p.c0; c < p.c1 && e == hipSuccess; c++)
+                    e = hipMemcpyAsync(dst_of(p) + (size_t)(c - p.c0) * p.rows, src_of(p, c), p.rows * 8, hipMemcpyDeviceToDevice, st);
+                if (e == hipSuccess) e = hipEventRecord(events_[i % slots_], st);
             } else {
                 char* slot = (char*)ctx_->staging + (i % slots_) * piece_bytes_;
                 for (uint32_t c = p.c0; c < p.c1; c++) memcpy(slot + (size_t)(c - p.c0) * p.rows * 8, src_of(p, c), p.rows * 8);
                 std::lock_guard<std::mutex> lk(issue_mu_);
-                e = hipMemcpyAsync(dst_of(p), slot, bytes_of(p), hipMemcpyHostToDevice, stream_);
-                if (e == hipSuccess) e = hipEventRecord(events_[i % slots_], stream_);
+                e = hipMemcpyAsync(dst_of(p), slot, bytes_of(p), hipMemcpyHostToDevice, st);
+                if (e == hipSuccess) e = hipEventRecord(events_[i % slots_], st);
             }
             if (e != hipSuccess) fail(e);
             issued_[i].store(e == hipSuccess ? 1 : 2);
@@ -228,45 +236,25 @@ class TraceUploader {
         }
         total_ms_ = since_start();
     }
-    // PAGEABLE / REGISTER (and nothing to stage): one thread, one copy per piece
+    // PAGEABLE: one thread, one copy per column group
     void run_direct() {
         (void)hipSetDevice(ctx_->device);
-        if (mode_ == REGISTER) {
-            for (size_t t = 0; t < jobs_.size() && !cancel_.load(); t++) {
-                const Job& j = jobs_[t];
-                if (!j.ncols || is_device_pointer(j.src.col(j.first, j.n))) continue;
-                if (j.src.cols) {
-                    for (uint32_t c = 0; c < j.ncols; c++) reg((void*)j.src.col(j.first + c, j.n), j.n * 8);
-                } else {
-                    reg((void*)j.src.col(j.first, j.n), (size_t)j.ncols * j.n * 8);
-                }
-            }
-            register_ms_ = since_start();
-            if (ctx_->timing) fprintf(stderr, "[ola-timing] trace upload: hipHostRegister of %zu range(s) took %.3f ms\n", registered_.size(), register_ms_);
-        }
         for (size_t i = 0; i < pieces_.size() && !cancel_.load(); i++) {
             const Piece& p = pieces_[i];
             hipError_t e = hipSuccess;
             if (p.c1 - p.c0 > 1 && contiguous(p)) {
-                e = hipMemcpyAsync(dst_of(p), src_of(p, p.c0), bytes_of(p), hipMemcpyDefault, stream_);
+                e = hipMemcpyAsync(dst_of(p), src_of(p, p.c0), bytes_of(p), hipMemcpyDefault, streams_[0]);
             } else {
                 for (uint32_t c = p.c0; c < p.c1 && e == hipSuccess; c++)
-                    e = hipMemcpyAsync(dst_of(p) + (size_t)(c - p.c0) * p.rows, src_of(p, c), p.rows * 8, hipMemcpyDefault, stream_);
+                    e = hipMemcpyAsync(dst_of(p) + (size_t)(c - p.c0) * p.rows, src_of(p, c), p.rows * 8, hipMemcpyDefault, streams_[0]);
             }
             // group boundary (or every piece from pageable memory, where the call itself is the copy): wait and publish
             const bool last_of_group = p.cols_done != p.c0 && (p.cols_done % jobs_[p.table].chunk == 0 || p.cols_done == jobs_[p.table].ncols);
-            if (e == hipSuccess && (last_of_group || p.device_src)) e = hipStreamSynchronize(stream_);
+            if (e == hipSuccess && (last_of_group || p.device_src)) e = hipStreamSynchronize(streams_[0]);
             if (e != hipSuccess) { fail(e); return; }
             if (last_of_group || p.device_src) publish(p, i + 1);
         }
         total_ms_ = since_start();
-    }
-    void reg(void* p, size_t bytes) {
-        // registration wants page-aligned ranges; neighbouring columns of one allocation may share a page, hence "already registered" is fine
-        const uintptr_t a = (uintptr_t)p & ~(uintptr_t)4095, b = ((uintptr_t)p + bytes + 4095) & ~(uintptr_t)4095;
-        const hipError_t e = hipHostRegister((void*)a, b - a, hipHostRegisterDefault);
-        if (e == hipSuccess) registered_.push_back((void*)a);
-        else (void)hipGetLastError();                   // not fatal: the copy then goes through the runtime's own staging
     }
     void join_all() {
         for (std::thread& t : copiers_) if (t.joinable()) t.join();
@@ -280,7 +268,6 @@ class TraceUploader {
     std::unique_ptr<std::atomic<char>[]> issued_;     // per piece: 0 not yet, 1 sent, 2 given up
     std::vector<hipEvent_t> events_;                  // per slot
     std::vector<std::thread> copiers_;
-    std::vector<void*> registered_;
     std::thread th_;
     std::mutex mu_, issue_mu_;
     std::condition_variable cv_;
@@ -288,13 +275,14 @@ class TraceUploader {
     size_t completed_ = 0;                            // pieces retired (guarded by mu_)
     std::atomic<bool> cancel_{false};
     Mode mode_ = STAGED;
-    size_t piece_bytes_ = 0, slots_ = 0, bytes_ = 0;
+    size_t piece_bytes_ = 0, slots_ = 0, nstreams_ = 2, bytes_ = 0;
+    std::vector<size_t> order_;
     unsigned nthreads_ = 1;
     std::chrono::steady_clock::time_point t_start_;
-    double waited_ms_ = 0, first_ms_ = 0, total_ms_ = 0, register_ms_ = 0;
+    double waited_ms_ = 0, first_ms_ = 0, total_ms_ = 0;
     bool failed_ = false;
     std::string error_;
-    hipStream_t stream_ = nullptr;
+    std::vector<hipStream_t> streams_;
     hipEvent_t start_ev_ = nullptr;
 };
 

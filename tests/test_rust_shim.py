@@ -110,7 +110,7 @@ def test_extern_block_matches_the_header():
 def test_structs_and_constants_match_the_header():
     h = _strip_c_comments(open(HEADER).read())
     rs = open(SYS_RS).read()
-    for struct in ("OlaGpuConfig", "OlaChallenger"):
+    for struct in ("OlaGpuConfig", "OlaChallenger", "OlaScopeTime"):
         cbody = re.search(r"typedef struct %s \{(.*?)\} %s;" % (struct, struct), h, flags=re.S).group(1)
         cf = []
         for ty, nm, arr in re.findall(r"([\w\s\*]+?)\s*\b(\w+)\s*(\[\d+\])?\s*;", cbody):
@@ -148,14 +148,53 @@ def test_patch_is_current_and_applies_to_the_reference(tmp_path):
         assert (tmp_path / dst).read_text() == open(os.path.join(ROOT, "integration", "rust", src)).read()
     prover = (tmp_path / "circuits/src/stark/prover.rs").read_text()
     assert prover.count('#[cfg(feature = "hip")]') == 1 and "prove_with_traces_hip::<F, C, D>" in prover
+    # the caller's TimingTree goes in (no `let _ = timing;` any more), and the one method the shim needs exists after the patch
+    hip_branch = prover[prover.index('#[cfg(feature = "hip")]'):prover.index("let rate_bits = config.fri_config.rate_bits;")]
+    assert "timing," in hip_branch and "let _ = timing" not in hip_branch
+    timing_rs = (tmp_path / "plonky2/plonky2/src/util/timing.rs").read_text()
+    assert timing_rs.count("pub fn record(") == 2            # with and without the `timing` feature, like push / pop
+    shim = open(os.path.join(ROOT, "integration", "rust", "hip_prover.rs")).read()
+    assert "timing.record(" in shim and "timing: &mut TimingTree" in shim and "ola_prove_with_traces_cols(" in shim
+    assert "c.values.as_ptr() as *const u64" in shim and "flat_map" not in shim          # one pointer per column, no gather
     # what the shim calls in the reference exists there under those names
     for path, needle in (("circuits/src/stark/serialization.rs", "pub fn read_all_proof<"), ("circuits/src/stark/serialization.rs", "pub fn new(buffer: Vec<u8>)"),
                          ("circuits/src/builtins/bitwise/bitwise_stark.rs", "pub fn get_compress_challenge(&self) -> Option<F>"),
                          ("circuits/src/program/program_stark.rs", "pub fn get_compress_challenge(&self) -> Option<F>"),
                          ("circuits/src/stark/ola_stark.rs", "Bitwise = 2,"), ("circuits/src/stark/ola_stark.rs", "Program = 10,"),
                          ("circuits/src/stark/ola_stark.rs", "pub(crate) const NUM_TABLES: usize = 12;"), ("plonky2/field/src/types.rs", "fn to_noncanonical_u64(&self) -> u64;"),
-                         ("plonky2/plonky2/src/fri/mod.rs", "pub proof_of_work_bits: u32,"), ("circuits/src/stark/proof.rs", "pub public_values: PublicValues,")):
+                         ("plonky2/plonky2/src/fri/mod.rs", "pub proof_of_work_bits: u32,"), ("circuits/src/stark/proof.rs", "pub public_values: PublicValues,"),
+                         ("plonky2/plonky2/src/fri/mod.rs", "pub reduction_strategy: FriReductionStrategy,"),
+                         ("plonky2/plonky2/src/fri/reduction_strategies.rs", "ConstantArityBits(usize, usize),"), ("circuits/src/stark/config.rs", "pub num_challenges: usize,"),
+                         ("plonky2/field/src/polynomial/mod.rs", "pub values: Vec<F>,"), ("plonky2/field/src/goldilocks_field.rs", "#[repr(transparent)]"),
+                         ("plonky2/plonky2/src/util/timing.rs", "children: Vec<TimingTree>,"), ("plonky2/plonky2/src/util/timing.rs", "exit_time: Option<Instant>,")):
         assert needle in open(os.path.join(REF, path)).read(), (path, needle)
+
+
+@needs_ref
+def test_scope_names_handed_to_the_timing_tree_are_the_references():
+    """"emit the same scope names ... so numbers line up 1:1".  The names the library marks as the reference's
+    (ScopeLog::is_reference_scope, olavm_amd/csrc/device_ctx.h) are exactly the `timed!` names of the path -- prover.rs:111-553,
+    fri/oracle.rs:56-90,221-225, fri/prover.rs:41-58 -- minus "transpose LDEs" (oracle.rs:84; the LDE is produced in leaf order, there is
+    no transpose to time); the formatted one is matched by its prefix."""
+    ref = set()
+    for path, lo, hi in (("circuits/src/stark/prover.rs", 111, 553), ("plonky2/plonky2/src/fri/oracle.rs", 56, 90), ("plonky2/plonky2/src/fri/oracle.rs", 221, 225),
+                         ("plonky2/plonky2/src/fri/prover.rs", 41, 58)):
+        text = "".join(open(os.path.join(REF, path)).readlines()[lo - 1:hi])
+        for m in re.finditer(r'timed!\(\s*timing,\s*(?:&format!\()?"([^"]+)"', text):
+            ref.add(m.group(1))
+    assert len(ref) == 14 and "transpose LDEs" in ref and "perform final FFT {}" in ref
+    src = open(os.path.join(ROOT, "olavm_amd", "csrc", "device_ctx.h")).read()
+    body = src[src.index("static bool is_reference_scope"):src.index("struct DeviceCtx;")]
+    ours = set(re.findall(r'"([^"]+)"', body[body.index("names[]"):body.index("for (const char* s : names)")]))
+    prefix = re.search(r'n\.rfind\("([^"]+)", 0\) == 0', body).group(1)
+    assert ours | {prefix + "{}"} == ref - {"transpose LDEs"}, (ours, ref)
+    # and every scope the library opens under one of those names uses the same spelling (PhaseTimer call sites)
+    opened = set()
+    for f in ("stark.hip", "batch.hip", "fri.hip"):
+        for m in re.finditer(r'PhaseTimer\w*\s*\w*\(ctx,\s*(?:nperm > 0 \? )?"\s*([^"]+)"', open(os.path.join(ROOT, "olavm_amd", "csrc", f)).read()):
+            opened.add(m.group(1).strip())
+    assert (ref - {"transpose LDEs", "perform final FFT {}"}) <= opened, (ref - opened)
+    assert any(o.startswith(prefix.strip()) for o in opened)
 
 
 def _resolve(path):

@@ -16,11 +16,14 @@ cols = [[np.array(t[c], dtype=np.uint64, copy=True) for c in range(t.shape[0])] 
 be = Backend(device=0, hasher=hasher)
 want = be.prove_with_traces(blob, traces, params, compress)
 be.prove_with_traces(blob, traces, params, compress)
-variants = [("pageable", {"OLA_UPLOAD": "pageable"}, traces), ("staged K=2", {"OLA_UPLOAD_THREADS": "2"}, traces), ("staged K=4", {"OLA_UPLOAD_THREADS": "4"}, traces),
-            ("staged K=6", {"OLA_UPLOAD_THREADS": "6"}, traces), ("staged K=8", {"OLA_UPLOAD_THREADS": "8"}, traces), ("staged K=12", {"OLA_UPLOAD_THREADS": "12"}, traces),
-            ("staged K=6 piece 8 MB", {"OLA_UPLOAD_THREADS": "6", "OLA_UPLOAD_PIECE_MB": "8", "OLA_UPLOAD_SLOTS": "16"}, traces),
-            ("staged K=6 piece 2 MB", {"OLA_UPLOAD_THREADS": "6", "OLA_UPLOAD_PIECE_MB": "2", "OLA_UPLOAD_SLOTS": "64"}, traces),
-            ("register", {"OLA_UPLOAD": "register"}, traces), ("pageable, scattered columns", {"OLA_UPLOAD": "pageable"}, cols),
+variants = [("pageable", {"OLA_UPLOAD": "pageable"}, traces), ("staged K=2", {"OLA_UPLOAD_THREADS": "2"}, traces), ("staged K=4 (default)", {}, traces),
+            ("staged K=8", {"OLA_UPLOAD_THREADS": "8"}, traces),
+            ("staged 1 stream, 4 MB x 32 (first version)", {"OLA_UPLOAD_THREADS": "6", "OLA_UPLOAD_PIECE_MB": "4", "OLA_UPLOAD_SLOTS": "32", "OLA_UPLOAD_STREAMS": "1"}, traces),
+            ("staged 1 stream, 8 MB", {"OLA_UPLOAD_STREAMS": "1"}, traces),
+            ("staged 2 streams, 4 MB x 32", {"OLA_UPLOAD_PIECE_MB": "4", "OLA_UPLOAD_SLOTS": "32"}, traces),
+            ("staged 2 streams, 16 MB x 8", {"OLA_UPLOAD_PIECE_MB": "16", "OLA_UPLOAD_SLOTS": "8"}, traces),
+            ("staged 3 streams, 8 MB", {"OLA_UPLOAD_STREAMS": "3"}, traces),
+            ("pageable, scattered columns", {"OLA_UPLOAD": "pageable"}, cols),
             ("staged default, scattered columns", {}, cols), ("staged default", {}, traces)]
 res = {name: [] for name, _, _ in variants}
 for r in range(rounds):

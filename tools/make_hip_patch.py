@@ -6,8 +6,9 @@ crate; the executor / client path is untouched).
     python tools/make_hip_patch.py [--reference /root/reference] [--check]      # --check: compare with the committed patch
 
 The patch adds circuits/build.rs, circuits/src/stark/{ola_gpu_sys,hip_prover}.rs (verbatim copies of integration/rust/*) and edits
-three files: circuits/Cargo.toml (feature + build script), circuits/src/stark/mod.rs (two `mod` lines) and
-circuits/src/stark/prover.rs (the `#[cfg(feature = "hip")]` branch at the top of prove_with_traces, prover.rs:79-105).
+four files: circuits/Cargo.toml (feature + build script), circuits/src/stark/mod.rs (two `mod` lines),
+circuits/src/stark/prover.rs (the `#[cfg(feature = "hip")]` branch at the top of prove_with_traces, prover.rs:79-105) and
+plonky2/plonky2/src/util/timing.rs (`TimingTree::record`: the GPU's scope times enter the caller's tree through it).
 """
 import argparse
 import os
@@ -19,7 +20,7 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PATCH = os.path.join(ROOT, "integration", "patches", "0001-feature-hip.patch")
-EDITED = ["circuits/Cargo.toml", "circuits/src/stark/mod.rs", "circuits/src/stark/prover.rs"]
+EDITED = ["circuits/Cargo.toml", "circuits/src/stark/mod.rs", "circuits/src/stark/prover.rs", "plonky2/plonky2/src/util/timing.rs"]
 ADDED = {"circuits/build.rs": "build.rs", "circuits/src/stark/ola_gpu_sys.rs": "ola_gpu_sys.rs", "circuits/src/stark/hip_prover.rs": "hip_prover.rs"}
 
 
@@ -43,12 +44,51 @@ def edit(path, text):
         new = ("    [(); ProgChunkStark::<F, D>::COLUMNS]:,\n{\n"
                "    // The MI355X backend proves all twelve tables in one call and returns the AllProof in the wire format of\n"
                "    // serialization.rs; everything below is the CPU prover.\n"
-               '    #[cfg(feature = "hip")]\n    {\n        let _ = timing;\n'
+               '    #[cfg(feature = "hip")]\n    {\n'
                "        return super::hip_prover::prove_with_traces_hip::<F, C, D>(\n            ola_stark,\n            config,\n"
-               "            &trace_poly_values,\n            public_values,\n        );\n    }\n\n"
+               "            &trace_poly_values,\n            public_values,\n            timing,\n        );\n    }\n\n"
                "    let rate_bits = config.fri_config.rate_bits;\n    let cap_height = config.fri_config.cap_height;\n\n"
                "    let mut twiddle_map = BTreeMap::new();\n")
         return replace_once(text, old, new, "head of prove_with_traces")
+    if path == "plonky2/plonky2/src/util/timing.rs":
+        # TimingTree's fields are private and push / pop read the host's clock: a scope that ran on the GPU and is already over
+        # needs one method that appends a closed node with given times
+        old = "    #[cfg(feature = \"timing\")]\n    fn duration(&self) -> Duration {\n"
+        new = ('    /// A scope that ran elsewhere (on a GPU) and is over: appended `depth` levels below the deepest open\n'
+               '    /// scope -- following the scopes recorded last -- with the times given.  Scopes arrive parents first.\n'
+               '    #[cfg(feature = "timing")]\n'
+               '    pub fn record(&mut self, depth: usize, ctx: &str, mut level: log::Level, enter_time: Instant, duration: Duration) {\n'
+               '        assert!(self.is_open());\n\n'
+               '        level = level.max(self.level);\n\n'
+               '        if let Some(last_child) = self.children.last_mut() {\n'
+               '            if last_child.is_open() {\n'
+               '                last_child.record(depth, ctx, level, enter_time, duration);\n'
+               '                return;\n'
+               '            }\n'
+               '        }\n\n'
+               '        let mut node = self;\n'
+               '        for _ in 0..depth {\n'
+               '            node = node.children.last_mut().expect("recorded scopes arrive parents first");\n'
+               '        }\n'
+               '        node.children.push(TimingTree {\n'
+               '            name: ctx.to_string(),\n'
+               '            level,\n'
+               '            enter_time,\n'
+               '            exit_time: Some(enter_time + duration),\n'
+               '            children: vec![],\n'
+               '        })\n'
+               '    }\n\n'
+               '    #[cfg(not(feature = "timing"))]\n'
+               '    pub fn record(\n'
+               '        &mut self,\n'
+               '        _depth: usize,\n'
+               '        _ctx: &str,\n'
+               '        _level: log::Level,\n'
+               '        _enter_time: std::time::Instant,\n'
+               '        _duration: std::time::Duration,\n'
+               '    ) {\n'
+               '    }\n\n') + old
+        return replace_once(text, old, new, "TimingTree::duration")
     raise KeyError(path)
 
 

@@ -2,7 +2,8 @@
 //   pinned      hipHostMalloc'ed source, one hipMemcpyAsync per 64 MB, queued back to back      (the link's rate)
 //   pageable    malloc'ed source, hipMemcpyAsync + synchronise per 64 MB                         (round 4's upload path)
 //   register    hipHostRegister of the malloc'ed source (time reported), then as pinned, then hipHostUnregister
-//   staged K    K threads memcpy 4 MB pieces into a ring of 32 pinned slots, each sent at once  (upload.h's path, without a prover)
+//   staged      K threads memcpy pieces into a ring of pinned slots, each sent at once on one of S streams in turn
+//               (upload.h's path, without a prover)
 // hipcc --offload-arch=gfx950 -O3 -pthread -o h2d_rates h2d_rates.hip && ./h2d_rates [GB=4]
 #include <hip/hip_runtime.h>
 
@@ -65,12 +66,18 @@ int main(int argc, char** argv) {
                total / 1e9 / t_copy, (now() - t0) * 1e3, total / 1e9 / (t_reg + t_copy + (now() - t0)));
     }
     {   // staged
-        const size_t piece = (size_t)4 << 20, slots = 32, npieces = total / piece;
+        const size_t ring_bytes = (size_t)128 << 20;
         char* ring = nullptr;
-        CK(hipHostMalloc(&ring, piece * slots, hipHostMallocDefault));
-        std::vector<hipEvent_t> ev(slots);
-        for (auto& e : ev) CK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        for (unsigned K : {1u, 2u, 4u, 6u, 8u, 12u}) {
+        CK(hipHostMalloc(&ring, ring_bytes, hipHostMallocDefault));
+        hipStream_t sts[3];
+        for (auto& x : sts) CK(hipStreamCreateWithFlags(&x, hipStreamNonBlocking));
+        struct V { unsigned K, S; size_t mb; };
+        const size_t piece0 = (size_t)4 << 20, slots0 = 32, npieces0 = total / piece0;
+        for (V v : {V{1, 1, 4}, V{2, 1, 4}, V{4, 1, 4}, V{8, 1, 4}, V{4, 1, 8}, V{4, 1, 16}, V{4, 2, 4}, V{4, 2, 8}, V{4, 2, 16}, V{4, 3, 8}, V{2, 2, 8}, V{8, 2, 8}}) {
+            const unsigned K = v.K;
+            const size_t piece = v.mb << 20, slots = ring_bytes / piece, npieces = total / piece;
+            std::vector<hipEvent_t> ev(slots);
+            for (auto& e : ev) CK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
             std::atomic<size_t> next{0};
             std::vector<std::atomic<char>> issued(npieces);
             for (auto& x : issued) x.store(0);
@@ -89,8 +96,8 @@ int main(int argc, char** argv) {
                         memcpy(slot, src + i * piece, piece);
                         {
                             std::lock_guard<std::mutex> lk(issue_mu);
-                            CK(hipMemcpyAsync(dev + i * piece, slot, piece, hipMemcpyHostToDevice, st));
-                            CK(hipEventRecord(ev[i % slots], st));
+                            CK(hipMemcpyAsync(dev + i * piece, slot, piece, hipMemcpyHostToDevice, sts[i % v.S]));
+                            CK(hipEventRecord(ev[i % slots], sts[i % v.S]));
                         }
                         issued[i].store(1);
                         { std::lock_guard<std::mutex> lk(mu); cv.notify_all(); }
@@ -102,8 +109,10 @@ int main(int argc, char** argv) {
                 { std::lock_guard<std::mutex> lk(mu); completed = i + 1; cv.notify_all(); }
             }
             for (auto& t : th) t.join();
-            printf("staged K=%-2u %7.1f ms  %6.1f GB/s\n", K, (now() - t0) * 1e3, total / 1e9 / (now() - t0));
+            printf("staged K=%-2u streams=%u piece=%2zu MB  %7.1f ms  %6.1f GB/s\n", K, v.S, v.mb, (now() - t0) * 1e3, total / 1e9 / (now() - t0));
+            for (auto& e : ev) CK(hipEventDestroy(e));
         }
+        const size_t piece = piece0, slots = slots0, npieces = npieces0;
         // how fast the host side alone is (no DMA): K threads copying into the ring
         for (unsigned K : {1u, 4u, 8u}) {
             std::atomic<size_t> next{0};
