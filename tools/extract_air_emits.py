@@ -1,0 +1,873 @@
+#!/usr/bin/env python3
+"""Which constraints the reference emits, in which order and of which kind -- read off its Rust SOURCE, not off this repo's transcription.
+
+The proof bytes depend on every emitted constraint's position (the alpha power it is combined with) and kind (`constraint`,
+`constraint_transition`, `constraint_first_row`, `constraint_last_row`: constraint_consumer.rs:34-78).  olavm_amd/air/ola_tables.py
+restates the twelve AIRs by hand; oracle and GPU both consume that restatement (include/ola_airset.bin), so a miscounted loop or a
+swapped pair of constraints would be common mode.  This script walks `eval_packed_generic` of the twelve `*_stark.rs` files (and the
+functions they call: the `cpu/*.rs` opcode files, `lookup.rs`) as a Rust-subset interpreter that only cares about control flow:
+
+  * `yield_constr.constraint*( ... )`  -> one emit of that kind;
+  * `for PAT in ITER { ... }`, `ITER.for_each(|..| ...)`: the body once per item, where the item count of ITER is evaluated from the
+    source's own constants (`const X: usize = ..`, `const R: Range<usize> = a..b`), array types (`[P; REGISTER_NUM]`), array
+    literals, slices (`&x[..N - 1]`, `lv[RANGE]`) and the adaptors `iter / rev / enumerate / skip / take / zip / izip! / map / ...`;
+  * `if COND { ... }` with COND over constants and range-loop variables (`if r != 0`);
+  * calls that pass the consumer on (`Self::constraint_ext_lines(&wrapper, yield_constr)`, `mov::eval_packed_generic(lv, nv, yield_constr)`,
+    `eval_lookups(vars, yield_constr, a, b)`) -> the callee's body, found by name in the reference tree.
+
+Everything else (the arithmetic inside a constraint) is skipped: it is pinned by other means (golden rows, executed programs, the
+verifier's extension-field evaluation; PARITY.md).  Per table the script also reads `COLUMNS`, `constraint_degree()`, the number of
+`PermutationPair`s, and from stark/ola_stark.rs:122-560 the cross-table lookups: per CTL the looked table and how many looking
+entries each table contributes.
+
+    python tools/extract_air_emits.py [--reference /root/reference] [--out tests/golden/air_emit_kinds.json] [--check]
+
+Runs in the build container only (it reads /root/reference); the fixture it writes is data: lists of kinds and counts.  A construct
+the walker does not understand raises with file:line -- nothing is guessed.
+"""
+import argparse
+import json
+import os
+import re
+import sys
+from collections import Counter
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FIXTURE = os.path.join(ROOT, "tests", "golden", "air_emit_kinds.json")
+
+# enum Table (stark/ola_stark.rs:103-118) -> the file whose `impl Stark` is walked
+TABLES = [("Cpu", "cpu/cpu_stark.rs"), ("Memory", "memory/memory_stark.rs"), ("Bitwise", "builtins/bitwise/bitwise_stark.rs"),
+          ("Cmp", "builtins/cmp/cmp_stark.rs"), ("RangeCheck", "builtins/rangecheck/rangecheck_stark.rs"),
+          ("Poseidon", "builtins/poseidon/poseidon_stark.rs"), ("PoseidonChunk", "builtins/poseidon/poseidon_chunk_stark.rs"),
+          ("StorageAccess", "builtins/storage/storage_access_stark.rs"), ("Tape", "builtins/tape/tape_stark.rs"),
+          ("SCCall", "builtins/sccall/sccall_stark.rs"), ("Program", "program/program_stark.rs"), ("ProgChunk", "program/prog_chunk_stark.rs")]
+KINDS = {"constraint": "all", "constraint_transition": "transition", "constraint_first_row": "first_row", "constraint_last_row": "last_row"}
+
+TOKEN = re.compile(r"""\s+|//[^\n]*|/\*.*?\*/|(?P<str>b?"(?:\\.|[^"\\])*")|(?P<chr>'(?:\\.|[^'\\])')|(?P<life>'[A-Za-z_]\w*)|(?P<num>\d[\d_]*(?:\.\d+)?(?:_?[uif]\d+|_?usize|_?isize)?)"""
+                   r"""|(?P<id>[A-Za-z_]\w*!?)|(?P<op>\.\.=|\.\.\.|\.\.|::|->|=>|==|!=|<=|>=|&&|\|\||<<|>>|\+=|-=|\*=|/=|[-+*/%=<>!&|^~.,;:#?@$(){}\[\]])""", re.S)
+
+
+class Unsupported(Exception):
+    pass
+
+
+class Src:
+    """One reference file as a token list [(text, line)]."""
+    cache = {}
+
+    def __init__(self, path):
+        self.path = path
+        text = open(path, errors="replace").read()
+        self.toks, pos, line = [], 0, 1
+        while pos < len(text):
+            m = TOKEN.match(text, pos)
+            if not m:
+                raise Unsupported(f"{path}:{line}: cannot tokenise {text[pos:pos + 20]!r}")
+            if m.lastgroup:
+                self.toks.append((m.group(m.lastgroup), line))
+            line += text.count("\n", pos, m.end())
+            pos = m.end()
+
+    @classmethod
+    def get(cls, path):
+        path = os.path.realpath(path)
+        if path not in cls.cache:
+            cls.cache[path] = Src(path)
+        return cls.cache[path]
+
+    def match(self, i):
+        """index of the bracket closing the one at i"""
+        pairs = {"(": ")", "[": "]", "{": "}"}
+        open_, close, depth = self.toks[i][0], pairs[self.toks[i][0]], 0
+        for j in range(i, len(self.toks)):
+            t = self.toks[j][0]
+            if t == open_:
+                depth += 1
+            elif t == close:
+                depth -= 1
+                if depth == 0:
+                    return j
+        raise Unsupported(f"{self.path}:{self.toks[i][1]}: unbalanced {open_}")
+
+    def functions(self):
+        """name -> (params (lo, hi), body (lo, hi)) for every `fn` with a body"""
+        out = {}
+        for i, (t, _) in enumerate(self.toks):
+            if t == "fn" and i + 1 < len(self.toks):
+                name = self.toks[i + 1][0]
+                j = i + 2
+                while self.toks[j][0] != "(":
+                    j += 1
+                pe = self.match(j)
+                k = pe + 1
+                while self.toks[k][0] not in ("{", ";"):
+                    k += 1
+                if self.toks[k][0] == "{":
+                    out.setdefault(name, ((j, pe), (k, self.match(k))))
+        return out
+
+
+class Ref:
+    """The reference tree: constants, functions, structs -- looked up by name, nearest file first."""
+
+    def __init__(self, root):
+        self.root = os.path.join(root, "circuits", "src")
+        self.files = []
+        for base in (self.root, os.path.join(root, "core", "src"), os.path.join(root, "plonky2", "plonky2", "src", "hash")):
+            for d, _, fs in os.walk(base):
+                self.files += [os.path.join(d, f) for f in sorted(fs) if f.endswith(".rs")]
+        self.consts = {}          # name -> [(file, expression tokens)]
+        for f in self.files:
+            s = Src.get(f)
+            T = s.toks
+            for i, (t, _) in enumerate(T):
+                if t == "const" and i + 2 < len(T) and T[i + 2][0] == ":" and re.match(r"^[A-Z_][A-Z0-9_]*$", T[i + 1][0]):
+                    j = i + 3
+                    depth = 0
+                    while j < len(T) and not (T[j][0] == "=" and depth == 0):
+                        if depth == 0 and T[j][0] in (",", ">", ")", "{", ";"):
+                            j = len(T)            # a const generic parameter, not an item
+                            break
+                        depth += T[j][0] in "<[(" and 1 or 0
+                        depth -= T[j][0] in ">])" and 1 or 0
+                        j += 1
+                    if j >= len(T):
+                        continue
+                    k = j + 1
+                    while T[k][0] != ";":
+                        k = s.match(k) if T[k][0] in "([{" else k
+                        k += 1
+                    self.consts.setdefault(T[i + 1][0], []).append((f, T[j + 1:k]))
+
+    def near(self, cands, here):
+        """the candidate file closest to `here` (same file, same directory, then a unique one)"""
+        here = os.path.realpath(here)
+        same = [c for c in cands if os.path.realpath(c[0]) == here]
+        if same:
+            return same[0]
+        d = os.path.dirname(here)
+        sib = [c for c in cands if os.path.dirname(os.path.realpath(c[0])) == d]
+        if len(sib) == 1:
+            return sib[0]
+        circ = [c for c in cands if os.path.realpath(c[0]).startswith(os.path.realpath(self.root))] or cands
+        vals = {json.dumps([t for t, _ in c[1]]) if isinstance(c[1], list) else c[1] for c in circ}
+        if len(vals) == 1:
+            return circ[0]
+        return None
+
+    def find_fn(self, name, here, module=None):
+        cands = []
+        for f in self.files:
+            if module and os.path.basename(f) != module + ".rs" and os.path.basename(os.path.dirname(f)) + "/mod.rs" != module + "/mod.rs":
+                continue
+            fns = Src.get(f).functions()
+            if name in fns:
+                cands.append((f, name))
+        if not cands:
+            return None
+        c = self.near(cands, here)
+        return c[0] if c else None
+
+
+class R:
+    """a Rust Range<usize>"""
+
+    def __init__(self, a, b):
+        self.start, self.end = a, b
+
+    def __len__(self):
+        return max(0, self.end - self.start)
+
+
+class Items:
+    """what an iterator yields: how many, and -- for ranges -- which integers"""
+
+    def __init__(self, n, ints=None):
+        self.n, self.ints = n, ints
+
+
+class Walker:
+    def __init__(self, ref, emit_names=KINDS, consumer_type="ConstraintConsumer"):
+        self.ref, self.emit_names, self.consumer_type = ref, emit_names, consumer_type
+        self.emits = []
+        self.stack = []
+
+    # ---------------------------------------------------------------- constant expressions
+    def const(self, name, src):
+        cands = self.ref.consts.get(name)
+        if not cands:
+            raise Unsupported(f"{src.path}: constant {name} not found")
+        c = self.ref.near(cands, src.path)
+        if c is None:
+            raise Unsupported(f"{src.path}: constant {name} is defined differently in {[x[0] for x in cands]}")
+        return self.expr(c[1], Src.get(c[0]), {})
+
+    def expr(self, toks, src, env):
+        """value of a constant expression (int, bool or R) given as [(text, line)]"""
+        pos = [0]
+        T = [t for t, _ in toks]
+        line = toks[0][1] if toks else 0
+
+        def peek():
+            return T[pos[0]] if pos[0] < len(T) else None
+
+        def take(x=None):
+            t = peek()
+            if x is not None and t != x:
+                raise Unsupported(f"{src.path}:{line}: expected {x} in {' '.join(T)}")
+            pos[0] += 1
+            return t
+
+        def primary():
+            t = take()
+            if t is None:
+                raise Unsupported(f"{src.path}:{line}: truncated expression {' '.join(T)}")
+            if t == "(":
+                v = rng()
+                take(")")
+            elif t == "-":
+                return -primary()
+            elif t == "!":
+                return not primary()
+            elif t in ("&", "*"):
+                return primary()
+            elif re.match(r"^\d", t):
+                v = int(re.sub(r"_?(?:[uif]\d+|usize|isize)$", "", t).replace("_", ""))
+            elif re.match(r"^[A-Za-z_]", t):
+                path = [t]
+                while peek() == "::":
+                    take()
+                    if peek() == "<":          # turbofish
+                        depth = 0
+                        while True:
+                            x = take()
+                            depth += x == "<"
+                            depth -= x == ">"
+                            if depth == 0:
+                                break
+                        continue
+                    path.append(take())
+                name = path[-1]
+                if name in env and len(path) == 1:
+                    v = env[name]
+                elif name in ("true", "false"):
+                    v = name == "true"
+                elif re.match(r"^[A-Z_][A-Z0-9_]*$", name):
+                    v = self.const(name, src)
+                else:
+                    raise Unsupported(f"{src.path}:{line}: `{'::'.join(path)}` is not a constant (in {' '.join(T)})")
+            else:
+                raise Unsupported(f"{src.path}:{line}: unexpected `{t}` in {' '.join(T)}")
+            while True:
+                if peek() == "." and pos[0] + 1 < len(T) and T[pos[0] + 1] in ("start", "end"):
+                    take()
+                    v = getattr(v, take())
+                elif peek() == "." and pos[0] + 1 < len(T) and T[pos[0] + 1] == "len":
+                    take(); take(); take("("); take(")")
+                    v = len(v)
+                elif peek() == "." and pos[0] + 1 < len(T) and T[pos[0] + 1] == "pow":
+                    take(); take(); take("(")
+                    e = rng()
+                    take(")")
+                    v = v ** e
+                elif peek() == "as":
+                    take(); take()
+                else:
+                    return v
+
+        def binary(level):
+            ops = [["||"], ["&&"], ["==", "!=", "<", ">", "<=", ">="], ["|"], ["^"], ["&"], ["<<", ">>"], ["+", "-"], ["*", "/", "%"]]
+            if level == len(ops):
+                return primary()
+            v = binary(level + 1)
+            while peek() in ops[level]:
+                o = take()
+                w = binary(level + 1)
+                v = {"||": lambda: v or w, "&&": lambda: v and w, "==": lambda: v == w, "!=": lambda: v != w, "<": lambda: v < w, ">": lambda: v > w,
+                     "<=": lambda: v <= w, ">=": lambda: v >= w, "|": lambda: v | w, "^": lambda: v ^ w, "&": lambda: v & w, "<<": lambda: v << w,
+                     ">>": lambda: v >> w, "+": lambda: v + w, "-": lambda: v - w, "*": lambda: v * w, "/": lambda: v // w, "%": lambda: v % w}[o]()
+            return v
+
+        def rng():
+            a = None if peek() in ("..", "..=") else binary(0)
+            if peek() in ("..", "..="):
+                inc = take() == "..="
+                b = None if peek() in (None, ")", "]", ",") else binary(0)
+                if a is None or b is None:
+                    return ("open", a, b, inc)
+                return R(a, b + 1 if inc else b)
+            return a
+
+        v = rng()
+        if pos[0] != len(T):
+            raise Unsupported(f"{src.path}:{line}: cannot evaluate `{' '.join(T)}` (stopped at `{peek()}`)")
+        return v
+
+    # ---------------------------------------------------------------- iterators
+    def split(self, toks, sep=","):
+        """top-level split of a token list"""
+        out, cur, depth = [], [], 0
+        for t in toks:
+            if t[0] in "([{":
+                depth += 1
+            elif t[0] in ")]}":
+                depth -= 1
+            if t[0] == sep and depth == 0:
+                out.append(cur)
+                cur = []
+            else:
+                cur.append(t)
+        if cur:
+            out.append(cur)
+        return out
+
+    def length_of_type(self, toks, src, env):
+        """[T; N] (possibly behind & / mut) -> N"""
+        T = [t for t in toks if t[0] not in ("&", "mut")]
+        if T and T[0][0] == "[" and T[-1][0] == "]":
+            parts = self.split(T[1:-1], ";")
+            if len(parts) == 2:
+                return self.expr(parts[1], src, env)
+        return None
+
+    def local_len(self, name, src, fn_range, env, upto):
+        """length of the local array / slice `name`, from its `let` (type annotation or initialiser) before token `upto`"""
+        T = src.toks
+        lo = fn_range[0]
+        best = None
+        for i in range(lo, upto):
+            if T[i][0] == "let":
+                j = i + 1
+                if T[j][0] == "mut":
+                    j += 1
+                if T[j][0] == name and T[j + 1][0] in (":", "="):
+                    best = j
+        if best is None:
+            return None
+        j = best + 1
+        ty = None
+        if T[j][0] == ":":
+            k = j + 1
+            depth = 0
+            while not (T[k][0] == "=" and depth == 0):
+                depth += T[k][0] in "([<"
+                depth -= T[k][0] in ")]>"
+                k += 1
+            ty = T[j + 1:k]
+            j = k
+        if ty:
+            n = self.length_of_type(ty, src, env)
+            if n is not None:
+                return Items(n)
+        k = j + 1
+        while T[k][0] != ";":
+            k = src.match(k) if T[k][0] in "([{" else k
+            k += 1
+        return self.items(T[j + 1:k], src, fn_range, env, best)
+
+    def field_len(self, field, src, env):
+        """`x.field` where some struct of this file declares `field: [T; N]`"""
+        T = src.toks
+        for i in range(len(T) - 2):
+            if T[i][0] == field and T[i + 1][0] == ":" and T[i + 2][0] in ("[", "&"):
+                k = i + 2
+                while T[k][0] != "[":
+                    k += 1
+                n = self.length_of_type(T[k:src.match(k) + 1], src, env)
+                if n is not None:
+                    return Items(n)
+        return None
+
+    def items(self, toks, src, fn_range, env, upto):
+        """what the iterator expression `toks` yields"""
+        toks = list(toks)
+        line = toks[0][1]
+        text = " ".join(t for t, _ in toks)
+        while toks and toks[0][0] in ("&", "*", "mut"):
+            toks = toks[1:]
+        # postfix chain: primary (. method ( args ))*
+        i = 0
+        if toks[0][0] == "izip!":
+            e = self.match_in(toks, 1)
+            cur = Items(min(self.items(a, src, fn_range, env, upto).n for a in self.split(toks[2:e])))
+            i = e + 1
+        elif toks[0][0] == "(":
+            e = self.match_in(toks, 0)
+            cur = self.items(toks[1:e], src, fn_range, env, upto)
+            i = e + 1
+        elif toks[0][0] == "[":
+            e = self.match_in(toks, 0)
+            inner = toks[1:e]
+            parts = self.split(inner, ";")
+            cur = Items(self.expr(parts[1], src, env)) if len(parts) == 2 else Items(len(self.split(inner)))
+            i = e + 1
+        elif toks[0][0] == "vec!":
+            e = self.match_in(toks, 1)
+            cur = Items(len(self.split(toks[2:e])))
+            i = e + 1
+        else:
+            # a path / identifier / field access, possibly a range expression: take everything up to the first `.method(` or `[`
+            j, depth = 0, 0
+            while j < len(toks):
+                t = toks[j][0]
+                if depth == 0 and t == "[":
+                    break
+                if depth == 0 and t == "." and j + 2 < len(toks) and toks[j + 2][0] == "(" and toks[j + 1][0] not in ("start", "end"):
+                    break
+                if depth == 0 and t == "." and j + 1 < len(toks) and re.match(r"^[a-z_]", toks[j + 1][0]) and toks[j + 1][0] not in ("start", "end") and \
+                        not (j + 2 < len(toks) and toks[j + 2][0] == "("):
+                    j += 2          # field access a.b
+                    continue
+                depth += t in "(["
+                depth -= t in ")]"
+                j += 1
+            head = toks[:j]
+            i = j
+            names = [t for t, _ in head]
+            if any(t in ("..", "..=") for t in names) or all(re.match(r"^[A-Z_0-9:]+$|^::$|^[+\-*/()]$|^\d", t) or t in ("start", "end", ".", "Self") for t in names):
+                v = self.expr(head, src, env)
+                if isinstance(v, R):
+                    cur = Items(len(v), list(range(v.start, v.end)))
+                else:
+                    raise Unsupported(f"{src.path}:{line}: `{text}` is not a range")
+            else:
+                base = names[-1]
+                cur = None
+                if len(names) == 1:
+                    try:
+                        cur = self.local_len(base, src, fn_range, env, upto)
+                    except Unsupported:
+                        if not (i < len(toks) and toks[i][0] == "["):
+                            raise
+                        cur = None         # `let nv = vars.next_values;` -- a row: only its slices have a known length
+                if cur is None and len(names) >= 3 and names[-2] == ".":
+                    cur = self.field_len(base, src, env)
+                if cur is None and i < len(toks) and toks[i][0] == "[":
+                    cur = Items(None)      # a row (`lv`, `vars.local_values`): only its slices have a known length
+                if cur is None:
+                    raise Unsupported(f"{src.path}:{line}: do not know how many items `{text}` has")
+        while i < len(toks):
+            t = toks[i][0]
+            if t == "[":
+                e = self.match_in(toks, i)
+                v = self.expr(toks[i + 1:e], src, env)
+                if isinstance(v, R):
+                    cur = Items(len(v))
+                elif isinstance(v, tuple) and v[0] == "open":
+                    _, a, b, inc = v
+                    if cur.n is None and b is None:
+                        raise Unsupported(f"{src.path}:{line}: open slice of a row in `{text}`")
+                    hi = (b + 1 if inc else b) if b is not None else cur.n
+                    cur = Items(hi - (a or 0))
+                else:
+                    raise Unsupported(f"{src.path}:{line}: element access in iterator `{text}`")
+                i = e + 1
+            elif t == "." and i + 1 < len(toks):
+                m = toks[i + 1][0]
+                if i + 2 < len(toks) and toks[i + 2][0] == "::":      # collect::<Vec<_>>()
+                    k = i + 3
+                    depth = 0
+                    while True:
+                        depth += toks[k][0] == "<"
+                        depth -= toks[k][0] == ">"
+                        k += 1
+                        if depth == 0:
+                            break
+                    args_lo = k
+                else:
+                    args_lo = i + 2
+                if args_lo >= len(toks) or toks[args_lo][0] != "(":
+                    raise Unsupported(f"{src.path}:{line}: field `{m}` in iterator `{text}`")
+                e = self.match_in(toks, args_lo)
+                args = toks[args_lo + 1:e]
+                if cur.n is None:
+                    raise Unsupported(f"{src.path}:{line}: iterating a whole row in `{text}`")
+                if m in ("iter", "into_iter", "iter_mut", "enumerate", "copied", "cloned", "map", "by_ref", "try_into", "unwrap", "collect", "to_vec", "into_par_iter", "par_iter"):
+                    if m == "enumerate":
+                        cur = Items(cur.n, list(range(cur.n)))
+                elif m == "rev":
+                    cur = Items(cur.n, cur.ints[::-1] if cur.ints else None)
+                elif m == "skip":
+                    k = self.expr(args, src, env)
+                    cur = Items(max(0, cur.n - k), cur.ints[k:] if cur.ints else None)
+                elif m == "take":
+                    k = self.expr(args, src, env)
+                    cur = Items(min(cur.n, k), cur.ints[:k] if cur.ints else None)
+                elif m == "step_by":
+                    k = self.expr(args, src, env)
+                    cur = Items(-(-cur.n // k), cur.ints[::k] if cur.ints else None)
+                elif m == "zip":
+                    cur = Items(min(cur.n, self.items(args, src, fn_range, env, upto).n))
+                elif m == "chain":
+                    cur = Items(cur.n + self.items(args, src, fn_range, env, upto).n)
+                else:
+                    raise Unsupported(f"{src.path}:{line}: iterator adaptor `.{m}()` in `{text}`")
+                i = e + 1
+            else:
+                raise Unsupported(f"{src.path}:{line}: cannot read iterator `{text}` at `{t}`")
+        if cur.n is None:
+            raise Unsupported(f"{src.path}:{line}: iterating a whole row in `{text}`")
+        return cur
+
+    @staticmethod
+    def match_in(toks, i):
+        pairs = {"(": ")", "[": "]", "{": "}"}
+        o, c, depth = toks[i][0], pairs[toks[i][0]], 0
+        for j in range(i, len(toks)):
+            depth += toks[j][0] == o
+            depth -= toks[j][0] == c
+            if depth == 0:
+                return j
+        raise Unsupported(f"unbalanced {o} at line {toks[i][1]}")
+
+    # ---------------------------------------------------------------- control flow
+    def consumer_of(self, src, params):
+        """name of the parameter whose type mentions the consumer"""
+        T = src.toks
+        for part in self.split(T[params[0] + 1:params[1]]):
+            names = [t for t, _ in part]
+            if self.consumer_type in names and ":" in names:
+                return names[names.index(":") - 1]
+        return None
+
+    def call(self, path, fn_name):
+        src = Src.get(path)
+        fns = src.functions()
+        if fn_name not in fns:
+            raise Unsupported(f"{path}: fn {fn_name} not found")
+        params, body = fns[fn_name]
+        consumer = self.consumer_of(src, params)
+        key = (os.path.realpath(path), fn_name)
+        if key in self.stack:
+            raise Unsupported(f"{path}: recursion into {fn_name}")
+        self.stack.append(key)
+        self.block(src, body[0] + 1, body[1], {}, (body[0], body[1]), consumer)
+        self.stack.pop()
+
+    def has_emit(self, src, lo, hi, consumer):
+        T = src.toks
+        return any(T[i][0] == consumer for i in range(lo, hi))
+
+    def block(self, src, lo, hi, env, fn_range, consumer):
+        T = src.toks
+        i = lo
+        stmt = lo          # first token of the current statement
+        while i < hi:
+            t, line = T[i]
+            if t in (";",):
+                i += 1
+                stmt = i
+            elif t == "for" and T[i + 1][0] != "<":
+                j = i + 1
+                while T[j][0] != "in":
+                    j = src.match(j) if T[j][0] in "([" else j
+                    j += 1
+                pat = T[i + 1:j]
+                k = j + 1
+                while T[k][0] != "{":
+                    k = src.match(k) if T[k][0] in "([" else k
+                    k += 1
+                e = src.match(k)
+                if self.has_emit(src, k, e, consumer):
+                    its = self.items(T[j + 1:k], src, fn_range, env, i)
+                    names = [p for p, _ in pat if re.match(r"^[a-z_]\w*$", p) and p != "mut"]
+                    for n in range(its.n):
+                        env2 = dict(env)
+                        if its.ints is not None and len(pat) == 1:
+                            env2[names[0]] = its.ints[n]
+                        elif its.ints is not None and pat[0][0] == "(" and names and [t for t, _ in T[j + 1:k]][-3:] == ["enumerate", "(", ")"]:
+                            env2[names[0]] = its.ints[n]
+                        self.block(src, k + 1, e, env2, fn_range, consumer)
+                i = e + 1
+                stmt = i
+            elif t == "if":
+                # if COND { A } [else if ... | else { B }]
+                taken = False
+                while True:
+                    k = i + 1
+                    while T[k][0] != "{":
+                        k = src.match(k) if T[k][0] in "([" else k
+                        k += 1
+                    e = src.match(k)
+                    chain_has_emit = self.has_emit(src, k, e, consumer)
+                    cond = None
+                    if T[i + 1][0] == "let":
+                        if chain_has_emit:
+                            raise Unsupported(f"{src.path}:{line}: `if let` around constraints")
+                    elif chain_has_emit or not taken:
+                        try:
+                            cond = self.expr(T[i + 1:k], src, env)
+                        except Unsupported:
+                            if chain_has_emit:
+                                raise
+                    if cond and not taken:
+                        taken = True
+                        self.block(src, k + 1, e, env, fn_range, consumer)
+                    i = e + 1
+                    if i < hi and T[i][0] == "else":
+                        if T[i + 1][0] == "if":
+                            i += 1
+                            continue
+                        k = i + 1
+                        e = src.match(k)
+                        if not taken:
+                            if cond is None and self.has_emit(src, k, e, consumer):
+                                raise Unsupported(f"{src.path}:{line}: undecided `if` with constraints in its else branch")
+                            self.block(src, k + 1, e, env, fn_range, consumer)
+                        i = e + 1
+                    break
+                stmt = i
+            elif t in ("match", "while", "loop"):
+                k = i + 1
+                while T[k][0] != "{":
+                    k = src.match(k) if T[k][0] in "([" else k
+                    k += 1
+                e = src.match(k)
+                if self.has_emit(src, i, e, consumer):
+                    raise Unsupported(f"{src.path}:{line}: `{t}` around constraints")
+                i = e + 1
+            elif t == consumer and T[i + 1][0] == "." and T[i + 2][0] in self.emit_names and T[i + 3][0] == "(":
+                e = src.match(i + 3)
+                if self.has_emit(src, i + 4, e, consumer):
+                    raise Unsupported(f"{src.path}:{line}: a constraint inside a constraint's argument")
+                self.emits.append((self.emit_names[T[i + 2][0]], os.path.relpath(src.path, self.ref.root), line))
+                i = e + 1
+            elif t == "." and T[i + 1][0] == "for_each" and T[i + 2][0] == "(":
+                e = src.match(i + 2)
+                if self.has_emit(src, i + 3, e, consumer):
+                    its = self.items(T[stmt:i], src, fn_range, env, stmt)
+                    k = i + 3
+                    if T[k][0] == "move":
+                        k += 1
+                    if T[k][0] == "||":
+                        k += 1
+                    else:
+                        assert T[k][0] == "|", f"{src.path}:{line}: closure expected"
+                        k += 1
+                        while T[k][0] != "|":
+                            k = src.match(k) if T[k][0] in "([" else k
+                            k += 1
+                        k += 1
+                    for _ in range(its.n):
+                        if T[k][0] == "{":
+                            self.block(src, k + 1, src.match(k), env, fn_range, consumer)
+                        else:
+                            self.block(src, k, e, env, fn_range, consumer)
+                i = e + 1
+            elif t == "|" and i > lo and T[i - 1][0] in ("(", ",", "=") and self.closure_with_emit(src, i, hi, consumer):
+                raise Unsupported(f"{src.path}:{line}: a closure other than for_each's emits constraints")
+            elif t == "(" and i > lo and re.match(r"^[A-Za-z_]\w*$", T[i - 1][0]) and T[i - 1][0] not in ("if", "for", "in", "return", "let", "mut", "as") and \
+                    not (i - 2 >= lo and T[i - 2][0] == "." ):
+                e = src.match(i)
+                args = [x for x, _ in T[i + 1:e]]
+                if consumer in args:
+                    name = T[i - 1][0]
+                    module = None
+                    if i - 2 >= lo and T[i - 2][0] == "::":
+                        q = T[i - 3][0]
+                        module = None if q == "Self" else q
+                    target = src.path if module is None and name in src.functions() else self.ref.find_fn(name, src.path, module)
+                    if target is None:
+                        raise Unsupported(f"{src.path}:{line}: callee `{(module + '::') if module else ''}{name}` not found")
+                    self.call(target, name)
+                    i = e + 1
+                else:
+                    i += 1
+            elif t == "{":
+                e = src.match(i)
+                # a plain nested block or a struct literal: walk it (struct literals contain no constraints)
+                self.block(src, i + 1, e, env, fn_range, consumer)
+                i = e + 1
+                if i < hi and T[i][0] != ";" and T[i][0] not in (".", ")", ",", "?"):
+                    stmt = i
+            else:
+                i += 1
+
+    def closure_with_emit(self, src, i, hi, consumer):
+        """does the closure whose parameter list opens at i mention the consumer in its body?"""
+        T = src.toks
+        k = i + 1
+        while k < hi and T[k][0] != "|":
+            k += 1
+        k += 1
+        if k >= hi:
+            return False
+        if T[k][0] == "{":
+            return self.has_emit(src, k, src.match(k), consumer)
+        depth, j = 0, k
+        while j < hi:
+            if T[j][0] in "([{":
+                depth += 1
+            elif T[j][0] in ")]}":
+                if depth == 0:
+                    break
+                depth -= 1
+            elif T[j][0] in (",", ";") and depth == 0:
+                break
+            j += 1
+        return self.has_emit(src, k, j, consumer)
+
+
+def table_facts(ref, name, rel):
+    path = os.path.join(ref.root, rel)
+    src = Src.get(path)
+    w = Walker(ref)
+    T = src.toks
+    # the trait impl's eval_packed_generic is the one that takes `&self` (cpu/*.rs have free functions of the same name)
+    start = None
+    for i, (t, _) in enumerate(T):
+        if t == "fn" and T[i + 1][0] == "eval_packed_generic":
+            j = i + 2
+            while T[j][0] != "(":
+                j += 1
+            if T[j + 1][0] == "&" and T[j + 2][0] == "self":
+                start = (j, src.match(j))
+                break
+    if start is None:
+        raise Unsupported(f"{path}: no eval_packed_generic(&self, ...)")
+    k = start[1] + 1
+    while T[k][0] != "{":
+        k += 1
+    body = (k, src.match(k))
+    consumer = w.consumer_of(src, start)
+    w.stack.append((os.path.realpath(path), "eval_packed_generic"))
+    w.block(src, body[0] + 1, body[1], {}, body, consumer)
+    facts = {"file": rel, "emit_kinds": [k for k, _, _ in w.emits], "emit_sites": ["%s:%d" % (f, l) for _, f, l in w.emits]}
+    # COLUMNS, constraint_degree(), permutation pairs
+    for i, (t, _) in enumerate(T):
+        if t == "const" and T[i + 1][0] == "COLUMNS":
+            j = i + 2
+            while T[j][0] != "=":
+                j += 1
+            e = j
+            while T[e][0] != ";":
+                e += 1
+            facts["columns"] = w.expr(T[j + 1:e], src, {})
+    fns = src.functions()
+    if "constraint_degree" in fns:
+        lo, hi = fns["constraint_degree"][1]
+        facts["constraint_degree"] = w.expr(T[lo + 1:hi], src, {})
+    facts["permutation_pairs"] = 0
+    if "permutation_pairs" in fns:
+        lo, hi = fns["permutation_pairs"][1]
+        facts["permutation_pairs"] = sum(1 for i in range(lo, hi) if T[i][0] == "PermutationPair" and T[i + 1][0] == "::" and T[i + 2][0] in ("singletons", "new"))
+        if any(T[i][0] in ("for", "map", "for_each", "extend") for i in range(lo, hi)):
+            raise Unsupported(f"{path}: permutation_pairs() builds its list in a loop")
+    return facts
+
+
+def ctl_facts(ref):
+    """stark/ola_stark.rs: per cross-table lookup, in all_cross_table_lookups() order: looked table, looking entries per table"""
+    path = os.path.join(ref.root, "stark", "ola_stark.rs")
+    src = Src.get(path)
+    T = src.toks
+    fns = src.functions()
+    lo, hi = fns["all_cross_table_lookups"][1]
+    names = [T[i][0] for i in range(lo, hi) if re.match(r"^ctl_\w+$", T[i][0]) and T[i + 1][0] == "("]
+    out = []
+    for name in names:
+        blo, bhi = fns[name][1]
+        w = Walker(ref)
+
+        def count(a, b, mult, looking):
+            """TableWithColumns::new(Table::X ...) occurrences between a and b, times the ranges they are mapped over"""
+            i = a
+            while i < b:
+                if T[i][0] == "(" and T[i + 1][0] not in (")",) and i + 2 < b:
+                    # `(A..B).map(|i| { ... })` / `.for_each`: the closure runs once per item (the result is consumed by extend / collect)
+                    e = src.match(i)
+                    if e + 3 < b and T[e + 1][0] == "." and T[e + 2][0] in ("map", "for_each", "flat_map") and any(x[0] == ".." for x in T[i + 1:e]):
+                        n = w.items(T[i:e + 1], src, (blo, bhi), {}, i).n
+                        ce = src.match(e + 3)
+                        count(e + 4, ce, mult * n, looking)
+                        i = ce + 1
+                        continue
+                if T[i][0] == "TableWithColumns" and T[i + 1][0] == "::" and T[i + 2][0] == "new" and T[i + 3][0] == "(" and T[i + 4][0] == "Table":
+                    # Table::X, then the data-columns function: `cpu_stark::ctl_data_cpu_mem_sccall(i)` -> its name
+                    j = i + 8
+                    while T[j + 1][0] == "::":
+                        j += 2
+                    looking.append((T[i + 6][0], mult, i, T[j][0]))
+                i += 1
+
+        found = []
+        count(blo, bhi, 1, found)
+        # the looked table: second argument of CrossTableLookup::new
+        idx = [i for i in range(blo, bhi) if T[i][0] == "CrossTableLookup" and T[i + 2][0] == "new"]
+        if len(idx) != 1:
+            raise Unsupported(f"{path}: {name} has {len(idx)} CrossTableLookup::new")
+        a = idx[0] + 3
+        args = w.split(T[a + 1:src.match(a)])
+        second = args[1]
+        if second[0][0] == "TableWithColumns":
+            looked_tok = T.index(second[0], a)
+        else:
+            var = second[0][0]
+            looked_tok = None
+            for i in range(blo, bhi):
+                if T[i][0] == "let" and T[i + 1][0] == var:
+                    j = i
+                    while T[j][0] != "TableWithColumns":
+                        j += 1
+                    looked_tok = j
+            if looked_tok is None:
+                raise Unsupported(f"{path}: {name}: looked table `{var}` not found")
+        looked = [f for f in found if f[2] == looked_tok]
+        if len(looked) != 1 or looked[0][1] != 1:
+            raise Unsupported(f"{path}: {name}: cannot identify the looked table")
+        cnt = Counter()
+        for tab, mult, tok, _ in found:
+            if tok != looked_tok:
+                cnt[tab] += mult
+        # in the order the entries are written down in the function (every ctl_* builds its vector in that order: a `vec![..]` literal,
+        # or lets followed by extend / chain in the same sequence)
+        order = [[tab, data_fn, mult] for tab, mult, tok, data_fn in found if tok != looked_tok]
+        out.append({"name": name, "looked": looked[0][0], "looked_data_fn": looked[0][3], "looking": dict(sorted(cnt.items())), "looking_in_source_order": order})
+    return out
+
+
+def extract(reference):
+    ref = Ref(reference)
+    tables, problems = [], []
+    for name, rel in TABLES:
+        try:
+            tables.append({"table": name, **table_facts(ref, name, rel)})
+        except Unsupported as e:
+            problems.append({"table": name, "reason": str(e)})
+            tables.append({"table": name, "file": rel, "unwalked": str(e)})
+    try:
+        ctls = ctl_facts(ref)
+    except Unsupported as e:
+        problems.append({"table": "ctl", "reason": str(e)})
+        ctls = []
+    return {"generator": "tools/extract_air_emits.py", "source": "Sin7Y/olavm circuits/src (walked, not transcribed)", "tables": tables,
+            "cross_table_lookups": ctls, "problems": problems}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reference", default="/root/reference")
+    ap.add_argument("--out", default=FIXTURE)
+    ap.add_argument("--check", action="store_true")
+    a = ap.parse_args()
+    data = extract(a.reference)
+    text = json.dumps(data, indent=1) + "\n"
+    for t in data["tables"]:
+        if "emit_kinds" in t:
+            c = Counter(t["emit_kinds"])
+            print("%-14s %4d emits %s  columns %s degree %s permutation pairs %s" % (t["table"], len(t["emit_kinds"]), dict(c), t.get("columns"), t.get("constraint_degree"), t.get("permutation_pairs")))
+        else:
+            print("%-14s NOT WALKED: %s" % (t["table"], t["unwalked"]))
+    print(len(data["cross_table_lookups"]), "cross-table lookups,", sum(sum(c["looking"].values()) for c in data["cross_table_lookups"]), "looking entries")
+    if a.check:
+        if open(a.out).read() != text:
+            raise SystemExit(a.out + " is stale")
+        print("fixture is up to date")
+        return
+    open(a.out, "w").write(text)
+    print("wrote", a.out)
+
+
+if __name__ == "__main__":
+    sys.setrecursionlimit(10000)
+    main()
