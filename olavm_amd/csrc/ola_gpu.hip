@@ -47,9 +47,15 @@ struct OlaCtx {
     std::string collective_note;
     ~OlaCtx() {
         if (tables) ntt_tables_destroy(tables);
+        // every rank's stream drains, then the communicators go (they enqueued on those streams), then the ranks with their streams
         for (OlaCtx* p : peers) {
             (void)hipSetDevice(p->dev.device);
             (void)hipStreamSynchronize(p->dev.stream);
+        }
+        if (!peers.empty()) { (void)hipSetDevice(dev.device); if (dev.stream) (void)hipStreamSynchronize(dev.stream); }
+        rccl.reset();
+        for (OlaCtx* p : peers) {
+            (void)hipSetDevice(p->dev.device);
             delete p;
         }
     }

@@ -10,6 +10,8 @@
 // for one thread per device (rccl.h: collectives on different communicators "must be called by different threads/processes or
 // use ncclGroupStart/ncclGroupEnd").  Before every collective the rank threads meet at the group's host barrier: a rank whose
 // prover threw never leaves its peers waiting inside a device-side collective (the barrier throws for everybody instead).
+// A rank whose ncclAllGather itself fails AFTER the barrier has peers that already enqueued theirs: it aborts every
+// communicator of the group (ncclCommAbort releases device-side waits), and the group refuses further use.
 // Ordering: the collective is enqueued on the rank's stream, after the kernels that produced `send`, before the ones that read
 // `recv` (OLA_SHARD_STREAM_ORDERED) -- no host synchronisation, as with the peer carrier.
 //
@@ -18,7 +20,26 @@
 #pragma once
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
+// The declarations only (nothing of RCCL is linked).  On a ROCm install without the RCCL development headers the five entry
+// points used here are declared locally, as rccl.h 2.x declares them, so that the library still builds (and still refuses the
+// carrier at run time when librccl.so is absent).
+#if __has_include(<rccl/rccl.h>)
 #include <rccl/rccl.h>
+#else
+extern "C" {
+typedef struct ncclComm* ncclComm_t;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclInt8 = 0, ncclUint8 = 1 } ncclDataType_t;
+ncclResult_t ncclCommInitAll(ncclComm_t* comm, int ndev, const int* devlist);
+ncclResult_t ncclCommDestroy(ncclComm_t comm);
+ncclResult_t ncclCommAbort(ncclComm_t comm);
+ncclResult_t ncclAllGather(const void* sendbuff, void* recvbuff, size_t sendcount, ncclDataType_t datatype, ncclComm_t comm, hipStream_t stream);
+const char* ncclGetErrorString(ncclResult_t result);
+ncclResult_t ncclGetVersion(int* version);
+}
+#endif
+
+#include <atomic>
 
 #include <memory>
 #include <string>
@@ -32,6 +53,7 @@ struct RcclApi {
     void* so = nullptr;
     decltype(&ncclCommInitAll) CommInitAll = nullptr;
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclCommAbort) CommAbort = nullptr;        // optional: absent in very old builds
     decltype(&ncclAllGather) AllGather = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
     decltype(&ncclGetVersion) GetVersion = nullptr;
@@ -48,6 +70,7 @@ struct RcclApi {
             auto sym = [](const char* n) { void* p = dlsym(api.so, n); if (!p) err += std::string(err.empty() ? "" : ", ") + n; return p; };
             api.CommInitAll = reinterpret_cast<decltype(api.CommInitAll)>(sym("ncclCommInitAll"));
             api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(sym("ncclCommDestroy"));
+            api.CommAbort = reinterpret_cast<decltype(api.CommAbort)>(dlsym(api.so, "ncclCommAbort"));
             api.AllGather = reinterpret_cast<decltype(api.AllGather)>(sym("ncclAllGather"));
             api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(sym("ncclGetErrorString"));
             api.GetVersion = reinterpret_cast<decltype(api.GetVersion)>(sym("ncclGetVersion"));
@@ -71,8 +94,13 @@ struct RcclGroup {
     std::vector<ncclComm_t> comms;
     std::vector<RcclRank> ranks;
     int version = 0;
+    std::atomic<bool> dead{false};          // a collective failed half-way: the communicators were aborted
+    void abort_all() {
+        if (dead.exchange(true)) return;
+        if (api && api->CommAbort) for (ncclComm_t c : comms) if (c) (void)api->CommAbort(c);
+    }
     ~RcclGroup() {
-        if (api) for (ncclComm_t c : comms) if (c) (void)api->CommDestroy(c);
+        if (api && !dead.load()) for (ncclComm_t c : comms) if (c) (void)api->CommDestroy(c);
     }
 };
 
@@ -111,9 +139,13 @@ inline int32_t rccl_all_gather(void* user, const void* send_dev, void* recv_dev,
     RcclRank& me = *static_cast<RcclRank*>(user);
     RcclGroup& g = *me.group;
     try {
+        if (g.dead.load()) throw OlaError(-5, "the RCCL communicators of this context were aborted after a failed collective");
         if (me.meet) me.meet->barrier();          // everybody is about to enqueue the same collective (or somebody failed: throws)
         const ncclResult_t rc = g.api->AllGather(send_dev, recv_dev, bytes, ncclUint8, g.comms[me.rank], me.stream);
-        if (rc != ncclSuccess) throw OlaError(-5, std::string("ncclAllGather: ") + g.api->GetErrorString(rc));
+        if (rc != ncclSuccess) {
+            g.abort_all();                        // the peers are past the barrier and have enqueued theirs: release them
+            throw OlaError(-5, std::string("ncclAllGather: ") + g.api->GetErrorString(rc));
+        }
         if (me.meet && me.rank == 0) { me.meet->exchanges++; me.meet->bytes_moved += (size_t)(g.comms.size() - 1) * bytes * g.comms.size(); }
         return 0;
     } catch (const OlaError&) {

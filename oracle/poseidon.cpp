@@ -25,24 +25,26 @@ static inline u64 sbox7(u64 x) {
 // reduced once per row.  Same value as the sum of 128-bit products reduced mod p (full-size commitments are checked against this
 // oracle: 10^8 permutations per batch).
 static void mds_layer(u64 s[12]) {
-    u64 lo[24], hi[24], out[12], al[12], ah[12];
+    // 32-bit halves in 32-bit arrays: the products below are then 32 x 32 -> 64-bit widening multiplications, which the
+    // compiler turns into vpmuludq (four rows per instruction) under -mavx2
+    uint32_t lo[24], hi[24];
+    u64 al[12], ah[12];
     for (int i = 0; i < 12; i++) {
-        lo[i] = lo[i + 12] = s[i] & 0xFFFFFFFFull;
-        hi[i] = hi[i + 12] = s[i] >> 32;
+        lo[i] = lo[i + 12] = (uint32_t)s[i];
+        hi[i] = hi[i + 12] = (uint32_t)(s[i] >> 32);
     }
     for (int r = 0; r < 12; r++) {
-        al[r] = lo[r] * OLA_POSEIDON_MDS_DIAG[r];
-        ah[r] = hi[r] * OLA_POSEIDON_MDS_DIAG[r];
+        al[r] = (u64)lo[r] * (uint32_t)OLA_POSEIDON_MDS_DIAG[r];
+        ah[r] = (u64)hi[r] * (uint32_t)OLA_POSEIDON_MDS_DIAG[r];
     }
     for (int i = 0; i < 12; i++) {          // row r takes s[(i + r) % 12] * circ[i]: twelve rows at a time
-        const u64 c = OLA_POSEIDON_MDS_CIRC[i];
+        const uint32_t c = (uint32_t)OLA_POSEIDON_MDS_CIRC[i];
         for (int r = 0; r < 12; r++) {
-            al[r] += lo[i + r] * c;
-            ah[r] += hi[i + r] * c;
+            al[r] += (u64)lo[i + r] * c;
+            ah[r] += (u64)hi[i + r] * c;
         }
     }
-    for (int r = 0; r < 12; r++) out[r] = gl_reduce128((u128)al[r] + ((u128)ah[r] << 32));
-    for (int r = 0; r < 12; r++) s[r] = out[r];
+    for (int r = 0; r < 12; r++) s[r] = gl_reduce128((u128)al[r] + ((u128)ah[r] << 32));
 }
 
 void poseidon_naive(u64 s[12]) {

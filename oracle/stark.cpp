@@ -14,6 +14,9 @@
 //   verifier.rs:35-206,220-324,381-388           verify_proof, verify_stark_proof_with_challenges, eval_l_0_and_l_last
 //   serialization.rs:349-358,377-393             write_proof / write_all_proof
 //   /root/reference/plonky2/field/src/zero_poly_coset.rs:18-52   ZeroPolyOnCoset
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <stdexcept>
 
@@ -232,6 +235,13 @@ struct StarkProof {
     FriProof fri;
 };
 
+// ORACLE_TIMING=1: where the checker's own time goes (stderr)
+struct OracleClock {
+    const char* what; std::chrono::steady_clock::time_point t0;
+    explicit OracleClock(const char* w) : what(w), t0(std::chrono::steady_clock::now()) {}
+    ~OracleClock() { if (getenv("ORACLE_TIMING")) fprintf(stderr, "[oracle-timing] %-28s %8.2f s\n", what, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count()); }
+};
+
 struct ProverConfig { int num_challenges = 2; FriConfig fri; };
 
 static std::vector<std::vector<u64>> compute_permutation_z_polys(const AirTable& air, const ProverConfig& cfg,
@@ -295,19 +305,25 @@ static std::vector<std::vector<u64>> compute_quotient_polys(const AirTable& air,
     for (auto& c : ctl) ctl_vars.push_back({c.challenge, c.twc});
     const int nch = (int)alphas.size();
     std::vector<std::vector<u64>> qvals(nch, std::vector<u64>(size));
-    u64 x = GL_GENERATOR;
-    for (size_t i = 0; i < size; i++) {
-        const size_t i_next = (i + next_step) % size;
-        Consumer<BaseF> consumer;
-        consumer.alphas = alphas;
-        consumer.accs.assign(nch, 0);
-        consumer.z_last = gl_sub(x, last);
-        consumer.lagrange_first = lag_first[i];
-        consumer.lagrange_last = lag_last[i];
-        eval_vanishing_poly<BaseF>(air, cfg.num_challenges, trace_c.get_lde_values(i, step), trace_c.get_lde_values(i_next, step), params,
-                                   zs_c.get_lde_values(i, step), zs_c.get_lde_values(i_next, step), perm_sets, ctl_vars, consumer);
-        for (int j = 0; j < nch; j++) qvals[j][i] = gl_mul(consumer.accs[j], zh_inv[i % zh_inv.size()]);
-        x = gl_mul(x, w);
+    // the reference walks the points with a running x (prover.rs:633-640, rayon over the points); here blocks of points on the host
+    // cores, every block starting from its own x = g w^start -- the checker's speed is test budget, its values are the same
+    const size_t block = 1024;
+#pragma omp parallel for schedule(dynamic, 1)
+    for (size_t b0 = 0; b0 < size; b0 += block) {
+        u64 x = gl_mul(GL_GENERATOR, gl_pow(w, b0));
+        for (size_t i = b0; i < std::min(size, b0 + block); i++) {
+            const size_t i_next = (i + next_step) % size;
+            Consumer<BaseF> consumer;
+            consumer.alphas = alphas;
+            consumer.accs.assign(nch, 0);
+            consumer.z_last = gl_sub(x, last);
+            consumer.lagrange_first = lag_first[i];
+            consumer.lagrange_last = lag_last[i];
+            eval_vanishing_poly<BaseF>(air, cfg.num_challenges, trace_c.get_lde_values(i, step), trace_c.get_lde_values(i_next, step), params,
+                                       zs_c.get_lde_values(i, step), zs_c.get_lde_values(i_next, step), perm_sets, ctl_vars, consumer);
+            for (int j = 0; j < nch; j++) qvals[j][i] = gl_mul(consumer.accs[j], zh_inv[i % zh_inv.size()]);
+            x = gl_mul(x, w);
+        }
     }
     for (auto& q : qvals) interpolate_poly_with_offset(q.data(), size, GL_GENERATOR);
     return qvals;
@@ -325,15 +341,19 @@ static StarkProof prove_single_table(const AirTable& air, const ProverConfig& cf
     const bool use_perm = air.uses_permutation_args();
     if (use_perm) for (int i = 0; i < air.permutation_batch_size(); i++) perm_sets.push_back(get_gp_challenge_set(ch, cfg.num_challenges));
     std::vector<std::vector<u64>> z_polys;
-    if (use_perm) z_polys = compute_permutation_z_polys(air, cfg, trace, perm_sets);
+    if (use_perm) { OracleClock c("  permutation Z"); z_polys = compute_permutation_z_polys(air, cfg, trace, perm_sets); }
     const int num_permutation_zs = (int)z_polys.size();
     for (auto& c : ctl) z_polys.push_back(c.z);
     if (z_polys.empty()) throw std::runtime_error("No CTL?");
+    OracleClock* c_zs = new OracleClock("  Zs commitment");
     PolynomialBatch zs_c = batch_from_values(z_polys, cfg.fri.rate_bits, cfg.fri.cap_height);
+    delete c_zs;
     ch.observe_cap(zs_c.merkle_tree.cap);
     std::vector<u64> alphas;
     for (int i = 0; i < cfg.num_challenges; i++) alphas.push_back(ch.get_challenge());
+    OracleClock* c_q = new OracleClock("  quotient polys");
     std::vector<std::vector<u64>> qpolys = compute_quotient_polys(air, cfg, trace_c, zs_c, use_perm ? &perm_sets : nullptr, ctl, alphas, params, degree_bits);
+    delete c_q;
     std::vector<std::vector<u64>> chunks;
     const size_t keep = degree * (size_t)air.quotient_degree_factor();
     for (auto& q : qpolys) {
@@ -341,8 +361,11 @@ static StarkProof prove_single_table(const AirTable& air, const ProverConfig& cf
             if (q[k] != 0) throw std::runtime_error("Quotient has failed, the vanishing polynomial is not divisible by Z_H");
         for (size_t c0 = 0; c0 < keep; c0 += degree) chunks.push_back(std::vector<u64>(q.begin() + c0, q.begin() + c0 + degree));
     }
+    OracleClock* c_qc = new OracleClock("  quotient commitment");
     PolynomialBatch q_c = batch_from_coeffs(chunks, cfg.fri.rate_bits, cfg.fri.cap_height);
+    delete c_qc;
     ch.observe_cap(q_c.merkle_tree.cap);
+    OracleClock c_open("  openings + FRI");
     OpeningProof op = open_and_prove(trace_c, zs_c, q_c, num_permutation_zs, ch, cfg.fri);
     if (ext_pow(op.zeta, (u64)1 << degree_bits) == EXT_ONE) throw std::runtime_error("Opening point is in the subgroup.");
     StarkProof p;
@@ -360,21 +383,25 @@ static AllProof prove_with_traces(const AirSet& set, const ProverConfig& cfg, co
                                   const std::vector<std::vector<u64>>& params, const std::vector<u64>& compress_challenges) {
     const size_t nt = set.tables.size();
     std::vector<PolynomialBatch> commits;
-    for (size_t t = 0; t < nt; t++) commits.push_back(batch_from_values(traces[t], cfg.fri.rate_bits, cfg.fri.cap_height));
+    { OracleClock c("trace commitments"); for (size_t t = 0; t < nt; t++) commits.push_back(batch_from_values(traces[t], cfg.fri.rate_bits, cfg.fri.cap_height)); }
     Challenger ch;
     for (size_t t = 0; t < nt; t++) ch.observe_cap(commits[t].merkle_tree.cap);
     // cross_table_lookup_data
     ChallengeSet ctl_ch = get_gp_challenge_set(ch, cfg.num_challenges);
     std::vector<std::vector<CtlZData>> ctl_data(nt);
+    OracleClock* c_ctl = new OracleClock("cross_table_lookup_data");
     for (const Ctl& ctl : set.ctls) {
         for (const GrandProductChallenge& c : ctl_ch) {
             for (const TableWithColumns& twc : ctl.looking) ctl_data[twc.table].push_back({partial_products(traces[twc.table], twc, c), c, &twc});
             ctl_data[ctl.looked.table].push_back({partial_products(traces[ctl.looked.table], ctl.looked, c), c, &ctl.looked});
         }
     }
+    delete c_ctl;
     AllProof all;
-    for (size_t t = 0; t < nt; t++)
+    for (size_t t = 0; t < nt; t++) {
+        OracleClock c("prove_single_table");
         all.proofs.push_back(prove_single_table(set.tables[t], cfg, traces[t], commits[t], ctl_data[t], params[t].data(), ch));
+    }
     all.compress_challenges = compress_challenges;
     return all;
 }

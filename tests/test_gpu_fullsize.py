@@ -248,29 +248,38 @@ def test_commitment_bytes_at_baseline_size_94_x_2p20(be, oracle):
     print("94 x 2^20: oracle extension + Poseidon tree %.1f s, Blake3 re-hash + checks %.1f s" % (t_oracle, time.perf_counter() - t0))
 
 
-def test_commitment_bytes_at_baseline_size_29_x_2p22_blake3(oracle):
-    """The memory table's shape at BASELINE config 4's height (29 columns x 2^22 rows, 2^25 leaves) under the reference's Blake3
-    configuration, byte for byte against the oracle: cap, eight leaves, eight paths (Poseidon at this size would keep the CPU
-    oracle busy for minutes; the 94 x 2^20 test above covers the Poseidon tree, this one the 2^25-leaf transforms and heap)."""
+def test_commitment_bytes_at_baseline_size_29_x_2p22(be, oracle):
+    """The memory table's shape at BASELINE config 4's height (29 columns x 2^22 rows, 2^25 leaves), byte for byte against the oracle
+    under BOTH hash configurations: cap, eight leaves, eight sibling paths.  The oracle extends the table once; its Poseidon tree
+    is 1.7 * 10^8 permutations on the host cores (round 5: the checker's quotient loop and tree run on all cores), the Blake3
+    tree re-hashes the same leaves.  Covers the 2^25-leaf transforms, leaf hashing and heap under the headline (Poseidon)
+    configuration at the headline height."""
     import torch
     from olavm_amd.backend import Backend
     from tests.inputs import splitmix_columns
     vals = splitmix_columns(torch, 29, 1 << 22).cpu().numpy().view(np.uint64) % np.uint64(P)
     torch.cuda.empty_cache()
     N = 8 << 22
+    t0 = time.perf_counter()
+    ob = oracle.batch(vals)
+    t_oracle = time.perf_counter() - t0
+    g = be.commit(vals)
+    assert np.array_equal(g.cap(), ob.cap()), "Poseidon Merkle cap of the 29 x 2^22 commitment differs from the oracle's"
+    _check_leaves_and_paths(g, ob, N, "poseidon")
+    g.free()
+    be.trim()
+    t0 = time.perf_counter()
     b3 = Backend(device=0, hasher="blake3")
     try:
         with oracle.hasher("blake3"):
-            t0 = time.perf_counter()
-            ob = oracle.batch(vals)
-            t_oracle = time.perf_counter() - t0
+            ob.rehash()
             g = b3.commit(vals)
             assert np.array_equal(g.cap(), ob.cap()), "Blake3 Merkle cap of the 29 x 2^22 commitment differs from the oracle's"
             _check_leaves_and_paths(g, ob, N, "blake3")
             g.free()
     finally:
         b3.close()
-    print("29 x 2^22 (Blake3): oracle %.1f s" % t_oracle)
+    print("29 x 2^22: oracle extension + Poseidon tree %.1f s, Blake3 re-hash + checks %.1f s" % (t_oracle, time.perf_counter() - t0))
 
 
 def test_2p16_row_execution_bytes_equal_the_oracle_prover(be, oracle):
@@ -282,6 +291,20 @@ def test_2p16_row_execution_bytes_equal_the_oracle_prover(be, oracle):
     assert traces[0].shape == (94, 1 << 16)
     got, _ = _prove_and_verify(be, oracle, traces, params, compress, blob)
     want = oracle.prove_with_traces(blob, traces, params, compress)
+    assert len(got) == len(want) and got == want
+
+
+def test_2p18_row_execution_bytes_equal_the_oracle_prover(be, oracle):
+    """One size up (round 5; the oracle's quotient loop runs on all host cores now): memory_program(12000), 2^18 CPU rows -- the three-launch
+    transforms, the generated quotient kernels on 2^21 points, five FRI layers -- AllProof bytes identical, byte for byte."""
+    from olavm_amd.air import fastexec, miniexec as M
+    blob = T.ola_stark().blob()
+    traces, params, compress = fastexec.instance(M.memory_program(12000), range_bits=16, limb_bits=8, max_steps=1 << 22)
+    assert traces[0].shape == (94, 1 << 18), traces[0].shape
+    got, _ = _prove_and_verify(be, oracle, traces, params, compress, blob)
+    t0 = time.perf_counter()
+    want = oracle.prove_with_traces(blob, traces, params, compress)
+    print("2^18-row execution: oracle prover %.1f s, %d bytes" % (time.perf_counter() - t0, len(want)))
     assert len(got) == len(want) and got == want
 
 
