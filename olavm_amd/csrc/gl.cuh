@@ -123,7 +123,42 @@ __device__ __forceinline__ u64 gl_reduce128_cc(u64 lo, u64 hi) {
         : "=&v"(r0), "=&v"(r1), "=&s"(m) : "s"(c), "s"(c2), "v"(tl), "v"(ul), "v"(th), "v"(uh) : "scc");   // s_or writes SCC
     return ((u64)r1 << 32) | r0;
 }
+// a * b mod p as any u64 of the residue class, for ANY u64 operands, without assembling the 128-bit product first (round 5
+// experiment for the S-boxes of the Poseidon permutation -- 472 multiplications per permutation, 55 % of its instructions;
+// checked by ola_gpu_selftest, measured slower than the 128-bit form and left out of the permutation, see poseidon.cuh mul_weak).  With a = a0 + a1 2^32,
+// b = b0 + b1 2^32:  al = a0 b0,  ah = a1 b1,  (c, mid) = a0 b1 + a1 b0 as a 65-bit sum (the carry-out of the second
+// v_mad_u64_u32), and with 2^64 = 2^32 - 1 =: EPS, 2^96 = -1 (mod p)
+//     a b = al_l + (al_h + mid_l) 2^32 + (mid_h + ah_l) 2^64 + (ah_h + c) 2^96
+//         = {al_l, Ah} - (ah_h + c + k2) + B EPS,     Ah + k1 2^32 = al_h + mid_l,   B + k2 2^32 = mid_h + ah_l + k1,
+// i.e. two 32-bit additions chained through the carry instead of the three 64-bit additions (each with its zero-extension move)
+// that build `hi` in mul_wide -- 15 VALU instructions against 17, all four multiplications independent of each other.
+// ah_h <= 2^32 - 2, so ah_h + c fits a word; the subtract-with-borrow takes k2 as its borrow-in.
+__device__ __forceinline__ u64 gl_mul_weak_cs(u64 a, u64 b) {
+    const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+    const u64 al = (u64)a0 * b0, ah = (u64)a1 * b1, m1 = (u64)a0 * b1;
+    u64 mid, c, k1, k2, kd, bw0, bw1, carry, t2;
+    u32 Ah, B, Dh, t0l, t0h, el, eh, e;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(mid), "=s"(c) : "v"(a1), "v"(b0), "v"(m1));
+    asm("v_add_co_u32_e64 %0, %1, %2, %3" : "=v"(Ah), "=s"(k1) : "v"((u32)(al >> 32)), "v"((u32)mid));
+    asm("s_nop 1\n\tv_addc_co_u32_e64 %0, %1, %2, %3, %4" : "=v"(B), "=s"(k2) : "v"((u32)(mid >> 32)), "v"((u32)ah), "s"(k1));
+    asm("s_nop 1\n\tv_addc_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(Dh), "=s"(kd) : "v"((u32)(ah >> 32)), "s"(c));
+    asm("s_nop 1\n\tv_subb_co_u32_e64 %0, %1, %2, %3, %4" : "=v"(t0l), "=s"(bw0) : "v"((u32)al), "v"(Dh), "s"(k2));
+    asm("s_nop 1\n\tv_subbrev_co_u32_e64 %0, %1, 0, %2, %3" : "=v"(t0h), "=s"(bw1) : "v"(Ah), "s"(bw0));
+    // borrowed: the wrapped difference is 2^64 = EPS too large (mod p): add -EPS = 0xFFFFFFFF00000001
+    asm("s_nop 1\n\tv_cndmask_b32_e64 %0, 0, 1, %2\n\tv_cndmask_b32_e64 %1, 0, -1, %2" : "=&v"(el), "=v"(eh) : "s"(bw1));
+    u64 fix = ((u64)eh << 32) | el, dif = ((u64)t0h << 32) | t0l;
+    asm("" : "+v"(fix), "+v"(dif));
+    const u64 t0 = dif + fix;
+    asm("v_mad_u64_u32 %0, %1, %2, -1, %3" : "=v"(t2), "=s"(carry) : "v"(B), "v"(t0));
+    asm("s_nop 1\n\tv_cndmask_b32_e64 %0, 0, -1, %1" : "=v"(e) : "s"(carry));
+    return t2 + e;
+}
 #else
+GL_HD u64 gl_mul_weak_cs(u64 a, u64 b) {
+    u64 lo, hi;
+    mul_wide(a, b, lo, hi);
+    return gl_reduce128_weak(lo, hi);
+}
 GL_HD u64 gl_reduce128_weak_cc(u64 lo, u64 hi) { return gl_reduce128_weak(lo, hi); }
 GL_HD u64 gl_reduce128_cc(u64 lo, u64 hi) { return gl_reduce128(lo, hi); }
 #endif

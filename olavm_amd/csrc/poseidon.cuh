@@ -37,9 +37,17 @@ __device__ __forceinline__ void mul_wide32(u64 a, u64 b, u64& lo, u64& hi) {
 }
 __device__ __forceinline__ u64 reduce128_weak(u64 lo, u64 hi) { return gl_reduce128_weak_cc(lo, hi); }   // carry-flag form, gl.cuh
 __device__ __forceinline__ u64 mul_weak(u64 a, u64 b) {
+#ifdef OLA_POSEIDON_MUL_ONECHAIN
+    // Round 5 experiment, measured and NOT adopted (profiles/r05_sbox_ab.txt): product and reduction as one carry chain
+    // (gl_mul_weak_cs, gl.cuh) -- 15 VALU instructions per multiplication instead of 17, bit-exact, and slower: the commitment of
+    // 94 x 2^22 196.5 -> 197.8 ms, the Poseidon-configuration proof 0.689 -> 0.715 s.  Every instruction of the chain waits for
+    // its predecessor's carry (two wait states each); the 128-bit form below has four independent multiply-adds in flight.
+    return gl_mul_weak_cs(a, b);
+#else
     u64 lo, hi;
     mul_wide32(a, b, lo, hi);
     return reduce128_weak(lo, hi);
+#endif
 }
 // x weak, c canonical -> weak
 __device__ __forceinline__ u64 add_weak(u64 x, u64 c) {

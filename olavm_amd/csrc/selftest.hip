@@ -26,6 +26,7 @@ __device__ __forceinline__ unsigned st_check(u64 x, u64 y) {
     u64 lo, hi;
     mul_wide(x, y, lo, hi);
     bad += gl_mul(x, y) != gl_reduce128(lo, hi);
+    bad += gl_canon(gl_mul_weak_cs(x, y)) != gl_reduce128(lo, hi);      // the one-chain product of the Poseidon S-boxes
     return bad;
 }
 __global__ __launch_bounds__(256) void field_selftest_kernel(const u64* __restrict__ edges, int nedges, u64 per_thread, unsigned long long* __restrict__ bad) {

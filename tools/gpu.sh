@@ -11,6 +11,12 @@ for step in "$@"; do
                  timeout 900 python -m pytest tests/test_gpu_upload.py tests/test_gpu_host_api.py -x -q 2>&1 | tail -15 | tee $O/pytest.log
                  timeout 900 python tools/bench_upload.py 22 blake3 3 2>&1 | grep -v amdgpu | tee $O/ab_blake3.txt
                  OLA_HASHER=blake3 OLA_TIMING=1 timeout 300 python tools/bench_prove.py 22 2 2> $O/phases_blake3.txt | tail -2 ;;
+    sbox_ab)     # Poseidon S-box multiplication: ab_tmp/libola_<v>.so alternated; commitment of 94 x 2^22 (leaf + tree hashing dominate) and the whole Poseidon-config proof
+                 cp olavm_amd/lib/libola_gpu.so ab_tmp/libola_cur.so
+                 for v in ${AB_VARIANTS:-cur onechain cur onechain}; do cp ab_tmp/libola_$v.so olavm_amd/lib/libola_gpu.so; echo "-- $v"
+                   timeout 300 python tools/bench_commit.py 22 94 3 2>/dev/null | tail -2
+                   timeout 300 python tools/bench_prove.py 22 3 2>/dev/null | tail -2
+                 done 2>&1 | grep -v amdgpu | tee $O/ab.txt; cp ab_tmp/libola_cur.so olavm_amd/lib/libola_gpu.so ;;
     multi)       timeout 900 python -m pytest tests/test_gpu_multi.py -x -q 2>&1 | tail -15 | tee $O/pytest.log ;;
     dist)        timeout 1200 python -m pytest tests/test_gpu_distributed.py tests/test_gpu_multi.py -x -q 2>&1 | tail -15 | tee $O/pytest.log ;;
     suite)       timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 | tee $O/pytest.log ;;
