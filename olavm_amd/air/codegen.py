@@ -34,9 +34,13 @@ class _Emitter:
     def add(self, s):
         self.lines.append("    " + s)
 
-    def emit(self, kind, expr):
-        i = self.idx
-        self.idx += 1
+    def emit(self, kind, expr, index=None):
+        """index: the constraint's position in the reference's emission order (its alpha power); evaluation order is free"""
+        if index is None:
+            i = self.idx
+            self.idx += 1
+        else:
+            i = index
         if kind == KIND_ALL:
             self.add("AIRQ_EMIT_ALL(%d, %s);" % (i, expr))
         elif kind == KIND_TRANSITION:
@@ -80,42 +84,158 @@ SEGMENT_OPS = 64     # field operations between two code-motion barriers
 CTL_REG_CELLS = 12   # cells most lookups of the table read (clk, the selectors, ...): in registers for the whole lookup section
 CTL_REG_MIN_USES = 6
 LDS_SLOTS = 20       # lane-private LDS slots per thread (20 x 2 KB per workgroup: four workgroups per CU still fit in 160 KB)
-LDS_MIN_USES = 2
+ORDER_WINDOWS = (0, 2, 3, 5, 8)   # candidate evaluation orders of the constraint program: 0 = the reference's, W = greedy with a window of W constraints
+
+
+def _emit_cells(tab):
+    """per emitted constraint: the trace cells under its expression"""
+    nodes, out = tab.nodes, []
+    memo = {}
+
+    def cells(j):
+        if j in memo:
+            return memo[j]
+        op, a, b = nodes[j]
+        if op == OP_LOCAL:
+            r = frozenset([("L", a)])
+        elif op == OP_NEXT:
+            r = frozenset([("N", a)])
+        elif op in (OP_CONST, OP_PARAM):
+            r = frozenset()
+        elif op == OP_ISZERO:
+            r = cells(a)
+        else:
+            r = cells(a) | cells(b)
+        memo[j] = r
+        return r
+
+    import sys
+    old = sys.getrecursionlimit()
+    sys.setrecursionlimit(max(old, 20000))
+    try:
+        for _, j in tab.emits:
+            out.append(cells(j))
+    finally:
+        sys.setrecursionlimit(old)
+    return out
+
+
+def emit_order(tab, window):
+    """Evaluation order of the table's constraints (emission indices -- the alpha powers -- stay attached to them): window 0 is the
+    reference's order; otherwise greedy -- the next constraint is the one that shares the most trace cells with the last `window`
+    constraints and brings the fewest new ones, so that the cells a stretch of the kernel touches fit the LDS slots."""
+    n = len(tab.emits)
+    if window == 0 or n < 3:
+        return list(range(n))
+    full = _emit_cells(tab)
+    left = set(range(1, n))
+    order, recent = [0], [full[0]]
+    while left:
+        win = frozenset().union(*recent[-window:])
+        best = max(left, key=lambda i: (2 * len(full[i] & win) - len(full[i] - win), -i))
+        order.append(best)
+        left.discard(best)
+        recent.append(full[best])
+    return order
+
+
+def _schedule(tab, order):
+    """dsl.AirTable.schedule with the emits visited in `order`: ('node', id) / ('emit', kind, id, emission index)"""
+    nodes, emits = tab.nodes, tab.emits
+    out, done = [], set()
+    for i in order:
+        kind, root = emits[i]
+        stack = [root]
+        while stack:
+            j = stack[-1]
+            if j in done:
+                stack.pop()
+                continue
+            op, a, b = nodes[j]
+            deps = [a, b] if op in (OP_ADD, OP_SUB, OP_MUL) else ([a] if op == OP_ISZERO else [])
+            pend = [d for d in deps if d not in done]
+            if pend:
+                stack.extend(pend)
+                continue
+            done.add(j)
+            out.append(("node", j))
+            stack.pop()
+        out.append(("emit", kind, root, i))
+    return out
+
+
+def plan_lds(segcells, capacity):
+    """Which trace cells live in the lane-private LDS slots while which segment runs.  The kernel is straight-line code, so every
+    future use is known: replacement is Belady's (keep what is used again soonest), decided segment by segment.  A cell enters a
+    slot in the segment that loads it from global memory (AIRQ_CACHE_PUT right after the load), into a slot that is free when that
+    segment starts -- a slot whose cell is still read in the segment is handed over one segment later.
+    -> per segment: {cell: slot} served from LDS, {cell: slot} loaded and parked; and the number of global loads."""
+    nseg = len(segcells)
+    INF = 1 << 30
+    uses = {}
+    for i, sc in enumerate(segcells):
+        for c in sc:
+            uses.setdefault(c, []).append(i)
+
+    def next_use(c, i):
+        for k in uses[c]:
+            if k > i:
+                return k
+        return INF
+
+    cache = {}            # cell -> slot
+    hits, puts, loads = [], [], 0
+    for i, sc in enumerate(segcells):
+        hit = {c: cache[c] for c in sc if c in cache}
+        miss = [c for c in sc if c not in cache]
+        loads += len(miss)
+        cand = sorted(set(cache) | set(miss), key=lambda c: (next_use(c, i), c))
+        keep = set(c for c in cand[:capacity] if next_use(c, i) < INF)
+        for c in [c for c in cache if c not in keep and c not in sc]:
+            del cache[c]                       # not read in this segment and not worth keeping: the slot is free right away
+        free = [sl for sl in range(capacity) if sl not in cache.values()]
+        put = {}
+        for c in sorted((c for c in miss if c in keep), key=lambda c: (next_use(c, i), c)):
+            if not free:
+                break
+            put[c] = free.pop(0)
+        hits.append(hit)
+        puts.append(put)
+        for c in [c for c in cache if c not in keep]:
+            del cache[c]                       # read in this segment for the last time: the slot frees for the next segment
+        cache.update(put)
+    return hits, puts, loads
 
 
 def table_kernel(airset, t, name, num_challenges=2):
-    """-> (source text of the kernel, K).  Printed twice per candidate phase length: the first print counts how often each
-    trace cell is loaded in each phase of the kernel, the second keeps the most re-loaded ones in registers (lookup section)
-    or in LDS (AIRQ_CACHE_*; the slots are re-assigned at every phase boundary).  The phase length with the fewest loads from
-    global memory wins (small tables: one phase for the whole constraint program)."""
+    """-> (source text of the kernel, K).  Printed several times: a counting print per candidate evaluation order finds the cells
+    the lookup section keeps in registers and the cells every segment touches; plan_lds decides from that which cells sit in the
+    LDS slots when; the order with the fewest loads from global memory is printed for good."""
     import re
+    tab = airset.tables[t]
     best = None
-    for phase_segments in PHASE_SEGMENT_CHOICES:
-        uses = {"phase": {}, "ctl": {}}
-        _table_kernel(airset, t, name, num_challenges, uses=uses, phase_segments=phase_segments)
-        ctl = sorted(((n, k) for k, n in uses["ctl"].items() if n >= CTL_REG_MIN_USES), key=lambda x: (-x[0], x[1]))[:CTL_REG_CELLS]
-        regs = [k for _, k in ctl]
-        lds_sets = {}
-        for phase, cnt in uses["phase"].items():
-            cnt = dict(cnt)
-            if phase == "tail":        # a register cell is loaded once, at the head of the lookup section: that load may come from LDS
-                for k in regs:
-                    cnt[k] = cnt.get(k, 0) - uses["ctl"][k] + 1
-            top = sorted(((n, k) for k, n in cnt.items() if n >= LDS_MIN_USES), key=lambda x: (-x[0], x[1]))[:LDS_SLOTS]
-            lds_sets[phase] = [k for _, k in top]
-        src, K = _table_kernel(airset, t, name, num_challenges, ctl_regs=regs, lds_sets=lds_sets, phase_segments=phase_segments)
-        loads = len(re.findall(r"\b[LN]C\(\d+\)", src))
-        if best is None or loads < best[0]:
-            best = (loads, src, K)
-    return best[1], best[2]
+    for window in ORDER_WINDOWS:
+        order = emit_order(tab, window)
+        for ctl_order in (False, True):
+            uses = {"ctl": {}, "segs": []}
+            _table_kernel(airset, t, name, num_challenges, uses=uses, order=order, ctl_order=ctl_order)
+            ctl = sorted(((n, k) for k, n in uses["ctl"].items() if n >= CTL_REG_MIN_USES), key=lambda x: (-x[0], x[1]))[:CTL_REG_CELLS]
+            regs = [k for _, k in ctl]
+            uses = {"ctl": {}, "segs": []}
+            _table_kernel(airset, t, name, num_challenges, uses=uses, ctl_regs=regs, order=order, ctl_order=ctl_order)
+            hits, puts, loads = plan_lds(uses["segs"], LDS_SLOTS)
+            if best is None or loads < best[0]:
+                best = (loads, order, regs, (hits, puts), ctl_order)
+        if len(tab.emits) < 3:
+            break
+    loads, order, regs, plan, ctl_order = best
+    src, K = _table_kernel(airset, t, name, num_challenges, ctl_regs=regs, plan=plan, order=order, ctl_order=ctl_order)
+    return src, K
 
 
-PHASE_SEGMENT_CHOICES = (7, 1 << 30)   # the constraint program is cut into phases of this many segments; each phase (and the
-                                       # permutation + lookup tail) parks ITS most re-loaded cells in the LDS slots
-
-
-def _table_kernel(airset, t, name, num_challenges=2, uses=None, ctl_regs=(), lds_sets=None, phase_segments=7):
-    """One print of the kernel.  uses: dict to fill with the loads per phase and cell (counting print); lds_sets: {phase: cells}.
+def _table_kernel(airset, t, name, num_challenges=2, uses=None, ctl_regs=(), plan=None, order=None, ctl_order=False):
+    """One print of the kernel.  uses: dict to fill with the cells every segment reads (counting print); plan: plan_lds's result;
+    order: evaluation order of the constraint program (emit_order).
 
     Register pressure is what limits these kernels (the CPU table keeps ~90 trace cells and ~65 shared subexpressions
     alive if every value is computed once), so the code is cut into segments separated by compiler barriers: trace
@@ -133,43 +253,47 @@ def _table_kernel(airset, t, name, num_challenges=2, uses=None, ctl_regs=(), lds
     e.add("AIRQ_PROLOGUE(%d)" % K)
     nodes = tab.nodes
     LEAF = (OP_LOCAL, OP_NEXT, OP_CONST, OP_PARAM)
-    lds_sets = lds_sets or {}
-    use_lds = any(lds_sets.values())
-    lds_slot = {}                        # cell -> slot, for the phase being printed
-    section = {"name": "program", "phase": None}
+    use_lds = plan is not None and any(plan[0]) or plan is not None and any(plan[1])
+    section = {"name": "program"}
     BARRIER = "AIRQ_SEGMENT_BARRIER_C;" if use_lds else "AIRQ_SEGMENT_BARRIER;"
+    state = {"seg": 0, "ops": 0, "local": {}, "cells": {}}      # seg: running index over ALL segments (program, permutation, lookups)
+    if uses is not None:
+        uses["segs"].append(set())
 
     def cell(row, c):
         """Expression of trace cell (row 'L' / 'N', column c) at this place of the kernel."""
         k = (row, c)
+        if section["name"] == "ctl" and k in ctl_regs:
+            if uses is not None:
+                uses["ctl"][k] = uses["ctl"].get(k, 0) + 1
+            return "h%s%d" % (row, c)
         if uses is not None:
-            ph = uses["phase"].setdefault(section["phase"], {})
-            ph[k] = ph.get(k, 0) + 1
+            uses["segs"][state["seg"]].add(k)
             if section["name"] == "ctl":
                 uses["ctl"][k] = uses["ctl"].get(k, 0) + 1
-        if section["name"] == "ctl" and k in ctl_regs:
-            return "h%s%d" % (row, c)
-        if k in lds_slot:
-            return "CL(%d)" % lds_slot[k]
+        if plan is not None:
+            hits, puts = plan
+            if k in hits[state["seg"]]:
+                return "CL(%d)" % hits[state["seg"]][k]
+            if k in puts[state["seg"]]:
+                if k not in state["cells"]:
+                    nm = "g%d_%s%d" % (state["seg"], row, c)
+                    e.add("const u64 %s = %sC(%d); AIRQ_CACHE_PUT(%d, %s);" % (nm, row, c, puts[state["seg"]][k], nm))
+                    state["cells"][k] = nm
+                return state["cells"][k]
         return "%sC(%d)" % (row, c)
 
-    def phase_begin(name):
-        """The LDS slots change hands: cells that stay keep their slot, the others are loaded into the freed ones."""
-        section["phase"] = name
-        want = lds_sets.get(name, [])
-        for k in [k for k in lds_slot if k not in want]:
-            del lds_slot[k]
-        free = [i for i in range(LDS_SLOTS) if i not in lds_slot.values()]
-        fresh = [k for k in want if k not in lds_slot]
-        for k in fresh:
-            lds_slot[k] = free.pop(0)
-            e.add("AIRQ_CACHE_PUT(%d, %sC(%d));" % (lds_slot[k], k[0], k[1]))
-        if fresh:
-            e.add(BARRIER)
+    def next_segment():
+        e.add(BARRIER)
+        state["seg"] += 1
+        state["ops"] = 0
+        state["local"] = {}
+        state["cells"] = {}
+        if uses is not None:
+            uses["segs"].append(set())
 
     if use_lds:
         e.add("AIRQ_CACHE_DECL(%d);" % LDS_SLOTS)
-    phase_begin("p0")
 
     def is_cheap(j):
         op, a, b = nodes[j]
@@ -177,15 +301,7 @@ def _table_kernel(airset, t, name, num_challenges=2, uses=None, ctl_regs=(), lds
             return True
         return op in (OP_ADD, OP_SUB) and nodes[a][0] in LEAF and nodes[b][0] in LEAF
 
-    state = {"seg": 0, "ops": 0, "local": {}}
-
-    def barrier():
-        e.add(BARRIER)
-        state["seg"] += 1
-        state["ops"] = 0
-        state["local"] = {}
-        if section["name"] == "program" and state["seg"] % phase_segments == 0:
-            phase_begin("p%d" % (state["seg"] // phase_segments))
+    barrier = next_segment
 
     def leaf_expr(j):
         op, a, _ = nodes[j]
@@ -216,9 +332,9 @@ def _table_kernel(airset, t, name, num_challenges=2, uses=None, ctl_regs=(), lds
         return nm
 
     # ---- the table's constraint program ----
-    for it in tab.schedule():
+    for it in _schedule(tab, order if order is not None else list(range(len(tab.emits)))):
         if it[0] == "emit":
-            e.emit(it[1], ref(it[2]))
+            e.emit(it[1], ref(it[2]), it[3])
             state["ops"] += 2
             if state["ops"] >= SEGMENT_OPS:
                 barrier()
@@ -240,9 +356,9 @@ def _table_kernel(airset, t, name, num_challenges=2, uses=None, ctl_regs=(), lds
         e.add("const u64 t%d = %s;" % (j, rhs))
         state["ops"] += 1
     barrier()
+    e.idx = len(tab.emits)
     # ---- permutation checks (permutation.rs:302-360) ----
     section["name"] = "perm"
-    phase_begin("tail")
     for b in range(nperm):
         e.emit(KIND_FIRST, "gl_sub(ZL(%d), 1)" % b)
     total = len(tab.permutation_pairs) * num_challenges
@@ -255,9 +371,9 @@ def _table_kernel(airset, t, name, num_challenges=2, uses=None, ctl_regs=(), lds
                 break
             pair = tab.permutation_pairs[inst // num_challenges]
             slot = d_perm + 2 * (b * bs + i)
-            e.add("    { const u64 beta = D[%d], gamma = D[%d];" % (slot, slot + 1))
-            ls = [cell("L", l) for l, _ in pair]
+            ls = [cell("L", l) for l, _ in pair]          # (a cell that is parked in LDS here is declared before the block opens)
             rs = [cell("L", r) for _, r in pair]
+            e.add("    { const u64 beta = D[%d], gamma = D[%d];" % (slot, slot + 1))
             e.add("      u64 l = %s, r = %s;" % (ls[-1], rs[-1]))
             for k in range(len(pair) - 2, -1, -1):
                 e.add("      l = gl_add(gl_mul(l, beta), %s); r = gl_add(gl_mul(r, beta), %s);" % (ls[k], rs[k]))
@@ -265,7 +381,7 @@ def _table_kernel(airset, t, name, num_challenges=2, uses=None, ctl_regs=(), lds
             inst += 1
         e.emit(KIND_ALL, "gl_sub(gl_mul(ZN(%d), pr), gl_mul(ZL(%d), pl))" % (b, b))
         e.add("}")
-        e.add(BARRIER)
+        next_segment()
     # ---- cross-table lookup checks (cross_table_lookup.rs:380-421) ----
     # Emits are indexed, so evaluation order is free: the Z columns that look at the same columns (one per challenge)
     # are evaluated together, streaming the column values through one Horner step per challenge.
@@ -283,7 +399,22 @@ def _table_kernel(airset, t, name, num_challenges=2, uses=None, ctl_regs=(), lds
     if ctl_regs:
         e.add("const u64 " + ", ".join("h%s%d = %s" % (r, c, cell(r, c)) for r, c in ctl_regs) + ";")
     section["name"] = "ctl"
-    for twc, idxs in groups.values():
+
+    def twc_cells(twc):
+        cols = list(twc.columns) + ([twc.filter_column] if twc.filter_column is not None else [])
+        return frozenset((r, c) for col in cols for c, _ in col.terms for r in "LN" if (r, c) not in ctl_regs)
+
+    # the lookups in an order in which neighbours read the same columns (their Z columns keep their emission indices)
+    glist = list(groups.values())
+    if ctl_order and len(glist) > 2:
+        left, chain = glist[1:], [glist[0]]
+        while left:
+            last = twc_cells(chain[-1][0])
+            nxt = max(left, key=lambda g: (2 * len(twc_cells(g[0]) & last) - len(twc_cells(g[0]) - last), -g[1][0]))
+            chain.append(nxt)
+            left.remove(nxt)
+        glist = chain
+    for twc, idxs in glist:
         e.add("{")
         e.add("  const u64 el0 = %s, en0 = %s;" % (_lincol(twc.columns[0], "L", cell), _lincol(twc.columns[0], "N", cell)))   # beta^0 term
         e.add("  Acc160 " + ", ".join("al%d = {el0, 0, 0}, an%d = {en0, 0, 0}" % (i, i) for i in idxs) + ";")
@@ -306,7 +437,7 @@ def _table_kernel(airset, t, name, num_challenges=2, uses=None, ctl_regs=(), lds
             e.emit(KIND_TRANSITION, "gl_sub(zn, gl_mul(zl, cn))")
             e.add("  }")
         e.add("}")
-        e.add(BARRIER)
+        next_segment()
     e.idx = first_idx + 2 * len(jobs)
     assert e.idx == K, (e.idx, K)
     e.add("AIRQ_EPILOGUE")
