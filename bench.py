@@ -328,9 +328,25 @@ def timed_proofs(be, blob, traces, params, compress, reps, hasher="poseidon"):
            "first_call_seconds": round(first, 4), **verify_proofs(blob, proofs, params, hasher)}
     try:
         up = be.upload_stats()
-        res["upload"] = {"path": up["mode"], "copier_threads": up["threads"], "GB": round(up["bytes"] / 1e9, 2), "ms": round(up["total_ms"], 1),
-                         "GBps": round(up["bytes"] / 1e6 / max(up["total_ms"], 1e-9), 1), "upload_wait_ms": round(up["waited_ms"], 1),
-                         "first_group_ms": round(up["first_group_ms"], 2)}
+        res["upload"] = {"path": up["mode"], "copier_threads": up["threads"], "trace_GB": round(up["bytes"] / 1e9, 2), "over_the_link_GB": round(up["link_bytes"] / 1e9, 2),
+                         "ms": round(up["total_ms"], 1), "trace_GBps": round(up["bytes"] / 1e6 / max(up["total_ms"], 1e-9), 1),
+                         "link_GBps": round(up["link_bytes"] / 1e6 / max(up["total_ms"], 1e-9), 1), "upload_wait_ms": round(up["waited_ms"], 1),
+                         "first_group_ms": round(up["first_group_ms"], 2),
+                         "note": "columns whose words are all below 2^32 cross the link as 32-bit words (olavm_amd/csrc/upload.h); every_column_64_bit = the same proof with that switched off"}
+        # what a trace of field-sized values in every column would cost: the same proof with the narrow-column path switched off
+        os.environ["OLA_UPLOAD_PACK"] = "0"
+        try:
+            ts, same = [], True
+            for _ in range(reps):
+                t0 = time.perf_counter()
+                same &= be.prove_with_traces(blob, traces, params, compress) == proofs[-1]
+                ts.append(time.perf_counter() - t0)
+            up0 = be.upload_stats()
+            ts.sort()
+            res["upload"]["every_column_64_bit"] = {"seconds": round(ts[len(ts) // 2], 4), "identical": bool(same), "upload_wait_ms": round(up0["waited_ms"], 1),
+                                                    "link_GBps": round(up0["link_bytes"] / 1e6 / max(up0["total_ms"], 1e-9), 1)}
+        finally:
+            del os.environ["OLA_UPLOAD_PACK"]
         # the same proof from the reference's own trace type: every column a separate allocation (ola_prove_with_traces_cols)
         cols = scattered_columns(traces)
         ts, same = [], True

@@ -176,9 +176,10 @@ typedef struct OlaScopeTime {
 int32_t ola_gpu_scope_times(OlaCtx* ctx, int32_t enable, OlaScopeTime* out, uint32_t cap, uint32_t* n_out);
 /* The trace upload of the last whole proof: out[0] milliseconds the proving thread was blocked waiting for column groups,
  * out[1] milliseconds from the first byte asked for to the last byte on the device, out[2] until the first column group was
- * complete, out[3] bytes, out[4] path (0 pinned staging ring, 1 pageable hipMemcpyAsync, 2 hipHostRegister: env OLA_UPLOAD),
- * out[5] copier threads.  On a multi-device context: rank 0's share. */
-int32_t ola_gpu_upload_stats(OlaCtx* ctx, double out[6]);
+ * complete, out[3] bytes, out[4] path (0 pinned staging ring, 1 pageable hipMemcpyAsync: env OLA_UPLOAD),
+ * out[5] copier threads, out[6] bytes that crossed the link (columns whose words are all below 2^32 travel as 32-bit words and are
+ * widened on the device: OLA_UPLOAD_PACK=0 switches that off), out[7] reserved.  On a multi-device context: rank 0's share. */
+int32_t ola_gpu_upload_stats(OlaCtx* ctx, double out[8]);
 /* Self-test of the device field arithmetic: the kernels' modular reduction is written with explicit carry chains in inline
  * assembly (olavm_amd/csrc/gl.cuh); this compares it with the plain C++ reduction on a table of edge values and on `pairs`
  * pseudo-random operand pairs and returns the number of disagreements (0 expected; about 10^9 pairs per 50 ms).  It also runs

@@ -319,10 +319,10 @@ class Backend:
 
     def upload_stats(self):
         """ola_gpu_upload_stats of the last whole proof."""
-        out = (C.c_double * 6)()
+        out = (C.c_double * 8)()
         self._chk(self.lib.ola_gpu_upload_stats(self.ctx, out))
         return {"waited_ms": out[0], "total_ms": out[1], "first_group_ms": out[2], "bytes": int(out[3]),
-                "mode": ("staged", "pageable", "register")[int(out[4])], "threads": int(out[5])}
+                "mode": ("staged", "pageable")[int(out[4])], "threads": int(out[5]), "link_bytes": int(out[6])}
 
     def _chk(self, rc):
         if rc != 0:

@@ -152,7 +152,8 @@ struct UploadStats {
     double total_ms = 0;        // first byte asked for -> last byte on the device
     double first_ms = 0;        // until the first column group was complete
     double bytes = 0;
-    uint32_t mode = 0;          // 0 staged, 1 pageable, 2 registered
+    double link_bytes = 0;      // bytes that crossed the link (narrow columns travel as 32-bit words)
+    uint32_t mode = 0;          // 0 staged, 1 pageable
     uint32_t threads = 0;
 };
 
@@ -197,6 +198,8 @@ struct DeviceCtx {
     // pinned staging ring of the trace upload (upload.h), kept from proof to proof: hipHostMalloc costs milliseconds per 100 MB
     void* staging = nullptr;
     size_t staging_bytes = 0;
+    void* staging_dev = nullptr;               // device side of the narrow-column path (upload.h)
+    size_t staging_dev_bytes = 0;
     UploadStats upload;
     ScopeLog scopes;
     size_t adopted_bytes = 0, adopted_blocks = 0;
@@ -393,6 +396,7 @@ struct DeviceCtx {
         for (auto& kv : live) (void)hipFree(kv.first);
         for (void* p : persistent) (void)hipFree(p);
         if (staging) (void)hipHostFree(staging);
+        if (staging_dev) (void)hipFree(staging_dev);
         if (owns_stream && stream) (void)hipStreamDestroy(stream);
     }
 };

@@ -942,11 +942,12 @@ int32_t ola_gpu_phase_stats(OlaCtx* ctx, double* out, uint32_t n_phases) {
     OLA_CATCH
 }
 
-int32_t ola_gpu_upload_stats(OlaCtx* ctx, double out[6]) {
+int32_t ola_gpu_upload_stats(OlaCtx* ctx, double out[8]) {
     OLA_TRY
     require(ctx && out, "null pointer");
     const UploadStats& u = ctx->dev.upload;
     out[0] = u.waited_ms; out[1] = u.total_ms; out[2] = u.first_ms; out[3] = u.bytes; out[4] = (double)u.mode; out[5] = (double)u.threads;
+    out[6] = u.link_bytes; out[7] = 0;
     OLA_CATCH
 }
 

@@ -13,7 +13,13 @@
 // table t have arrived".  Tables are sent in the order the caller gives (prove_with_traces: small tables first, then the large
 // ones in descending size, so that what is left to do after the last byte is the smallest large table's Merkle tree).
 //   OLA_UPLOAD=staged (default) | pageable (round 4's path: hipMemcpyAsync from the caller's memory, kept as the A/B control)
-//   OLA_UPLOAD_THREADS (default 4), OLA_UPLOAD_PIECE_MB (16), OLA_UPLOAD_SLOTS (8), OLA_UPLOAD_STREAMS (2)
+//   OLA_UPLOAD_THREADS (default 4), OLA_UPLOAD_PIECE_MB (16), OLA_UPLOAD_SLOTS (8), OLA_UPLOAD_STREAMS (2), OLA_UPLOAD_PACK (1)
+// Narrow columns (OLA_UPLOAD_PACK, default on): most columns of an execution trace hold small values -- selectors, opcodes,
+// addresses, clocks, 32-bit limbs.  While a copier thread fills a slot with a piece of ONE column it checks, block by block,
+// whether every word of the piece is below 2^32; if so only the low halves go into the slot, half the bytes cross the link,
+// and a kernel on the upload stream widens them into the prover's buffer (through a small device-side ring).  The first word
+// of 2^32 or more ends the attempt (a column of field-sized values fails in its first block) and the piece travels as 64-bit
+// words.  The device buffer holds the same canonical words either way.
 // Tables that are already in device memory are copied device to device without staging.
 // Not built: hipHostRegister of the caller's columns -- pinning 4.29 GB took 212.8 ms on the test box (50 ms per GB, three
 // times the transfer itself; tools/ubench/h2d_rates.hip, profiles/r05_h2d_rates.txt), and page-rounded registrations take in
@@ -44,6 +50,17 @@ struct TraceSource {
     const u64* col(uint32_t c, size_t n) const { return cols ? cols[c] : base + (size_t)c * n; }
 };
 
+// widens the low halves a copier thread packed into 64-bit words (narrow columns)
+__global__ __launch_bounds__(256) void upload_widen_kernel(const uint32_t* __restrict__ in, u64* __restrict__ out, size_t n) {
+    const size_t i0 = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i0 + 4 <= n) {
+        const uint4 v = *reinterpret_cast<const uint4*>(in + i0);
+        out[i0] = v.x; out[i0 + 1] = v.y; out[i0 + 2] = v.z; out[i0 + 3] = v.w;
+    } else {
+        for (size_t i = i0; i < n; i++) out[i] = in[i];
+    }
+}
+
 class TraceUploader {
   public:
     enum Mode { STAGED = 0, PAGEABLE = 1 };
@@ -54,6 +71,7 @@ class TraceUploader {
         piece_bytes_ = (size_t)env_int("OLA_UPLOAD_PIECE_MB", 16, 1, 256) << 20;
         slots_ = (size_t)env_int("OLA_UPLOAD_SLOTS", 8, 2, 1024);
         nstreams_ = (size_t)env_int("OLA_UPLOAD_STREAMS", 2, 1, 4);
+        pack_ = env_int("OLA_UPLOAD_PACK", 1, 0, 1) != 0;
         const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
         // the ranks of a multi-device context upload side by side: keep the copier threads of all of them within the machine
         const unsigned share = std::max(1u, hw / std::max(1u, ctx->shard.world));
@@ -89,6 +107,7 @@ class TraceUploader {
         t_start_ = std::chrono::steady_clock::now();
         if (mode_ == STAGED && !pieces_.empty()) {
             ensure_ring();
+            if (pack_) ensure_device_ring();
             events_.assign(slots_, nullptr);
             for (auto& e : events_) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
             issued_.reset(new std::atomic<char>[pieces_.size()]);
@@ -111,9 +130,10 @@ class TraceUploader {
         UploadStats& s = ctx_->upload;
         s.waited_ms = waited_ms_; s.total_ms = total_ms_; s.first_ms = first_ms_; s.bytes = (double)bytes_; s.mode = (uint32_t)mode_;
         s.threads = mode_ == STAGED ? nthreads_ : 1;
+        s.link_bytes = mode_ == STAGED ? (double)link_bytes_.load() : (double)bytes_;
         if (ctx_->timing)
-            fprintf(stderr, "[ola-timing] trace upload (%s, %u copier thread(s)): %.2f GB in %.3f ms = %.1f GB/s; the proving thread waited %.3f ms for column groups; first group complete after %.3f ms\n",
-                    mode_ == STAGED ? "pinned staging ring" : "pageable hipMemcpyAsync", s.threads, bytes_ / 1e9, total_ms_,
+            fprintf(stderr, "[ola-timing] trace upload (%s, %u copier thread(s)): %.2f GB of trace (%.2f GB over the link: narrow columns travel as 32-bit words) in %.3f ms = %.1f GB/s of trace; the proving thread waited %.3f ms for column groups; first group complete after %.3f ms\n",
+                    mode_ == STAGED ? "pinned staging ring" : "pageable hipMemcpyAsync", s.threads, bytes_ / 1e9, s.link_bytes / 1e9, total_ms_,
                     total_ms_ > 0 ? bytes_ / 1e6 / total_ms_ : 0.0, waited_ms_, first_ms_);
         if (failed_) throw OlaError(-5, "trace upload failed: " + error_);
     }
@@ -173,6 +193,25 @@ class TraceUploader {
         HIP_CHECK(hipHostMalloc(&ctx_->staging, want, hipHostMallocDefault));
         ctx_->staging_bytes = want;
     }
+    // device side of the narrow-column path: one half-size slot per host slot
+    void ensure_device_ring() {
+        const size_t want = piece_bytes_ / 2 * slots_;
+        if (ctx_->staging_dev && ctx_->staging_dev_bytes >= want) return;
+        if (ctx_->staging_dev) { (void)hipFree(ctx_->staging_dev); ctx_->staging_dev = nullptr; ctx_->staging_dev_bytes = 0; }
+        HIP_CHECK(hipMalloc(&ctx_->staging_dev, want));
+        ctx_->staging_dev_bytes = want;
+    }
+    // low halves of src[0, n) into dst while every word is below 2^32; false (dst garbage) at the first larger one
+    static bool pack_low_halves(uint32_t* __restrict__ dst, const u64* __restrict__ src, size_t n) {
+        const size_t block = 4096;
+        for (size_t b = 0; b < n; b += block) {
+            const size_t e = std::min(n, b + block);
+            u64 hi = 0;
+            for (size_t i = b; i < e; i++) { hi |= src[i]; dst[i] = (uint32_t)src[i]; }
+            if (hi >> 32) return false;
+        }
+        return true;
+    }
     void fail(hipError_t e) {
         std::lock_guard<std::mutex> lk(mu_);
         if (!failed_) { failed_ = true; error_ = hipGetErrorString(e); }
@@ -211,9 +250,22 @@ class TraceUploader {
                 if (e == hipSuccess) e = hipEventRecord(events_[i % slots_], st);
             } else {
                 char* slot = (char*)ctx_->staging + (i % slots_) * piece_bytes_;
-                for (uint32_t c = p.c0; c < p.c1; c++) memcpy(slot + (size_t)(c - p.c0) * p.rows * 8, src_of(p, c), p.rows * 8);
+                const bool narrow = pack_ && p.c1 - p.c0 == 1 && p.rows >= 4096 && pack_low_halves((uint32_t*)slot, src_of(p, p.c0), p.rows);
+                if (!narrow)
+                    for (uint32_t c = p.c0; c < p.c1; c++) memcpy(slot + (size_t)(c - p.c0) * p.rows * 8, src_of(p, c), p.rows * 8);
                 std::lock_guard<std::mutex> lk(issue_mu_);
-                e = hipMemcpyAsync(dst_of(p), slot, bytes_of(p), hipMemcpyHostToDevice, st);
+                if (narrow) {
+                    uint32_t* d32 = (uint32_t*)((char*)ctx_->staging_dev + (i % slots_) * (piece_bytes_ / 2));
+                    e = hipMemcpyAsync(d32, slot, p.rows * 4, hipMemcpyHostToDevice, st);
+                    if (e == hipSuccess) {
+                        hipLaunchKernelGGL(upload_widen_kernel, dim3((unsigned)((p.rows + 1023) / 1024)), dim3(256), 0, st, d32, dst_of(p), p.rows);
+                        e = hipGetLastError();
+                    }
+                    link_bytes_.fetch_add(p.rows * 4);
+                } else {
+                    e = hipMemcpyAsync(dst_of(p), slot, bytes_of(p), hipMemcpyHostToDevice, st);
+                    link_bytes_.fetch_add(bytes_of(p));
+                }
                 if (e == hipSuccess) e = hipEventRecord(events_[i % slots_], st);
             }
             if (e != hipSuccess) fail(e);
@@ -272,6 +324,8 @@ class TraceUploader {
     std::mutex mu_, issue_mu_;
     std::condition_variable cv_;
     std::atomic<size_t> next_{0};
+    std::atomic<size_t> link_bytes_{0};               // what actually crossed the link
+    bool pack_ = true;
     size_t completed_ = 0;                            // pieces retired (guarded by mu_)
     std::atomic<bool> cancel_{false};
     Mode mode_ = STAGED;

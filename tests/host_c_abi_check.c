@@ -45,7 +45,7 @@ static size_t prove_both_ways(uint32_t n_gpus, const uint64_t* airset, size_t ai
     size_t len = 0, len2 = 0, t, c, ok = 1;
     uint8_t* out2 = (uint8_t*)malloc(cap);
     uint64_t*** cols = (uint64_t***)calloc(n_tables, sizeof *cols);
-    double up[6];
+    double up[8];
     if (!out2 || !cols) return 0;
     for (t = 0; t < n_tables && ok; t++) {
         const size_t n = (size_t)1 << log_n[t];

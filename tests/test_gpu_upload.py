@@ -71,6 +71,36 @@ def test_upload_paths_and_ring_geometries_agree(be, oracle, monkeypatch):
             monkeypatch.delenv(k)
 
 
+def test_narrow_columns_travel_as_32_bit_words(be, oracle, monkeypatch):
+    """Columns whose words are all below 2^32 cross the link as 32-bit words and are widened on the device (upload.h); columns with
+    field-sized values (hashes, products, inverses) travel whole, also when the first large word comes late in the column.  An executed
+    program has all three kinds.  Same proof bytes with the packing on and off."""
+    from olavm_amd.air import fastexec
+    blob = T.ola_stark().blob()
+    traces, params, compress = fastexec.instance(M.memory_program(6000), range_bits=16, limb_bits=8, max_steps=1 << 21)
+    assert traces[0].shape[1] == 1 << 17
+    monkeypatch.setenv("OLA_UPLOAD_PIECE_MB", "1")          # a 2^17-row column is 1 MB: every column of the large tables is a piece of its own
+    want = be.prove_with_traces(blob, traces, params, compress)
+    st = be.upload_stats()
+    total = sum(t.size * 8 for t in traces)
+    assert st["bytes"] == total and 0 < st["link_bytes"] < total, st
+    big = [t for t in traces if t.shape[1] >= 1 << 17]
+    wide_from_the_start = sum(int((t[:, :4096] >= (1 << 32)).any(axis=1).sum()) for t in big)
+    wide_later_only = sum(int(((t >= (1 << 32)).any(axis=1) & ~(t[:, :4096] >= (1 << 32)).any(axis=1)).sum()) for t in big)
+    narrow = sum(int((~(t >= (1 << 32)).any(axis=1)).sum()) for t in big)
+    assert wide_from_the_start > 0 and wide_later_only > 0 and narrow > 0, (wide_from_the_start, wide_later_only, narrow)
+    # at least the narrow columns of the large tables were halved (a piece is judged by itself: the narrow first half of a 2^18-row
+    # column whose large words come later travels narrow, too)
+    saved = total - st["link_bytes"]
+    assert sum(int((~(t >= (1 << 32)).any(axis=1)).sum()) * t.shape[1] * 4 for t in big) <= saved < total // 2, st
+    rc, why = oracle.verify_all_proof(blob, want, params)
+    assert rc == 0, why
+    monkeypatch.setenv("OLA_UPLOAD_PACK", "0")
+    assert be.prove_with_traces(blob, traces, params, compress) == want
+    st = be.upload_stats()
+    assert st["link_bytes"] == st["bytes"] == total
+
+
 def test_resident_and_host_tables_mixed_column_by_column(be, oracle):
     import torch
     blob = T.ola_stark(range_bits=4, limb_bits=2).blob()
