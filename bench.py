@@ -80,11 +80,11 @@ def cpu_baseline_prove(be, log_n=14):
 
 def pmc_record(log_n, cols):
     """HBM bytes per launch and VALU instructions per element of the NTT pass kernels from the rocprofv3 PMC record
-    profiles/r04_ntt_pmc.json (tools/pmc_ntt.sh: FETCH_SIZE with the gfx950 x2 correction + WRITE_SIZE + SQ_INSTS_VALU, separate
+    profiles/r05_ntt_pmc.json (tools/pmc_ntt.sh: FETCH_SIZE with the gfx950 x2 correction + WRITE_SIZE + SQ_INSTS_VALU, separate
     passes over the same 94 x 2^22 transform).  bench.py cannot run the profiler on itself; the record carries the hash of the
     kernel sources it was taken from and is used only while those sources are unchanged -- otherwise the fields are null."""
     import hashlib
-    path = os.path.join(ROOT, "profiles", "r04_ntt_pmc.json")
+    path = os.path.join(ROOT, "profiles", "r05_ntt_pmc.json")
     try:
         d = json.load(open(path))
         h = hashlib.sha256()
@@ -94,7 +94,7 @@ def pmc_record(log_n, cols):
             return None
         r = d["ntt_94x2^22"]
         return {"traffic": r["traffic_bytes_per_launch"], "valu_insts_per_element": r["valu_insts_per_element"],
-                "source": f"profiles/r04_ntt_pmc.json ({d['timestamp']}, kernel sources {d['source_sha16']} unchanged)"}
+                "source": f"profiles/r05_ntt_pmc.json ({d['timestamp']}, kernel sources {d['source_sha16']} unchanged)"}
     except (OSError, KeyError, ValueError, TypeError):
         return None
 
@@ -116,7 +116,7 @@ def valu_roofline(rec, log_n, cols, ms_per_transform):
 
 
 VALU_PEAK_GUIDE = 256 * 4 * 2.4e9 / 2.0        # wave64 instructions/s: one per SIMD every 2 cycles (MI355X_MICROARCH.md, SIMD-32)
-POSEIDON_VALU_PER_PERMUTATION = 15.5e3           # SQ_INSTS_VALU per permutation, profiles/r04_ntt_pmc.json (poseidon.cuh unchanged since)
+POSEIDON_VALU_PER_PERMUTATION = 15.5e3           # SQ_INSTS_VALU per permutation, profiles/r05_ntt_pmc.json (poseidon.cuh unchanged since)
 
 
 def partition_projection(st):
@@ -172,8 +172,8 @@ def phase_block(be, hasher="poseidon"):
     if ms > 0:      # quotient row streaming is HBM-class -- bytes = the LDE cells a point reads (local and next row of the trace and Z batches) + 16 written
         out["quotient"] = {"ms": round(ms, 2), "points_per_s_G": round(pts / (ms * 1e-3) / 1e9, 3), "bytes": int(byts),
                            "GBps": round(byts / (ms * 1e-3) / 1e9, 1), "frac": round(byts / (ms * 1e-3) / (HBM_PEAK_GBPS * 1e9), 4), "bound": "hbm (contract); measured: re-loads of trace cells on top of 48 k VALU instructions per point -- "
-                                    "the CPU table's kernel fetches 221 GB per launch for 93 GB algorithmic (profiles/r04_proof_pmc_blake3.txt), "
-                                    "and runs in 44 ms instead of 61 when its loads hit L2 (profiles/r04_quotient_cell_cache.txt)"}
+                                    "the CPU table's kernel issues 611 cell loads per point for 346 distinct cells (758 in round 4: profiles/r05_quotient_belady_order.txt, "
+                                    "per-kernel HBM bytes in profiles/r05_proof_pmc_blake3.txt), and runs in 44 ms when its loads hit L2 (profiles/r04_quotient_cell_cache.txt)"}
     ms, prods, byts = ph["open_eval"]
     if ms > 0:      # every coefficient of every committed polynomial read once per point pair
         out["open_eval"] = {"ms": round(ms, 2), "coefficient_point_products_per_s_G": round(prods / (ms * 1e-3) / 1e9, 2), "bytes": int(byts),

@@ -103,11 +103,16 @@ class TraceUploader {
         HIP_CHECK(hipEventCreateWithFlags(&start_ev_, hipEventDisableTiming));
         HIP_CHECK(hipEventRecord(start_ev_, ctx_->stream));
         for (hipStream_t st : streams_) HIP_CHECK(hipStreamWaitEvent(st, start_ev_, 0));
+        pieces_plan_ = mode_;
         plan();
         t_start_ = std::chrono::steady_clock::now();
         if (mode_ == STAGED && !pieces_.empty()) {
-            ensure_ring();
-            if (pack_) ensure_device_ring();
+            // a host that cannot pin another 128 MB (locked-memory limit) still proves: through the runtime's own staging
+            try { ensure_ring(); } catch (const OlaError&) { (void)hipGetLastError(); mode_ = PAGEABLE; }
+        }
+        if (mode_ == PAGEABLE && !pieces_.empty() && pieces_plan_ == STAGED) { pieces_.clear(); bytes_ = 0; pieces_plan_ = PAGEABLE; plan(); }
+        if (mode_ == STAGED && !pieces_.empty()) {
+            if (pack_) { try { ensure_device_ring(); } catch (const OlaError&) { (void)hipGetLastError(); pack_ = false; } }
             events_.assign(slots_, nullptr);
             for (auto& e : events_) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
             issued_.reset(new std::atomic<char>[pieces_.size()]);
@@ -328,7 +333,7 @@ class TraceUploader {
     bool pack_ = true;
     size_t completed_ = 0;                            // pieces retired (guarded by mu_)
     std::atomic<bool> cancel_{false};
-    Mode mode_ = STAGED;
+    Mode mode_ = STAGED, pieces_plan_ = STAGED;       // pieces_plan_: the mode plan() cut the pieces for
     size_t piece_bytes_ = 0, slots_ = 0, nstreams_ = 2, bytes_ = 0;
     std::vector<size_t> order_;
     unsigned nthreads_ = 1;

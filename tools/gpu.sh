@@ -115,13 +115,13 @@ PY
                    timeout 300 python bench.py --steps 30 --warmup 3 --no-prove --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('  ntt ms', d['ms_per_step'], 'frac', d['roofline']['frac'])"
                    timeout 300 python tools/bench_ntt_matrix.py --log-n 22 --cols 94 --reps 5 --out $O/m_$v.json 2>&1 | grep -E '"op"' | cut -c1-110
                  done 2>&1 | tee $O/ab.txt; cp ab_tmp/libola_cur.so olavm_amd/lib/libola_gpu.so ;;
-    pmc)         bash tools/pmc_ntt.sh r04 2>&1 | tail -30 ;;
+    pmc)         bash tools/pmc_ntt.sh r05 2>&1 | tail -30 ;;
     quot_final)  # after a change to the quotient kernels: the proof tests, the full-size and multi-rank ones, smoke
                  timeout 1500 python -m pytest tests/test_gpu_fullsize.py tests/test_gpu_multi.py tests/test_gpu_pool.py tests/test_gpu_host_api.py -x -q > $O/pytest_full.log 2>&1; grep -E ' passed| failed| error' $O/pytest_full.log | tee $O/pytest.log
                  ;;
     sq_proof)    # SQ issue / stall counters of every kernel of one 2^22-row proof (Blake3 configuration)
                  OLA_HASHER=blake3 bash tools/pmc_sq.sh sq_proof python tools/bench_prove.py 22 1 2>&1 | tail -10 | tee $O/sq.txt ;;
-    pmc_proof)   bash tools/pmc_proof.sh r04 blake3 2>&1 | tail -34; bash tools/pmc_proof.sh r04 poseidon 2>&1 | tail -34 ;;
+    pmc_proof)   bash tools/pmc_proof.sh r05 blake3 2>&1 | tail -34; bash tools/pmc_proof.sh r05 poseidon 2>&1 | tail -34 ;;
     cold_preheat) OLA_COLD_PREHEAT=8 OLA_HASHER=blake3 timeout 300 python tools/cold_phases.py 22 2> $O/cold_b3_preheat.txt >/dev/null; grep "\[cold\]" $O/cold_b3_preheat.txt | head -8 ;;
     cold_b3)     # one figure per call: only the first process on a fresh box sees a cold runtime (and, with luck, clean VRAM)
                  OLA_HASHER=blake3 timeout 300 python tools/cold_phases.py 22 2> $O/cold_b3.txt >/dev/null; grep -E "\[cold\]|trace upload:" $O/cold_b3.txt | head -12 ;;
