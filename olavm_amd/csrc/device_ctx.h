@@ -66,6 +66,7 @@ struct ShardInfo {
 // the caller's TimingTree (integration/rust/hip_prover.rs); bench.py turns it into the breakdown of the replicated share.
 struct ScopeLog {
     struct Rec { std::string name; uint32_t depth, ref_depth; int parent, table; bool ref; hipEvent_t a, b; double start_ms, ms, sharded_ms; };
+    static constexpr size_t kMaxScopes = 4096;     // a 12-table proof opens about 330
     bool on = false;
     std::vector<Rec> recs;
     int open = -1;                 // innermost open scope
@@ -462,7 +463,8 @@ struct PhaseTimer {
     std::chrono::steady_clock::time_point t0;
     int rec = -1;
     PhaseTimer(DeviceCtx* c, const std::string& n) : ctx(c), name(n) {
-        if (ctx->scopes.on) {
+        // (a bound on the list: entry points outside a whole proof open scopes too and nobody resets the list between them)
+        if (ctx->scopes.on && ctx->scopes.recs.size() < ScopeLog::kMaxScopes) {
             ScopeLog& L = ctx->scopes;
             const std::string bare = n.substr(std::min(n.size(), n.find_first_not_of(' ')));
             ScopeLog::Rec r{bare, L.depth, L.ref_depth, L.open, L.table, ScopeLog::is_reference_scope(bare), ctx->acct.get(), nullptr, 0, 0, 0};
