@@ -46,6 +46,25 @@ def test_emission_order_and_kinds_equal_the_reference_source(golden):
         assert len(ours.permutation_pairs) == ref["permutation_pairs"], ref["table"]
 
 
+def test_cells_the_reference_names_directly_are_read_by_the_same_constraint_here(golden):
+    """For 403 of the 669 constraints the walker could read trace cells straight off the argument of the reference's `yield_constr` call
+    (`lv[COL_X]`, `wrapper.nv[COL_Y.start + i]`: 905 cells, indices evaluated from the source's constants and loop variables).  Each of
+    them must be a cell the transcription's expression for THAT emit reads -- a swapped column or a local / next mix-up in a direct
+    reference, or an emit attached to the wrong expression, fails here."""
+    from olavm_amd.air import codegen
+    stark = T.ola_stark()
+    named = 0
+    for ours, ref in zip(stark.tables, golden["tables"]):
+        full = codegen._emit_cells(ours)
+        assert len(full) == len(ref["emit_direct_cells"])
+        for i, cells in enumerate(ref["emit_direct_cells"]):
+            have = {r + str(c) for r, c in full[i]}
+            for c in cells:
+                assert c in have, f"{ref['table']}: emit {i} ({ref['emit_sites'][i]}) names {c} in the reference; the transcription's emit {i} reads {sorted(have)}"
+                named += 1
+    assert named == 905
+
+
 def test_the_blob_the_library_reads_carries_the_same_header(golden):
     """include/ola_airset.bin (what the Rust shim embeds, integration/rust/build.rs) = AirSet.blob(): table headers word for word"""
     import numpy as np
@@ -103,4 +122,11 @@ def test_the_walker_notices_a_changed_loop_bound_and_a_swapped_kind(tmp_path):
     X.Src.cache.clear()
     changed = {t["table"]: t["emit_kinds"] for t in X.extract(str(ref))["tables"]}
     assert changed["Tape"] != base["Tape"] and len(changed["Tape"]) == len(base["Tape"])
+    # a direct reference to another column is read as such
+    q.write_text(s.replace("nv[COL_TAPE_IS_INIT_SEG]", "nv[COL_TAPE_OPCODE]", 1))
+    X.Src.cache.clear()
+    cells0 = X.extract("/root/reference")["tables"][8]["emit_direct_cells"]
+    X.Src.cache.clear()
+    cells1 = X.extract(str(ref))["tables"][8]["emit_direct_cells"]
+    assert cells0 != cells1
     X.Src.cache.clear()

@@ -15,7 +15,10 @@ functions they call: the `cpu/*.rs` opcode files, `lookup.rs`) as a Rust-subset 
   * calls that pass the consumer on (`Self::constraint_ext_lines(&wrapper, yield_constr)`, `mov::eval_packed_generic(lv, nv, yield_constr)`,
     `eval_lookups(vars, yield_constr, a, b)`) -> the callee's body, found by name in the reference tree.
 
-Everything else (the arithmetic inside a constraint) is skipped: it is pinned by other means (golden rows, executed programs, the
+Of the arithmetic inside a constraint one thing is read: the trace cells its argument names DIRECTLY (`lv[COL_X]`,
+`wrapper.nv[COL_Y.start + i]`, indices evaluated from constants and loop variables) -- a subset of the cells the constraint reads
+(values that arrive through local variables are not followed), compared with the transcription's expression for the same emit.
+Everything else (the arithmetic itself) is skipped: it is pinned by other means (golden rows, executed programs, the
 verifier's extension-field evaluation; PARITY.md).  Per table the script also reads `COLUMNS`, `constraint_degree()`, the number of
 `PermutationPair`s, and from stark/ola_stark.rs:122-560 the cross-table lookups: per CTL the looked table and how many looking
 entries each table contributes.
@@ -116,6 +119,7 @@ class Ref:
         for base in (self.root, os.path.join(root, "core", "src"), os.path.join(root, "plonky2", "plonky2", "src", "hash")):
             for d, _, fs in os.walk(base):
                 self.files += [os.path.join(d, f) for f in sorted(fs) if f.endswith(".rs")]
+        self.values = {}          # (name, file) -> evaluated constant
         self.consts = {}          # name -> [(file, expression tokens)]
         for f in self.files:
             s = Src.get(f)
@@ -200,7 +204,10 @@ class Walker:
         c = self.ref.near(cands, src.path)
         if c is None:
             raise Unsupported(f"{src.path}: constant {name} is defined differently in {[x[0] for x in cands]}")
-        return self.expr(c[1], Src.get(c[0]), {})
+        key = (name, c[0])
+        if key not in self.ref.values:
+            self.ref.values[key] = self.expr(c[1], Src.get(c[0]), {})
+        return self.ref.values[key]
 
     def expr(self, toks, src, env):
         """value of a constant expression (int, bool or R) given as [(text, line)]"""
@@ -630,13 +637,14 @@ class Walker:
                 e = src.match(i + 3)
                 if self.has_emit(src, i + 4, e, consumer):
                     raise Unsupported(f"{src.path}:{line}: a constraint inside a constraint's argument")
-                self.emits.append((self.emit_names[T[i + 2][0]], os.path.relpath(src.path, self.ref.root), line))
+                self.emits.append((self.emit_names[T[i + 2][0]], os.path.relpath(src.path, self.ref.root), line, self.direct_cells(src, i + 4, e, env)))
                 i = e + 1
             elif t == "." and T[i + 1][0] == "for_each" and T[i + 2][0] == "(":
                 e = src.match(i + 2)
                 if self.has_emit(src, i + 3, e, consumer):
                     its = self.items(T[stmt:i], src, fn_range, env, stmt)
                     k = i + 3
+                    param = None
                     if T[k][0] == "move":
                         k += 1
                     if T[k][0] == "||":
@@ -644,15 +652,21 @@ class Walker:
                     else:
                         assert T[k][0] == "|", f"{src.path}:{line}: closure expected"
                         k += 1
+                        p0 = k
                         while T[k][0] != "|":
                             k = src.match(k) if T[k][0] in "([" else k
                             k += 1
+                        if k - p0 == 1 and re.match(r"^[a-z_]\w*$", T[p0][0]):
+                            param = T[p0][0]          # |col| over a range: the closure's argument is the integer
                         k += 1
-                    for _ in range(its.n):
+                    for n in range(its.n):
+                        env2 = dict(env)
+                        if param and its.ints is not None:
+                            env2[param] = its.ints[n]
                         if T[k][0] == "{":
-                            self.block(src, k + 1, src.match(k), env, fn_range, consumer)
+                            self.block(src, k + 1, src.match(k), env2, fn_range, consumer)
                         else:
-                            self.block(src, k, e, env, fn_range, consumer)
+                            self.block(src, k, e, env2, fn_range, consumer)
                 i = e + 1
             elif t == "|" and i > lo and T[i - 1][0] in ("(", ",", "=") and self.closure_with_emit(src, i, hi, consumer):
                 raise Unsupported(f"{src.path}:{line}: a closure other than for_each's emits constraints")
@@ -682,6 +696,27 @@ class Walker:
                     stmt = i
             else:
                 i += 1
+
+    ROWS = {"lv": "L", "local_values": "L", "nv": "N", "next_values": "N"}
+
+    def direct_cells(self, src, lo, hi, env):
+        """Trace cells a constraint's argument names DIRECTLY -- `lv[COL_X]`, `wrapper.nv[COL_Y.start + i]`, `vars.local_values[..]` with an
+        index that evaluates from constants and loop variables.  Values that reach the constraint through a local variable are not
+        followed: this is a subset of the cells the constraint reads, enough to catch a column mix-up in a direct reference."""
+        T = src.toks
+        out = set()
+        i = lo
+        while i < hi:
+            if T[i][0] == "[" and i > lo and T[i - 1][0] in self.ROWS:
+                e = src.match(i)
+                try:
+                    v = self.expr(T[i + 1:e], src, env)
+                    if isinstance(v, int) and not isinstance(v, bool):
+                        out.add(self.ROWS[T[i - 1][0]] + str(v))
+                except Unsupported:
+                    pass
+            i += 1
+        return sorted(out, key=lambda c: (c[0], int(c[1:])))
 
     def closure_with_emit(self, src, i, hi, consumer):
         """does the closure whose parameter list opens at i mention the consumer in its body?"""
@@ -732,7 +767,8 @@ def table_facts(ref, name, rel):
     consumer = w.consumer_of(src, start)
     w.stack.append((os.path.realpath(path), "eval_packed_generic"))
     w.block(src, body[0] + 1, body[1], {}, body, consumer)
-    facts = {"file": rel, "emit_kinds": [k for k, _, _ in w.emits], "emit_sites": ["%s:%d" % (f, l) for _, f, l in w.emits]}
+    facts = {"file": rel, "emit_kinds": [k for k, _, _, _ in w.emits], "emit_sites": ["%s:%d" % (f, l) for _, f, l, _ in w.emits],
+             "emit_direct_cells": [c for _, _, _, c in w.emits]}
     # COLUMNS, constraint_degree(), permutation pairs
     for i, (t, _) in enumerate(T):
         if t == "const" and T[i + 1][0] == "COLUMNS":
@@ -855,7 +891,9 @@ def main():
     for t in data["tables"]:
         if "emit_kinds" in t:
             c = Counter(t["emit_kinds"])
-            print("%-14s %4d emits %s  columns %s degree %s permutation pairs %s" % (t["table"], len(t["emit_kinds"]), dict(c), t.get("columns"), t.get("constraint_degree"), t.get("permutation_pairs")))
+            named = sum(1 for x in t["emit_direct_cells"] if x)
+            print("%-14s %4d emits %s  columns %s degree %s permutation pairs %s; %d emits name %d cells directly" % (
+                t["table"], len(t["emit_kinds"]), dict(c), t.get("columns"), t.get("constraint_degree"), t.get("permutation_pairs"), named, sum(len(x) for x in t["emit_direct_cells"])))
         else:
             print("%-14s NOT WALKED: %s" % (t["table"], t["unwalked"]))
     print(len(data["cross_table_lookups"]), "cross-table lookups,", sum(sum(c["looking"].values()) for c in data["cross_table_lookups"]), "looking entries")
