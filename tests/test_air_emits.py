@@ -47,8 +47,9 @@ def test_emission_order_and_kinds_equal_the_reference_source(golden):
 
 
 def test_cells_the_reference_names_directly_are_read_by_the_same_constraint_here(golden):
-    """For 403 of the 669 constraints the walker could read trace cells straight off the argument of the reference's `yield_constr` call
-    (`lv[COL_X]`, `wrapper.nv[COL_Y.start + i]`: 905 cells, indices evaluated from the source's constants and loop variables).  Each of
+    """For 495 of the 669 constraints the walker could read trace cells off the argument of the reference's `yield_constr` call, directly or
+    through immutable locals of the same function (`lv[COL_X]`, `wrapper.nv[COL_Y.start + i]`, `let lv_is_padding = lv[COL_IS_PADDING]`:
+    1 309 cells, indices evaluated from the source's constants and loop variables).  Each of
     them must be a cell the transcription's expression for THAT emit reads -- a swapped column or a local / next mix-up in a direct
     reference, or an emit attached to the wrong expression, fails here."""
     from olavm_amd.air import codegen
@@ -62,7 +63,7 @@ def test_cells_the_reference_names_directly_are_read_by_the_same_constraint_here
             for c in cells:
                 assert c in have, f"{ref['table']}: emit {i} ({ref['emit_sites'][i]}) names {c} in the reference; the transcription's emit {i} reads {sorted(have)}"
                 named += 1
-    assert named == 905
+    assert named == 1309
 
 
 def test_the_blob_the_library_reads_carries_the_same_header(golden):

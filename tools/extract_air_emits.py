@@ -637,7 +637,7 @@ class Walker:
                 e = src.match(i + 3)
                 if self.has_emit(src, i + 4, e, consumer):
                     raise Unsupported(f"{src.path}:{line}: a constraint inside a constraint's argument")
-                self.emits.append((self.emit_names[T[i + 2][0]], os.path.relpath(src.path, self.ref.root), line, self.direct_cells(src, i + 4, e, env)))
+                self.emits.append((self.emit_names[T[i + 2][0]], os.path.relpath(src.path, self.ref.root), line, self.direct_cells(src, i + 4, e, env, fn_range)))
                 i = e + 1
             elif t == "." and T[i + 1][0] == "for_each" and T[i + 2][0] == "(":
                 e = src.match(i + 2)
@@ -699,15 +699,18 @@ class Walker:
 
     ROWS = {"lv": "L", "local_values": "L", "nv": "N", "next_values": "N"}
 
-    def direct_cells(self, src, lo, hi, env):
-        """Trace cells a constraint's argument names DIRECTLY -- `lv[COL_X]`, `wrapper.nv[COL_Y.start + i]`, `vars.local_values[..]` with an
-        index that evaluates from constants and loop variables.  Values that reach the constraint through a local variable are not
-        followed: this is a subset of the cells the constraint reads, enough to catch a column mix-up in a direct reference."""
+    def direct_cells(self, src, lo, hi, env, fn_range=None, depth=0, upto=None):
+        """Trace cells a constraint's argument names -- `lv[COL_X]`, `wrapper.nv[COL_Y.start + i]`, `vars.local_values[..]` with an index
+        that evaluates from constants and loop variables -- directly or through immutable locals of the same function
+        (`let lv_is_padding = lv[COL_IS_PADDING];`: the initialiser is scanned the same way).  Mutable variables, struct fields and
+        function results are not followed: this is a subset of the cells the constraint reads, enough to catch a column mix-up."""
         T = src.toks
         out = set()
+        upto = lo if upto is None else upto
         i = lo
         while i < hi:
-            if T[i][0] == "[" and i > lo and T[i - 1][0] in self.ROWS:
+            t = T[i][0]
+            if t == "[" and i > lo and T[i - 1][0] in self.ROWS:
                 e = src.match(i)
                 try:
                     v = self.expr(T[i + 1:e], src, env)
@@ -715,6 +718,22 @@ class Walker:
                         out.add(self.ROWS[T[i - 1][0]] + str(v))
                 except Unsupported:
                     pass
+            elif fn_range is not None and depth < 6 and re.match(r"^[a-z_]\w*$", t) and t not in self.ROWS and t not in env and \
+                    T[i - 1][0] not in (".", "::") and T[i + 1][0] not in ("(", "::", "!", "["):
+                # an immutable local of this function, defined before the use: follow its initialiser
+                best = None
+                for k in range(fn_range[0], upto):
+                    if T[k][0] == "let" and T[k + 1][0] == t and T[k + 2][0] in ("=", ":"):
+                        best = k
+                if best is not None:
+                    k = best + 2
+                    while T[k][0] != "=":
+                        k += 1
+                    e = k + 1
+                    while T[e][0] != ";":
+                        e = src.match(e) if T[e][0] in "([{" else e
+                        e += 1
+                    out |= set(self.direct_cells(src, k + 1, e, env, fn_range, depth + 1, best))
             i += 1
         return sorted(out, key=lambda c: (c[0], int(c[1:])))
 
