@@ -84,8 +84,8 @@ def test_cross_table_lookups_equal_the_reference_source(golden):
     stark = T.ola_stark()
     assert len(stark.ctls) == len(golden["cross_table_lookups"])
     for ours, ref in zip(stark.ctls, golden["cross_table_lookups"]):
-        assert ours.looked_table.table == TABLE_INDEX[ref["looked"]], ref["name"]
-        seq = [TABLE_INDEX[tab] for tab, _, mult in ref["looking_in_source_order"] for _ in range(mult)]
+        assert ours.looked_table.table == TABLE_INDEX[ref["looked"]["table"]], ref["name"]
+        seq = [TABLE_INDEX[r["table"]] for r in ref["looking_in_source_order"]]
         assert [t.table for t in ours.looking_tables] == seq, ref["name"]
         assert sum(ref["looking"].values()) == len(ours.looking_tables)
 
@@ -131,3 +131,30 @@ def test_the_walker_notices_a_changed_loop_bound_and_a_swapped_kind(tmp_path):
     cells1 = X.extract(str(ref))["tables"][8]["emit_direct_cells"]
     assert cells0 != cells1
     X.Src.cache.clear()
+
+
+def test_lookup_columns_equal_the_columns_the_references_functions_name(golden):
+    """Per TableWithColumns the reference constructs (19 looked + 69 looking entries, stark/ola_stark.rs:146-560): the column indices its
+    `ctl_data_*` and `ctl_filter_*` functions name -- every constant expression of the function's body evaluated from the source, with
+    the entry's argument bound (`ctl_data_with_mem_src(3)`) -- against the columns the transcription's entry reads.  Equal where the
+    function names exactly what it returns (80 of 88 entries); a subset where the body selects among named columns (`match i`)."""
+    stark = T.ola_stark()
+
+    def cols_of(cols):
+        return {int(c) for col in cols for c, _ in col.terms}
+
+    checked = exact = 0
+    for ours, ref in zip(stark.ctls, golden["cross_table_lookups"]):
+        pairs = [(ours.looked_table, ref["looked"])] + list(zip(ours.looking_tables, ref["looking_in_source_order"]))
+        assert len(pairs) == 1 + len(ours.looking_tables) == 1 + len(ref["looking_in_source_order"])
+        for twc, r in pairs:
+            assert twc.table == TABLE_INDEX[r["table"]], (ref["name"], r["data_fn"])
+            have, want = cols_of(twc.columns), set(r["data_columns"])
+            assert have <= want and (have == want or not r["data_exact"]), (ref["name"], r["data_fn"], sorted(have), sorted(want))
+            assert (twc.filter_column is None) == ("filter_fn" not in r), (ref["name"], r["data_fn"])
+            if twc.filter_column is not None:
+                have, want = cols_of([twc.filter_column]), set(r["filter_columns"])
+                assert have <= want and (have == want or not r["filter_exact"]), (ref["name"], r["filter_fn"], sorted(have), sorted(want))
+            checked += 1
+            exact += bool(r["data_exact"] and r.get("filter_exact", True))
+    assert checked == 88 and exact >= 80

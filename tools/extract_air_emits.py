@@ -811,42 +811,132 @@ def table_facts(ref, name, rel):
     return facts
 
 
+def named_columns(ref, path, fn_name, argval):
+    """Column indices a `ctl_data_*` / `ctl_filter_*` function of the reference names: every constant expression of its body (`COL_X`,
+    `COL_R.start + i`, a range `A..B` or a bare range constant = all of its columns) evaluated with the function's usize parameter bound to `argval`.
+    -> (sorted indices, exact): exact is False when the body selects among the named columns (`match`, `skip`, `take`, `filter`, `if`):
+    the set is then an upper bound of what the returned columns read."""
+    src = Src.get(path)
+    T = src.toks
+    params, body = src.functions()[fn_name]
+    w = Walker(ref)
+    env = {}
+    ptoks = [t for t, _ in T[params[0] + 1:params[1]]]
+    if "usize" in ptoks and ":" in ptoks:
+        env[ptoks[ptoks.index(":") - 1]] = argval if argval is not None else 0
+    cols, exact = set(), True
+    i = body[0] + 1
+    while i < body[1]:
+        t = T[i][0]
+        if t in ("match", "skip", "take", "filter", "if", "step_by"):
+            exact = False
+        if re.match(r"^[A-Z][A-Z0-9_]*$", t) and T[i - 1][0] != "::" and T[i + 1][0] != "::":
+            # the longest run of tokens from here that still evaluates: CONST (.start | .end)? ((+|-) term)*
+            j, best = i + 1, None
+            while j <= body[1]:
+                try:
+                    v = w.expr(T[i:j], src, env)
+                    best = (j, v)
+                except (Unsupported, TypeError, AttributeError, KeyError):
+                    pass
+                if j < body[1] and (T[j][0] in (".", "start", "end", "+", "-", "..") or re.match(r"^\d", T[j][0]) or T[j][0] in env or re.match(r"^[A-Z][A-Z0-9_]*$", T[j][0])):
+                    j += 1
+                else:
+                    break
+            if best is not None:
+                j, v = best
+                if isinstance(v, R):
+                    cols |= set(range(v.start, v.end))
+                elif isinstance(v, int) and not isinstance(v, bool):
+                    cols.add(v)
+                i = j
+                continue
+        i += 1
+    return sorted(cols), exact
+
+
 def ctl_facts(ref):
-    """stark/ola_stark.rs: per cross-table lookup, in all_cross_table_lookups() order: looked table, looking entries per table"""
+    """stark/ola_stark.rs: per cross-table lookup, in all_cross_table_lookups() order: looked table, looking entries per table, and per
+    entry the columns its data / filter functions name"""
     path = os.path.join(ref.root, "stark", "ola_stark.rs")
     src = Src.get(path)
     T = src.toks
     fns = src.functions()
     lo, hi = fns["all_cross_table_lookups"][1]
     names = [T[i][0] for i in range(lo, hi) if re.match(r"^ctl_\w+$", T[i][0]) and T[i + 1][0] == "("]
+
+    def call_of(toks):
+        """`Some(cpu_stark::ctl_filter_x(i))` / `mem_ctl_data()` / `None` -> (module or None, function, has an argument) or None"""
+        names_ = [t for t, _ in toks]
+        if names_ == ["None"]:
+            return None
+        if names_[0] == "Some":
+            names_ = names_[2:-1]
+        k = names_.index("(")
+        path_ = [x for x in names_[:k] if x != "::"]
+        if len(path_) == 1 and path_[0] in imports:
+            path_ = list(imports[path_[0]])
+        return (path_[-2] if len(path_) > 1 else None, path_[-1], names_[k + 1] != ")")
+
+    # `use crate::memory::memory_stark::{self, ctl_data as mem_ctl_data, ctl_filter as mem_ctl_filter};`: local name -> (module, name there)
+    imports = {}
+    i = 0
+    while i < len(T):
+        if T[i][0] == "use":
+            j = i + 1
+            path_ = []
+            while T[j][0] not in (";", "{"):
+                if T[j][0] != "::":
+                    path_.append(T[j][0])
+                j += 1
+            if T[j][0] == "{":
+                e = src.match(j)
+                for item in Walker(ref).split(T[j + 1:e]):
+                    it = [t for t, _ in item]
+                    if len(it) == 3 and it[1] == "as":
+                        imports[it[2]] = (path_[-1], it[0])
+                    elif len(it) == 1 and it[0] != "self":
+                        imports[it[0]] = (path_[-1], it[0])
+                j = e
+            elif len(path_) >= 2:
+                imports[path_[-1]] = (path_[-2], path_[-1])
+            i = j
+        i += 1
+
+    def file_of(module, fn):
+        cands = [f for f in ref.files if fn in Src.get(f).functions() and (module is None or os.path.basename(f) == module + ".rs")]
+        cands = [f for f in cands if os.path.realpath(f).startswith(os.path.realpath(ref.root))]
+        if len(cands) != 1:
+            raise Unsupported(f"{path}: {module}::{fn} resolves to {cands}")
+        return cands[0]
+
     out = []
     for name in names:
         blo, bhi = fns[name][1]
         w = Walker(ref)
 
-        def count(a, b, mult, looking):
-            """TableWithColumns::new(Table::X ...) occurrences between a and b, times the ranges they are mapped over"""
+        def count(a, b, argvals, looking):
+            """TableWithColumns::new(Table::X ...) occurrences between a and b, with the values the enclosing `(A..B).map(|i| ..)` feeds them"""
             i = a
             while i < b:
                 if T[i][0] == "(" and T[i + 1][0] not in (")",) and i + 2 < b:
                     # `(A..B).map(|i| { ... })` / `.for_each`: the closure runs once per item (the result is consumed by extend / collect)
                     e = src.match(i)
                     if e + 3 < b and T[e + 1][0] == "." and T[e + 2][0] in ("map", "for_each", "flat_map") and any(x[0] == ".." for x in T[i + 1:e]):
-                        n = w.items(T[i:e + 1], src, (blo, bhi), {}, i).n
+                        its = w.items(T[i:e + 1], src, (blo, bhi), {}, i)
+                        if argvals != [None] or its.ints is None:
+                            raise Unsupported(f"{path}:{T[i][1]}: nested or unevaluable map around TableWithColumns")
                         ce = src.match(e + 3)
-                        count(e + 4, ce, mult * n, looking)
+                        count(e + 4, ce, list(its.ints), looking)
                         i = ce + 1
                         continue
                 if T[i][0] == "TableWithColumns" and T[i + 1][0] == "::" and T[i + 2][0] == "new" and T[i + 3][0] == "(" and T[i + 4][0] == "Table":
-                    # Table::X, then the data-columns function: `cpu_stark::ctl_data_cpu_mem_sccall(i)` -> its name
-                    j = i + 8
-                    while T[j + 1][0] == "::":
-                        j += 2
-                    looking.append((T[i + 6][0], mult, i, T[j][0]))
+                    args = w.split(T[i + 4:src.match(i + 3)])
+                    looking.append({"table": T[i + 6][0], "tok": i, "args": argvals, "data": call_of(args[1]), "filter": call_of(args[2])})
                 i += 1
 
         found = []
-        count(blo, bhi, 1, found)
+        count(blo, bhi, [None], found)
         # the looked table: second argument of CrossTableLookup::new
         idx = [i for i in range(blo, bhi) if T[i][0] == "CrossTableLookup" and T[i + 2][0] == "new"]
         if len(idx) != 1:
@@ -867,17 +957,32 @@ def ctl_facts(ref):
                     looked_tok = j
             if looked_tok is None:
                 raise Unsupported(f"{path}: {name}: looked table `{var}` not found")
-        looked = [f for f in found if f[2] == looked_tok]
-        if len(looked) != 1 or looked[0][1] != 1:
+        looked = [f for f in found if f["tok"] == looked_tok]
+        if len(looked) != 1 or looked[0]["args"] != [None]:
             raise Unsupported(f"{path}: {name}: cannot identify the looked table")
+
+        def entry(f):
+            """one record per TableWithColumns the reference constructs: the columns its data and filter functions name"""
+            recs = []
+            for av in f["args"]:
+                m, fn, has = f["data"]
+                dcols, dexact = named_columns(ref, file_of(m, fn), fn, av if has else None)
+                r = {"table": f["table"], "data_fn": fn + ("(%d)" % av if has and av is not None else "()"), "data_columns": dcols, "data_exact": dexact}
+                if f["filter"] is not None:
+                    m, fn, has = f["filter"]
+                    fcols, fexact = named_columns(ref, file_of(m, fn), fn, av if has else None)
+                    r.update({"filter_fn": fn + ("(%d)" % av if has and av is not None else "()"), "filter_columns": fcols, "filter_exact": fexact})
+                recs.append(r)
+            return recs
+
         cnt = Counter()
-        for tab, mult, tok, _ in found:
-            if tok != looked_tok:
-                cnt[tab] += mult
+        for f in found:
+            if f["tok"] != looked_tok:
+                cnt[f["table"]] += len(f["args"])
         # in the order the entries are written down in the function (every ctl_* builds its vector in that order: a `vec![..]` literal,
         # or lets followed by extend / chain in the same sequence)
-        order = [[tab, data_fn, mult] for tab, mult, tok, data_fn in found if tok != looked_tok]
-        out.append({"name": name, "looked": looked[0][0], "looked_data_fn": looked[0][3], "looking": dict(sorted(cnt.items())), "looking_in_source_order": order})
+        order = [r for f in found if f["tok"] != looked_tok for r in entry(f)]
+        out.append({"name": name, "looked": entry(looked[0])[0], "looking": dict(sorted(cnt.items())), "looking_in_source_order": order})
     return out
 
 
