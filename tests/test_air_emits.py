@@ -44,6 +44,8 @@ def test_emission_order_and_kinds_equal_the_reference_source(golden):
         assert ours.ncols == ref["columns"], ref["table"]
         assert ours.constraint_degree == ref["constraint_degree"], ref["table"]
         assert len(ours.permutation_pairs) == ref["permutation_pairs"], ref["table"]
+        if ref["permutation_pairs"]:       # PermutationPair::singletons(lhs, rhs), both columns evaluated from the source
+            assert [[list(map(int, p)) for p in pair] for pair in ours.permutation_pairs] == [[pr] for pr in ref["permutation_pair_columns"]], ref["table"]
 
 
 def test_cells_the_reference_names_directly_are_read_by_the_same_constraint_here(golden):

@@ -806,6 +806,14 @@ def table_facts(ref, name, rel):
     if "permutation_pairs" in fns:
         lo, hi = fns["permutation_pairs"][1]
         facts["permutation_pairs"] = sum(1 for i in range(lo, hi) if T[i][0] == "PermutationPair" and T[i + 1][0] == "::" and T[i + 2][0] in ("singletons", "new"))
+        # PermutationPair::singletons(lhs, rhs): the two columns, evaluated
+        pairs = []
+        for i in range(lo, hi):
+            if T[i][0] == "PermutationPair" and T[i + 1][0] == "::" and T[i + 2][0] == "singletons" and T[i + 3][0] == "(":
+                a, b = w.split(T[i + 4:src.match(i + 3)])
+                pairs.append([w.expr(a, src, {}), w.expr(b, src, {})])
+        if len(pairs) == facts["permutation_pairs"]:
+            facts["permutation_pair_columns"] = pairs
         if any(T[i][0] in ("for", "map", "for_each", "extend") for i in range(lo, hi)):
             raise Unsupported(f"{path}: permutation_pairs() builds its list in a loop")
     return facts
