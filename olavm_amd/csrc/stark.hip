@@ -1144,7 +1144,14 @@ void prove_with_traces(DeviceCtx* ctx, NttTables& tables, const OlaGpuConfig& cf
         feed.chunk_cols = up.chunk_cols(t);
         feed.before_chunk = [&, t, n_t](uint32_t c0, uint32_t c1) {
             up.wait(t, c1);
-            canonicalize(ctx, dev[t].vals + (size_t)c0 * n_t, (size_t)(c1 - c0) * n_t);
+            // columns that crossed the link as 32-bit words are canonical as they arrive: only runs of the others are reduced
+            for (uint32_t c = c0; c < c1;) {
+                if (up.column_is_narrow(t, c)) { c++; continue; }
+                uint32_t e = c + 1;
+                while (e < c1 && !up.column_is_narrow(t, e)) e++;
+                canonicalize(ctx, dev[t].vals + (size_t)c * n_t, (size_t)(e - c) * n_t);
+                c = e;
+            }
         };
         commits[t].reset(new BatchHolder(ctx));
         if (cpr[t]) {

@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) void upload_widen_kernel(const uint32_t* __res
 class TraceUploader {
   public:
     enum Mode { STAGED = 0, PAGEABLE = 1 };
-    TraceUploader(DeviceCtx* ctx, size_t ntables) : ctx_(ctx), jobs_(ntables), done_(ntables) {
+    TraceUploader(DeviceCtx* ctx, size_t ntables) : ctx_(ctx), jobs_(ntables), done_(ntables), narrow_(ntables) {
         for (auto& d : done_) d.store(0);
         const char* m = getenv("OLA_UPLOAD");
         mode_ = (m && !strcmp(m, "pageable")) ? PAGEABLE : STAGED;
@@ -90,7 +90,11 @@ class TraceUploader {
         const size_t target = (size_t)64 << 20;
         uint32_t cc = (uint32_t)std::max<size_t>(1, target / (n * 8));
         jobs_[t] = {src, first, dst, ncols, n, std::max(1u, std::min(cc, ncols))};      // ncols may be 0: a rank without columns of its own
+        narrow_[t].reset(new std::atomic<char>[ncols ? ncols : 1]);
+        for (uint32_t c = 0; c < ncols; c++) narrow_[t][c].store(1);
     }
+    // after wait(t, c + 1): every word of column c went over the link as a 32-bit word, i.e. the column holds canonical values already
+    bool column_is_narrow(size_t t, uint32_t c) const { return mode_ == STAGED && pack_ && narrow_[t] && narrow_[t][c].load() != 0; }
     // granularity the proving thread should ask in (about 64 MB of columns)
     uint32_t chunk_cols(size_t t) const { return jobs_[t].chunk; }
     // tables are sent in this order (default: as numbered)
@@ -250,14 +254,20 @@ class TraceUploader {
             hipStream_t st = streams_[i % streams_.size()];
             if (p.device_src) {
                 std::lock_guard<std::mutex> lk(issue_mu_);
-                for (uint32_t c = p.c0; c < p.c1 && e == hipSuccess; c++)
+                for (uint32_t c = p.c0; c < p.c1 && e == hipSuccess; c++) {
+                    narrow_[p.table][c].store(0);
                     e = hipMemcpyAsync(dst_of(p) + (size_t)(c - p.c0) * p.rows, src_of(p, c), p.rows * 8, hipMemcpyDeviceToDevice, st);
+                }
                 if (e == hipSuccess) e = hipEventRecord(events_[i % slots_], st);
             } else {
                 char* slot = (char*)ctx_->staging + (i % slots_) * piece_bytes_;
                 const bool narrow = pack_ && p.c1 - p.c0 == 1 && p.rows >= 4096 && pack_low_halves((uint32_t*)slot, src_of(p, p.c0), p.rows);
-                if (!narrow)
-                    for (uint32_t c = p.c0; c < p.c1; c++) memcpy(slot + (size_t)(c - p.c0) * p.rows * 8, src_of(p, c), p.rows * 8);
+                if (!narrow) {
+                    for (uint32_t c = p.c0; c < p.c1; c++) {
+                        memcpy(slot + (size_t)(c - p.c0) * p.rows * 8, src_of(p, c), p.rows * 8);
+                        narrow_[p.table][c].store(0);
+                    }
+                }
                 std::lock_guard<std::mutex> lk(issue_mu_);
                 if (narrow) {
                     uint32_t* d32 = (uint32_t*)((char*)ctx_->staging_dev + (i % slots_) * (piece_bytes_ / 2));
@@ -322,6 +332,7 @@ class TraceUploader {
     std::vector<Job> jobs_;
     std::vector<Piece> pieces_;
     std::vector<std::atomic<uint32_t>> done_;
+    std::vector<std::unique_ptr<std::atomic<char>[]>> narrow_;   // per table and column: every piece of it travelled narrow
     std::unique_ptr<std::atomic<char>[]> issued_;     // per piece: 0 not yet, 1 sent, 2 given up
     std::vector<hipEvent_t> events_;                  // per slot
     std::vector<std::thread> copiers_;

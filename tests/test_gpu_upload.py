@@ -148,6 +148,14 @@ def test_timed_scopes_come_back_with_device_times(be, oracle):
     total = [s for s in sc if s["name"] == "prove_with_traces total"]
     assert len(total) == 1 and total[0]["depth"] == 0
     assert all(s["start_ms"] + s["ms"] <= total[0]["start_ms"] + total[0]["ms"] + 1e-2 for s in sc)
+    # a buffer that is too small is refused and the count comes back
+    import ctypes as C
+    from olavm_amd.backend import OlaScopeTime
+    n = C.c_uint32()
+    small = (OlaScopeTime * 3)()
+    be.scope_times(enable=True)
+    be.prove_with_traces(blob, traces, params, compress)
+    assert be.lib.ola_gpu_scope_times(be.ctx, 0, small, 3, C.byref(n)) == -1 and n.value == len(sc)
     # switched off again: the next proof leaves no scopes behind
     be.prove_with_traces(blob, traces, params, compress)
     assert be.scope_times() == []
