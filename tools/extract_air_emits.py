@@ -46,7 +46,7 @@ TABLES = [("Cpu", "cpu/cpu_stark.rs"), ("Memory", "memory/memory_stark.rs"), ("B
           ("SCCall", "builtins/sccall/sccall_stark.rs"), ("Program", "program/program_stark.rs"), ("ProgChunk", "program/prog_chunk_stark.rs")]
 KINDS = {"constraint": "all", "constraint_transition": "transition", "constraint_first_row": "first_row", "constraint_last_row": "last_row"}
 
-TOKEN = re.compile(r"""\s+|//[^\n]*|/\*.*?\*/|(?P<str>b?"(?:\\.|[^"\\])*")|(?P<chr>'(?:\\.|[^'\\])')|(?P<life>'[A-Za-z_]\w*)|(?P<num>\d[\d_]*(?:\.\d+)?(?:_?[uif]\d+|_?usize|_?isize)?)"""
+TOKEN = re.compile(r"""\s+|//[^\n]*|/\*.*?\*/|(?P<str>b?"(?:\\.|[^"\\])*")|(?P<chr>'(?:\\.|[^'\\])')|(?P<life>'[A-Za-z_]\w*)|(?P<num>0x[0-9a-fA-F_]+(?:_?[ui]\d+|usize)?|0b[01_]+(?:_?[ui]\d+|usize)?|\d[\d_]*(?:\.\d+)?(?:_?[uif]\d+|_?usize|_?isize)?)"""
                    r"""|(?P<id>[A-Za-z_]\w*!?)|(?P<op>\.\.=|\.\.\.|\.\.|::|->|=>|==|!=|<=|>=|&&|\|\||<<|>>|\+=|-=|\*=|/=|[-+*/%=<>!&|^~.,;:#?@$(){}\[\]])""", re.S)
 
 
@@ -94,19 +94,30 @@ class Src:
 
     def functions(self):
         """name -> (params (lo, hi), body (lo, hi)) for every `fn` with a body"""
+        if getattr(self, "_functions", None) is not None:
+            return self._functions
         out = {}
         for i, (t, _) in enumerate(self.toks):
             if t == "fn" and i + 1 < len(self.toks):
                 name = self.toks[i + 1][0]
                 j = i + 2
+                if self.toks[j][0] == "<":          # generics may contain parentheses: `<I: IntoIterator<Item = (usize, F)>>`
+                    depth = 0
+                    while True:
+                        t = self.toks[j][0]
+                        depth += {"<": 1, ">": -1, "<<": 2, ">>": -2}.get(t, 0)
+                        j += 1
+                        if depth <= 0:
+                            break
                 while self.toks[j][0] != "(":
                     j += 1
                 pe = self.match(j)
                 k = pe + 1
                 while self.toks[k][0] not in ("{", ";"):
-                    k += 1
+                    k = self.match(k) + 1 if self.toks[k][0] in ("[", "(") else k + 1      # `-> [P; N]`: the `;` of an array type is not the end
                 if self.toks[k][0] == "{":
                     out.setdefault(name, ((j, pe), (k, self.match(k))))
+        self._functions = out
         return out
 
 
@@ -239,7 +250,7 @@ class Walker:
             elif t in ("&", "*"):
                 return primary()
             elif re.match(r"^\d", t):
-                v = int(re.sub(r"_?(?:[uif]\d+|usize|isize)$", "", t).replace("_", ""))
+                v = int(re.sub(r"_?(?:[uif]\d+|usize|isize)$", "", t).replace("_", ""), 0)
             elif re.match(r"^[A-Za-z_]", t):
                 path = [t]
                 while peek() == "::":
@@ -975,11 +986,13 @@ def ctl_facts(ref):
             for av in f["args"]:
                 m, fn, has = f["data"]
                 dcols, dexact = named_columns(ref, file_of(m, fn), fn, av if has else None)
-                r = {"table": f["table"], "data_fn": fn + ("(%d)" % av if has and av is not None else "()"), "data_columns": dcols, "data_exact": dexact}
+                r = {"table": f["table"], "data_fn": fn + ("(%d)" % av if has and av is not None else "()"), "data_file": os.path.relpath(file_of(m, fn), ref.root),
+                     "data_columns": dcols, "data_exact": dexact}
                 if f["filter"] is not None:
                     m, fn, has = f["filter"]
                     fcols, fexact = named_columns(ref, file_of(m, fn), fn, av if has else None)
-                    r.update({"filter_fn": fn + ("(%d)" % av if has and av is not None else "()"), "filter_columns": fcols, "filter_exact": fexact})
+                    r.update({"filter_fn": fn + ("(%d)" % av if has and av is not None else "()"), "filter_file": os.path.relpath(file_of(m, fn), ref.root),
+                              "filter_columns": fcols, "filter_exact": fexact})
                 recs.append(r)
             return recs
 

@@ -1,0 +1,1405 @@
+#!/usr/bin/env python3
+"""The reference's twelve `eval_packed_generic` EVALUATED from their Rust source on given rows -- a small interpreter for the subset
+of Rust the AIR files are written in.
+
+tools/extract_air_emits.py pins how many constraints each table emits, in which order, of which kind, and which cells they name.
+This goes the rest of the way: it RUNS the reference's constraint code.  `eval_packed_generic` of every `*_stark.rs` (and whatever it
+calls: the `cpu/*.rs` opcode files, `CpuAdjacentRowWrapper::from_vars`, `lookup.rs`, `plonk_common.rs::reduce_with_powers`, the
+Poseidon layers of `core/src/util/poseidon_utils.rs` with plonky2's constant tables, `OlaOpcode::binary_bit_mask`) is parsed into an
+AST and interpreted with `P` = one Goldilocks element: `lv` / `nv` are the rows handed in, `yield_constr.constraint*(x)` records
+(kind, value of x).  The values are then compared, constraint by constraint, with what olavm_amd/air/ola_tables.py -- the
+hand transcription that the oracle, the verifier restatement and the GPU all consume -- evaluates to on the same rows
+(tests/test_air_eval.py), and committed as vectors (tests/golden/air_eval_vectors.json) so that the comparison also runs where the
+reference tree is absent.
+
+The interpreter knows Rust's expression grammar (precedence, closures, blocks, if / match / for, patterns, struct literals, macros
+`vec!` / `izip!`), the iterator adaptors the files use, arrays / slices / ranges / tuples, mutable locals and element assignment,
+associated constants and functions, and enum values with `match`.  Types, generics, lifetimes and trait bounds are skipped.  It
+does not know anything about the AIRs: every constant, column index, loop bound and formula comes out of the reference's files.
+Anything it cannot parse or evaluate raises with file:line.
+
+    python tools/rust_air_eval.py [--reference /root/reference] [--points 3] [--out tests/golden/air_eval_vectors.json] [--check]
+"""
+import argparse
+import json
+import os
+import re
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import extract_air_emits as X          # noqa: E402  (tokeniser, file index, table list)
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FIXTURE = os.path.join(ROOT, "tests", "golden", "air_eval_vectors.json")
+P = 0xFFFFFFFF00000001
+
+
+class RustError(Exception):
+    pass
+
+
+class Fe:
+    """one Goldilocks element (what `P: PackedField`, `P::Scalar`, `F` and `FE` all are here)"""
+    __slots__ = ("v",)
+
+    def __init__(self, v):
+        self.v = int(v) % P
+
+    def __repr__(self):
+        return "Fe(%d)" % self.v
+
+
+class Rng:
+    def __init__(self, a, b):
+        self.start, self.end = a, b
+
+    def items(self):
+        return list(range(self.start, self.end))
+
+
+class Enum:
+    def __init__(self, ty, variant):
+        self.ty, self.variant = ty, variant
+
+    def __eq__(self, o):
+        return isinstance(o, Enum) and (self.ty, self.variant) == (o.ty, o.variant)
+
+    def __hash__(self):
+        return hash((self.ty, self.variant))
+
+
+class Struct(dict):
+    pass
+
+
+class Closure:
+    def __init__(self, params, body, env, src):
+        self.params, self.body, self.env, self.src = params, body, env, src
+
+
+class Return(Exception):
+    def __init__(self, v):
+        self.v = v
+
+
+class Consumer:
+    """ConstraintConsumer<P> (constraint_consumer.rs:34-78), recording instead of accumulating"""
+
+    def __init__(self):
+        self.emits = []
+
+
+# ------------------------------------------------------------------------------------------------ parser
+BINOPS = [["||"], ["&&"], ["==", "!=", "<", ">", "<=", ">="], ["|"], ["^"], ["&"], ["<<", ">>"], ["+", "-"], ["*", "/", "%"]]
+ASSIGN = ("=", "+=", "-=", "*=", "/=")
+
+
+class Parser:
+    def __init__(self, src, lo, hi):
+        self.src, self.T, self.i, self.hi = src, src.toks, lo, hi
+
+    def err(self, what):
+        line = self.T[min(self.i, len(self.T) - 1)][1]
+        ctx = " ".join(t for t, _ in self.T[max(0, self.i - 6):self.i + 6])
+        return RustError(f"{self.src.path}:{line}: {what} (near `{ctx}`)")
+
+    def peek(self, k=0):
+        j = self.i + k
+        return self.T[j][0] if j < self.hi else None
+
+    def next(self):
+        t = self.peek()
+        if t is None:
+            raise self.err("unexpected end")
+        self.i += 1
+        return t
+
+    def eat(self, t):
+        if self.peek() == t:
+            self.i += 1
+            return True
+        return False
+
+    def expect(self, t):
+        if self.peek() != t:
+            raise self.err(f"expected `{t}`, found `{self.peek()}`")
+        self.i += 1
+
+    def line(self):
+        return self.T[min(self.i, len(self.T) - 1)][1]
+
+    # ---- types are skipped
+    def skip_generics(self):
+        """at `<`: skip to the matching `>` (`>>` closes two)"""
+        depth = 0
+        while True:
+            t = self.next()
+            if t == "<":
+                depth += 1
+            elif t == ">":
+                depth -= 1
+            elif t == ">>":
+                depth -= 2
+            elif t == "<<":
+                depth += 2
+            elif t in ("(", "[", "{"):
+                self.i = self.src.match(self.i - 1) + 1
+            if depth <= 0:
+                return
+
+    def skip_type(self, stops):
+        depth = 0
+        while True:
+            t = self.peek()
+            if t is None:
+                return
+            if depth == 0 and t in stops:
+                return
+            if t in ("(", "["):
+                self.i = self.src.match(self.i) + 1
+                continue
+            if t == "{":          # const generic `{ N }`
+                self.i = self.src.match(self.i) + 1
+                continue
+            if t == "<":
+                depth += 1
+            elif t == ">":
+                depth -= 1
+            elif t == ">>":
+                depth -= 2
+            self.i += 1
+
+    # ---- patterns
+    def pattern(self):
+        alts = [self.pattern1()]
+        while self.peek() == "|" and self.peek(1) not in ("|",):
+            # only inside match arms (closure parameter lists never reach here with a bare `|`)
+            self.next()
+            alts.append(self.pattern1())
+        return alts[0] if len(alts) == 1 else ("por", alts)
+
+    def pattern1(self):
+        t = self.peek()
+        if t in ("&", "&&"):
+            self.next()
+            self.eat("mut")
+            return self.pattern1()
+        if t in ("mut", "ref"):
+            self.next()
+            return self.pattern1()
+        if t == "_":
+            self.next()
+            return ("pwild",)
+        if t == "(":
+            self.next()
+            items = []
+            while not self.eat(")"):
+                items.append(self.pattern())
+                self.eat(",")
+            return ("ptuple", items)
+        if t == "[":
+            self.next()
+            items = []
+            while not self.eat("]"):
+                items.append(self.pattern())
+                self.eat(",")
+            return ("ptuple", items)
+        if t == "-" or re.match(r"^\d", t):
+            neg = self.eat("-")
+            v = parse_int(self.next())
+            return ("plit", -v if neg else v)
+        if re.match(r"^[A-Za-z_]", t):
+            segs = [self.next()]
+            while self.peek() == "::":
+                self.next()
+                segs.append(self.next())
+            if self.peek() == "(":           # Some(x)
+                self.next()
+                inner = []
+                while not self.eat(")"):
+                    inner.append(self.pattern())
+                    self.eat(",")
+                return ("pcall", segs, inner)
+            if len(segs) == 1 and re.match(r"^[a-z_]", segs[0]):
+                return ("pid", segs[0])
+            return ("ppath", segs)
+        raise self.err("pattern")
+
+    # ---- statements
+    def block(self):
+        self.expect("{")
+        stmts, tail = [], None
+        while self.peek() != "}":
+            if self.peek() == "#":           # attribute
+                self.next()
+                self.i = self.src.match(self.i) + 1
+                continue
+            if self.eat(";"):
+                continue
+            s, is_expr, needs_semi = self.statement()
+            if is_expr and self.peek() == "}":
+                tail = s
+                break
+            if needs_semi and not self.eat(";") and self.peek() != "}":
+                raise self.err("expected `;`")
+            stmts.append(s)
+        self.expect("}")
+        return ("block", stmts, tail)
+
+    def statement(self):
+        t = self.peek()
+        ln = self.line()
+        if t == "let":
+            self.next()
+            pat = self.pattern()
+            if self.eat(":"):
+                self.skip_type(("=", ";"))
+            init = None
+            if self.eat("="):
+                init = self.expr()
+            return ("let", pat, init, ln), False, True
+        if t == "for" and self.peek(1) != "<":
+            self.next()
+            pat = self.pattern()
+            self.expect("in")
+            it = self.expr(no_struct=True)
+            body = self.block()
+            return ("for", pat, it, body, ln), False, False
+        if t == "while":
+            self.next()
+            cond = self.expr(no_struct=True)
+            body = self.block()
+            return ("while", cond, body, ln), False, False
+        if t == "return":
+            self.next()
+            e = None if self.peek() in (";", "}") else self.expr()
+            return ("return", e, ln), False, True
+        if t in ("if", "match", "{", "unsafe"):
+            e = self.expr()
+            # block-like expressions need no semicolon; they may still be the tail
+            return e, True, False
+        e = self.expr()
+        return e, True, True
+
+    # ---- expressions
+    def expr(self, no_struct=False):
+        return self.assign(no_struct)
+
+    def assign(self, ns):
+        lhs = self.range_(ns)
+        if self.peek() in ASSIGN:
+            op = self.next()
+            rhs = self.assign(ns)
+            return ("assign", op, lhs, rhs, self.line())
+        return lhs
+
+    def range_(self, ns):
+        if self.peek() in ("..", "..="):
+            incl = self.next() == "..="
+            hi = None if self.peek() in (None, ")", "]", ",", ";", "}") else self.binary(0, ns)
+            return ("range", None, hi, incl)
+        lo = self.binary(0, ns)
+        if self.peek() in ("..", "..="):
+            incl = self.next() == "..="
+            stop = self.peek() in (None, ")", "]", ",", ";", "}") or (ns and self.peek() == "{")
+            hi = None if stop else self.binary(0, ns)
+            return ("range", lo, hi, incl)
+        return lo
+
+    def binary(self, level, ns):
+        if level == len(BINOPS):
+            return self.cast(ns)
+        a = self.binary(level + 1, ns)
+        while self.peek() in BINOPS[level]:
+            # `|` as a binary operator never follows an expression in these files except as bit-or on integers; closures start a primary
+            op = self.next()
+            b = self.binary(level + 1, ns)
+            a = ("bin", op, a, b, self.line())
+        return a
+
+    def cast(self, ns):
+        e = self.unary(ns)
+        while self.peek() == "as":
+            self.next()
+            self.next()                       # the type's head
+            while self.peek() == "::":
+                self.next()
+                self.next()
+            if self.peek() == "<":
+                self.skip_generics()
+            e = ("cast", e)
+        return e
+
+    def unary(self, ns):
+        t = self.peek()
+        if t == "-":
+            self.next()
+            return ("neg", self.unary(ns), self.line())
+        if t == "!":
+            self.next()
+            return ("not", self.unary(ns))
+        if t == "*":
+            self.next()
+            return self.unary(ns)              # deref: references are transparent
+        if t in ("&", "&&"):
+            self.next()
+            self.eat("mut")
+            return self.unary(ns)
+        return self.postfix(ns)
+
+    def args(self):
+        self.expect("(")
+        out = []
+        while not self.eat(")"):
+            out.append(self.expr())
+            self.eat(",")
+        return out
+
+    def postfix(self, ns):
+        e = self.primary(ns)
+        while True:
+            t = self.peek()
+            if t == "(":
+                e = ("call", e, self.args(), self.line())
+            elif t == "[":
+                self.next()
+                idx = self.expr()
+                self.expect("]")
+                e = ("index", e, idx, self.line())
+            elif t == "?":
+                self.next()
+            elif t == ".":
+                self.next()
+                name = self.next()
+                if re.match(r"^\d", name):
+                    e = ("tfield", e, int(name))
+                    continue
+                if self.peek() == "::":
+                    self.next()
+                    self.skip_generics()
+                if self.peek() == "(":
+                    e = ("mcall", e, name, self.args(), self.line())
+                else:
+                    e = ("field", e, name, self.line())
+            else:
+                return e
+
+    def closure(self):
+        params = []
+        if self.eat("||"):
+            pass
+        else:
+            self.expect("|")
+            while not self.eat("|"):
+                params.append(self.pattern1())
+                if self.eat(":"):
+                    self.skip_type((",", "|"))
+                self.eat(",")
+        if self.peek() == "->":
+            self.next()
+            self.skip_type(("{",))
+        body = self.expr()
+        return ("closure", params, body)
+
+    def primary(self, ns):
+        t = self.peek()
+        ln = self.line()
+        if t is None:
+            raise self.err("expression expected")
+        if t == "(":
+            self.next()
+            items, trailing = [], False
+            while not self.eat(")"):
+                items.append(self.expr())
+                trailing = self.eat(",")
+            if len(items) == 1 and not trailing:
+                return items[0]
+            return ("tuple", items)
+        if t == "[":
+            self.next()
+            if self.eat("]"):
+                return ("array", [])
+            first = self.expr()
+            if self.eat(";"):
+                n = self.expr()
+                self.expect("]")
+                return ("repeat", first, n)
+            items = [first]
+            while not self.eat("]"):
+                self.expect(",")
+                if self.eat("]"):
+                    break
+                items.append(self.expr())
+            return ("array", items)
+        if t == "{":
+            return self.block()
+        if t == "unsafe":
+            self.next()
+            return self.block()
+        if t in ("|", "||", "move"):
+            self.eat("move")
+            return self.closure()
+        if t == "if":
+            self.next()
+            if self.peek() == "let":
+                self.next()
+                pat = self.pattern()
+                self.expect("=")
+                cond = ("iflet", pat, self.expr(no_struct=True))
+            else:
+                cond = self.expr(no_struct=True)
+            then = self.block()
+            other = None
+            if self.eat("else"):
+                other = self.primary(ns) if self.peek() == "if" else self.block()
+            return ("if", cond, then, other)
+        if t == "match":
+            self.next()
+            subj = self.expr(no_struct=True)
+            self.expect("{")
+            arms = []
+            while not self.eat("}"):
+                pat = self.pattern()
+                guard = None
+                if self.eat("if"):
+                    guard = self.expr()
+                self.expect("=>")
+                body = self.expr()
+                self.eat(",")
+                arms.append((pat, guard, body))
+            return ("match", subj, arms, ln)
+        if re.match(r"^\d", t):
+            self.next()
+            return ("num", parse_int(t))
+        if t.startswith('"') or t.startswith('b"'):
+            self.next()
+            return ("str", t)
+        if t.startswith("'"):
+            self.next()
+            return ("str", t)
+        if t.endswith("!"):               # macro
+            name = self.next()
+            open_ = self.peek()
+            close = {"(": ")", "[": "]", "{": "}"}[open_]
+            end = self.src.match(self.i)
+            if name in ("vec!", "izip!", "array!"):
+                self.next()
+                if name == "vec!":
+                    first = None if self.peek() == close else self.expr()
+                    if first is not None and self.eat(";"):
+                        n = self.expr()
+                        self.expect(close)
+                        return ("repeat", first, n)
+                    items = [] if first is None else [first]
+                    while not self.eat(close):
+                        self.expect(",")
+                        if self.eat(close):
+                            break
+                        items.append(self.expr())
+                    return ("array", items)
+                items = []
+                while not self.eat(close):
+                    items.append(self.expr())
+                    self.eat(",")
+                return ("macro", name, items)
+            self.i = end + 1                  # assert! / debug_assert! / println! ...: no value
+            return ("unit",)
+        if re.match(r"^[A-Za-z_]", t):
+            segs = [self.next()]
+            while self.peek() == "::":
+                self.next()
+                if self.peek() == "<":
+                    self.skip_generics()
+                    continue
+                segs.append(self.next())
+            if segs[0] == "<":
+                raise self.err("qualified path")
+            if self.peek() == "{" and not ns and re.match(r"^[A-Z]", segs[-1]) and self.looks_like_struct_literal():
+                self.next()
+                fields = []
+                while not self.eat("}"):
+                    if self.eat(".."):
+                        fields.append(("..", self.expr()))
+                        continue
+                    name = self.next()
+                    if self.eat(":"):
+                        fields.append((name, self.expr()))
+                    else:
+                        fields.append((name, ("path", [name], ln)))
+                    self.eat(",")
+                return ("struct", segs, fields)
+            return ("path", segs, ln)
+        if t == "<":                        # <T as Trait>::f
+            self.skip_generics()
+            segs = []
+            while self.peek() == "::":
+                self.next()
+                segs.append(self.next())
+            return ("path", segs, ln)
+        raise self.err(f"unexpected `{t}`")
+
+    def looks_like_struct_literal(self):
+        # `Name { ident: ...` or `Name { ident, ...` or `Name { }`
+        a, b = self.peek(1), self.peek(2)
+        return a == "}" or (a is not None and re.match(r"^[a-z_]", a) and b in (":", ",", "}")) or a == ".."
+
+
+def parse_int(t):
+    t = re.sub(r"_?(?:[ui](?:8|16|32|64|128|size))$", "", t).replace("_", "")
+    if t.startswith("0x"):
+        return int(t, 16)
+    if t.startswith("0b"):
+        return int(t, 2)
+    return int(t)
+
+
+# ------------------------------------------------------------------------------------------------ interpreter
+FIELD_CTORS = {"from_canonical_u64", "from_canonical_usize", "from_canonical_u32", "from_canonical_u16", "from_canonical_u8",
+               "from_noncanonical_u64", "from_canonical_i64", "from_noncanonical_u128", "from_basefield", "from_canonical_u128"}
+FIELD_CONSTS = {"ONES": 1, "ZEROS": 0, "ONE": 1, "ZERO": 0, "TWO": 2, "NEG_ONE": P - 1}
+INT_TYPES = {"u8", "u16", "u32", "u64", "u128", "usize", "i32", "i64", "isize"}
+
+
+class Interp:
+    def __init__(self, ref):
+        self.ref = ref
+        self.fn_cache = {}
+        self.const_cache = {}
+        self.find_cache = {}
+        self.depth = 0
+
+    # ---- lookup of functions and constants in the reference tree
+    def fn_ast(self, path, name):
+        key = (os.path.realpath(path), name)
+        if key not in self.fn_cache:
+            src = X.Src.get(path)
+            fns = src.functions()
+            if name not in fns:
+                raise RustError(f"{path}: fn {name} not found")
+            (plo, phi), (blo, bhi) = fns[name]
+            pp = Parser(src, plo + 1, phi)
+            params = []
+            while pp.peek() is not None:
+                if pp.peek() in ("&", "mut") or pp.peek().startswith("'"):
+                    pp.next()
+                    continue
+                if pp.peek() == "self":
+                    pp.next()
+                    params.append(("pid", "self"))
+                    pp.eat(",")
+                    continue
+                pat = pp.pattern1()
+                pp.expect(":")
+                pp.skip_type((",",))
+                pp.eat(",")
+                params.append(pat)
+            body = Parser(src, blo, bhi + 1).block()
+            self.fn_cache[key] = (params, body, src)
+        return self.fn_cache[key]
+
+    def find_fn_file(self, name, here, module=None):
+        key = (name, os.path.realpath(here), module)
+        if key not in self.find_cache:
+            f = self.ref.find_fn(name, here, module)
+            if f is None and module is not None:
+                f = self.ref.find_fn(name, here, None)
+            self.find_cache[key] = f
+        return self.find_cache[key]
+
+    def const_value(self, name, src):
+        cands = self.ref.consts.get(name)
+        if not cands:
+            return None
+        c = self.ref.near(cands, src.path)
+        if c is None:
+            c = cands[0]
+        key = (name, c[0])
+        if key not in self.const_cache:
+            csrc = X.Src.get(c[0])
+            toks = c[1]
+            # the expression's token span inside csrc
+            lo = csrc.toks.index(toks[0]) if toks else 0
+            # (token tuples are unique objects per position only by identity: find by identity)
+            for k in range(len(csrc.toks)):
+                if csrc.toks[k] is toks[0]:
+                    lo = k
+                    break
+            p = Parser(csrc, lo, lo + len(toks))
+            self.const_cache[key] = self.ev(p.expr(), {"__src__": csrc}, csrc)
+        return self.const_cache[key]
+
+    # ---- helpers
+    def err(self, src, line, what):
+        return RustError(f"{src.path}:{line}: {what}")
+
+    @staticmethod
+    def truthy(v):
+        return bool(v)
+
+    def bind(self, pat, v, env, src):
+        k = pat[0]
+        if k == "pid":
+            env[pat[1]] = v
+        elif k == "pwild":
+            pass
+        elif k == "ptuple":
+            v = list(v)
+            if len(v) != len(pat[1]):
+                raise RustError(f"{src.path}: tuple pattern of {len(pat[1])} against {len(v)} values")
+            for p, x in zip(pat[1], v):
+                self.bind(p, x, env, src)
+        elif k == "pcall":
+            self.bind(pat[2][0], v, env, src)            # Some(x)
+        else:
+            raise RustError(f"{src.path}: pattern {k} cannot bind")
+
+    def matches(self, pat, v, env, src):
+        k = pat[0]
+        if k == "pwild":
+            return True
+        if k == "pid":
+            env[pat[1]] = v
+            return True
+        if k == "plit":
+            return (v.v if isinstance(v, Fe) else v) == pat[1]
+        if k == "por":
+            return any(self.matches(p, v, env, src) for p in pat[1])
+        if k == "ppath":
+            segs = pat[1]
+            if segs[-1] == "None":
+                return v is None
+            if isinstance(v, Enum):
+                return v.variant == segs[-1]
+            c = self.const_value(segs[-1], src)
+            return c is not None and c == v
+        if k == "pcall":
+            if pat[1][-1] == "Some":
+                if v is None:
+                    return False
+                return self.matches(pat[2][0], v, env, src)
+            return False
+        if k == "ptuple":
+            return len(v) == len(pat[1]) and all(self.matches(p, x, env, src) for p, x in zip(pat[1], v))
+        raise RustError(f"{src.path}: pattern {k}")
+
+    def call_closure(self, c, args):
+        env = dict(c.env)
+        if len(c.params) == 1 and len(args) != 1:
+            args = [tuple(args)]
+        if len(c.params) != len(args):
+            if len(args) == 1 and isinstance(args[0], (tuple, list)) and len(args[0]) == len(c.params):
+                args = list(args[0])
+            else:
+                raise RustError(f"{c.src.path}: closure of {len(c.params)} parameters called with {len(args)}")
+        for p, a in zip(c.params, args):
+            self.bind(p, a, env, c.src)
+        return self.ev(c.body, env, c.src)
+
+    def call_fn(self, path, name, args, self_val=None):
+        params, body, src = self.fn_ast(path, name)
+        env = {"__src__": src}
+        ps = list(params)
+        if ps and ps[0] == ("pid", "self"):
+            env["self"] = self_val
+            ps = ps[1:]
+        if len(ps) != len(args):
+            raise RustError(f"{path}: {name} takes {len(ps)} arguments, {len(args)} given")
+        for p, a in zip(ps, args):
+            self.bind(p, a, env, src)
+        self.depth += 1
+        if self.depth > 200:
+            raise RustError(f"{path}: call depth")
+        try:
+            return self.ev(body, env, src)
+        except Return as r:
+            return r.v
+        finally:
+            self.depth -= 1
+
+    def iterate(self, v, src, line=0):
+        if isinstance(v, Rng):
+            return v.items()
+        if isinstance(v, (list, tuple)):
+            return list(v)
+        raise self.err(src, line, f"cannot iterate {type(v).__name__}")
+
+    # ---- arithmetic
+    def binop(self, op, a, b, src, line):
+        if isinstance(a, Fe) or isinstance(b, Fe):
+            if not (isinstance(a, Fe) and isinstance(b, Fe)):
+                # `P * u64` does not type-check in Rust: a sign that the interpreter mis-typed a value
+                raise self.err(src, line, f"field element {op} {type(b).__name__ if isinstance(a, Fe) else type(a).__name__}")
+            if op == "+":
+                return Fe(a.v + b.v)
+            if op == "-":
+                return Fe(a.v - b.v)
+            if op == "*":
+                return Fe(a.v * b.v)
+            if op == "==":
+                return a.v == b.v
+            if op == "!=":
+                return a.v != b.v
+            raise self.err(src, line, f"field element operator {op}")
+        if isinstance(a, Enum) or isinstance(b, Enum):
+            if op == "==":
+                return a == b
+            if op == "!=":
+                return a != b
+        f = {"+": lambda: a + b, "-": lambda: a - b, "*": lambda: a * b, "/": lambda: a // b, "%": lambda: a % b, "==": lambda: a == b,
+             "!=": lambda: a != b, "<": lambda: a < b, ">": lambda: a > b, "<=": lambda: a <= b, ">=": lambda: a >= b, "&&": lambda: a and b,
+             "||": lambda: a or b, "<<": lambda: a << b, ">>": lambda: a >> b, "&": lambda: a & b, "|": lambda: a | b, "^": lambda: a ^ b}.get(op)
+        if f is None:
+            raise self.err(src, line, f"operator {op}")
+        return f()
+
+    # ---- evaluation
+    def ev(self, n, env, src):
+        k = n[0]
+        if k == "num":
+            return n[1]
+        if k == "path":
+            return self.path_value(n[1], env, src, n[2])
+        if k == "bin":
+            op = n[1]
+            if op == "&&":
+                return self.truthy(self.ev(n[2], env, src)) and self.truthy(self.ev(n[3], env, src))
+            if op == "||":
+                return self.truthy(self.ev(n[2], env, src)) or self.truthy(self.ev(n[3], env, src))
+            return self.binop(op, self.ev(n[2], env, src), self.ev(n[3], env, src), src, n[4])
+        if k == "neg":
+            v = self.ev(n[1], env, src)
+            return Fe(-v.v) if isinstance(v, Fe) else -v
+        if k == "not":
+            return not self.ev(n[1], env, src)
+        if k == "cast":
+            v = self.ev(n[1], env, src)
+            return v.v if isinstance(v, Fe) else (int(v) if isinstance(v, bool) else v)
+        if k == "index":
+            base = self.ev(n[1], env, src)
+            idx = self.ev(n[2], env, src)
+            return self.index(base, idx, src, n[3])
+        if k == "field":
+            base = self.ev(n[1], env, src)
+            return self.field(base, n[2], src, n[3])
+        if k == "tfield":
+            return self.ev(n[1], env, src)[n[2]]
+        if k == "tuple":
+            return tuple(self.ev(x, env, src) for x in n[1])
+        if k == "array":
+            return [self.ev(x, env, src) for x in n[1]]
+        if k == "repeat":
+            v, cnt = self.ev(n[1], env, src), self.ev(n[2], env, src)
+            return [clone(v) for _ in range(cnt)]
+        if k == "range":
+            a = None if n[1] is None else self.ev(n[1], env, src)
+            b = None if n[2] is None else self.ev(n[2], env, src)
+            if n[3] and b is not None:
+                b += 1
+            return Rng(a, b)
+        if k == "closure":
+            return Closure(n[1], n[2], env, src)
+        if k == "block":
+            return self.block(n, env, src)
+        if k == "if":
+            cond = n[1]
+            inner = dict(env)
+            if cond[0] == "iflet":
+                ok = self.matches(cond[1], self.ev(cond[2], env, src), inner, src)
+            else:
+                ok = self.truthy(self.ev(cond, env, src))
+            if ok:
+                return self.scoped(n[2], env, src, inner if cond[0] == "iflet" else None)
+            return self.scoped(n[3], env, src) if n[3] is not None else None
+        if k == "match":
+            v = self.ev(n[1], env, src)
+            for pat, guard, body in n[2]:
+                inner = dict(env)
+                if self.matches(pat, v, inner, src) and (guard is None or self.truthy(self.ev(guard, inner, src))):
+                    r = self.ev(body, inner, src)
+                    self.write_back(env, inner)
+                    return r
+            raise self.err(src, n[3], f"no match arm for {v!r}")
+        if k == "struct":
+            s = Struct()
+            s["__name__"] = n[1][-1]
+            for name, e in n[2]:
+                if name == "..":
+                    s.update(self.ev(e, env, src))
+                else:
+                    s[name] = self.ev(e, env, src)
+            return s
+        if k == "macro":
+            if n[1] == "izip!":
+                cols = [self.iterate(self.ev(x, env, src), src) for x in n[2]]
+                return [tuple(t) for t in zip(*cols)]
+            raise RustError(f"{src.path}: macro {n[1]}")
+        if k == "call":
+            return self.call(n, env, src)
+        if k == "mcall":
+            return self.mcall(n, env, src)
+        if k == "assign":
+            return self.assign(n, env, src)
+        if k == "unit":
+            return None
+        if k == "str":
+            return n[1]
+        if k in ("let", "for", "while", "return"):
+            return self.stmt(n, env, src)
+        raise RustError(f"{src.path}: cannot evaluate node {k}")
+
+    def scoped(self, node, env, src, inner=None):
+        inner = dict(env) if inner is None else inner
+        r = self.ev(node, inner, src)
+        self.write_back(env, inner)
+        return r
+
+    @staticmethod
+    def write_back(env, inner):
+        """assignments to OUTER variables made inside a nested scope (a fresh dict per scope keeps shadowing `let`s local)"""
+        for name in inner.get("__assigned__", ()):
+            if name in env and name not in inner.get("__declared__", ()):
+                env[name] = inner[name]
+                env.setdefault("__assigned__", set()).add(name)
+
+    def block(self, n, env, src):
+        inner = dict(env)
+        inner["__declared__"] = set()
+        inner["__assigned__"] = set()
+        try:
+            for s in n[1]:
+                self.stmt(s, inner, src)
+            return self.ev(n[2], inner, src) if n[2] is not None else None
+        finally:
+            self.write_back(env, inner)
+
+    def stmt(self, s, env, src):
+        k = s[0]
+        if k == "let":
+            v = self.ev(s[2], env, src) if s[2] is not None else None
+            names = pattern_names(s[1])
+            env.setdefault("__declared__", set()).update(names)
+            self.bind(s[1], v, env, src)
+            return None
+        if k == "for":
+            for item in self.iterate(self.ev(s[2], env, src), src, s[4]):
+                inner = dict(env)
+                inner["__declared__"] = set(pattern_names(s[1]))
+                inner["__assigned__"] = set()
+                self.bind(s[1], item, inner, src)
+                self.ev(s[3], inner, src)
+                self.write_back(env, inner)
+            return None
+        if k == "while":
+            guard = 0
+            while self.truthy(self.ev(s[1], env, src)):
+                self.scoped(s[2], env, src)
+                guard += 1
+                if guard > 1 << 20:
+                    raise self.err(src, s[3], "while loop does not end")
+            return None
+        if k == "return":
+            raise Return(self.ev(s[1], env, src) if s[1] is not None else None)
+        return self.ev(s, env, src)
+
+    def assign(self, n, env, src):
+        op, lhs, rhs, line = n[1], n[2], self.ev(n[3], env, src), n[4]
+        if lhs[0] == "path" and len(lhs[1]) == 1:
+            name = lhs[1][0]
+            if name not in env:
+                raise self.err(src, line, f"assignment to unknown `{name}`")
+            env[name] = rhs if op == "=" else self.binop(op[0], env[name], rhs, src, line)
+            env.setdefault("__assigned__", set()).add(name)
+            return None
+        if lhs[0] == "index":
+            base = self.ev(lhs[1], env, src)
+            idx = self.ev(lhs[2], env, src)
+            base[idx] = rhs if op == "=" else self.binop(op[0], base[idx], rhs, src, line)
+            return None
+        if lhs[0] == "field":
+            base = self.ev(lhs[1], env, src)
+            base[lhs[2]] = rhs if op == "=" else self.binop(op[0], base[lhs[2]], rhs, src, line)
+            return None
+        raise self.err(src, line, "assignment target")
+
+    def index(self, base, idx, src, line):
+        if isinstance(idx, Rng):
+            a = idx.start or 0
+            b = len(base) if idx.end is None else idx.end
+            if not (0 <= a <= b <= len(base)):
+                raise self.err(src, line, f"slice {a}..{b} of {len(base)}")
+            return list(base[a:b])
+        if isinstance(idx, Fe):
+            raise self.err(src, line, "field element as index")
+        if not (0 <= idx < len(base)):
+            raise self.err(src, line, f"index {idx} of {len(base)}")
+        return base[idx]
+
+    def field(self, base, name, src, line):
+        if isinstance(base, Rng) and name in ("start", "end"):
+            return getattr(base, name)
+        if isinstance(base, (Struct, dict)):
+            if name in base:
+                return base[name]
+            raise self.err(src, line, f"no field `{name}` in {base.get('__name__')}")
+        raise self.err(src, line, f"field `{name}` of {type(base).__name__}")
+
+    def path_value(self, segs, env, src, line):
+        name = segs[-1]
+        if len(segs) == 1:
+            if name in env:
+                return env[name]
+            if name == "None":
+                return None
+            if name in ("true", "false"):
+                return name == "true"
+        if len(segs) >= 2 and name in FIELD_CONSTS and segs[-2] in ("P", "F", "FE", "Scalar", "GoldilocksField", "Self"):
+            return Fe(FIELD_CONSTS[name])
+        if len(segs) == 2 and segs[0] in INT_TYPES and name in ("MAX", "MIN"):
+            bits = {"u8": 8, "u16": 16, "u32": 32, "u64": 64, "u128": 128, "usize": 64}.get(segs[0])
+            return (1 << bits) - 1 if name == "MAX" else 0
+        if re.match(r"^[A-Z][A-Z0-9_]*$", name):
+            v = self.const_value(name, src)
+            if v is not None:
+                return v
+        if len(segs) >= 2 and re.match(r"^[A-Z]", segs[-2]) and re.match(r"^[A-Z]", name):
+            return Enum(segs[-2], name)                   # OlaOpcode::ADD
+        raise self.err(src, line, f"unknown name `{'::'.join(segs)}`")
+
+    def call(self, n, env, src):
+        callee, line = n[1], n[3]
+        args = [self.ev(a, env, src) for a in n[2]]
+        if callee[0] != "path":
+            f = self.ev(callee, env, src)
+            if isinstance(f, Closure):
+                return self.call_closure(f, args)
+            raise self.err(src, line, "call of a non-function")
+        segs = callee[1]
+        name = segs[-1]
+        if len(segs) == 1 and name in env and isinstance(env[name], Closure):
+            return self.call_closure(env[name], args)
+        if name in FIELD_CTORS:
+            v = args[0]
+            return v if isinstance(v, Fe) else Fe(v)
+        if name in ("Some", "Ok", "Box", "Reverse"):
+            return args[0]
+        if name == "new" and len(segs) >= 2 and segs[-2] in ("Vec", "String"):
+            return []
+        if name == "once" and "iter" in segs:
+            return [args[0]]
+        if name == "repeat" and ("iter" in segs or (len(segs) == 1 and self.find_fn_file(name, src.path) is None)):
+            return RepeatForever(args[0])
+        if name == "from" and len(segs) >= 2 and segs[-2] in INT_TYPES | {"F", "P", "FE"}:
+            return args[0]
+        if name == "default" and len(segs) >= 2:
+            return Struct({"__name__": segs[-2]})
+        module = None
+        if len(segs) >= 2 and segs[-2] not in ("Self",) and re.match(r"^[a-z_]", segs[-2]):
+            module = segs[-2]
+        target = None
+        cur = src.path
+        if (module is None) and name in X.Src.get(cur).functions():
+            target = cur
+        if target is None:
+            target = self.find_fn_file(name, cur, module)
+        if target is None:
+            raise self.err(src, line, f"function `{'::'.join(segs)}` not found")
+        params, _, _ = self.fn_ast(target, name)
+        if params and params[0] == ("pid", "self"):
+            return self.call_fn(target, name, args[1:], args[0] if args else None)
+        return self.call_fn(target, name, args)
+
+    def mcall(self, n, env, src):
+        recv_node, name, line = n[1], n[2], n[4]
+        # the consumer
+        recv = self.ev(recv_node, env, src)
+        if isinstance(recv, Consumer):
+            if name not in X.KINDS:
+                raise self.err(src, line, f"consumer method {name}")
+            v = self.ev(n[3][0], env, src)
+            if not isinstance(v, Fe):
+                raise self.err(src, line, "constraint argument is not a field element")
+            recv.emits.append((X.KINDS[name], v.v, os.path.relpath(src.path, self.ref.root), line))
+            return None
+        args = [self.ev(a, env, src) for a in n[3]]
+        return self.method(recv, name, args, src, line)
+
+    def method(self, r, name, args, src, line):
+        # ---- adaptors that do nothing here
+        if name in ("iter", "into_iter", "iter_mut", "copied", "cloned", "collect", "collect_vec", "to_vec", "try_into", "unwrap", "expect", "by_ref",
+                    "as_ref", "as_mut", "borrow", "into", "to_owned", "as_slice_of_cells", "peekable", "into_par_iter", "par_iter", "unwrap_or_default"):
+            if name in ("unwrap", "expect") and r is None:
+                raise self.err(src, line, "unwrap of None")
+            if name == "to_vec" or name == "collect" or name == "collect_vec":
+                return list(self.iterate(r, src, line)) if isinstance(r, (list, tuple, Rng)) else r
+            if isinstance(r, Rng) and name in ("iter", "into_iter"):
+                return r.items()
+            return r
+        if name == "clone":
+            return clone(r)
+        if isinstance(r, Fe):
+            if name == "square":
+                return Fe(r.v * r.v)
+            if name == "cube":
+                return Fe(r.v * r.v * r.v)
+            if name == "double":
+                return Fe(2 * r.v)
+            if name == "is_zero":
+                return r.v == 0
+            if name == "is_one":
+                return r.v == 1
+            if name == "as_slice":
+                return [r]
+            if name in ("to_canonical_u64", "to_noncanonical_u64"):
+                return r.v
+            if name in ("exp_u64", "exp_power_of_2"):
+                return Fe(pow(r.v, args[0] if name == "exp_u64" else 1 << args[0], P))
+            if name == "inverse":
+                return Fe(pow(r.v, P - 2, P))
+            if name in ("mul", "add", "sub"):
+                return self.binop({"mul": "*", "add": "+", "sub": "-"}[name], r, args[0], src, line)
+            if name == "powers":
+                return Powers(r)
+        if isinstance(r, int) and not isinstance(r, bool):
+            if name == "pow":
+                return r ** args[0]
+            if name in ("min", "max"):
+                return min(r, args[0]) if name == "min" else max(r, args[0])
+            if name in ("add", "sub", "mul", "div"):
+                return self.binop({"add": "+", "sub": "-", "mul": "*", "div": "/"}[name], r, args[0], src, line)
+            if name in ("wrapping_add", "saturating_sub", "checked_sub"):
+                return r + args[0] if name == "wrapping_add" else max(0, r - args[0])
+            if name == "trailing_zeros":
+                return (r & -r).bit_length() - 1
+            if name == "is_power_of_two":
+                return r > 0 and r & (r - 1) == 0
+        if r is None or (not isinstance(r, (list, tuple, Rng, Struct, Enum, Fe, int, RepeatForever))):
+            if name in ("is_some", "is_none"):
+                return (r is not None) == (name == "is_some")
+        if name in ("is_some", "is_none"):
+            return (r is not None) == (name == "is_some")
+        if isinstance(r, Rng) and name in ("contains",):
+            return r.start <= args[0] < r.end
+        if isinstance(r, (list, tuple, Rng, RepeatForever)):
+            if isinstance(r, RepeatForever):
+                if name == "take":
+                    return [clone(r.v) for _ in range(args[0])]
+                if name == "zip":
+                    other = self.iterate(args[0], src, line)
+                    return [(clone(r.v), o) for o in other]
+                raise self.err(src, line, f"iter::repeat().{name}")
+            items = self.iterate(r, src, line)
+            if name == "len":
+                return len(items)
+            if name == "rev":
+                return items[::-1]
+            if name == "enumerate":
+                return [(i, x) for i, x in enumerate(items)]
+            if name == "zip":
+                o = args[0]
+                if isinstance(o, RepeatForever):
+                    return [(x, clone(o.v)) for x in items]
+                if isinstance(o, Powers):
+                    out, w = [], Fe(1)
+                    for x in items:
+                        out.append((x, w))
+                        w = Fe(w.v * o.base.v)
+                    return out
+                return [tuple(t) for t in zip(items, self.iterate(o, src, line))]
+            if name == "chain":
+                return items + self.iterate(args[0], src, line)
+            if name == "skip":
+                return items[args[0]:]
+            if name == "take":
+                return items[:args[0]]
+            if name == "step_by":
+                return items[::args[0]]
+            if name == "map":
+                return [self.call_closure(args[0], [x]) for x in items]
+            if name == "for_each":
+                for x in items:
+                    self.call_closure(args[0], [x])
+                return None
+            if name == "filter":
+                return [x for x in items if self.truthy(self.call_closure(args[0], [x]))]
+            if name == "flat_map":
+                out = []
+                for x in items:
+                    out += self.iterate(self.call_closure(args[0], [x]), src, line)
+                return out
+            if name == "flatten":
+                out = []
+                for x in items:
+                    out += self.iterate(x, src, line)
+                return out
+            if name == "all":
+                return all(self.truthy(self.call_closure(args[0], [x])) for x in items)
+            if name == "any":
+                return any(self.truthy(self.call_closure(args[0], [x])) for x in items)
+            if name == "sum":
+                if not items:
+                    return Fe(0)
+                acc = items[0]
+                for x in items[1:]:
+                    acc = self.binop("+", acc, x, src, line)
+                return acc
+            if name == "product":
+                acc = items[0]
+                for x in items[1:]:
+                    acc = self.binop("*", acc, x, src, line)
+                return acc
+            if name == "scan":
+                # .scan(init, |state, x| { *state = ...; Some(y) }): the closure's first parameter is the running state
+                c, state, out = args[1], args[0], []
+                for x in items:
+                    env = dict(c.env)
+                    self.bind(c.params[0], state, env, c.src)
+                    self.bind(c.params[1], x, env, c.src)
+                    y = self.ev(c.body, env, c.src)
+                    state = env[pattern_names(c.params[0])[0]]
+                    if y is None:
+                        break
+                    out.append(y)
+                return out
+            if name == "fold":
+                acc = args[0]
+                for x in items:
+                    acc = self.call_closure(args[1], [acc, x])
+                return acc
+            if name == "reduce":
+                acc = items[0]
+                for x in items[1:]:
+                    acc = self.call_closure(args[0], [acc, x])
+                return acc
+            if name in ("first", "last"):
+                return (items[0] if name == "first" else items[-1]) if items else None
+            if name == "chunks":
+                return [items[i:i + args[0]] for i in range(0, len(items), args[0])]
+            if name == "windows":
+                return [items[i:i + args[0]] for i in range(0, len(items) - args[0] + 1)]
+            if name == "push" and isinstance(r, list):
+                r.append(args[0])
+                return None
+            if name == "extend" and isinstance(r, list):
+                r.extend(self.iterate(args[0], src, line))
+                return None
+            if name == "contains":
+                return any(same(x, args[0]) for x in items)
+            if name == "concat":
+                out = []
+                for x in items:
+                    out += list(x)
+                return out
+            if name == "as_slice":
+                return items
+            if name == "is_empty":
+                return not items
+        # ---- a method of the reference (on `self` structs, enums): found by name
+        target = self.find_fn_file(name, src.path)
+        if target is not None:
+            params, _, _ = self.fn_ast(target, name)
+            if params and params[0] == ("pid", "self"):
+                return self.call_fn(target, name, args, r)
+        raise self.err(src, line, f"method `.{name}()` on {type(r).__name__}")
+
+
+class RepeatForever:
+    def __init__(self, v):
+        self.v = v
+
+
+class Powers:
+    """F::powers(): 1, b, b^2, ... (only ever zipped against a finite iterator)"""
+
+    def __init__(self, base):
+        self.base = base
+
+
+def clone(v):
+    if isinstance(v, list):
+        return [clone(x) for x in v]
+    if isinstance(v, Struct):
+        s = Struct()
+        for k, x in v.items():
+            s[k] = clone(x)
+        return s
+    return v
+
+
+def same(a, b):
+    if isinstance(a, Fe) and isinstance(b, Fe):
+        return a.v == b.v
+    return a == b
+
+
+def pattern_names(pat):
+    k = pat[0]
+    if k == "pid":
+        return [pat[1]]
+    if k in ("ptuple",):
+        return [n for p in pat[1] for n in pattern_names(p)]
+    if k == "pcall":
+        return [n for p in pat[2] for n in pattern_names(p)]
+    return []
+
+
+# ------------------------------------------------------------------------------------------------ driving it
+def make_ref(reference):
+    ref = X.Ref(reference)
+    extra = os.path.join(reference, "plonky2", "plonky2", "src", "plonk", "plonk_common.rs")
+    if os.path.exists(extra) and extra not in ref.files:
+        ref.files.append(extra)
+    # constants of the added file
+    return ref
+
+
+def rows_for(seed, table, ncols):
+    """deterministic rows: the fixture stores the recipe, not the rows.  seed = int: pseudo-random (splitmix64, reduced mod p);
+    seed = {"fill": v}: every cell of both rows is v (0, 1, p - 1, and the reference's ADDR_HEAP_PTR: the rows on which the memory
+    table's `is_zero` branch, memory_stark.rs:292-300, takes its other side)"""
+    if isinstance(seed, dict):
+        return [seed["fill"] % P] * ncols, [seed["fill"] % P] * ncols
+    x = (seed * 0x9E3779B97F4A7C15 + table * 0xD1342543DE82EF95 + 0x1234567) & (2**64 - 1)
+    out = []
+    for _ in range(2 * ncols):
+        x = (x + 0x9E3779B97F4A7C15) & (2**64 - 1)
+        z = x
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & (2**64 - 1)
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & (2**64 - 1)
+        z ^= z >> 31
+        out.append(z % P)
+    return out[:ncols], out[ncols:]
+
+
+PARAM = 0x0123456789ABCDEF % P          # the compress challenge handed to the bitwise and program tables
+
+
+def eval_table(it, ref, index, rel, lv, nv):
+    """-> [(kind, value, file, line)] of the reference's eval_packed_generic of table `index` on rows (lv, nv)"""
+    path = os.path.join(ref.root, rel)
+    src = X.Src.get(path)
+    T = src.toks
+    # the trait impl's eval_packed_generic: the one that takes &self
+    fn = None
+    for i, (t, _) in enumerate(T):
+        if t == "fn" and T[i + 1][0] == "eval_packed_generic":
+            j = i + 2
+            while T[j][0] != "(":
+                j += 1
+            if T[j + 1][0] == "&" and T[j + 2][0] == "self":
+                fn = (j, src.match(j))
+                break
+    if fn is None:
+        raise RustError(f"{path}: no eval_packed_generic(&self, ...)")
+    k = fn[1] + 1
+    while T[k][0] != "{":
+        k += 1
+    body = Parser(src, k, src.match(k) + 1).block()
+    cons = Consumer()
+    vars_ = Struct({"__name__": "StarkEvaluationVars", "local_values": [Fe(x) for x in lv], "next_values": [Fe(x) for x in nv], "public_inputs": []})
+    me = Struct({"__name__": "Stark", "compress_challenge": Fe(PARAM), "_phantom": None})
+    env = {"__src__": src, "self": me, "vars": vars_, "yield_constr": cons}
+    # the consumer's parameter may have another name
+    pp = [t for t, _ in T[fn[0] + 1:fn[1]]]
+    for a in range(len(pp)):
+        if pp[a] == ":" and "ConstraintConsumer" in pp[a:a + 8] and a >= 1:
+            env[pp[a - 1]] = cons
+        if pp[a] == ":" and "StarkEvaluationVars" in pp[a:a + 4] and a >= 1:
+            env[pp[a - 1]] = vars_
+    try:
+        it.ev(body, env, src)
+    except Return:
+        pass
+    return cons.emits
+
+
+def eval_ctl_entry(it, ref, entry, row):
+    """One TableWithColumns of stark/ola_stark.rs: its `ctl_data_*` / `ctl_filter_*` functions are CALLED (they build `Column`s with
+    the reference's constructors, cross_table_lookup.rs:34-98), and every column is evaluated on `row` with the reference's own
+    `Column::eval` (:100-109) -> ([values of the data columns], value of the filter or None)"""
+    ctl_rs = os.path.join(ref.root, "stark", "cross_table_lookup.rs")
+
+    def call(fn_str, rel):
+        m = re.match(r"^(\w+)\((\d*)\)$", fn_str)
+        args = [int(m.group(2))] if m.group(2) else []
+        return it.call_fn(os.path.join(ref.root, rel), m.group(1), args)
+
+    vals = [Fe(x) for x in row]
+    cols = it.iterate(call(entry["data_fn"], entry["data_file"]), X.Src.get(ctl_rs))
+    data = [it.call_fn(ctl_rs, "eval", [vals], c).v for c in cols]
+    filt = None
+    if "filter_fn" in entry:
+        filt = it.call_fn(ctl_rs, "eval", [vals], call(entry["filter_fn"], entry["filter_file"])).v
+    return data, filt
+
+
+def extract(reference, points):
+    ref = make_ref(reference)
+    it = Interp(ref)
+    golden = json.load(open(X.FIXTURE))
+    heap_ptr = it.const_value("ADDR_HEAP_PTR", X.Src.get(os.path.join(ref.root, "memory", "memory_stark.rs")))
+    seeds = list(range(points)) + [{"fill": 0}, {"fill": 1}, {"fill": P - 1}, {"fill": int(heap_ptr)}]
+    tables, problems = [], []
+    for index, (name, rel) in enumerate(X.TABLES):
+        ncols = golden["tables"][index]["columns"]
+        rec = {"table": name, "file": rel, "columns": ncols, "points": []}
+        try:
+            for s in seeds:
+                lv, nv = rows_for(s, index, ncols)
+                emits = eval_table(it, ref, index, rel, lv, nv)
+                rec["points"].append({"seed": s, "kinds": [e[0] for e in emits], "values": [e[1] for e in emits]})
+            rec["emit_sites"] = ["%s:%d" % (e[2], e[3]) for e in emits]
+        except (RustError, RecursionError, IndexError, KeyError, TypeError, AttributeError, AssertionError) as e:
+            problems.append({"table": name, "reason": "%s: %s" % (type(e).__name__, e)})
+            rec = {"table": name, "file": rel, "columns": ncols, "unevaluated": "%s: %s" % (type(e).__name__, e)}
+        tables.append(rec)
+    index_of = {name: i for i, (name, _) in enumerate(X.TABLES)}
+    ctls = []
+    for c in golden["cross_table_lookups"]:
+        rec = {"name": c["name"], "entries": []}
+        try:
+            for entry in [c["looked"]] + c["looking_in_source_order"]:
+                t = index_of[entry["table"]]
+                pts = []
+                for sd in list(range(points)) + [{"fill": 1}]:
+                    lv, _ = rows_for(sd, t, golden["tables"][t]["columns"])
+                    data, filt = eval_ctl_entry(it, ref, entry, lv)
+                    pts.append({"seed": sd, "data": data, "filter": filt})
+                rec["entries"].append({"table": entry["table"], "data_fn": entry["data_fn"], "filter_fn": entry.get("filter_fn"), "points": pts})
+        except (RustError, RecursionError, IndexError, KeyError, TypeError, AttributeError, AssertionError) as e:
+            problems.append({"table": c["name"], "reason": "%s: %s" % (type(e).__name__, e)})
+            rec = {"name": c["name"], "unevaluated": "%s: %s" % (type(e).__name__, e)}
+        ctls.append(rec)
+    return {"generator": "tools/rust_air_eval.py", "cross_table_lookups": ctls, "what": "values of the constraints the reference's eval_packed_generic emits on pseudo-random rows "
+            "(rows_for(seed, table, columns): splitmix64 mod p; compress challenge PARAM), obtained by interpreting the reference's Rust source",
+            "param": PARAM, "tables": tables, "problems": problems}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reference", default="/root/reference")
+    ap.add_argument("--points", type=int, default=2)
+    ap.add_argument("--out", default=FIXTURE)
+    ap.add_argument("--check", action="store_true")
+    a = ap.parse_args()
+    sys.setrecursionlimit(20000)
+    data = extract(a.reference, a.points)
+    for t in data["tables"]:
+        if "points" in t:
+            print("%-14s %4d constraints evaluated at %d points" % (t["table"], len(t["points"][0]["values"]), len(t["points"])))
+        else:
+            print("%-14s NOT EVALUATED: %s" % (t["table"], t["unevaluated"]))
+    bad = [c for c in data["cross_table_lookups"] if "unevaluated" in c]
+    print("%d cross-table lookups: %d lookup entries evaluated%s" % (len(data["cross_table_lookups"]), sum(len(c.get("entries", ())) for c in data["cross_table_lookups"]),
+                                                                      "".join("\n  NOT EVALUATED %s: %s" % (c["name"], c["unevaluated"]) for c in bad)))
+    text = json.dumps(data, separators=(",", ":")) + "\n"
+    if a.check:
+        if open(a.out).read() != text:
+            raise SystemExit(a.out + " is stale")
+        print("fixture is up to date")
+        return
+    open(a.out, "w").write(text)
+    print("wrote", a.out, "(%d bytes)" % len(text))
+
+
+if __name__ == "__main__":
+    main()
