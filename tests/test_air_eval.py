@@ -121,6 +121,86 @@ def test_lookup_column_values_equal_the_interpreted_reference(vectors):
     assert compared == 88 * 3
 
 
+def stream_for(seed, salt, count):
+    """tools/rust_air_eval.py stream_for: the Z openings and challenges of the vanishing-polynomial vectors"""
+    m = 2**64 - 1
+    x = (seed * 0x9E3779B97F4A7C15 + salt * 0xD1342543DE82EF95 + 0x7654321) & m
+    out = []
+    for _ in range(count):
+        x = (x + 0x9E3779B97F4A7C15) & m
+        z = x
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & m
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & m
+        z ^= z >> 31
+        out.append(z % P)
+    return out
+
+
+def test_whole_vanishing_polynomial_equals_the_interpreted_reference(vectors):
+    """`eval_vanishing_poly` (vanishing_poly.rs:20-45) as the reference computes it -- the table's AIR, then `eval_permutation_checks`
+    (permutation.rs:302-360: Z(1) = 1 per batch, then Z(gx) prod(rhs) = Z(x) prod(lhs) with `get_permutation_batches`' chunking), then
+    `eval_cross_table_lookup_checks` (cross_table_lookup.rs:380-421) over the `CtlCheckVars` that the reference's own
+    `CtlCheckVars::from_proofs` (:330-378) builds from `all_cross_table_lookups()` -- interpreted from the source for all twelve tables
+    (1 049 constraints) on two sets of rows, Z openings and challenges.  The same sequence from the AIR data in Python: what
+    olavm_amd/air/codegen.py prints into the quotient kernels and oracle/stark.cpp evaluates -- kinds, order (in particular the order
+    in which a table's lookup Z columns are consumed) and values."""
+    stark = T.ola_stark()
+    nch, zper = 2, 256
+
+    def col_eval(col, row):
+        return (sum(int(f) * row[int(c)] for c, f in col.terms) + int(col.constant)) % P
+
+    assert len(vectors["vanishing_poly"]) == 2
+    compared = 0
+    for vs in vectors["vanishing_poly"]:
+        seed = vs["seed"]
+        cc = stream_for(seed, 99, 2 * nch)
+        for t, (tab, ref) in enumerate(zip(stark.tables, vs["tables"])):
+            lv, nv = rows_for(seed, t, tab.ncols)
+            z = stream_for(seed, 100 + t, 2 * zper)
+            zl, zn = z[:zper], z[zper:]
+            emits = eval_emits(tab, lv, nv, [vectors["param"]] * max(1, tab.n_params))
+            nperm, bs = tab.num_permutation_batches(nch), tab.quotient_degree_factor
+            assert nperm == ref["num_permutation_zs"], tab.name
+            if tab.permutation_pairs:
+                pc = stream_for(seed, 200 + t, 2 * bs * nch)
+                emits += [("first_row", (zl[b] - 1) % P) for b in range(nperm)]
+                total, inst = len(tab.permutation_pairs) * nch, 0
+                for b in range(nperm):
+                    pl = pr = 1
+                    for i in range(bs):
+                        if inst >= total:
+                            break
+                        pair, c = tab.permutation_pairs[inst // nch], inst % nch
+                        beta, gamma = pc[2 * (i * nch + c)], pc[2 * (i * nch + c) + 1]
+                        pl = pl * (sum(lv[lc] * pow(beta, k, P) for k, (lc, _) in enumerate(pair)) + gamma) % P
+                        pr = pr * (sum(lv[rc] * pow(beta, k, P) for k, (_, rc) in enumerate(pair)) + gamma) % P
+                        inst += 1
+                    emits.append(("all", (zn[b] * pr - zl[b] * pl) % P))
+            k = 0
+            for ctl in stark.ctls:                    # AirSet.ctl_jobs order: per lookup, per challenge, this table's looking entries, then the looked one
+                for c in range(nch):
+                    beta, gamma = cc[2 * c], cc[2 * c + 1]
+                    for twc in list(ctl.looking_tables) + [ctl.looked_table]:
+                        if twc.table != t:
+                            continue
+                        sel = []
+                        for row in (lv, nv):
+                            combo = (sum(col_eval(col, row) * pow(beta, j, P) for j, col in enumerate(twc.columns)) + gamma) % P
+                            if twc.filter_column is not None:
+                                f = col_eval(twc.filter_column, row)
+                                combo = (f * combo + 1 - f) % P
+                            sel.append(combo)
+                        emits.append(("first_row", (zl[nperm + k] - sel[0]) % P))
+                        emits.append(("transition", (zn[nperm + k] - zl[nperm + k] * sel[1]) % P))
+                        k += 1
+            assert k == ref["num_ctl_zs"] == len(stark.ctl_jobs(t, nch)), tab.name
+            assert [e[0] for e in emits] == ref["kinds"], tab.name
+            assert [e[1] for e in emits] == ref["values"], tab.name
+            compared += len(emits)
+    assert compared == 2 * 1049
+
+
 @pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="the reference tree is not on this machine")
 def test_vectors_are_what_the_interpreter_computes_today_and_it_notices_a_changed_formula(tmp_path):
     import shutil

@@ -82,6 +82,9 @@ class Return(Exception):
         self.v = v
 
 
+NOT_FOUND = object()
+
+
 class Consumer:
     """ConstraintConsumer<P> (constraint_consumer.rs:34-78), recording instead of accumulating"""
 
@@ -220,6 +223,19 @@ class Parser:
                     inner.append(self.pattern())
                     self.eat(",")
                 return ("pcall", segs, inner)
+            if self.peek() == "{" and re.match(r"^[A-Z]", segs[-1]):        # PermutationInstance { pair, challenge: GrandProductChallenge { beta, gamma }, .. }
+                self.next()
+                fields = []
+                while not self.eat("}"):
+                    if self.eat(".."):
+                        continue
+                    self.eat("ref")
+                    self.eat("mut")
+                    name = self.next()
+                    sub = self.pattern() if self.eat(":") else ("pid", name)
+                    fields.append((name, sub))
+                    self.eat(",")
+                return ("pstruct", segs, fields)
             if len(segs) == 1 and re.match(r"^[a-z_]", segs[0]):
                 return ("pid", segs[0])
             return ("ppath", segs)
@@ -566,6 +582,10 @@ class Interp:
         self.fn_cache = {}
         self.const_cache = {}
         self.find_cache = {}
+        self.impl_cache = {}
+        self.enum_cache = {}
+        self.import_cache = {}
+        self.assoc_cache = {}
         self.depth = 0
 
     # ---- lookup of functions and constants in the reference tree
@@ -596,6 +616,218 @@ class Interp:
             body = Parser(src, blo, bhi + 1).block()
             self.fn_cache[key] = (params, body, src)
         return self.fn_cache[key]
+
+    def impl_index(self, path):
+        """(type, fn) -> (params range, body range) for the functions inside `impl .. Type { }` and `trait Name { }` blocks of a file
+        (trait blocks are indexed under the trait's name: default methods)"""
+        key = os.path.realpath(path)
+        if key in self.impl_cache:
+            return self.impl_cache[key]
+        src = X.Src.get(path)
+        T = src.toks
+        out = {}
+        i = 0
+        while i < len(T):
+            t = T[i][0]
+            if t in ("impl", "trait") and (i == 0 or T[i - 1][0] not in ("::", ".")):
+                j = i + 1
+                if T[j][0] == "<":
+                    depth = 0
+                    while True:
+                        depth += {"<": 1, ">": -1, "<<": 2, ">>": -2}.get(T[j][0], 0)
+                        j += 1
+                        if depth <= 0:
+                            break
+                names, depth = [], 0
+                while T[j][0] not in ("{", ";") or depth > 0:
+                    x = T[j][0]
+                    if x == "where" and depth == 0:
+                        break
+                    depth += {"<": 1, ">": -1, "<<": 2, ">>": -2}.get(x, 0)
+                    if depth == 0 and re.match(r"^[A-Za-z_]\w*$", x) and x not in ("for", "dyn", "const", "mut") and T[j - 1][0] not in ("'",):
+                        names.append(x)
+                    if x == "for" and depth == 0:
+                        names = []
+                    j += 1
+                while T[j][0] not in ("{", ";"):
+                    j = src.match(j) + 1 if T[j][0] in ("(", "[") else j + 1
+                if T[j][0] == "{" and names:
+                    ty = names[-1] if t == "impl" else names[0]
+                    end = src.match(j)
+                    k = j + 1
+                    while k < end:
+                        if T[k][0] == "fn":
+                            name = T[k + 1][0]
+                            q = k + 2
+                            if T[q][0] == "<":
+                                depth = 0
+                                while True:
+                                    depth += {"<": 1, ">": -1, "<<": 2, ">>": -2}.get(T[q][0], 0)
+                                    q += 1
+                                    if depth <= 0:
+                                        break
+                            while T[q][0] != "(":
+                                q += 1
+                            pe = src.match(q)
+                            b = pe + 1
+                            while T[b][0] not in ("{", ";"):
+                                b = src.match(b) + 1 if T[b][0] in ("[", "(") else b + 1
+                            if T[b][0] == "{":
+                                out.setdefault((ty, name), ((q, pe), (b, src.match(b))))
+                                k = src.match(b)
+                        elif T[k][0] == "{":
+                            k = src.match(k)
+                        k += 1
+                    i = end
+            i += 1
+        self.impl_cache[key] = out
+        return out
+
+    def find_assoc(self, ty, name, here):
+        """the file and ranges of `ty::name`, nearest file first"""
+        key = (ty, name, here)
+        if key not in self.assoc_cache:
+            found = None
+            for f in [here] + self.ref.files:
+                r = self.impl_index(f).get((ty, name))
+                if r is not None:
+                    found = (f, r)
+                    break
+            self.assoc_cache[key] = found
+        return self.assoc_cache[key]
+
+    def fn_ast_at(self, path, ranges):
+        key = (os.path.realpath(path), ranges[1][0])
+        if key not in self.fn_cache:
+            src = X.Src.get(path)
+            (plo, phi), (blo, bhi) = ranges
+            self.fn_cache[key] = (self.parse_params(src, plo, phi), Parser(src, blo, bhi + 1).block(), src)
+        return self.fn_cache[key]
+
+    @staticmethod
+    def parse_params(src, plo, phi):
+        pp = Parser(src, plo + 1, phi)
+        params = []
+        while pp.peek() is not None:
+            if pp.peek() in ("&", "mut") or pp.peek().startswith("'"):
+                pp.next()
+                continue
+            if pp.peek() == "self":
+                pp.next()
+                params.append(("pid", "self"))
+                pp.eat(",")
+                continue
+            pat = pp.pattern1()
+            pp.expect(":")
+            pp.skip_type((",",))
+            pp.eat(",")
+            params.append(pat)
+        return params
+
+    def call_assoc(self, ty, name, args, here, self_val=None, has_self=False):
+        found = self.find_assoc(ty, name, here)
+        if found is None:
+            return NOT_FOUND
+        path, ranges = found
+        params, body, src = self.fn_ast_at(path, ranges)
+        env = {"__src__": src, "__impl__": ty}
+        ps = list(params)
+        if ps and ps[0] == ("pid", "self"):
+            if not has_self:
+                self_val, args = args[0], args[1:]
+            env["self"] = self_val
+            ps = ps[1:]
+        elif has_self:
+            return NOT_FOUND
+        if len(ps) != len(args):
+            raise RustError(f"{path}: {ty}::{name} takes {len(ps)} arguments, {len(args)} given")
+        for p_, a in zip(ps, args):
+            self.bind(p_, a, env, src)
+        self.depth += 1
+        if self.depth > 200:
+            raise RustError(f"{path}: call depth")
+        try:
+            return self.ev(body, env, src)
+        except Return as r:
+            return r.v
+        finally:
+            self.depth -= 1
+
+    def enum_value(self, e, src):
+        """discriminant of an enum value (`Table::Memory as usize`)"""
+        key = e.ty
+        if key not in self.enum_cache:
+            table = None
+            for f in self.ref.files:
+                T = X.Src.get(f).toks
+                for i in range(len(T) - 2):
+                    if T[i][0] == "enum" and T[i + 1][0] == e.ty and T[i + 2][0] == "{":
+                        end = X.Src.get(f).match(i + 2)
+                        table, nxt, k = {}, 0, i + 3
+                        while k < end:
+                            if T[k][0] == "#":
+                                k = X.Src.get(f).match(k + 1) + 1
+                                continue
+                            name = T[k][0]
+                            k += 1
+                            if T[k][0] == "=":
+                                nxt = parse_int(T[k + 1][0])
+                                k += 2
+                            table[name] = nxt
+                            nxt += 1
+                            if T[k][0] in ("(", "{"):
+                                k = X.Src.get(f).match(k) + 1
+                            if T[k][0] == ",":
+                                k += 1
+                        break
+                if table is not None:
+                    break
+            if table is None:
+                raise RustError(f"{src.path}: enum {e.ty} not found")
+            self.enum_cache[key] = table
+        return self.enum_cache[key][e.variant]
+
+    def imports(self, src):
+        """`use a::b::{self, x as y, z};` of a file: local name -> (module, name there)"""
+        key = os.path.realpath(src.path)
+        if key in self.import_cache:
+            return self.import_cache[key]
+        T, out, i = src.toks, {}, 0
+        while i < len(T):
+            if T[i][0] == "use":
+                j, path_ = i + 1, []
+                while T[j][0] not in (";", "{"):
+                    if T[j][0] != "::":
+                        path_.append(T[j][0])
+                    j += 1
+                if T[j][0] == "{" and path_:
+                    e = src.match(j)
+                    k, item = j + 1, []
+                    depth = 0
+                    while k <= e:
+                        t = T[k][0]
+                        if (t == "," and depth == 0) or k == e:
+                            if len(item) == 3 and item[1] == "as":
+                                out[item[2]] = (path_[-1], item[0])
+                            elif len(item) == 1 and item[0] != "self":
+                                out[item[0]] = (path_[-1], item[0])
+                            item = []
+                        else:
+                            depth += t == "{"
+                            depth -= t == "}"
+                            if depth == 0 and t not in ("{", "}"):
+                                item.append(t)
+                        k += 1
+                    j = e
+                elif len(path_) >= 2:
+                    if len(path_) >= 4 and path_[-2] == "as":
+                        out[path_[-1]] = (path_[-4], path_[-3])
+                    else:
+                        out[path_[-1]] = (path_[-2], path_[-1])
+                i = j
+            i += 1
+        self.import_cache[key] = out
+        return out
 
     def find_fn_file(self, name, here, module=None):
         key = (name, os.path.realpath(here), module)
@@ -650,6 +882,11 @@ class Interp:
                 self.bind(p, x, env, src)
         elif k == "pcall":
             self.bind(pat[2][0], v, env, src)            # Some(x)
+        elif k == "pstruct":
+            for name, sub in pat[2]:
+                if name not in v:
+                    raise RustError(f"{src.path}: no field `{name}` in {v.get('__name__')}")
+                self.bind(sub, v[name], env, src)
         else:
             raise RustError(f"{src.path}: pattern {k} cannot bind")
 
@@ -680,6 +917,8 @@ class Interp:
             return False
         if k == "ptuple":
             return len(v) == len(pat[1]) and all(self.matches(p, x, env, src) for p, x in zip(pat[1], v))
+        if k == "pstruct":
+            return isinstance(v, dict) and all(name in v and self.matches(sub, v[name], env, src) for name, sub in pat[2])
         raise RustError(f"{src.path}: pattern {k}")
 
     def call_closure(self, c, args):
@@ -773,6 +1012,8 @@ class Interp:
             return not self.ev(n[1], env, src)
         if k == "cast":
             v = self.ev(n[1], env, src)
+            if isinstance(v, Enum):
+                return self.enum_value(v, src)
             return v.v if isinstance(v, Fe) else (int(v) if isinstance(v, bool) else v)
         if k == "index":
             base = self.ev(n[1], env, src)
@@ -821,7 +1062,7 @@ class Interp:
             raise self.err(src, n[3], f"no match arm for {v!r}")
         if k == "struct":
             s = Struct()
-            s["__name__"] = n[1][-1]
+            s["__name__"] = env.get("__impl__", "Self") if n[1][-1] == "Self" else n[1][-1]
             for name, e in n[2]:
                 if name == "..":
                     s.update(self.ev(e, env, src))
@@ -992,9 +1233,17 @@ class Interp:
             return args[0]
         if name == "default" and len(segs) >= 2:
             return Struct({"__name__": segs[-2]})
+        if len(segs) >= 2 and (segs[-2] == "Self" or (re.match(r"^[A-Z]", segs[-2]) and segs[-2] not in ("P", "F", "FE", "C", "S", "D", "T", "H"))):
+            ty = env.get("__impl__") if segs[-2] == "Self" else segs[-2]
+            if ty is not None:
+                r = self.call_assoc(ty, name, args, src.path)
+                if r is not NOT_FOUND:
+                    return r
         module = None
         if len(segs) >= 2 and segs[-2] not in ("Self",) and re.match(r"^[a-z_]", segs[-2]):
             module = segs[-2]
+        if len(segs) == 1 and name not in X.Src.get(src.path).functions() and name in self.imports(src):
+            module, name = self.imports(src)[name]          # `use ..::{ctl_data as mem_ctl_data}`
         target = None
         cur = src.path
         if (module is None) and name in X.Src.get(cur).functions():
@@ -1170,6 +1419,21 @@ class Interp:
                 for x in items[1:]:
                     acc = self.call_closure(args[0], [acc, x])
                 return acc
+            if name == "next" and isinstance(r, list):
+                return r.pop(0) if r else None
+            if name == "unzip":
+                return [x[0] for x in items], [x[1] for x in items]
+            if name == "cartesian_product":
+                other = self.iterate(args[0], src, line)
+                return [(x, y) for x in items for y in other]
+            if name == "count":
+                return len(items)
+            if name == "unique":
+                out = []
+                for x in items:
+                    if not any(same(x, y) for y in out):
+                        out.append(x)
+                return out
             if name in ("first", "last"):
                 return (items[0] if name == "first" else items[-1]) if items else None
             if name == "chunks":
@@ -1193,6 +1457,12 @@ class Interp:
                 return items
             if name == "is_empty":
                 return not items
+        if isinstance(r, Struct) and "__name__" in r:
+            for ty in (r["__name__"], r.get("__trait__")):
+                if ty:
+                    v = self.call_assoc(ty, name, args, r.get("__file__", src.path), self_val=r, has_self=True)
+                    if v is not NOT_FOUND:
+                        return v
         # ---- a method of the reference (on `self` structs, enums): found by name
         target = self.find_fn_file(name, src.path)
         if target is not None:
@@ -1239,15 +1509,18 @@ def pattern_names(pat):
         return [n for p in pat[1] for n in pattern_names(p)]
     if k == "pcall":
         return [n for p in pat[2] for n in pattern_names(p)]
+    if k == "pstruct":
+        return [n for _, p in pat[2] for n in pattern_names(p)]
     return []
 
 
 # ------------------------------------------------------------------------------------------------ driving it
 def make_ref(reference):
     ref = X.Ref(reference)
-    extra = os.path.join(reference, "plonky2", "plonky2", "src", "plonk", "plonk_common.rs")
-    if os.path.exists(extra) and extra not in ref.files:
-        ref.files.append(extra)
+    for rel in ("plonky2/plonky2/src/plonk/plonk_common.rs", "plonky2/plonky2/src/util/reducing.rs", "plonky2/util/src/lib.rs"):
+        extra = os.path.join(reference, rel)
+        if os.path.exists(extra) and extra not in ref.files:
+            ref.files.append(extra)
     # constants of the added file
     return ref
 
@@ -1332,6 +1605,77 @@ def eval_ctl_entry(it, ref, entry, row):
     return data, filt
 
 
+def stream_for(seed, salt, count):
+    """`count` deterministic field elements (splitmix64 mod p) -- Z values and challenges of the vanishing-polynomial vectors"""
+    m = 2**64 - 1
+    x = (seed * 0x9E3779B97F4A7C15 + salt * 0xD1342543DE82EF95 + 0x7654321) & m
+    out = []
+    for _ in range(count):
+        x = (x + 0x9E3779B97F4A7C15) & m
+        z = x
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & m
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & m
+        z ^= z >> 31
+        out.append(z % P)
+    return out
+
+
+NUM_CHALLENGES = 2
+Z_PER_TABLE = 256          # Z openings handed to from_proofs per table: more than any table has (it takes what it needs, in its order)
+
+
+def stark_struct(it, ref, rel):
+    """a value standing for `&S` (the table's Stark impl): methods resolve through the impl blocks of the table's file, then the trait's defaults"""
+    path = os.path.join(ref.root, rel)
+    ty = [t for (t, n) in it.impl_index(path) if n == "eval_packed_generic"][0]
+    return Struct({"__name__": ty, "__trait__": "Stark", "__file__": path, "compress_challenge": Fe(PARAM), "_phantom": None})
+
+
+def eval_vanishing(it, ref, seed, golden):
+    """`eval_vanishing_poly` (vanishing_poly.rs:20-45) of every table on one set of inputs: the table's AIR, then `eval_permutation_checks`
+    (permutation.rs:302-360), then `eval_cross_table_lookup_checks` (cross_table_lookup.rs:380-421), with the per-table `CtlCheckVars` built by
+    the reference's own `CtlCheckVars::from_proofs` (:330-378) from `all_cross_table_lookups()` (ola_stark.rs:122-560) -- so the ORDER in which a
+    table's lookup Z columns are consumed is the reference's, too.  Inputs: rows_for(seed, t, columns); Z openings stream_for(seed, 100 + t,
+    2 * Z_PER_TABLE) (local then next); lookup challenges stream_for(seed, 99, 4) = (beta, gamma) x 2; permutation challenge sets of table t
+    stream_for(seed, 200 + t, ...) = [batch slot][challenge](beta, gamma).  -> per table [(kind, value)]"""
+    stark_dir = os.path.join(ref.root, "stark")
+    ola = os.path.join(stark_dir, "ola_stark.rs")
+    config = Struct({"__name__": "StarkConfig", "num_challenges": NUM_CHALLENGES, "security_bits": 100})
+    starks = [stark_struct(it, ref, rel) for _, rel in X.TABLES]
+    ctls = it.call_fn(ola, "all_cross_table_lookups", [])
+    cc = stream_for(seed, 99, 2 * NUM_CHALLENGES)
+    ctl_challenges = Struct({"__name__": "GrandProductChallengeSet", "challenges": [
+        Struct({"__name__": "GrandProductChallenge", "beta": Fe(cc[2 * c]), "gamma": Fe(cc[2 * c + 1])}) for c in range(NUM_CHALLENGES)]})
+    nperm = [it.method(st, "num_permutation_batches", [config], X.Src.get(ola), 0) for st in starks]
+    proofs, zs = [], []
+    for t in range(len(starks)):
+        z = stream_for(seed, 100 + t, 2 * Z_PER_TABLE)
+        zs.append((z[:Z_PER_TABLE], z[Z_PER_TABLE:]))
+        proofs.append(Struct({"__name__": "StarkProof", "openings": Struct({"__name__": "StarkOpeningSet", "permutation_ctl_zs": [Fe(x) for x in z[:Z_PER_TABLE]],
+                                                                            "permutation_ctl_zs_next": [Fe(x) for x in z[Z_PER_TABLE:]]})}))
+    r = it.call_assoc("CtlCheckVars", "from_proofs", [proofs, ctls, ctl_challenges, nperm], os.path.join(stark_dir, "cross_table_lookup.rs"))
+    if r is NOT_FOUND:
+        raise RustError("CtlCheckVars::from_proofs not found")
+    out = []
+    for t, (st, (_, rel)) in enumerate(zip(starks, X.TABLES)):
+        ncols = golden["tables"][t]["columns"]
+        lv, nv = rows_for(seed, t, ncols)
+        vars_ = Struct({"__name__": "StarkEvaluationVars", "local_values": [Fe(x) for x in lv], "next_values": [Fe(x) for x in nv], "public_inputs": []})
+        pv = None
+        if it.method(st, "uses_permutation_args", [], X.Src.get(ola), 0):
+            bs = it.method(st, "permutation_batch_size", [], X.Src.get(ola), 0)
+            pc = stream_for(seed, 200 + t, 2 * bs * NUM_CHALLENGES)
+            sets = [Struct({"__name__": "GrandProductChallengeSet", "challenges": [
+                Struct({"__name__": "GrandProductChallenge", "beta": Fe(pc[2 * (i * NUM_CHALLENGES + c)]), "gamma": Fe(pc[2 * (i * NUM_CHALLENGES + c) + 1])})
+                for c in range(NUM_CHALLENGES)]}) for i in range(bs)]
+            pv = Struct({"__name__": "PermutationCheckVars", "local_zs": [Fe(x) for x in zs[t][0][:nperm[t]]], "next_zs": [Fe(x) for x in zs[t][1][:nperm[t]]],
+                         "permutation_challenge_sets": sets})
+        cons = Consumer()
+        it.call_fn(os.path.join(stark_dir, "vanishing_poly.rs"), "eval_vanishing_poly", [st, config, vars_, pv, r[t], cons])
+        out.append({"kinds": [e[0] for e in cons.emits], "values": [e[1] for e in cons.emits], "num_permutation_zs": nperm[t], "num_ctl_zs": len(r[t])})
+    return out
+
+
 def extract(reference, points):
     ref = make_ref(reference)
     it = Interp(ref)
@@ -1369,7 +1713,13 @@ def extract(reference, points):
             problems.append({"table": c["name"], "reason": "%s: %s" % (type(e).__name__, e)})
             rec = {"name": c["name"], "unevaluated": "%s: %s" % (type(e).__name__, e)}
         ctls.append(rec)
-    return {"generator": "tools/rust_air_eval.py", "cross_table_lookups": ctls, "what": "values of the constraints the reference's eval_packed_generic emits on pseudo-random rows "
+    vanishing = []
+    try:
+        for sd in range(points):
+            vanishing.append({"seed": sd, "tables": eval_vanishing(it, ref, sd, golden)})
+    except (RustError, RecursionError, IndexError, KeyError, TypeError, AttributeError, AssertionError) as e:
+        problems.append({"table": "eval_vanishing_poly", "reason": "%s: %s" % (type(e).__name__, e)})
+    return {"generator": "tools/rust_air_eval.py", "cross_table_lookups": ctls, "vanishing_poly": vanishing, "what": "values of the constraints the reference's eval_packed_generic emits on pseudo-random rows "
             "(rows_for(seed, table, columns): splitmix64 mod p; compress challenge PARAM), obtained by interpreting the reference's Rust source",
             "param": PARAM, "tables": tables, "problems": problems}
 
@@ -1391,6 +1741,10 @@ def main():
     bad = [c for c in data["cross_table_lookups"] if "unevaluated" in c]
     print("%d cross-table lookups: %d lookup entries evaluated%s" % (len(data["cross_table_lookups"]), sum(len(c.get("entries", ())) for c in data["cross_table_lookups"]),
                                                                       "".join("\n  NOT EVALUATED %s: %s" % (c["name"], c["unevaluated"]) for c in bad)))
+    for pr in data["problems"]:
+        print("PROBLEM", pr["table"], pr["reason"][:300])
+    if data["vanishing_poly"]:
+        print("eval_vanishing_poly: %d constraints over the 12 tables, %d input sets" % (sum(len(t["values"]) for t in data["vanishing_poly"][0]["tables"]), len(data["vanishing_poly"])))
     text = json.dumps(data, separators=(",", ":")) + "\n"
     if a.check:
         if open(a.out).read() != text:
