@@ -48,6 +48,12 @@ class Fe:
     def __repr__(self):
         return "Fe(%d)" % self.v
 
+    def __eq__(self, o):                    # arrays and structs of elements compare by value (`digest == cap.0[i]`)
+        return isinstance(o, Fe) and o.v == self.v
+
+    def __hash__(self):
+        return hash(self.v)
+
 
 class Rng:
     def __init__(self, a, b):
@@ -58,8 +64,8 @@ class Rng:
 
 
 class Enum:
-    def __init__(self, ty, variant):
-        self.ty, self.variant = ty, variant
+    def __init__(self, ty, variant, payload=None):
+        self.ty, self.variant, self.payload = ty, variant, payload
 
     def __eq__(self, o):
         return isinstance(o, Enum) and (self.ty, self.variant) == (o.ty, o.variant)
@@ -281,6 +287,11 @@ class Parser:
             it = self.expr(no_struct=True)
             body = self.block()
             return ("for", pat, it, body, ln), False, False
+        if t == "loop":
+            ln = self.line()
+            self.next()
+            body = self.block()
+            return ("while", ("path", ["true"], ln), body, ln), False, False
         if t == "while":
             self.next()
             cond = self.expr(no_struct=True)
@@ -303,6 +314,10 @@ class Parser:
 
     def assign(self, ns):
         lhs = self.range_(ns)
+        if self.peek() in (">>", "<<") and self.peek(1) == "=":
+            op = self.next() + self.next()
+            rhs = self.assign(ns)
+            return ("assign", op, lhs, rhs, self.line())
         if self.peek() in ASSIGN:
             op = self.next()
             rhs = self.assign(ns)
@@ -326,7 +341,7 @@ class Parser:
         if level == len(BINOPS):
             return self.cast(ns)
         a = self.binary(level + 1, ns)
-        while self.peek() in BINOPS[level]:
+        while self.peek() in BINOPS[level] and not (self.peek() in (">>", "<<") and self.peek(1) == "="):      # `x >>= 1` is tokenised `>>` `=`
             # `|` as a binary operator never follows an expression in these files except as bit-or on integers; closures start a primary
             op = self.next()
             b = self.binary(level + 1, ns)
@@ -337,13 +352,13 @@ class Parser:
         e = self.unary(ns)
         while self.peek() == "as":
             self.next()
-            self.next()                       # the type's head
+            ty = self.next()                  # the type's head
             while self.peek() == "::":
                 self.next()
-                self.next()
+                ty = self.next()
             if self.peek() == "<":
                 self.skip_generics()
-            e = ("cast", e)
+            e = ("cast", e, ty)
         return e
 
     def unary(self, ns):
@@ -356,10 +371,11 @@ class Parser:
             return ("not", self.unary(ns))
         if t == "*":
             self.next()
-            return self.unary(ns)              # deref: references are transparent
+            return ("deref", self.unary(ns))   # references are transparent, except as the target of `*x = ...`
         if t in ("&", "&&"):
             self.next()
-            self.eat("mut")
+            if self.eat("mut"):
+                return ("mutref", self.unary(ns))      # `&mut x`: a callee may assign through it
             return self.unary(ns)
         return self.postfix(ns)
 
@@ -518,6 +534,12 @@ class Parser:
                     items.append(self.expr())
                     self.eat(",")
                 return ("macro", name, items)
+            if name == "ensure!":             # anyhow's ensure!(cond, "..."): the condition matters, the message does not
+                ln = self.line()
+                self.next()
+                cond = self.expr()
+                self.i = end + 1
+                return ("macro", name, [cond], ln)
             self.i = end + 1                  # assert! / debug_assert! / println! ...: no value
             return ("unit",)
         if re.match(r"^[A-Za-z_]", t):
@@ -586,6 +608,11 @@ class Interp:
         self.enum_cache = {}
         self.import_cache = {}
         self.assoc_cache = {}
+        self.pending_writeback = []
+        self.near_cache = {}
+        self.extra_files = []               # files outside the AIR tree whose impl blocks a driver needs (plonky2's fri/, iop/challenger.rs)
+        self.generics = {}                  # generic parameter -> the types tried for `H::f(..)`: {"H": ["PoseidonHash", "Hasher"]} (set by a driver)
+        self.permutation_hook = None        # what `H::Permutation::permute` runs (the driver installs the interpreted poseidon_naive)
         self.depth = 0
 
     # ---- lookup of functions and constants in the reference tree
@@ -596,7 +623,7 @@ class Interp:
             fns = src.functions()
             if name not in fns:
                 raise RustError(f"{path}: fn {name} not found")
-            (plo, phi), (blo, bhi) = fns[name]
+            (plo, phi), (blo, bhi) = self.impl_index(path).get(("", name), fns[name])       # a free function before a method of the same name
             pp = Parser(src, plo + 1, phi)
             params = []
             while pp.peek() is not None:
@@ -679,16 +706,42 @@ class Interp:
                             k = src.match(k)
                         k += 1
                     i = end
+            elif t == "fn":                     # a free function: indexed under the empty type name
+                name = T[i + 1][0]
+                q = i + 2
+                if T[q][0] == "<":
+                    depth = 0
+                    while True:
+                        depth += {"<": 1, ">": -1, "<<": 2, ">>": -2}.get(T[q][0], 0)
+                        q += 1
+                        if depth <= 0:
+                            break
+                while T[q][0] != "(":
+                    q += 1
+                pe = src.match(q)
+                b = pe + 1
+                while T[b][0] not in ("{", ";"):
+                    b = src.match(b) + 1 if T[b][0] in ("[", "(") else b + 1
+                if T[b][0] == "{":
+                    out.setdefault(("", name), ((q, pe), (b, src.match(b))))
+                    i = src.match(b)
             i += 1
         self.impl_cache[key] = out
         return out
+
+    def call_free(self, path, name, args):
+        """a free function of one file (`call_fn` takes the first `fn` of that name, which may be a method)"""
+        v = self.call_assoc("", name, args, path)
+        if v is NOT_FOUND:
+            raise RustError(f"{path}: no free fn {name}")
+        return v
 
     def find_assoc(self, ty, name, here):
         """the file and ranges of `ty::name`, nearest file first"""
         key = (ty, name, here)
         if key not in self.assoc_cache:
             found = None
-            for f in [here] + self.ref.files:
+            for f in [here] + self.ref.files + self.extra_files:
                 r = self.impl_index(f).get((ty, name))
                 if r is not None:
                     found = (f, r)
@@ -743,6 +796,8 @@ class Interp:
             raise RustError(f"{path}: {ty}::{name} takes {len(ps)} arguments, {len(args)} given")
         for p_, a in zip(ps, args):
             self.bind(p_, a, env, src)
+        wb, self.pending_writeback = self.pending_writeback, []
+        shift = 1 if (params and params[0] == ("pid", "self") and not has_self) else 0
         self.depth += 1
         if self.depth > 200:
             raise RustError(f"{path}: call depth")
@@ -752,6 +807,11 @@ class Interp:
             return r.v
         finally:
             self.depth -= 1
+            for i, cenv, cname in wb:
+                j = i - shift
+                if 0 <= j < len(ps) and ps[j][0] == "pid" and ps[j][1] in env:
+                    cenv[cname] = env[ps[j][1]]
+                    cenv.setdefault("__assigned__", set()).add(cname)
 
     def enum_value(self, e, src):
         """discriminant of an enum value (`Table::Memory as usize`)"""
@@ -839,12 +899,18 @@ class Interp:
         return self.find_cache[key]
 
     def const_value(self, name, src):
-        cands = self.ref.consts.get(name)
-        if not cands:
-            return None
-        c = self.ref.near(cands, src.path)
+        nk = (name, src.path)
+        if nk not in self.near_cache:
+            cands = self.ref.consts.get(name)
+            c = None
+            if cands:
+                c = self.ref.near(cands, src.path)
+                if c is None:
+                    c = cands[0]
+            self.near_cache[nk] = c
+        c = self.near_cache[nk]
         if c is None:
-            c = cands[0]
+            return None
         key = (name, c[0])
         if key not in self.const_cache:
             csrc = X.Src.get(c[0])
@@ -914,6 +980,8 @@ class Interp:
                 if v is None:
                     return False
                 return self.matches(pat[2][0], v, env, src)
+            if isinstance(v, Enum) and v.variant == pat[1][-1] and v.payload is not None and len(v.payload) == len(pat[2]):
+                return all(self.matches(p_, x, env, src) for p_, x in zip(pat[2], v.payload))
             return False
         if k == "ptuple":
             return len(v) == len(pat[1]) and all(self.matches(p, x, env, src) for p, x in zip(pat[1], v))
@@ -945,6 +1013,7 @@ class Interp:
             raise RustError(f"{path}: {name} takes {len(ps)} arguments, {len(args)} given")
         for p, a in zip(ps, args):
             self.bind(p, a, env, src)
+        wb, self.pending_writeback = self.pending_writeback, []
         self.depth += 1
         if self.depth > 200:
             raise RustError(f"{path}: call depth")
@@ -954,6 +1023,10 @@ class Interp:
             return r.v
         finally:
             self.depth -= 1
+            for i, cenv, cname in wb:
+                if i < len(ps) and ps[i][0] == "pid" and ps[i][1] in env:
+                    cenv[cname] = env[ps[i][1]]
+                    cenv.setdefault("__assigned__", set()).add(cname)
 
     def iterate(self, v, src, line=0):
         if isinstance(v, Rng):
@@ -1014,7 +1087,11 @@ class Interp:
             v = self.ev(n[1], env, src)
             if isinstance(v, Enum):
                 return self.enum_value(v, src)
-            return v.v if isinstance(v, Fe) else (int(v) if isinstance(v, bool) else v)
+            v = v.v if isinstance(v, Fe) else (int(v) if isinstance(v, bool) else v)
+            bits = {"u8": 8, "u16": 16, "u32": 32, "u64": 64, "u128": 128, "usize": 64}.get(n[2] if len(n) > 2 else None)
+            if bits is not None and isinstance(v, int):
+                v &= (1 << bits) - 1               # `sum as u64`: truncation
+            return v
         if k == "index":
             base = self.ev(n[1], env, src)
             idx = self.ev(n[2], env, src)
@@ -1037,6 +1114,8 @@ class Interp:
             if n[3] and b is not None:
                 b += 1
             return Rng(a, b)
+        if k in ("mutref", "deref"):
+            return self.ev(n[1], env, src)
         if k == "closure":
             return Closure(n[1], n[2], env, src)
         if k == "block":
@@ -1073,6 +1152,10 @@ class Interp:
             if n[1] == "izip!":
                 cols = [self.iterate(self.ev(x, env, src), src) for x in n[2]]
                 return [tuple(t) for t in zip(*cols)]
+            if n[1] == "ensure!":
+                if not self.truthy(self.ev(n[2][0], env, src)):
+                    raise Return(Enum("Result", "Err", [f"{os.path.basename(src.path)}:{n[3]}"]))
+                return None
             raise RustError(f"{src.path}: macro {n[1]}")
         if k == "call":
             return self.call(n, env, src)
@@ -1144,21 +1227,28 @@ class Interp:
 
     def assign(self, n, env, src):
         op, lhs, rhs, line = n[1], n[2], self.ev(n[3], env, src), n[4]
+        if lhs[0] == "deref":
+            lhs = lhs[1]
+            if op == "=" and isinstance(rhs, list):
+                cur = self.ev(lhs, env, src)
+                if isinstance(cur, list):              # `*state = new_array`: the caller's array changes
+                    cur[:] = rhs
+                    return None
         if lhs[0] == "path" and len(lhs[1]) == 1:
             name = lhs[1][0]
             if name not in env:
                 raise self.err(src, line, f"assignment to unknown `{name}`")
-            env[name] = rhs if op == "=" else self.binop(op[0], env[name], rhs, src, line)
+            env[name] = rhs if op == "=" else self.binop(op[:-1], env[name], rhs, src, line)
             env.setdefault("__assigned__", set()).add(name)
             return None
         if lhs[0] == "index":
             base = self.ev(lhs[1], env, src)
             idx = self.ev(lhs[2], env, src)
-            base[idx] = rhs if op == "=" else self.binop(op[0], base[idx], rhs, src, line)
+            base[idx] = rhs if op == "=" else self.binop(op[:-1], base[idx], rhs, src, line)
             return None
         if lhs[0] == "field":
             base = self.ev(lhs[1], env, src)
-            base[lhs[2]] = rhs if op == "=" else self.binop(op[0], base[lhs[2]], rhs, src, line)
+            base[lhs[2]] = rhs if op == "=" else self.binop(op[:-1], base[lhs[2]], rhs, src, line)
             return None
         raise self.err(src, line, "assignment target")
 
@@ -1207,8 +1297,17 @@ class Interp:
         raise self.err(src, line, f"unknown name `{'::'.join(segs)}`")
 
     def call(self, n, env, src):
+        try:
+            return self._call(n, env, src)
+        finally:
+            self.pending_writeback = []         # a built-in took the call: nothing to copy back
+
+    def _call(self, n, env, src):
         callee, line = n[1], n[3]
         args = [self.ev(a, env, src) for a in n[2]]
+        # `f(&mut counter)`: scalars are values here, so what the callee left in that parameter is copied back afterwards
+        self.pending_writeback = [(i, env, a[1][1][0]) for i, a in enumerate(n[2])
+                                  if a[0] == "mutref" and a[1][0] == "path" and len(a[1][1]) == 1 and not isinstance(env.get(a[1][1][0]), (list, dict))]
         if callee[0] != "path":
             f = self.ev(callee, env, src)
             if isinstance(f, Closure):
@@ -1223,8 +1322,16 @@ class Interp:
             return v if isinstance(v, Fe) else Fe(v)
         if name in ("Some", "Ok", "Box", "Reverse"):
             return args[0]
-        if name == "new" and len(segs) >= 2 and segs[-2] in ("Vec", "String"):
+        if name in ("new", "with_capacity") and len(segs) >= 2 and segs[-2] in ("Vec", "String"):
             return []
+        if name == "from_noncanonical_u96":
+            return Fe(args[0][0] + (args[0][1] << 64))
+        if name in ("from_basefield_array",):
+            return tuple(args[0])
+        if name == "default" and len(segs) >= 2 and segs[-2] == "Default":
+            return None
+        if name == "permute" and len(segs) >= 2 and segs[-2] in ("Permutation", "P", "PoseidonPermutation") and self.permutation_hook is not None:
+            return self.permutation_hook(args[0])
         if name == "once" and "iter" in segs:
             return [args[0]]
         if name == "repeat" and ("iter" in segs or (len(segs) == 1 and self.find_fn_file(name, src.path) is None)):
@@ -1233,6 +1340,11 @@ class Interp:
             return args[0]
         if name == "default" and len(segs) >= 2:
             return Struct({"__name__": segs[-2]})
+        if len(segs) >= 2 and segs[-2] in self.generics:
+            for ty in self.generics[segs[-2]]:
+                r = self.call_assoc(ty, name, args, src.path)
+                if r is not NOT_FOUND:
+                    return r
         if len(segs) >= 2 and (segs[-2] == "Self" or (re.match(r"^[A-Z]", segs[-2]) and segs[-2] not in ("P", "F", "FE", "C", "S", "D", "T", "H"))):
             ty = env.get("__impl__") if segs[-2] == "Self" else segs[-2]
             if ty is not None:
@@ -1250,6 +1362,8 @@ class Interp:
             target = cur
         if target is None:
             target = self.find_fn_file(name, cur, module)
+        if target is None and len(segs) >= 2 and re.match(r"^[A-Z]", segs[-2]) and re.match(r"^[A-Z]", name):
+            return Enum(segs[-2], name, list(args))         # FriReductionStrategy::ConstantArityBits(4, 5)
         if target is None:
             raise self.err(src, line, f"function `{'::'.join(segs)}` not found")
         params, _, _ = self.fn_ast(target, name)
@@ -1270,9 +1384,28 @@ class Interp:
             recv.emits.append((X.KINDS[name], v.v, os.path.relpath(src.path, self.ref.root), line))
             return None
         args = [self.ev(a, env, src) for a in n[3]]
+        if name in ("copy_from_slice", "clone_from_slice", "fill") and recv_node[0] in ("index", "mutref", "deref"):
+            # `state[..k].copy_from_slice(chunk)`: a slice of a list is a copy here, so the write goes to the indexed array itself
+            node = recv_node
+            while node[0] in ("mutref", "deref"):
+                node = node[1]
+            if node[0] == "index":
+                base, idx = self.ev(node[1], env, src), self.ev(node[2], env, src)
+                if isinstance(idx, Rng) and isinstance(base, list):
+                    a = idx.start or 0
+                    b = len(base) if idx.end is None else idx.end
+                    new = list(args[0]) if name != "fill" else [args[0]] * (b - a)
+                    if len(new) != b - a or not (0 <= a <= b <= len(base)):
+                        raise self.err(src, line, f"{name}: {len(new)} elements into {a}..{b} of {len(base)}")
+                    base[a:b] = new
+                    return None
         return self.method(recv, name, args, src, line)
 
     def method(self, r, name, args, src, line):
+        if name == "to_vec" and isinstance(r, Struct) and "__name__" in r:         # HashOut::to_vec (hash_types.rs:80), not the slice adaptor
+            v = self.call_assoc(r["__name__"], name, args, r.get("__file__", src.path), self_val=r, has_self=True)
+            if v is not NOT_FOUND:
+                return v
         # ---- adaptors that do nothing here
         if name in ("iter", "into_iter", "iter_mut", "copied", "cloned", "collect", "collect_vec", "to_vec", "try_into", "unwrap", "expect", "by_ref",
                     "as_ref", "as_mut", "borrow", "into", "to_owned", "as_slice_of_cells", "peekable", "into_par_iter", "par_iter", "unwrap_or_default"):
@@ -1308,6 +1441,10 @@ class Interp:
                 return self.binop({"mul": "*", "add": "+", "sub": "-"}[name], r, args[0], src, line)
             if name == "powers":
                 return Powers(r)
+            if name == "add_canonical_u64":
+                return Fe(r.v + args[0])
+            if name == "to_basefield_array":
+                return [r]
         if isinstance(r, int) and not isinstance(r, bool):
             if name == "pow":
                 return r ** args[0]
@@ -1326,6 +1463,8 @@ class Interp:
                 return (r is not None) == (name == "is_some")
         if name in ("is_some", "is_none"):
             return (r is not None) == (name == "is_some")
+        if isinstance(r, tuple) and name == "to_basefield_array":
+            return list(r)
         if isinstance(r, Rng) and name in ("contains",):
             return r.start <= args[0] < r.end
         if isinstance(r, (list, tuple, Rng, RepeatForever)):
@@ -1440,6 +1579,26 @@ class Interp:
                 return [items[i:i + args[0]] for i in range(0, len(items), args[0])]
             if name == "windows":
                 return [items[i:i + args[0]] for i in range(0, len(items) - args[0] + 1)]
+            if isinstance(r, list) and name in ("clear", "pop", "drain", "extend_from_slice", "shrink_to_fit", "copy_from_slice", "truncate", "reserve"):
+                if name == "clear":
+                    del r[:]
+                    return None
+                if name == "pop":
+                    return r.pop() if r else None
+                if name == "drain":
+                    out = list(r)
+                    del r[:]
+                    return out
+                if name == "extend_from_slice":
+                    r.extend(self.iterate(args[0], src, line))
+                    return None
+                if name == "copy_from_slice":
+                    r[:] = self.iterate(args[0], src, line)
+                    return None
+                if name == "truncate":
+                    del r[args[0]:]
+                    return None
+                return None
             if name == "push" and isinstance(r, list):
                 r.append(args[0])
                 return None
@@ -1463,6 +1622,10 @@ class Interp:
                     v = self.call_assoc(ty, name, args, r.get("__file__", src.path), self_val=r, has_self=True)
                     if v is not NOT_FOUND:
                         return v
+        if isinstance(r, Enum):
+            v = self.call_assoc(r.ty, name, args, src.path, self_val=r, has_self=True)
+            if v is not NOT_FOUND:
+                return v
         # ---- a method of the reference (on `self` structs, enums): found by name
         target = self.find_fn_file(name, src.path)
         if target is not None:
@@ -1724,14 +1887,138 @@ def extract(reference, points):
             "param": PARAM, "tables": tables, "problems": problems}
 
 
+PRIMITIVES_FIXTURE = os.path.join(ROOT, "tests", "golden", "ref_primitive_vectors.json")
+
+
+def plonky2_interp(reference):
+    """an interpreter whose `H` is PoseidonHash and whose permutation is the interpreted `Poseidon::poseidon_naive` (hash/poseidon.rs:617)"""
+    it = Interp(make_ref(reference))
+    base = os.path.join(reference, "plonky2", "plonky2", "src")
+    it.plonky2 = base
+    pos = os.path.join(base, "hash", "poseidon.rs")
+    it.extra_files = [os.path.join(base, "fri", "mod.rs"), os.path.join(base, "fri", "reduction_strategies.rs"), os.path.join(base, "iop", "challenger.rs"),
+                      os.path.join(base, "hash", "merkle_proofs.rs")]
+    it.generics = {"H": ["PoseidonHash", "Hasher"], "OH": ["PoseidonHash", "Hasher"]}
+    it.permutation_hook = lambda st: it.call_assoc("Poseidon", "poseidon_naive", [list(st)], pos)
+    return it
+
+
+def hash_out(d):
+    return Struct({"__name__": "HashOut", "elements": [Fe(int(x)) for x in d]})
+
+
+def verify_merkle_proof_to_cap(it, leaf, index, cap, siblings):
+    """hash/merkle_proofs.rs:46 interpreted; True when it returns Ok(())"""
+    r = it.call_free(os.path.join(it.plonky2, "hash", "merkle_proofs.rs"), "verify_merkle_proof_to_cap",
+                     [[Fe(int(x)) for x in leaf], int(index), Struct({"__name__": "MerkleCap", 0: [hash_out(c) for c in cap]}),
+                      Struct({"__name__": "MerkleProof", "siblings": [hash_out(x) for x in siblings]})])
+    return not isinstance(r, Enum)
+
+
+def primitives(reference):
+    """Outputs of the reference's own hashing, transcript and FRI-parameter code, interpreted: the vectors the oracle and the product's host code
+    are compared with (tests/test_ref_primitives.py)."""
+    it = plonky2_interp(reference)
+    base = it.plonky2
+    pos = os.path.join(base, "hash", "poseidon.rs")
+    hashing = os.path.join(base, "hash", "hashing.rs")
+    chal = os.path.join(base, "iop", "challenger.rs")
+    out = {"generated_by": "tools/rust_air_eval.py --primitives", "sources": {}}
+
+    # ---- the permutation (poseidon.rs:617 poseidon_naive: constant_layer, sbox_layer, mds_layer as written there)
+    inputs = [[0] * 12, [P - 1] * 12, list(range(12))] + [stream_for(900 + k, 1, 12) for k in range(5)]
+    out["poseidon"] = [{"input": v, "output": [x.v for x in it.call_assoc("Poseidon", "poseidon_naive", [[Fe(x) for x in v]], pos)]} for v in inputs]
+    out["sources"]["poseidon"] = "plonky2/plonky2/src/hash/poseidon.rs: Poseidon::poseidon_naive"
+
+    # ---- sponge hashing (hashing.rs:93 hash_n_to_m_no_pad, :117 hash_n_to_hash_no_pad, :77 compress) through PoseidonHash (poseidon.rs:640)
+    out["hash_no_pad"] = []
+    for n in (0, 1, 4, 5, 7, 8, 9, 15, 16, 17, 29, 76, 135):
+        v = stream_for(1000 + n, 2, n)
+        h = it.call_assoc("PoseidonHash", "hash_no_pad", [[Fe(x) for x in v]], pos)
+        out["hash_no_pad"].append({"input": v, "digest": [x.v for x in h["elements"]]})
+    out["two_to_one"] = []
+    for k in range(4):
+        l, r = stream_for(1100 + k, 3, 4), stream_for(1100 + k, 4, 4)
+        h = it.call_assoc("PoseidonHash", "two_to_one", [hash_out(l), hash_out(r)], pos)
+        out["two_to_one"].append({"left": l, "right": r, "digest": [x.v for x in h["elements"]]})
+    out["sources"]["hash_no_pad"] = "plonky2/plonky2/src/hash/poseidon.rs: PoseidonHash::hash_no_pad -> hashing.rs: hash_n_to_hash_no_pad"
+    out["sources"]["two_to_one"] = "plonky2/plonky2/src/hash/poseidon.rs: PoseidonHash::two_to_one -> hashing.rs: compress"
+
+    # ---- the transcript (iop/challenger.rs:36-162): scripts of observe / observe_cap / get / compact
+    scripts = [
+        [["get", 1]],
+        [["observe", 1], ["get", 1]],
+        [["observe", 8], ["get", 3], ["get", 6], ["observe", 3], ["get", 2]],
+        [["observe", 7], ["observe", 1], ["observe", 1], ["get", 9], ["compact"], ["get", 1]],
+        [["observe_cap", 16], ["get", 2], ["compact"], ["observe_cap", 16], ["get", 2], ["observe", 20], ["get", 2], ["compact"], ["observe", 5], ["compact"], ["get", 4]],
+        [["observe", 23], ["compact"], ["compact"], ["get", 8], ["get", 1], ["observe", 8], ["observe", 8], ["get", 1]],
+    ]
+    out["challenger"] = []
+    for k, script in enumerate(scripts):
+        c = it.call_assoc("Challenger", "new", [], chal)
+        ops, outputs = [], []
+        for j, op in enumerate(script):
+            if op[0] == "observe":
+                v = stream_for(1200 + k, j, op[1])
+                it.call_assoc("Challenger", "observe_elements", [c, [Fe(x) for x in v]], chal)
+                ops.append(["observe", v])
+            elif op[0] == "observe_cap":
+                v = stream_for(1200 + k, j, 4 * op[1])
+                cap = Struct({"__name__": "MerkleCap", 0: [hash_out(v[4 * i:4 * i + 4]) for i in range(op[1])]})
+                it.call_assoc("Challenger", "observe_cap", [c, cap], chal)
+                ops.append(["observe_cap", v])
+            elif op[0] == "get":
+                got = it.call_assoc("Challenger", "get_n_challenges", [c, op[1]], chal)
+                ops.append(["get", op[1]])
+                outputs.append([x.v for x in got])
+            else:
+                st = it.call_assoc("Challenger", "compact", [c], chal)
+                ops.append(["compact"])
+                outputs.append([x.v for x in st])
+        out["challenger"].append({"ops": ops, "outputs": outputs, "state": [x.v for x in c["sponge_state"]]})
+    out["sources"]["challenger"] = "plonky2/plonky2/src/iop/challenger.rs: Challenger::{new, observe_elements, observe_cap, get_n_challenges, compact}"
+
+    # ---- the proving configuration and the FRI reduction plan (circuits/src/stark/config.rs:18 standard_fast_config, :32 fri_params;
+    #      plonky2 fri/mod.rs:36 FriConfig::fri_params; fri/reduction_strategies.rs:30 reduction_arity_bits)
+    cfgf = os.path.join(reference, "circuits", "src", "stark", "config.rs")
+    cfg = it.call_assoc("StarkConfig", "standard_fast_config", [], cfgf)
+    fc = cfg["fri_config"]
+    strat = fc["reduction_strategy"]
+    out["stark_config"] = {"security_bits": cfg["security_bits"], "num_challenges": cfg["num_challenges"], "rate_bits": fc["rate_bits"], "cap_height": fc["cap_height"],
+                           "proof_of_work_bits": fc["proof_of_work_bits"], "num_query_rounds": fc["num_query_rounds"],
+                           "reduction_strategy": [strat.variant] + list(strat.payload)}
+    out["fri_params"] = []
+    for db in range(0, 31):
+        fp = it.call_assoc("StarkConfig", "fri_params", [cfg, db], cfgf)
+        out["fri_params"].append({"degree_bits": db, "hiding": fp["hiding"], "reduction_arity_bits": list(fp["reduction_arity_bits"])})
+    out["sources"]["stark_config"] = "circuits/src/stark/config.rs: StarkConfig::standard_fast_config"
+    out["sources"]["fri_params"] = "circuits/src/stark/config.rs: StarkConfig::fri_params -> plonky2 fri/mod.rs: FriConfig::fri_params -> reduction_strategies.rs"
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reference", default="/root/reference")
     ap.add_argument("--points", type=int, default=2)
     ap.add_argument("--out", default=FIXTURE)
     ap.add_argument("--check", action="store_true")
+    ap.add_argument("--primitives", action="store_true", help="the hashing / transcript / FRI-parameter vectors instead of the AIR vectors")
     a = ap.parse_args()
     sys.setrecursionlimit(20000)
+    if a.primitives:
+        out = PRIMITIVES_FIXTURE if a.out == FIXTURE else a.out
+        data = primitives(a.reference)
+        text = json.dumps(data, separators=(",", ":")) + "\n"
+        print("%d permutations, %d sponge hashes, %d compressions, %d transcripts, %d FRI plans" % (
+            len(data["poseidon"]), len(data["hash_no_pad"]), len(data["two_to_one"]), len(data["challenger"]), len(data["fri_params"])))
+        if a.check:
+            if open(out).read() != text:
+                raise SystemExit(out + " is stale")
+            print("fixture is up to date")
+            return
+        open(out, "w").write(text)
+        print("wrote", out, "(%d bytes)" % len(text))
+        return
     data = extract(a.reference, a.points)
     for t in data["tables"]:
         if "points" in t:
