@@ -1,0 +1,262 @@
+#!/usr/bin/env python3
+"""The reference's VERIFIER, run from its source on a proof of this repository's provers.
+
+The reference is Rust and this image has no Rust toolchain, so no binary of it can judge a proof here.  tools/rust_air_eval.py
+interprets the subset of Rust the reference is written in; this driver hands an AllProof (the bytes `ola_prove_with_traces` /
+the oracle prover return, reference wire format) to
+  * `Buffer::write_all_proof` (circuits/src/stark/serialization.rs:377): the decoded proof, re-encoded by the reference's own
+    writer, must give back the bytes;
+  * `verify_proof` (circuits/src/stark/verifier.rs:35): `AllProof::get_challenges` (get_challenges.rs:18, the whole Fiat-Shamir
+    transcript), `CtlCheckVars::from_proofs`, per table `verify_stark_proof_with_challenges` (proof shape, `eval_vanishing_poly`
+    of the table's AIR over the extension field at zeta, the quotient identity, `verify_fri_proof` of plonky2 with its Merkle
+    paths, reduced openings, folding and final polynomial), and `verify_cross_table_lookups`.
+The only pieces not interpreted are the Goldilocks / quadratic-extension arithmetic (Fe, Fe2 of rust_air_eval.py) and, for speed,
+the Poseidon permutation inside Merkle paths: a direct Python permutation that is first checked against the interpreted
+`Poseidon::poseidon_naive` on fresh inputs.
+
+    python tools/ref_verifier.py PROOF [--reference /root/reference]      (exit status 0 = the reference's verifier returned Ok(()))
+"""
+import argparse
+import os
+import re
+import struct
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import rust_air_eval as R  # noqa: E402
+from rust_air_eval import Enum, Fe, Fe2, P, Struct  # noqa: E402
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# the proof as the structs of circuits/src/stark/proof.rs and plonky2 fri/proof.rs
+def hash_out(raw, off):
+    return Struct({"__name__": "HashOut", "elements": [Fe(x) for x in struct.unpack_from("<4Q", raw, off)]})
+
+
+def decode_all_proof(raw):
+    """bytes -> AllProof { stark_proofs: [StarkProof; 12], compress_challenges }.  Canonical encodings only: a word >= p is an error
+    (the reference's reader would reduce it; a prover must not emit it)."""
+    off = 0
+
+    def u32():
+        nonlocal off
+        (v,) = struct.unpack_from("<I", raw, off)
+        off += 4
+        return v
+
+    def u8():
+        nonlocal off
+        v = raw[off]
+        off += 1
+        return v
+
+    def field():
+        nonlocal off
+        (v,) = struct.unpack_from("<Q", raw, off)
+        off += 8
+        if v >= P:
+            raise ValueError(f"non-canonical field element at byte {off - 8}")
+        return Fe(v)
+
+    def ext():
+        a = field()
+        b = field()
+        return Fe2(a.v, b.v)
+
+    def digest():
+        nonlocal off
+        h = hash_out(raw, off)
+        off += 32
+        return h
+
+    def cap():
+        return Struct({"__name__": "MerkleCap", 0: [digest() for _ in range(u32())]})
+
+    def merkle_proof():
+        return Struct({"__name__": "MerkleProof", "siblings": [digest() for _ in range(u8())]})
+
+    def ext_vec():
+        return [ext() for _ in range(u32())]
+
+    def field_vec():
+        return [field() for _ in range(u32())]
+
+    proofs = []
+    for _ in range(u32()):
+        trace_cap, zs_cap, quot_cap = cap(), cap(), cap()
+        openings = Struct({"__name__": "StarkOpeningSet", "local_values": ext_vec(), "next_values": ext_vec(), "permutation_ctl_zs": ext_vec(),
+                           "permutation_ctl_zs_next": ext_vec(), "ctl_zs_last": field_vec(), "quotient_polys": ext_vec()})
+        caps = [cap() for _ in range(u32())]
+        rounds = []
+        for _ in range(u32()):
+            evals_proofs = [(field_vec(), merkle_proof()) for _ in range(u32())]
+            steps = []
+            for _ in range(u32()):
+                evals = [ext() for _ in range(u32())]
+                steps.append(Struct({"__name__": "FriQueryStep", "evals": evals, "merkle_proof": merkle_proof()}))
+            rounds.append(Struct({"__name__": "FriQueryRound", "initial_trees_proof": Struct({"__name__": "FriInitialTreeProof", "evals_proofs": evals_proofs}),
+                                  "steps": steps}))
+        final_poly = Struct({"__name__": "PolynomialCoeffs", "coeffs": ext_vec()})
+        pow_witness = field()
+        fri = Struct({"__name__": "FriProof", "commit_phase_merkle_caps": caps, "query_round_proofs": rounds, "final_poly": final_poly, "pow_witness": pow_witness})
+        proofs.append(Struct({"__name__": "StarkProof", "trace_cap": trace_cap, "permutation_ctl_zs_cap": zs_cap, "quotient_polys_cap": quot_cap,
+                              "openings": openings, "opening_proof": fri}))
+    compress = field_vec()
+    if off != len(raw):
+        raise ValueError(f"{len(raw) - off} trailing bytes")
+    return Struct({"__name__": "AllProof", "stark_proofs": proofs, "compress_challenges": compress, "public_values": Struct({"__name__": "PublicValues"})})
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+def poseidon_tables(reference):
+    """MDS rows and round constants read from the reference's poseidon_goldilocks.rs / poseidon.rs through the interpreter's constant lookup"""
+    it = R.plonky2_interp(reference)
+    src = R.X.Src.get(os.path.join(it.plonky2, "hash", "poseidon.rs"))
+    gsrc = R.X.Src.get(os.path.join(it.plonky2, "hash", "poseidon_goldilocks.rs"))
+    circ = it.const_value("MDS_MATRIX_CIRC", gsrc)
+    diag = it.const_value("MDS_MATRIX_DIAG", gsrc)
+    rc = it.const_value("ALL_ROUND_CONSTANTS", src)
+    return it, [int(x) for x in circ], [int(x) for x in diag], [int(x) for x in rc]
+
+
+class FastPoseidon:
+    """x^7 S-box, the circulant + diagonal MDS layer, 4 + 22 + 4 rounds: the permutation of poseidon.rs written directly, for the tens of
+    thousands of Merkle-path hashes of a verification.  `check` compares it with the interpreted `poseidon_naive`."""
+
+    def __init__(self, circ, diag, rc):
+        self.circ, self.diag, self.rc = circ, diag, rc
+
+    def permute(self, state):
+        s = [x.v for x in state]
+        circ, diag, rc = self.circ, self.diag, self.rc
+        r = 0
+        for phase, rounds in (("full", 4), ("partial", 22), ("full", 4)):
+            for _ in range(rounds):
+                s = [(s[i] + rc[12 * r + i]) % P for i in range(12)]
+                if phase == "full":
+                    s = [pow(x, 7, P) for x in s]
+                else:
+                    s[0] = pow(s[0], 7, P)
+                s = [(sum(s[(i + r_) % 12] * circ[i] for i in range(12)) + s[r_] * diag[r_]) % P for r_ in range(12)]
+                r += 1
+        return [Fe(x) for x in s]
+
+    def check(self, it, count=6):
+        pos = os.path.join(it.plonky2, "hash", "poseidon.rs")
+        for k in range(count):
+            v = [Fe(x) for x in ([P - 1] * 12 if k == 0 else R.stream_for(7700 + k, 9, 12))]
+            want = it.call_assoc("Poseidon", "poseidon_naive", [list(v)], pos)
+            if [x.v for x in want] != [x.v for x in self.permute(v)]:
+                raise SystemExit("the direct Poseidon permutation disagrees with the interpreted poseidon_naive")
+
+
+def verifier_interp(reference, fast_hash=True):
+    it, circ, diag, rc = poseidon_tables(reference)
+    base = it.plonky2
+    it.extra_files += [os.path.join(base, p) for p in (
+        "fri/verifier.rs", "fri/challenges.rs", "fri/structure.rs", "fri/proof.rs", "fri/validate_shape.rs", "util/reducing.rs", "plonk/plonk_common.rs",
+        "hash/hash_types.rs", "hash/merkle_tree/mod.rs", "util/mod.rs")]
+    it.extra_files += [os.path.join(reference, "plonky2", p) for p in (
+        "util/src/lib.rs", "field/src/interpolation.rs", "field/src/polynomial/mod.rs", "field/src/extension/mod.rs")]
+    it.generics.update({"C": ["PoseidonGoldilocksConfig"], "InnerHasher": ["PoseidonHash", "Hasher"], "Hasher": ["PoseidonHash", "Hasher"]})
+    it.extension = True
+    gf = open(os.path.join(reference, "plonky2", "field", "src", "goldilocks_field.rs")).read()
+    for name in ("TWO_ADICITY", "POWER_OF_TWO_GENERATOR", "MULTIPLICATIVE_GROUP_GENERATOR"):
+        m = re.search(r"const %s: \w+ = (?:Self\()?(\d+)\)?;" % name, gf)
+        it.field_consts[name] = int(m.group(1))
+    if re.search(r"const W: Self = Self\((\d+)\);", open(os.path.join(reference, "plonky2", "field", "src", "goldilocks_extensions.rs")).read()).group(1) != str(Fe2.W):
+        raise SystemExit("the quadratic extension's W is not 7")
+    if fast_hash:
+        fp = FastPoseidon(circ, diag, rc)
+        fp.check(it)
+        it.permutation_hook = fp.permute
+    return it
+
+
+STARK_FIELDS = ["cpu_stark", "memory_stark", "bitwise_stark", "cmp_stark", "rangecheck_stark", "poseidon_stark", "poseidon_chunk_stark", "storage_access_stark",
+                "tape_stark", "sccall_stark", "program_stark", "prog_chunk_stark"]
+
+
+class RefVerifier:
+    """The reference's verifier over one reference tree.  `verify(raw)` -> (True, None) or (False, "file.rs:line" of the `ensure!` that failed)."""
+
+    def __init__(self, reference="/root/reference", fast_hash=True):
+        sys.setrecursionlimit(max(sys.getrecursionlimit(), 20000))
+        self.reference = reference
+        self.it = verifier_interp(reference, fast_hash)
+        self.stark_dir = os.path.join(reference, "circuits", "src", "stark")
+        self.config = self.it.call_assoc("StarkConfig", "standard_fast_config", [], os.path.join(self.stark_dir, "config.rs"))
+
+    def ola_stark(self):
+        """what `OlaStark::default()` (ola_stark.rs:45-64) builds, minus its init_gpu() call: twelve default table structs (compress challenges unset,
+        as `#[derive(Default)]` leaves them) and `all_cross_table_lookups()`"""
+        ola = Struct({"__name__": "OlaStark"})
+        for f, (_, rel) in zip(STARK_FIELDS, R.X.TABLES):
+            st = R.stark_struct(self.it, self.it.ref, rel)
+            st["compress_challenge"] = None
+            ola[f] = st
+        ola["cross_table_lookups"] = self.it.call_fn(os.path.join(self.stark_dir, "ola_stark.rs"), "all_cross_table_lookups", [])
+        return ola
+
+    @staticmethod
+    def _verdict(r):
+        if isinstance(r, Enum):
+            if r.variant != "Err":
+                raise R.RustError("unexpected result " + r.variant)
+            return False, r.payload[0] if r.payload else "?"
+        return True, None
+
+    def verify(self, raw):
+        """`verify_proof(OlaStark::default(), all_proof, &StarkConfig::standard_fast_config())`, verifier.rs:35"""
+        proof = raw if isinstance(raw, Struct) else decode_all_proof(raw)
+        try:
+            r = self.it.call_free(os.path.join(self.stark_dir, "verifier.rs"), "verify_proof", [self.ola_stark(), proof, self.config])
+        except ZeroDivisionError as e:           # an inverse of zero: Rust would panic
+            return False, "panic: %s" % e
+        return self._verdict(r)
+
+    def encode(self, proof):
+        """`Buffer::write_all_proof` (serialization.rs:377) of a decoded proof -> bytes"""
+        buf = Struct({"__name__": "Buffer", 0: R.Cursor()})
+        r = self.it.call_assoc("Buffer", "write_all_proof", [buf, proof], os.path.join(self.stark_dir, "serialization.rs"))
+        if isinstance(r, Enum):
+            raise R.RustError("write_all_proof returned " + r.variant)
+        return bytes(buf[0].data)
+
+    def challenges(self, raw):
+        """`AllProof::get_challenges` (get_challenges.rs:18): every Fiat-Shamir challenge of the proof, as plain integers"""
+        proof = raw if isinstance(raw, Struct) else decode_all_proof(raw)
+        ch = self.it.call_assoc("AllProof", "get_challenges", [proof, self.ola_stark(), self.config], os.path.join(self.stark_dir, "get_challenges.rs"))
+
+        def plain(v):
+            if isinstance(v, Fe):
+                return v.v
+            if isinstance(v, Fe2):
+                return [v.a, v.b]
+            if isinstance(v, dict):
+                return {k: plain(x) for k, x in v.items() if k != "__name__"}
+            if isinstance(v, (list, tuple)):
+                return [plain(x) for x in v]
+            return v
+        return plain(ch)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("proof")
+    ap.add_argument("--reference", default="/root/reference")
+    a = ap.parse_args()
+    raw = open(a.proof, "rb").read()
+    proof = decode_all_proof(raw)
+    print("decoded: %d tables, %d bytes" % (len(proof["stark_proofs"]), len(raw)))
+    rv = RefVerifier(a.reference)
+    if rv.encode(proof) != raw:
+        raise SystemExit("write_all_proof of the decoded proof does not give back the bytes")
+    print("write_all_proof (serialization.rs:377), interpreted, reproduces the %d bytes" % len(raw))
+    ok, where = rv.verify(proof)
+    print("verify_proof (verifier.rs:35), interpreted: %s" % ("Ok(())" if ok else "Err at " + where))
+    raise SystemExit(0 if ok else 1)
+
+
+if __name__ == "__main__":
+    main()

@@ -55,6 +55,57 @@ class Fe:
         return hash(self.v)
 
 
+class Fe2:
+    """one element of the quadratic extension F[X]/(X^2 - 7) (plonky2_field extension/quadratic.rs with GoldilocksField's W = 7,
+    goldilocks_extensions.rs:12): what `F::Extension` / `FE` are when the verifier runs"""
+    __slots__ = ("a", "b")
+    W = 7
+
+    def __init__(self, a, b=0):
+        self.a, self.b = int(a) % P, int(b) % P
+
+    @staticmethod
+    def of(x):
+        return x if isinstance(x, Fe2) else Fe2(x.v, 0)
+
+    def __repr__(self):
+        return "Fe2(%d,%d)" % (self.a, self.b)
+
+    def __eq__(self, o):
+        if isinstance(o, Fe):
+            o = Fe2(o.v, 0)
+        return isinstance(o, Fe2) and (self.a, self.b) == (o.a, o.b)
+
+    def __hash__(self):
+        return hash((self.a, self.b))
+
+    def add(self, o):
+        return Fe2(self.a + o.a, self.b + o.b)
+
+    def sub(self, o):
+        return Fe2(self.a - o.a, self.b - o.b)
+
+    def mul(self, o):
+        return Fe2(self.a * o.a + Fe2.W * self.b * o.b, self.a * o.b + self.b * o.a)
+
+    def inverse(self):
+        # 1 / (a + bX) = (a - bX) / (a^2 - 7 b^2)
+        n = (self.a * self.a - Fe2.W * self.b * self.b) % P
+        if n == 0:
+            raise ZeroDivisionError("inverse of zero in the extension field")
+        i = pow(n, P - 2, P)
+        return Fe2(self.a * i, -self.b * i)
+
+    def pow(self, e):
+        r, b = Fe2(1, 0), self
+        while e:
+            if e & 1:
+                r = r.mul(b)
+            b = b.mul(b)
+            e >>= 1
+        return r
+
+
 class Rng:
     def __init__(self, a, b):
         self.start, self.end = a, b
@@ -81,6 +132,69 @@ class Struct(dict):
 class Closure:
     def __init__(self, params, body, env, src):
         self.params, self.body, self.env, self.src = params, body, env, src
+
+
+class FnRef:
+    """a path that names a function, used as a value"""
+
+    def __init__(self, segs, env, src, line):
+        self.segs, self.env, self.src, self.line = segs, env, src, line
+
+
+class TInt(int):
+    """an integer whose Rust type is known (a cast, a typed parameter, to_canonical_u64): only `to_le_bytes` cares"""
+    bits = 64
+
+    def __new__(cls, v, bits):
+        o = int.__new__(cls, v)
+        o.bits = bits
+        return o
+
+
+INT_BITS = {"u8": 8, "u16": 16, "u32": 32, "u64": 64, "u128": 128, "usize": 64}
+
+
+class Cursor:
+    """std::io::Cursor<Vec<u8>> as far as serialization.rs uses it for writing"""
+
+    def __init__(self, data=()):
+        self.data = list(data)
+
+    def write_all(self, b):
+        for x in b:
+            if not (isinstance(x, int) and 0 <= x < 256):
+                raise RustError("write_all: not a byte")
+            self.data.append(int(x))
+        return None                             # Ok(())
+
+
+class ElemRef:
+    """`&mut xs[i]` for a scalar element, made where the source says so (`&mut xs` / `xs.iter_mut()` iterated or zipped): `*r = v` writes the
+    array; a plain read of the variable gives the current value"""
+    __slots__ = ("c", "k")
+
+    def __init__(self, c, k):
+        self.c, self.k = c, k
+
+    def get(self):
+        return self.c[self.k]
+
+    def set(self, v):
+        self.c[self.k] = v
+
+
+def refs_of(lst):
+    return [ElemRef(lst, i) if (x is None or isinstance(x, (Fe, Fe2, int, bool))) else x for i, x in enumerate(lst)]
+
+
+def is_mut_iter(node):
+    """`&mut xs`, `xs.iter_mut()` (possibly followed by adaptors that keep the items: enumerate is handled by the caller)"""
+    return node[0] == "mutref" or (node[0] == "mcall" and node[2] == "iter_mut")
+
+
+class Params(list):
+    """a function's parameter patterns; `.types[i]` = the tokens of parameter i's type (None for self)"""
+    types = ()
 
 
 class Return(Exception):
@@ -400,6 +514,7 @@ class Parser:
                 e = ("index", e, idx, self.line())
             elif t == "?":
                 self.next()
+                e = ("try", e)
             elif t == ".":
                 self.next()
                 name = self.next()
@@ -610,6 +725,8 @@ class Interp:
         self.assoc_cache = {}
         self.pending_writeback = []
         self.near_cache = {}
+        self.field_consts = {}              # TWO_ADICITY, POWER_OF_TWO_GENERATOR, MULTIPLICATIVE_GROUP_GENERATOR of goldilocks_field.rs (set by a driver)
+        self.extension = False              # True while the verifier runs: FE = F::Extension is the quadratic extension (D = 2), not F itself
         self.extra_files = []               # files outside the AIR tree whose impl blocks a driver needs (plonky2's fri/, iop/challenger.rs)
         self.generics = {}                  # generic parameter -> the types tried for `H::f(..)`: {"H": ["PoseidonHash", "Hasher"]} (set by a driver)
         self.permutation_hook = None        # what `H::Permutation::permute` runs (the driver installs the interpreted poseidon_naive)
@@ -624,22 +741,7 @@ class Interp:
             if name not in fns:
                 raise RustError(f"{path}: fn {name} not found")
             (plo, phi), (blo, bhi) = self.impl_index(path).get(("", name), fns[name])       # a free function before a method of the same name
-            pp = Parser(src, plo + 1, phi)
-            params = []
-            while pp.peek() is not None:
-                if pp.peek() in ("&", "mut") or pp.peek().startswith("'"):
-                    pp.next()
-                    continue
-                if pp.peek() == "self":
-                    pp.next()
-                    params.append(("pid", "self"))
-                    pp.eat(",")
-                    continue
-                pat = pp.pattern1()
-                pp.expect(":")
-                pp.skip_type((",",))
-                pp.eat(",")
-                params.append(pat)
+            params = self.parse_params(src, plo, phi)
             body = Parser(src, blo, bhi + 1).block()
             self.fn_cache[key] = (params, body, src)
         return self.fn_cache[key]
@@ -760,7 +862,7 @@ class Interp:
     @staticmethod
     def parse_params(src, plo, phi):
         pp = Parser(src, plo + 1, phi)
-        params = []
+        params, types = Params(), []
         while pp.peek() is not None:
             if pp.peek() in ("&", "mut") or pp.peek().startswith("'"):
                 pp.next()
@@ -768,14 +870,38 @@ class Interp:
             if pp.peek() == "self":
                 pp.next()
                 params.append(("pid", "self"))
+                types.append(None)
                 pp.eat(",")
                 continue
             pat = pp.pattern1()
             pp.expect(":")
+            t0 = pp.i
             pp.skip_type((",",))
+            types.append([t for t, _ in src.toks[t0:pp.i] if t not in ("&", "mut") and not t.startswith("'")])
             pp.eat(",")
             params.append(pat)
+        params.types = types
         return params
+
+    @staticmethod
+    def bind_generics(params, shift, args, env):
+        """`stark: S` / `stark: &S`: inside the function `S::COLUMNS` is the associated constant of that argument's type"""
+        for i, a in enumerate(args):                        # `x: u32`: the width travels with the value
+            j = i + shift
+            if j < len(params.types) and params.types[j] and len(params.types[j]) == 1 and params.types[j][0] in INT_BITS \
+                    and isinstance(a, int) and not isinstance(a, bool) and params[j][0] == "pid":
+                bits = INT_BITS[params.types[j][0]]
+                if not 0 <= a < 1 << bits:
+                    raise RustError(f"argument {a} does not fit {params.types[j][0]}")
+                env[params[j][1]] = TInt(a, bits)
+        g = None
+        for i, a in enumerate(args):
+            j = i + shift
+            if j < len(params.types) and params.types[j] and len(params.types[j]) == 1 and re.match(r"^[A-Z]\w?$", params.types[j][0]) and isinstance(a, Struct):
+                g = g if g is not None else dict(env.get("__generic__", {}))
+                g[params.types[j][0]] = a
+        if g is not None:
+            env["__generic__"] = g
 
     def call_assoc(self, ty, name, args, here, self_val=None, has_self=False):
         found = self.find_assoc(ty, name, here)
@@ -796,6 +922,8 @@ class Interp:
             raise RustError(f"{path}: {ty}::{name} takes {len(ps)} arguments, {len(args)} given")
         for p_, a in zip(ps, args):
             self.bind(p_, a, env, src)
+        if isinstance(params, Params):
+            self.bind_generics(params, len(params) - len(ps), args, env)
         wb, self.pending_writeback = self.pending_writeback, []
         shift = 1 if (params and params[0] == ("pid", "self") and not has_self) else 0
         self.depth += 1
@@ -895,6 +1023,11 @@ class Interp:
             f = self.ref.find_fn(name, here, module)
             if f is None and module is not None:
                 f = self.ref.find_fn(name, here, None)
+            if f is None:
+                for x in self.extra_files:          # plonky2's fri/, util/: free functions only
+                    if ("", name) in self.impl_index(x):
+                        f = x
+                        break
             self.find_cache[key] = f
         return self.find_cache[key]
 
@@ -989,7 +1122,19 @@ class Interp:
             return isinstance(v, dict) and all(name in v and self.matches(sub, v[name], env, src) for name, sub in pat[2])
         raise RustError(f"{src.path}: pattern {k}")
 
+    def powers(self, pw, n, src, line):
+        out, w = [], Fe(1)
+        for _ in range(n):
+            v = w
+            for f in pw.maps:
+                v = self.call_closure(f, [v])
+            out.append(v)
+            w = self.binop("*", w, pw.base, src, line)
+        return out
+
     def call_closure(self, c, args):
+        if isinstance(c, FnRef):
+            return self.call(("call", ("path", c.segs, c.line), [("value", a) for a in args], c.line), c.env, c.src)
         env = dict(c.env)
         if len(c.params) == 1 and len(args) != 1:
             args = [tuple(args)]
@@ -1013,6 +1158,8 @@ class Interp:
             raise RustError(f"{path}: {name} takes {len(ps)} arguments, {len(args)} given")
         for p, a in zip(ps, args):
             self.bind(p, a, env, src)
+        if isinstance(params, Params):
+            self.bind_generics(params, len(params) - len(ps), args, env)
         wb, self.pending_writeback = self.pending_writeback, []
         self.depth += 1
         if self.depth > 200:
@@ -1037,6 +1184,27 @@ class Interp:
 
     # ---- arithmetic
     def binop(self, op, a, b, src, line):
+        if isinstance(a, (ZeroSum, OneProduct)) and isinstance(b, (Fe, Fe2)):
+            a = Fe(int(a))
+        if isinstance(b, (ZeroSum, OneProduct)) and isinstance(a, (Fe, Fe2)):
+            b = Fe(int(b))
+        if isinstance(a, Fe2) or isinstance(b, Fe2):
+            if not (isinstance(a, (Fe, Fe2)) and isinstance(b, (Fe, Fe2))):
+                raise self.err(src, line, f"extension element {op} {type(b).__name__ if isinstance(a, Fe2) else type(a).__name__}")
+            a, b = Fe2.of(a), Fe2.of(b)
+            if op == "+":
+                return a.add(b)
+            if op == "-":
+                return a.sub(b)
+            if op == "*":
+                return a.mul(b)
+            if op == "/":
+                return a.mul(b.inverse())
+            if op == "==":
+                return a == b
+            if op == "!=":
+                return not (a == b)
+            raise self.err(src, line, f"extension element operator {op}")
         if isinstance(a, Fe) or isinstance(b, Fe):
             if not (isinstance(a, Fe) and isinstance(b, Fe)):
                 # `P * u64` does not type-check in Rust: a sign that the interpreter mis-typed a value
@@ -1051,6 +1219,8 @@ class Interp:
                 return a.v == b.v
             if op == "!=":
                 return a.v != b.v
+            if op == "/":
+                return Fe(a.v * pow(b.v, P - 2, P))
             raise self.err(src, line, f"field element operator {op}")
         if isinstance(a, Enum) or isinstance(b, Enum):
             if op == "==":
@@ -1088,9 +1258,9 @@ class Interp:
             if isinstance(v, Enum):
                 return self.enum_value(v, src)
             v = v.v if isinstance(v, Fe) else (int(v) if isinstance(v, bool) else v)
-            bits = {"u8": 8, "u16": 16, "u32": 32, "u64": 64, "u128": 128, "usize": 64}.get(n[2] if len(n) > 2 else None)
+            bits = INT_BITS.get(n[2] if len(n) > 2 else None)
             if bits is not None and isinstance(v, int):
-                v &= (1 << bits) - 1               # `sum as u64`: truncation
+                v = TInt(v & ((1 << bits) - 1), bits)          # `sum as u64`: truncation
             return v
         if k == "index":
             base = self.ev(n[1], env, src)
@@ -1116,6 +1286,11 @@ class Interp:
             return Rng(a, b)
         if k in ("mutref", "deref"):
             return self.ev(n[1], env, src)
+        if k == "try":                           # `expr?`: an Err leaves the function (Ok(x) and Some(x) are x here)
+            v = self.ev(n[1], env, src)
+            if isinstance(v, Enum) and v.variant == "Err":
+                raise Return(v)
+            return v
         if k == "closure":
             return Closure(n[1], n[2], env, src)
         if k == "block":
@@ -1163,6 +1338,8 @@ class Interp:
             return self.mcall(n, env, src)
         if k == "assign":
             return self.assign(n, env, src)
+        if k == "value":
+            return n[1]
         if k == "unit":
             return None
         if k == "str":
@@ -1205,7 +1382,10 @@ class Interp:
             self.bind(s[1], v, env, src)
             return None
         if k == "for":
-            for item in self.iterate(self.ev(s[2], env, src), src, s[4]):
+            seq = self.ev(s[2], env, src)
+            if is_mut_iter(s[2]) and isinstance(seq, list):
+                seq = refs_of(seq)
+            for item in self.iterate(seq, src, s[4]):
                 inner = dict(env)
                 inner["__declared__"] = set(pattern_names(s[1]))
                 inner["__assigned__"] = set()
@@ -1227,6 +1407,10 @@ class Interp:
 
     def assign(self, n, env, src):
         op, lhs, rhs, line = n[1], n[2], self.ev(n[3], env, src), n[4]
+        if lhs[0] == "deref" and lhs[1][0] == "path" and len(lhs[1][1]) == 1 and isinstance(env.get(lhs[1][1][0]), ElemRef):
+            r = env[lhs[1][1][0]]
+            r.set(rhs if op == "=" else self.binop(op[:-1], r.get(), rhs, src, line))
+            return None
         if lhs[0] == "deref":
             lhs = lhs[1]
             if op == "=" and isinstance(rhs, list):
@@ -1278,22 +1462,35 @@ class Interp:
         name = segs[-1]
         if len(segs) == 1:
             if name in env:
-                return env[name]
+                v = env[name]
+                return v.get() if isinstance(v, ElemRef) else v
             if name == "None":
                 return None
             if name in ("true", "false"):
                 return name == "true"
-        if len(segs) >= 2 and name in FIELD_CONSTS and segs[-2] in ("P", "F", "FE", "Scalar", "GoldilocksField", "Self"):
+        if len(segs) >= 2 and name in FIELD_CONSTS and segs[-2] in ("P", "F", "FE", "Scalar", "GoldilocksField", "Self", "Extension"):
             return Fe(FIELD_CONSTS[name])
+        if len(segs) >= 2 and name in self.field_consts and segs[-2] in ("F", "Self", "GoldilocksField"):
+            return Fe(self.field_consts[name]) if name != "TWO_ADICITY" else self.field_consts[name]
+        if len(segs) == 2 and segs[0] in INT_TYPES and name == "BITS":
+            return {"u8": 8, "u16": 16, "u32": 32, "u64": 64, "u128": 128, "usize": 64, "i32": 32, "i64": 64, "isize": 64}[segs[0]]
         if len(segs) == 2 and segs[0] in INT_TYPES and name in ("MAX", "MIN"):
             bits = {"u8": 8, "u16": 16, "u32": 32, "u64": 64, "u128": 128, "usize": 64}.get(segs[0])
             return (1 << bits) - 1 if name == "MAX" else 0
         if re.match(r"^[A-Z][A-Z0-9_]*$", name):
+            if len(segs) == 2:
+                owner = env.get("self") if segs[0] == "Self" else env.get("__generic__", {}).get(segs[0])
+                if isinstance(owner, Struct) and owner.get("__file__"):
+                    osrc = X.Src.get(owner["__file__"])
+                    if any(c[0] == owner["__file__"] for c in self.ref.consts.get(name, ())):
+                        return self.const_value(name, osrc)           # `const COLUMNS` of that type's impl block (its own file)
             v = self.const_value(name, src)
             if v is not None:
                 return v
         if len(segs) >= 2 and re.match(r"^[A-Z]", segs[-2]) and re.match(r"^[A-Z]", name):
             return Enum(segs[-2], name)                   # OlaOpcode::ADD
+        if re.match(r"^[a-z_]", name) and len(segs) >= 2:
+            return FnRef(segs, env, src, line)            # `.map(F::Extension::from_basefield)`: a function named, not called
         raise self.err(src, line, f"unknown name `{'::'.join(segs)}`")
 
     def call(self, n, env, src):
@@ -1317,6 +1514,8 @@ class Interp:
         name = segs[-1]
         if len(segs) == 1 and name in env and isinstance(env[name], Closure):
             return self.call_closure(env[name], args)
+        if name == "from_basefield" and self.extension and isinstance(args[0], (Fe, Fe2)):
+            return Fe2.of(args[0])
         if name in FIELD_CTORS:
             v = args[0]
             return v if isinstance(v, Fe) else Fe(v)
@@ -1327,11 +1526,41 @@ class Interp:
         if name == "from_noncanonical_u96":
             return Fe(args[0][0] + (args[0][1] << 64))
         if name in ("from_basefield_array",):
-            return tuple(args[0])
+            return Fe2(args[0][0].v, args[0][1].v) if len(args[0]) == 2 else tuple(args[0])
         if name == "default" and len(segs) >= 2 and segs[-2] == "Default":
             return None
         if name == "permute" and len(segs) >= 2 and segs[-2] in ("Permutation", "P", "PoseidonPermutation") and self.permutation_hook is not None:
             return self.permutation_hook(args[0])
+        # ---- the field's own functions (plonky2_field types.rs), with the constants a driver read from goldilocks_field.rs
+        if name == "primitive_root_of_unity" and self.field_consts:
+            if not 0 <= args[0] <= self.field_consts["TWO_ADICITY"]:
+                raise self.err(src, line, "primitive_root_of_unity: n_log out of range")
+            return Fe(pow(self.field_consts["POWER_OF_TWO_GENERATOR"], 1 << (self.field_consts["TWO_ADICITY"] - args[0]), P))
+        if name == "order" and self.field_consts and len(args) == 0:
+            return P
+        if name == "coset_shift" and self.field_consts:
+            return Fe(self.field_consts["MULTIPLICATIVE_GROUP_GENERATOR"])
+        if name == "batch_multiplicative_inverse" and len(args) == 1:
+            return [self.method(x, "inverse", [], src, line) for x in args[0]]
+        if name in ("reverse_index_bits_in_place", "reverse_index_bits") and len(args) == 1 and isinstance(args[0], list):
+            # plonky2_util's cache-blocked, `unsafe` permutation (util/src/lib.rs:80-215); what it computes is its doc line: "Bit-reverse the order
+            # of elements in arr"
+            a = args[0]
+            n_ = len(a)
+            if n_ & (n_ - 1) or n_ == 0:
+                raise self.err(src, line, f"{name}: length {n_} is not a power of two")
+            bits = n_.bit_length() - 1
+            out = [a[int(format(i, "0%db" % bits)[::-1], 2) if bits else 0] for i in range(n_)]
+            if name == "reverse_index_bits":
+                return out
+            a[:] = out
+            return None
+        if name == "from_fn" and "array" in segs:
+            # std::array::from_fn: the length is the array type's, which only inference knows; every use in the reference is [_; NUM_TABLES]
+            n_ = self.const_value("NUM_TABLES", src)
+            return [self.call_closure(args[0], [i]) for i in range(n_)]
+        if name == "init_gpu":
+            return None
         if name == "once" and "iter" in segs:
             return [args[0]]
         if name == "repeat" and ("iter" in segs or (len(segs) == 1 and self.find_fn_file(name, src.path) is None)):
@@ -1362,6 +1591,12 @@ class Interp:
             target = cur
         if target is None:
             target = self.find_fn_file(name, cur, module)
+            if target is not None and len(segs) == 1 and ("", name) not in self.impl_index(target):
+                # `flatten(evals)` names a free function; the first `fn flatten` found was a method (MerkleCap::flatten)
+                for x in self.ref.files + self.extra_files:
+                    if ("", name) in self.impl_index(x):
+                        target = x
+                        break
         if target is None and len(segs) >= 2 and re.match(r"^[A-Z]", segs[-2]) and re.match(r"^[A-Z]", name):
             return Enum(segs[-2], name, list(args))         # FriReductionStrategy::ConstantArityBits(4, 5)
         if target is None:
@@ -1379,11 +1614,15 @@ class Interp:
             if name not in X.KINDS:
                 raise self.err(src, line, f"consumer method {name}")
             v = self.ev(n[3][0], env, src)
-            if not isinstance(v, Fe):
+            if not isinstance(v, (Fe, Fe2)):
                 raise self.err(src, line, "constraint argument is not a field element")
-            recv.emits.append((X.KINDS[name], v.v, os.path.relpath(src.path, self.ref.root), line))
+            recv.emits.append((X.KINDS[name], v.v if isinstance(v, Fe) else (v.a, v.b), os.path.relpath(src.path, self.ref.root), line))
             return None
         args = [self.ev(a, env, src) for a in n[3]]
+        if name == "zip" and n[3] and is_mut_iter(n[3][0]) and isinstance(args[0], list):
+            args[0] = refs_of(args[0])
+        if name in ("zip", "enumerate", "for_each") and is_mut_iter(recv_node) and isinstance(recv, list):
+            recv = refs_of(recv)
         if name in ("copy_from_slice", "clone_from_slice", "fill") and recv_node[0] in ("index", "mutref", "deref"):
             # `state[..k].copy_from_slice(chunk)`: a slice of a list is a copy here, so the write goes to the indexed array itself
             node = recv_node
@@ -1402,6 +1641,12 @@ class Interp:
         return self.method(recv, name, args, src, line)
 
     def method(self, r, name, args, src, line):
+        if isinstance(r, Cursor):
+            if name == "write_all":
+                return r.write_all(args[0])
+            if name == "get_ref":
+                return r.data
+            raise self.err(src, line, f"Cursor::{name}")
         if name == "to_vec" and isinstance(r, Struct) and "__name__" in r:         # HashOut::to_vec (hash_types.rs:80), not the slice adaptor
             v = self.call_assoc(r["__name__"], name, args, r.get("__file__", src.path), self_val=r, has_self=True)
             if v is not NOT_FOUND:
@@ -1432,19 +1677,55 @@ class Interp:
             if name == "as_slice":
                 return [r]
             if name in ("to_canonical_u64", "to_noncanonical_u64"):
-                return r.v
+                return TInt(r.v, 64)
             if name in ("exp_u64", "exp_power_of_2"):
                 return Fe(pow(r.v, args[0] if name == "exp_u64" else 1 << args[0], P))
             if name == "inverse":
+                if r.v == 0:
+                    raise self.err(src, line, "inverse of zero")
                 return Fe(pow(r.v, P - 2, P))
-            if name in ("mul", "add", "sub"):
-                return self.binop({"mul": "*", "add": "+", "sub": "-"}[name], r, args[0], src, line)
+            if name == "try_inverse":
+                return None if r.v == 0 else Fe(pow(r.v, P - 2, P))
+            if name in ("mul", "add", "sub", "div"):
+                return self.binop({"mul": "*", "add": "+", "sub": "-", "div": "/"}[name], r, args[0], src, line)
+            if name == "scalar_mul":
+                return Fe(r.v * args[0].v)
             if name == "powers":
                 return Powers(r)
             if name == "add_canonical_u64":
                 return Fe(r.v + args[0])
             if name == "to_basefield_array":
+                return [r, Fe(0)] if self.extension else [r]
+        if isinstance(r, Fe2):
+            if name == "square":
+                return r.mul(r)
+            if name == "double":
+                return r.add(r)
+            if name == "cube":
+                return r.mul(r).mul(r)
+            if name == "is_zero":
+                return r.a == 0 and r.b == 0
+            if name in ("exp_u64", "exp_power_of_2"):
+                return r.pow(args[0] if name == "exp_u64" else 1 << args[0])
+            if name == "inverse":
+                return r.inverse()
+            if name == "try_inverse":
+                return None if (r.a == 0 and r.b == 0) else r.inverse()
+            if name in ("mul", "add", "sub", "div"):
+                return self.binop({"mul": "*", "add": "+", "sub": "-", "div": "/"}[name], r, args[0], src, line)
+            if name == "scalar_mul":
+                return Fe2(r.a * args[0].v, r.b * args[0].v)
+            if name == "to_basefield_array":
+                return [Fe(r.a), Fe(r.b)]
+            if name == "powers":
+                return Powers(r)
+            if name == "as_slice":
                 return [r]
+        if isinstance(r, bool):
+            if name == "then":
+                return self.call_closure(args[0], []) if r else None
+            if name == "then_some":
+                return args[0] if r else None
         if isinstance(r, int) and not isinstance(r, bool):
             if name == "pow":
                 return r ** args[0]
@@ -1454,11 +1735,27 @@ class Interp:
                 return self.binop({"add": "+", "sub": "-", "mul": "*", "div": "/"}[name], r, args[0], src, line)
             if name in ("wrapping_add", "saturating_sub", "checked_sub"):
                 return r + args[0] if name == "wrapping_add" else max(0, r - args[0])
+            if name == "to_le_bytes":
+                if not isinstance(r, TInt):
+                    raise self.err(src, line, "to_le_bytes of an integer whose type the interpreter does not know")
+                return [TInt((r >> (8 * i)) & 0xFF, 8) for i in range(r.bits // 8)]
+            if name == "leading_zeros":
+                if not 0 <= r < 1 << 64:
+                    raise self.err(src, line, "leading_zeros of a value that is not a u64")
+                return 64 - r.bit_length()
+            if name == "bits":
+                return r.bit_length()
+            if name == "reverse_bits":              # of a usize (64 bits)
+                return int(format(r, "064b")[::-1], 2)
+            if name == "overflowing_shr":           # (value shifted by the amount mod 64, whether the amount was >= 64)
+                return ((r >> (args[0] % 64)) & ((1 << 64) - 1), args[0] >= 64)
+            if name == "count_ones":
+                return bin(r).count("1")
             if name == "trailing_zeros":
                 return (r & -r).bit_length() - 1
             if name == "is_power_of_two":
                 return r > 0 and r & (r - 1) == 0
-        if r is None or (not isinstance(r, (list, tuple, Rng, Struct, Enum, Fe, int, RepeatForever))):
+        if r is None or (not isinstance(r, (list, tuple, Rng, Struct, Enum, Fe, Fe2, int, RepeatForever))):
             if name in ("is_some", "is_none"):
                 return (r is not None) == (name == "is_some")
         if name in ("is_some", "is_none"):
@@ -1467,6 +1764,15 @@ class Interp:
             return list(r)
         if isinstance(r, Rng) and name in ("contains",):
             return r.start <= args[0] < r.end
+        if isinstance(r, Powers):
+            if name == "map":
+                return Powers(r.base, r.maps + (args[0],))
+            if name == "take":
+                return self.powers(r, args[0], src, line)
+            if name == "zip":
+                other = self.iterate(args[0], src, line)
+                return [(w, o) for w, o in zip(self.powers(r, len(other), src, line), other)]
+            raise self.err(src, line, f"powers().{name}")
         if isinstance(r, (list, tuple, Rng, RepeatForever)):
             if isinstance(r, RepeatForever):
                 if name == "take":
@@ -1487,14 +1793,13 @@ class Interp:
                 if isinstance(o, RepeatForever):
                     return [(x, clone(o.v)) for x in items]
                 if isinstance(o, Powers):
-                    out, w = [], Fe(1)
-                    for x in items:
-                        out.append((x, w))
-                        w = Fe(w.v * o.base.v)
-                    return out
+                    return [(x, w) for x, w in zip(items, self.powers(o, len(items), src, line))]
                 return [tuple(t) for t in zip(items, self.iterate(o, src, line))]
             if name == "chain":
-                return items + self.iterate(args[0], src, line)
+                o = args[0]
+                if o is None or isinstance(o, (Fe, Fe2, int, Struct)):      # an Option is an iterator of zero or one item (`Some(x)` is x here)
+                    return items + ([] if o is None else [o])
+                return items + self.iterate(o, src, line)
             if name == "skip":
                 return items[args[0]:]
             if name == "take":
@@ -1525,12 +1830,14 @@ class Interp:
                 return any(self.truthy(self.call_closure(args[0], [x])) for x in items)
             if name == "sum":
                 if not items:
-                    return Fe(0)
+                    return ZeroSum(0)
                 acc = items[0]
                 for x in items[1:]:
                     acc = self.binop("+", acc, x, src, line)
                 return acc
             if name == "product":
+                if not items:
+                    return OneProduct(1)
                 acc = items[0]
                 for x in items[1:]:
                     acc = self.binop("*", acc, x, src, line)
@@ -1641,10 +1948,18 @@ class RepeatForever:
 
 
 class Powers:
-    """F::powers(): 1, b, b^2, ... (only ever zipped against a finite iterator)"""
+    """F::powers(): 1, b, b^2, ... -- infinite, so `.map(f)` is kept pending until a finite iterator is zipped on or `.take(n)` cuts it"""
 
-    def __init__(self, base):
-        self.base = base
+    def __init__(self, base, maps=()):
+        self.base, self.maps = base, tuple(maps)
+
+
+class ZeroSum(int):
+    """the sum of an empty iterator: 0 of whatever type the context wants"""
+
+
+class OneProduct(int):
+    """the product of an empty iterator"""
 
 
 def clone(v):
@@ -1731,7 +2046,8 @@ def eval_table(it, ref, index, rel, lv, nv):
         k += 1
     body = Parser(src, k, src.match(k) + 1).block()
     cons = Consumer()
-    vars_ = Struct({"__name__": "StarkEvaluationVars", "local_values": [Fe(x) for x in lv], "next_values": [Fe(x) for x in nv], "public_inputs": []})
+    lift = (lambda x: x) if (lv and isinstance(lv[0], Fe2)) else Fe
+    vars_ = Struct({"__name__": "StarkEvaluationVars", "local_values": [lift(x) for x in lv], "next_values": [lift(x) for x in nv], "public_inputs": []})
     me = Struct({"__name__": "Stark", "compress_challenge": Fe(PARAM), "_phantom": None})
     env = {"__src__": src, "self": me, "vars": vars_, "yield_constr": cons}
     # the consumer's parameter may have another name
