@@ -1660,6 +1660,8 @@ class Interp:
                 return list(self.iterate(r, src, line)) if isinstance(r, (list, tuple, Rng)) else r
             if isinstance(r, Rng) and name in ("iter", "into_iter"):
                 return r.items()
+            if isinstance(r, list) and name in ("iter", "into_iter"):
+                return list(r)                      # an iterator is its own object: `.next()` on it must not eat the vector it came from
             return r
         if name == "clone":
             return clone(r)
