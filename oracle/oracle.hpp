@@ -1,6 +1,10 @@
 // ORACLE -- test infrastructure only.  Declarations of the CPU restatement of the reference's
 // `prove_with_traces` hot path.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
 // use anything under oracle/, and only as the checker.  See each .cpp for the reference file:line it follows.
+// Pinned by: the reference's Poseidon known answers and golden Poseidon-table rows; outputs of the reference's own hashing,
+// transcript, FRI-parameter and AIR code run from its source by tools/rust_air_eval.py (tests/golden/ref_primitive_vectors.json,
+// air_eval_vectors.json); and the reference's verify_proof, interpreted (tools/ref_verifier.py), accepting this prover's proof
+// (tests/golden/ref_verified/).  NOT compared byte for byte with the Rust prover (no Rust toolchain in the image).
 #pragma once
 #include <array>
 #include <cstdint>
