@@ -1,17 +1,18 @@
 #!/usr/bin/env python3
 """Writes tests/golden/ref_verified/: a proof of the ORACLE prover and what the REFERENCE's verifier, run from its source, said of it.
 
-    python -m tests.make_ref_verdict            (this container only: needs /root/reference; about 12 minutes)
+    python -m tests.make_ref_verdict [poseidon] [blake3]      (this container only: needs /root/reference; about 12 minutes each)
 
 The instance is `miniexec.wide_program()` with its program-hash proof, against the reference's own AIR set (ola_stark(): range-check
 table of 2^16 rows, bitwise table of 2^18): 32-bit operands through AND / OR / XOR / GTE / RC kept in memory between uses, the
 program hashed by Poseidon and looked up in the state tree -- all twelve tables active except tape and sccall (padding only).
-The oracle proves it (StarkConfig::standard_fast_config, PoseidonGoldilocksConfig); tools/ref_verifier.py then
+The oracle proves it (StarkConfig::standard_fast_config) under PoseidonGoldilocksConfig and under Blake3GoldilocksConfig -- the
+configuration of the reference's own end-to-end tests (stark/ola_stark.rs:684); for each, tools/ref_verifier.py
   * re-encodes the decoded proof with the interpreted `Buffer::write_all_proof` (serialization.rs:377): the same bytes;
   * runs the interpreted `verify_proof` (verifier.rs:35): Ok(());
   * runs it again on the proof with ONE BIT flipped in each of a list of spans, recording where the reference's verifier stops;
   * records every challenge `AllProof::get_challenges` derives.
-wide_program.proof is the oracle's proof, wide_program.json the record.  tests/test_ref_verifier.py replays part of this where the
+wide_program[_blake3].proof is the oracle's proof, wide_program[_blake3].json the record.  tests/test_ref_verifier.py replays part of this where the
 reference is present, checks the oracle's own verifier against the record everywhere, and (-m gpu) holds the GPU prover's bytes
 for the same instance to wide_program.proof."""
 import hashlib
@@ -62,12 +63,18 @@ def main():
     oracle = oracle_lib.load()
     traces, params, compress = instance()
     blob = T.ola_stark().blob()
+    for hasher in [a for a in sys.argv[1:] if a in ("poseidon", "blake3")] or ["poseidon", "blake3"]:
+        with oracle.hasher(hasher):
+            one(oracle, V, CD, blob, traces, params, compress, hasher)
+
+
+def one(oracle, V, CD, blob, traces, params, compress, hasher):
     t = time.time()
     raw = oracle.prove_with_traces(blob, traces, params, compress)
-    print("oracle proof: %d bytes, %.0f s" % (len(raw), time.time() - t), flush=True)
+    print("%s: oracle proof: %d bytes, %.0f s" % (hasher, len(raw), time.time() - t), flush=True)
     assert oracle.verify_all_proof(blob, raw, params) == (0, "")
-    rv = V.RefVerifier("/root/reference")
-    proof = V.decode_all_proof(raw)
+    rv = V.RefVerifier("/root/reference", hasher=hasher)
+    proof = V.decode_all_proof(raw, hasher)
     assert rv.encode(proof) == raw, "write_all_proof does not reproduce the bytes"
     challenges = rv.challenges(proof)
     t = time.time()
@@ -77,7 +84,8 @@ def main():
     assert ok
     spans = {n: (a, b) for n, a, b in CD.parse_all_proof(raw)}
     record = {"generated_by": "python -m tests.make_ref_verdict",
-              "instance": "miniexec.wide_program(), range_bits=16, limb_bits=8, prove_program_hash=True; ola_stark(); standard_fast_config; Poseidon",
+              "instance": "miniexec.wide_program(), range_bits=16, limb_bits=8, prove_program_hash=True; ola_stark(); standard_fast_config",
+              "config": {"poseidon": "PoseidonGoldilocksConfig", "blake3": "Blake3GoldilocksConfig"}[hasher],
               "trace_shapes": [[int(x) for x in tr.shape] for tr in traces],
               "proof_bytes": len(raw), "proof_sha256": hashlib.sha256(raw).hexdigest(),
               "write_all_proof_reproduces_the_bytes": True, "verify_proof": "Ok(())",
@@ -93,9 +101,10 @@ def main():
         print("%-55s reference: %-24s oracle: %s (%.0f s)" % (name, "Ok(())" if ok else "Err " + where, "accept" if o_rc == 0 else "reject", time.time() - t), flush=True)
         record["tampered"].append({"span": name, "byte": off, "bit": 0, "reference": "Ok(())" if ok else "Err " + where, "oracle_accepts": o_rc == 0})
     os.makedirs(OUT, exist_ok=True)
-    open(os.path.join(OUT, "wide_program.proof"), "wb").write(raw)
-    open(os.path.join(OUT, "wide_program.json"), "w").write(json.dumps(record, indent=1) + "\n")
-    print("wrote", OUT)
+    stem = "wide_program" if hasher == "poseidon" else "wide_program_" + hasher
+    open(os.path.join(OUT, stem + ".proof"), "wb").write(raw)
+    open(os.path.join(OUT, stem + ".json"), "w").write(json.dumps(record, indent=1) + "\n")
+    print("wrote", OUT, stem)
 
 
 if __name__ == "__main__":

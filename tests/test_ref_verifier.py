@@ -1,7 +1,7 @@
 """The reference's verifier, run from its source, on a proof of this repository (PARITY.md "the reference's verifier").
 
-tests/golden/ref_verified/wide_program.proof is a proof of the oracle prover for the reference's own AIR set (see
-tests/make_ref_verdict.py for the instance); wide_program.json records what tools/ref_verifier.py -- the reference's
+tests/golden/ref_verified/wide_program[_blake3].proof are proofs of the oracle prover for the reference's own AIR set under
+PoseidonGoldilocksConfig and Blake3GoldilocksConfig (see tests/make_ref_verdict.py for the instance); the .json beside each records what tools/ref_verifier.py -- the reference's
 `verify_proof`, `AllProof::get_challenges` and `Buffer::write_all_proof`, interpreted from /root/reference -- made of it:
 the writer gives back the bytes, the verifier returns Ok(()), and on nineteen one-bit corruptions it stops where recorded.
 
@@ -26,14 +26,23 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 sys.path.insert(0, os.path.join(ROOT, "integration", "pin"))
 
 
-@pytest.fixture(scope="module")
-def record():
-    return json.load(open(os.path.join(DIR, "wide_program.json")))
+STEM = {"poseidon": "wide_program", "blake3": "wide_program_blake3"}
+
+
+@pytest.fixture(scope="module", params=["poseidon", "blake3"])
+def config(request):
+    """PoseidonGoldilocksConfig / Blake3GoldilocksConfig (the configuration of the reference's end-to-end tests, ola_stark.rs:684)"""
+    return request.param
 
 
 @pytest.fixture(scope="module")
-def raw():
-    return open(os.path.join(DIR, "wide_program.proof"), "rb").read()
+def record(config):
+    return json.load(open(os.path.join(DIR, STEM[config] + ".json")))
+
+
+@pytest.fixture(scope="module")
+def raw(config):
+    return open(os.path.join(DIR, STEM[config] + ".proof"), "rb").read()
 
 
 @pytest.fixture(scope="module")
@@ -44,8 +53,9 @@ def lib():
     return load_library()
 
 
-def test_record_belongs_to_the_proof_and_says_accepted(record, raw):
+def test_record_belongs_to_the_proof_and_says_accepted(record, raw, config):
     import compare_with_dump as CD
+    assert record["config"] == {"poseidon": "PoseidonGoldilocksConfig", "blake3": "Blake3GoldilocksConfig"}[config]
     assert len(raw) == record["proof_bytes"] and hashlib.sha256(raw).hexdigest() == record["proof_sha256"]
     assert record["verify_proof"] == "Ok(())" and record["write_all_proof_reproduces_the_bytes"] is True
     spans = CD.parse_all_proof(raw)
@@ -59,25 +69,31 @@ def test_record_belongs_to_the_proof_and_says_accepted(record, raw):
     assert {"Err verifier.rs:295", "Err verifier.rs:52", "Err merkle_proofs.rs:71"} <= stops
 
 
-def test_oracle_verifier_agrees_with_the_reference_verifier_on_every_case(record, raw, oracle):
+def test_oracle_verifier_agrees_with_the_reference_verifier_on_every_case(record, raw, oracle, config):
     from olavm_amd.air import ola_tables as T
     blob = T.ola_stark().blob()
     compress = np.frombuffer(raw[-96:], dtype="<u8")              # the proof's last field: the twelve compress challenges
     params = [int(compress[2]), int(compress[10])]                # the AIR parameters: the bitwise and the program table's
-    assert oracle.verify_all_proof(blob, raw, params) == (0, "")
-    for t in record["tampered"]:
-        bad = bytearray(raw)
-        bad[t["byte"]] ^= 1 << t["bit"]
-        # a corrupted compress challenge reaches the oracle's verifier as the AIR parameter it is
-        c = np.frombuffer(bytes(bad[-96:]), dtype="<u8")
-        rc, _ = oracle.verify_all_proof(blob, bytes(bad), [int(c[2]), int(c[10])])
-        assert (rc == 0) == t["oracle_accepts"], t["span"]
-        assert (rc == 0) == (t["reference"] == "Ok(())"), t["span"]
+    with oracle.hasher(config):
+        assert oracle.verify_all_proof(blob, raw, params) == (0, "")
+        for t in record["tampered"]:
+            bad = bytearray(raw)
+            bad[t["byte"]] ^= 1 << t["bit"]
+            # a corrupted compress challenge reaches the oracle's verifier as the AIR parameter it is
+            c = np.frombuffer(bytes(bad[-96:]), dtype="<u8")
+            rc, _ = oracle.verify_all_proof(blob, bytes(bad), [int(c[2]), int(c[10])])
+            assert (rc == 0) == t["oracle_accepts"], t["span"]
+            assert (rc == 0) == (t["reference"] == "Ok(())"), t["span"]
+    with oracle.hasher({"poseidon": "blake3", "blake3": "poseidon"}[config]):
+        assert oracle.verify_all_proof(blob, raw, params)[0] != 0          # the other configuration's verifier does not take it
     assert sum(t["reference"] != "Ok(())" for t in record["tampered"]) >= 18
 
 
 def cap_array(cap):
-    return np.array([[e.v for e in h["elements"]] for h in cap[0]], dtype=np.uint64)
+    """digests as the C ABI takes them: 32 bytes = 4 little-endian words each, under either configuration"""
+    if "elements" in cap[0][0]:
+        return np.array([[e.v for e in h["elements"]] for h in cap[0]], dtype=np.uint64)
+    return np.frombuffer(b"".join(bytes(h[0]) for h in cap[0]), dtype="<u8").reshape(-1, 4).copy()
 
 
 def ext_words(values):
@@ -87,16 +103,16 @@ def ext_words(values):
     return np.array(out, dtype=np.uint64)
 
 
-def test_host_transcript_rederives_the_challenges_the_reference_derived(record, raw, lib, oracle):
+def test_host_transcript_rederives_the_challenges_the_reference_derived(record, raw, lib, oracle, config):
     """get_challenges.rs:18-150 replayed with the product's host challenger over the decoded proof: lookup challenges, then per table
     compact / permutation challenge sets / alphas / zeta / FRI alpha, betas, proof-of-work response, query indices."""
     import ref_verifier as V
     from olavm_amd.air import ola_tables as T
     from olavm_amd.backend import Challenger
-    proof = V.decode_all_proof(raw)
+    proof = V.decode_all_proof(raw, config)
     want = record["challenges"]
     tables = T.ola_stark().tables
-    ch = Challenger(lib)
+    ch = Challenger(lib, hasher=config)
     for sp in proof["stark_proofs"]:
         ch.observe_cap(cap_array(sp["trace_cap"]))
     got = [int(x) for x in ch.get(4)]
@@ -141,10 +157,10 @@ reference = pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="the
 
 
 @reference
-def test_the_references_writer_and_verifier_today(record, raw):
+def test_the_references_writer_and_verifier_today(record, raw, config):
     import ref_verifier as V
-    rv = V.RefVerifier("/root/reference")
-    proof = V.decode_all_proof(raw)
+    rv = V.RefVerifier("/root/reference", hasher=config)
+    proof = V.decode_all_proof(raw, config)
     assert rv.encode(proof) == raw
     assert rv.challenges(proof) == record["challenges"]
     assert rv.verify(proof) == (True, None)
@@ -156,13 +172,13 @@ def test_the_references_writer_and_verifier_today(record, raw):
 
 
 @pytest.mark.gpu
-def test_gpu_prover_returns_the_bytes_the_reference_verifier_accepted(record, raw):
+def test_gpu_prover_returns_the_bytes_the_reference_verifier_accepted(record, raw, config):
     from olavm_amd.air import ola_tables as T
     from olavm_amd.backend import Backend
     from tests.make_ref_verdict import instance
     traces, params, compress = instance()
     assert [[int(x) for x in tr.shape] for tr in traces] == record["trace_shapes"]
-    be = Backend()
+    be = Backend(hasher=config)
     got = bytes(be.prove_with_traces(T.ola_stark().blob(), traces, params, compress))
     assert hashlib.sha256(got).hexdigest() == record["proof_sha256"]
     assert got == raw

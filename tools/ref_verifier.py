@@ -33,7 +33,7 @@ def hash_out(raw, off):
     return Struct({"__name__": "HashOut", "elements": [Fe(x) for x in struct.unpack_from("<4Q", raw, off)]})
 
 
-def decode_all_proof(raw):
+def decode_all_proof(raw, hasher="poseidon"):
     """bytes -> AllProof { stark_proofs: [StarkProof; 12], compress_challenges }.  Canonical encodings only: a word >= p is an error
     (the reference's reader would reduce it; a prover must not emit it)."""
     off = 0
@@ -65,7 +65,9 @@ def decode_all_proof(raw):
 
     def digest():
         nonlocal off
-        h = hash_out(raw, off)
+        h = hash_out(raw, off) if hasher == "poseidon" else bytes_hash(raw[off:off + 32])
+        if hasher == "poseidon" and any(x.v != w for x, w in zip(h["elements"], struct.unpack_from("<4Q", raw, off))):
+            raise ValueError(f"non-canonical digest word at byte {off}")
         off += 32
         return h
 
@@ -125,19 +127,24 @@ class FastPoseidon:
 
     def __init__(self, circ, diag, rc):
         self.circ, self.diag, self.rc = circ, diag, rc
+        # row r of the MDS matrix: out[r] = sum_i state[(i + r) % 12] * circ[i] + state[r] * diag[r]
+        self.rows = [[circ[(j - r) % 12] + (diag[r] if j == r else 0) for j in range(12)] for r in range(12)]
 
     def permute(self, state):
         s = [x.v for x in state]
-        circ, diag, rc = self.circ, self.diag, self.rc
+        rows, rc = self.rows, self.rc
         r = 0
         for phase, rounds in (("full", 4), ("partial", 22), ("full", 4)):
             for _ in range(rounds):
-                s = [(s[i] + rc[12 * r + i]) % P for i in range(12)]
+                k = 12 * r
                 if phase == "full":
-                    s = [pow(x, 7, P) for x in s]
+                    s = [pow(s[i] + rc[k + i], 7, P) for i in range(12)]
                 else:
+                    s = [s[i] + rc[k + i] for i in range(12)]
                     s[0] = pow(s[0], 7, P)
-                s = [(sum(s[(i + r_) % 12] * circ[i] for i in range(12)) + s[r_] * diag[r_]) % P for r_ in range(12)]
+                s0, s1, s2, s3, s4, s5, s6, s7, s8, s9, s10, s11 = s
+                s = [(m[0] * s0 + m[1] * s1 + m[2] * s2 + m[3] * s3 + m[4] * s4 + m[5] * s5 + m[6] * s6 + m[7] * s7 + m[8] * s8 + m[9] * s9
+                      + m[10] * s10 + m[11] * s11) % P for m in rows]
                 r += 1
         return [Fe(x) for x in s]
 
@@ -150,7 +157,123 @@ class FastPoseidon:
                 raise SystemExit("the direct Poseidon permutation disagrees with the interpreted poseidon_naive")
 
 
-def verifier_interp(reference, fast_hash=True):
+# ------------------------------------------------------------------------------------------------------------------------------
+# BLAKE3 (the `blake3` crate the reference's Blake3_256 hasher calls is not part of the reference tree): the published algorithm, hash mode,
+# any length; checked against tests/golden/blake3_vectors.json (the official C implementation's outputs) before use
+B3_IV = (0x6A09E667, 0xBB67AE85, 0x3C6EF372, 0xA54FF53A, 0x510E527F, 0x9B05688C, 0x1F83D9AB, 0x5BE0CD19)
+B3_PERM = (2, 6, 3, 10, 7, 0, 4, 13, 1, 11, 12, 5, 9, 14, 15, 8)
+M32 = 0xFFFFFFFF
+
+
+def _b3_compress(cv, block_words, counter, block_len, flags):
+    v = list(cv) + [B3_IV[0], B3_IV[1], B3_IV[2], B3_IV[3], counter & M32, (counter >> 32) & M32, block_len, flags]
+    m = list(block_words)
+
+    def g(a, b, c, d, x, y):
+        va, vb, vc, vd = v[a], v[b], v[c], v[d]
+        va = (va + vb + x) & M32
+        vd ^= va
+        vd = ((vd >> 16) | (vd << 16)) & M32
+        vc = (vc + vd) & M32
+        vb ^= vc
+        vb = ((vb >> 12) | (vb << 20)) & M32
+        va = (va + vb + y) & M32
+        vd ^= va
+        vd = ((vd >> 8) | (vd << 24)) & M32
+        vc = (vc + vd) & M32
+        vb ^= vc
+        vb = ((vb >> 7) | (vb << 25)) & M32
+        v[a], v[b], v[c], v[d] = va, vb, vc, vd
+
+    for r in range(7):
+        g(0, 4, 8, 12, m[0], m[1])
+        g(1, 5, 9, 13, m[2], m[3])
+        g(2, 6, 10, 14, m[4], m[5])
+        g(3, 7, 11, 15, m[6], m[7])
+        g(0, 5, 10, 15, m[8], m[9])
+        g(1, 6, 11, 12, m[10], m[11])
+        g(2, 7, 8, 13, m[12], m[13])
+        g(3, 4, 9, 14, m[14], m[15])
+        if r < 6:
+            m = [m[i] for i in B3_PERM]
+    return [v[i] ^ v[i + 8] for i in range(8)]
+
+
+def blake3(data):
+    """32-byte BLAKE3 hash of `data`"""
+    CHUNK_START, CHUNK_END, PARENT, ROOT = 1, 2, 4, 8
+    data = bytes(data)
+    chunks = [data[i:i + 1024] for i in range(0, len(data), 1024)] or [b""]
+
+    def chunk_cv(chunk, counter, root):
+        cv = list(B3_IV)
+        blocks = [chunk[i:i + 64] for i in range(0, len(chunk), 64)] or [b""]
+        for i, blk in enumerate(blocks):
+            flags = (CHUNK_START if i == 0 else 0) | (CHUNK_END if i == len(blocks) - 1 else 0)
+            if root and i == len(blocks) - 1:
+                flags |= ROOT
+            words = struct.unpack("<16I", blk.ljust(64, b"\0"))
+            cv = _b3_compress(cv, words, counter, len(blk), flags)
+        return cv
+
+    if len(chunks) == 1:
+        return struct.pack("<8I", *chunk_cv(chunks[0], 0, True))
+    cvs = [chunk_cv(c, i, False) for i, c in enumerate(chunks)]
+
+    def merge(nodes, root):
+        # left subtree: the largest power of two of chunks strictly less than the count
+        if len(nodes) == 1:
+            return nodes[0]
+        left = 1 << ((len(nodes) - 1).bit_length() - 1)
+        l, r = merge(nodes[:left], False), merge(nodes[left:], False)
+        return _b3_compress(B3_IV, l + r, 0, 64, PARENT | (ROOT if root else 0))
+
+    return struct.pack("<8I", *merge(cvs, True))
+
+
+def check_blake3():
+    import json
+    fx = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "blake3_vectors.json")))
+    for v in fx["vectors"]:
+        n = int(v["len"])
+        if blake3(bytes(i % 251 for i in range(n))).hex() != v["hash"]:
+            raise SystemExit("BLAKE3 restatement fails the official vector of length %d" % n)
+    for t in fx["text"]:
+        if blake3(t["ascii"].encode()).hex() != t["hash"]:
+            raise SystemExit("BLAKE3 restatement fails the official text vector")
+
+
+def bytes_hash(b):
+    return Struct({"__name__": "BytesHash", 0: [R.TInt(x, 8) for x in b]})
+
+
+def blake3_hooks(it):
+    """`Blake3_256::<32>::hash_no_pad / two_to_one` and `Blake3Permutation::permute` (hash/blake3.rs:167-235): the three functions of the
+    reference that call the external crate, restated.  hash_no_pad hashes the elements' memory -- 8 little-endian bytes each (a proof's
+    elements are canonical); two_to_one hashes left || right; the permutation is the 'hash onion': hash the 96 state bytes, then keep hashing
+    the previous output, cut the outputs into little-endian u64 words, drop words >= p, take twelve."""
+    def hash_no_pad(args):
+        return bytes_hash(blake3(b"".join(struct.pack("<Q", x.v) for x in args[0])))
+
+    def two_to_one(args):
+        return bytes_hash(blake3(bytes(args[0][0]) + bytes(args[1][0])))
+
+    def permute(state):
+        cur = b"".join(struct.pack("<Q", x.v) for x in state)
+        out = []
+        while len(out) < 12:
+            cur = blake3(cur)
+            for w in struct.unpack("<4Q", cur):
+                if w < P and len(out) < 12:
+                    out.append(Fe(w))
+        return out
+
+    it.assoc_hooks[("Blake3_256", "hash_no_pad")] = hash_no_pad
+    it.assoc_hooks[("Blake3_256", "two_to_one")] = two_to_one
+    return permute
+
+
+def verifier_interp(reference, fast_hash=True, hasher="poseidon"):
     it, circ, diag, rc = poseidon_tables(reference)
     base = it.plonky2
     it.extra_files += [os.path.join(base, p) for p in (
@@ -166,10 +289,23 @@ def verifier_interp(reference, fast_hash=True):
         it.field_consts[name] = int(m.group(1))
     if re.search(r"const W: Self = Self\((\d+)\);", open(os.path.join(reference, "plonky2", "field", "src", "goldilocks_extensions.rs")).read()).group(1) != str(Fe2.W):
         raise SystemExit("the quadratic extension's W is not 7")
+    poseidon = it.permutation_hook
     if fast_hash:
         fp = FastPoseidon(circ, diag, rc)
         fp.check(it)
-        it.permutation_hook = fp.permute
+        poseidon = lambda st, segs=None: fp.permute(st)        # noqa: E731
+    it.permutation_hook = poseidon
+    if hasher == "blake3":
+        # Blake3GoldilocksConfig (plonk/config.rs:155-161): Hasher = Blake3_256<32>, InnerHasher = PoseidonHash (the proof of work)
+        check_blake3()
+        onion = blake3_hooks(it)
+        it.extra_files.append(os.path.join(base, "hash", "blake3.rs"))
+        it.generics.update({"C": ["Blake3GoldilocksConfig"], "Hasher": ["Blake3_256", "Hasher"], "H": ["Blake3_256", "Hasher"], "OH": ["Blake3_256", "Hasher"],
+                            "Hash": ["BytesHash"]})
+        # `H::Permutation::permute` (the challenger's sponge) is the config hasher's; `P::permute` inside hashing.rs is PoseidonHash's own
+        it.permutation_hook = lambda st, segs=None: onion(st) if (segs and "Permutation" in segs) else poseidon(st)
+    elif hasher != "poseidon":
+        raise ValueError(hasher)
     return it
 
 
@@ -180,10 +316,11 @@ STARK_FIELDS = ["cpu_stark", "memory_stark", "bitwise_stark", "cmp_stark", "rang
 class RefVerifier:
     """The reference's verifier over one reference tree.  `verify(raw)` -> (True, None) or (False, "file.rs:line" of the `ensure!` that failed)."""
 
-    def __init__(self, reference="/root/reference", fast_hash=True):
+    def __init__(self, reference="/root/reference", fast_hash=True, hasher="poseidon"):
         sys.setrecursionlimit(max(sys.getrecursionlimit(), 20000))
         self.reference = reference
-        self.it = verifier_interp(reference, fast_hash)
+        self.hasher = hasher
+        self.it = verifier_interp(reference, fast_hash, hasher)
         self.stark_dir = os.path.join(reference, "circuits", "src", "stark")
         self.config = self.it.call_assoc("StarkConfig", "standard_fast_config", [], os.path.join(self.stark_dir, "config.rs"))
 
@@ -208,7 +345,7 @@ class RefVerifier:
 
     def verify(self, raw):
         """`verify_proof(OlaStark::default(), all_proof, &StarkConfig::standard_fast_config())`, verifier.rs:35"""
-        proof = raw if isinstance(raw, Struct) else decode_all_proof(raw)
+        proof = raw if isinstance(raw, Struct) else decode_all_proof(raw, self.hasher)
         try:
             r = self.it.call_free(os.path.join(self.stark_dir, "verifier.rs"), "verify_proof", [self.ola_stark(), proof, self.config])
         except ZeroDivisionError as e:           # an inverse of zero: Rust would panic
@@ -225,7 +362,7 @@ class RefVerifier:
 
     def challenges(self, raw):
         """`AllProof::get_challenges` (get_challenges.rs:18): every Fiat-Shamir challenge of the proof, as plain integers"""
-        proof = raw if isinstance(raw, Struct) else decode_all_proof(raw)
+        proof = raw if isinstance(raw, Struct) else decode_all_proof(raw, self.hasher)
         ch = self.it.call_assoc("AllProof", "get_challenges", [proof, self.ola_stark(), self.config], os.path.join(self.stark_dir, "get_challenges.rs"))
 
         def plain(v):
@@ -245,11 +382,12 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("proof")
     ap.add_argument("--reference", default="/root/reference")
+    ap.add_argument("--hasher", default="poseidon", choices=("poseidon", "blake3"), help="PoseidonGoldilocksConfig or Blake3GoldilocksConfig")
     a = ap.parse_args()
     raw = open(a.proof, "rb").read()
-    proof = decode_all_proof(raw)
+    proof = decode_all_proof(raw, a.hasher)
     print("decoded: %d tables, %d bytes" % (len(proof["stark_proofs"]), len(raw)))
-    rv = RefVerifier(a.reference)
+    rv = RefVerifier(a.reference, hasher=a.hasher)
     if rv.encode(proof) != raw:
         raise SystemExit("write_all_proof of the decoded proof does not give back the bytes")
     print("write_all_proof (serialization.rs:377), interpreted, reproduces the %d bytes" % len(raw))

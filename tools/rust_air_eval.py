@@ -21,6 +21,7 @@ Anything it cannot parse or evaluate raises with file:line.
     python tools/rust_air_eval.py [--reference /root/reference] [--points 3] [--out tests/golden/air_eval_vectors.json] [--check]
 """
 import argparse
+import functools
 import json
 import os
 import re
@@ -36,6 +37,11 @@ P = 0xFFFFFFFF00000001
 
 class RustError(Exception):
     pass
+
+
+@functools.lru_cache(maxsize=None)
+def _rp(path):
+    return os.path.realpath(path)
 
 
 class Fe:
@@ -727,6 +733,7 @@ class Interp:
         self.near_cache = {}
         self.field_consts = {}              # TWO_ADICITY, POWER_OF_TWO_GENERATOR, MULTIPLICATIVE_GROUP_GENERATOR of goldilocks_field.rs (set by a driver)
         self.extension = False              # True while the verifier runs: FE = F::Extension is the quadratic extension (D = 2), not F itself
+        self.assoc_hooks = {}               # (type, fn) -> python function of the argument list: the reference's calls into crates outside its tree
         self.extra_files = []               # files outside the AIR tree whose impl blocks a driver needs (plonky2's fri/, iop/challenger.rs)
         self.generics = {}                  # generic parameter -> the types tried for `H::f(..)`: {"H": ["PoseidonHash", "Hasher"]} (set by a driver)
         self.permutation_hook = None        # what `H::Permutation::permute` runs (the driver installs the interpreted poseidon_naive)
@@ -734,7 +741,7 @@ class Interp:
 
     # ---- lookup of functions and constants in the reference tree
     def fn_ast(self, path, name):
-        key = (os.path.realpath(path), name)
+        key = (_rp(path), name)
         if key not in self.fn_cache:
             src = X.Src.get(path)
             fns = src.functions()
@@ -749,7 +756,7 @@ class Interp:
     def impl_index(self, path):
         """(type, fn) -> (params range, body range) for the functions inside `impl .. Type { }` and `trait Name { }` blocks of a file
         (trait blocks are indexed under the trait's name: default methods)"""
-        key = os.path.realpath(path)
+        key = _rp(path)
         if key in self.impl_cache:
             return self.impl_cache[key]
         src = X.Src.get(path)
@@ -852,7 +859,7 @@ class Interp:
         return self.assoc_cache[key]
 
     def fn_ast_at(self, path, ranges):
-        key = (os.path.realpath(path), ranges[1][0])
+        key = (_rp(path), ranges[1][0])
         if key not in self.fn_cache:
             src = X.Src.get(path)
             (plo, phi), (blo, bhi) = ranges
@@ -904,6 +911,8 @@ class Interp:
             env["__generic__"] = g
 
     def call_assoc(self, ty, name, args, here, self_val=None, has_self=False):
+        if (ty, name) in self.assoc_hooks:
+            return self.assoc_hooks[(ty, name)](args)
         found = self.find_assoc(ty, name, here)
         if found is None:
             return NOT_FOUND
@@ -977,7 +986,7 @@ class Interp:
 
     def imports(self, src):
         """`use a::b::{self, x as y, z};` of a file: local name -> (module, name there)"""
-        key = os.path.realpath(src.path)
+        key = _rp(src.path)
         if key in self.import_cache:
             return self.import_cache[key]
         T, out, i = src.toks, {}, 0
@@ -1018,7 +1027,7 @@ class Interp:
         return out
 
     def find_fn_file(self, name, here, module=None):
-        key = (name, os.path.realpath(here), module)
+        key = (name, _rp(here), module)
         if key not in self.find_cache:
             f = self.ref.find_fn(name, here, module)
             if f is None and module is not None:
@@ -1530,7 +1539,7 @@ class Interp:
         if name == "default" and len(segs) >= 2 and segs[-2] == "Default":
             return None
         if name == "permute" and len(segs) >= 2 and segs[-2] in ("Permutation", "P", "PoseidonPermutation") and self.permutation_hook is not None:
-            return self.permutation_hook(args[0])
+            return self.permutation_hook(args[0], segs)
         # ---- the field's own functions (plonky2_field types.rs), with the constants a driver read from goldilocks_field.rs
         if name == "primitive_root_of_unity" and self.field_consts:
             if not 0 <= args[0] <= self.field_consts["TWO_ADICITY"]:
@@ -1555,6 +1564,10 @@ class Interp:
                 return out
             a[:] = out
             return None
+        if name == "from_le_bytes" and len(segs) == 2 and segs[0] in INT_BITS and isinstance(args[0], list):
+            if len(args[0]) * 8 != INT_BITS[segs[0]] or not all(isinstance(x, int) and 0 <= x < 256 for x in args[0]):
+                raise self.err(src, line, f"{segs[0]}::from_le_bytes of {len(args[0])} items")
+            return TInt(sum(int(x) << (8 * i) for i, x in enumerate(args[0])), INT_BITS[segs[0]])
         if name == "from_fn" and "array" in segs:
             # std::array::from_fn: the length is the array type's, which only inference knows; every use in the reference is [_; NUM_TABLES]
             n_ = self.const_value("NUM_TABLES", src)
@@ -2217,7 +2230,7 @@ def plonky2_interp(reference):
     it.extra_files = [os.path.join(base, "fri", "mod.rs"), os.path.join(base, "fri", "reduction_strategies.rs"), os.path.join(base, "iop", "challenger.rs"),
                       os.path.join(base, "hash", "merkle_proofs.rs")]
     it.generics = {"H": ["PoseidonHash", "Hasher"], "OH": ["PoseidonHash", "Hasher"]}
-    it.permutation_hook = lambda st: it.call_assoc("Poseidon", "poseidon_naive", [list(st)], pos)
+    it.permutation_hook = lambda st, segs=None: it.call_assoc("Poseidon", "poseidon_naive", [list(st)], pos)
     return it
 
 
