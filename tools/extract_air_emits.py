@@ -132,7 +132,16 @@ class Ref:
                 self.files += [os.path.join(d, f) for f in sorted(fs) if f.endswith(".rs")]
         self.values = {}          # (name, file) -> evaluated constant
         self.consts = {}          # name -> [(file, expression tokens)]
+        self.const_files = set()
         for f in self.files:
+            self.index_consts(f)
+
+    def index_consts(self, f):
+        """the `const NAME: T = expr;` items of one file (also called for files outside the AIR tree a driver adds later)"""
+        if f in self.const_files:
+            return
+        self.const_files.add(f)
+        if True:
             s = Src.get(f)
             T = s.toks
             for i, (t, _) in enumerate(T):

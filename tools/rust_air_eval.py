@@ -174,6 +174,31 @@ class Cursor:
         return None                             # Ok(())
 
 
+class RayonScope:
+    """the `s` of `rayon::scope(|s| ..)`: `s.spawn(f)` runs f now"""
+
+
+class ChunksMut:
+    """`xs.chunks_mut(n)` (also chunks_exact_mut / par_chunks_mut): the chunks are handed out as copies and written back after each use --
+    a chunk is only ever changed through the closure or loop body it was handed to"""
+
+    def __init__(self, base, n, enumerate_=False, left=None):
+        self.base, self.n, self.enumerate_, self.left = base, n, enumerate_, left        # left: what `xs.zip(ys.chunks_mut(n))` pairs the chunks with
+
+    def run(self, body):
+        for k in range(0, len(self.base), self.n):
+            c = self.base[k:k + self.n]
+            item = c
+            if self.left is not None:
+                if k // self.n >= len(self.left):
+                    break
+                item = (self.left[k // self.n], c)
+            body((k // self.n, item) if self.enumerate_ else item)
+            if len(c) != min(self.n, len(self.base) - k):
+                raise RustError("a chunk of chunks_mut changed its length")
+            self.base[k:k + self.n] = c
+
+
 class ElemRef:
     """`&mut xs[i]` for a scalar element, made where the source says so (`&mut xs` / `xs.iter_mut()` iterated or zipped): `*r = v` writes the
     array; a plain read of the variable gives the current value"""
@@ -195,7 +220,7 @@ def refs_of(lst):
 
 def is_mut_iter(node):
     """`&mut xs`, `xs.iter_mut()` (possibly followed by adaptors that keep the items: enumerate is handled by the caller)"""
-    return node[0] == "mutref" or (node[0] == "mcall" and node[2] == "iter_mut")
+    return node[0] == "mutref" or (node[0] == "mcall" and node[2] in ("iter_mut", "par_iter_mut"))
 
 
 class Params(list):
@@ -472,6 +497,11 @@ class Parser:
         e = self.unary(ns)
         while self.peek() == "as":
             self.next()
+            if self.peek() == "*" and self.peek(1) in ("mut", "const"):      # `as *mut [F]`: a pointer to the same memory
+                self.next()
+                self.next()
+                self.skip_type((")", ",", ";", "}", "]"))
+                continue
             ty = self.next()                  # the type's head
             while self.peek() == "::":
                 self.next()
@@ -655,6 +685,12 @@ class Parser:
                     items.append(self.expr())
                     self.eat(",")
                 return ("macro", name, items)
+            if name == "cfg!":                # cfg!(feature = "parallel"): asked of the driver's feature set
+                toks = [t for t, _ in self.src.toks[self.i + 1:end]]
+                self.i = end + 1
+                if len(toks) == 3 and toks[0] == "feature" and toks[1] == "=":
+                    return ("macro", name, [], toks[2].strip('"'))
+                return ("unit",)
             if name == "ensure!":             # anyhow's ensure!(cond, "..."): the condition matters, the message does not
                 ln = self.line()
                 self.next()
@@ -733,6 +769,8 @@ class Interp:
         self.near_cache = {}
         self.field_consts = {}              # TWO_ADICITY, POWER_OF_TWO_GENERATOR, MULTIPLICATIVE_GROUP_GENERATOR of goldilocks_field.rs (set by a driver)
         self.extension = False              # True while the verifier runs: FE = F::Extension is the quadratic extension (D = 2), not F itself
+        self.features = set()               # cargo features `cfg!(feature = "..")` sees: the reference builds with "parallel" (a driver sets it)
+        self.num_threads = 8                # what maybe_rayon::current_num_threads() answers (results must not depend on it)
         self.assoc_hooks = {}               # (type, fn) -> python function of the argument list: the reference's calls into crates outside its tree
         self.extra_files = []               # files outside the AIR tree whose impl blocks a driver needs (plonky2's fri/, iop/challenger.rs)
         self.generics = {}                  # generic parameter -> the types tried for `H::f(..)`: {"H": ["PoseidonHash", "Hasher"]} (set by a driver)
@@ -1031,6 +1069,18 @@ class Interp:
         if key not in self.find_cache:
             f = self.ref.find_fn(name, here, module)
             if f is None and module is not None:
+                for x in self.extra_files:          # `serial::permute` from cfft/mod.rs: the sibling file of that name
+                    if os.path.basename(x) == module + ".rs" and os.path.dirname(x) == os.path.dirname(here) and ("", name) in self.impl_index(x):
+                        f = x
+                        break
+            if f is None and module in ("super", "self", "crate") and ("", name) in self.impl_index(here):
+                f = here
+            if f is None and module == "super":
+                for x in self.extra_files:
+                    if os.path.basename(x) == "mod.rs" and os.path.dirname(x) == os.path.dirname(here) and ("", name) in self.impl_index(x):
+                        f = x
+                        break
+            if f is None and module is not None:
                 f = self.ref.find_fn(name, here, None)
             if f is None:
                 for x in self.extra_files:          # plonky2's fri/, util/: free functions only
@@ -1043,6 +1093,8 @@ class Interp:
     def const_value(self, name, src):
         nk = (name, src.path)
         if nk not in self.near_cache:
+            for x in self.extra_files:
+                self.ref.index_consts(x)
             cands = self.ref.consts.get(name)
             c = None
             if cands:
@@ -1336,6 +1388,8 @@ class Interp:
             if n[1] == "izip!":
                 cols = [self.iterate(self.ev(x, env, src), src) for x in n[2]]
                 return [tuple(t) for t in zip(*cols)]
+            if n[1] == "cfg!":
+                return n[3] in self.features
             if n[1] == "ensure!":
                 if not self.truthy(self.ev(n[2][0], env, src)):
                     raise Return(Enum("Result", "Err", [f"{os.path.basename(src.path)}:{n[3]}"]))
@@ -1358,7 +1412,10 @@ class Interp:
         raise RustError(f"{src.path}: cannot evaluate node {k}")
 
     def scoped(self, node, env, src, inner=None):
-        inner = dict(env) if inner is None else inner
+        if inner is None:
+            inner = dict(env)
+            inner["__declared__"] = set()       # a fresh scope: what the enclosing block declared is OUTER here
+            inner["__assigned__"] = set()
         r = self.ev(node, inner, src)
         self.write_back(env, inner)
         return r
@@ -1392,6 +1449,16 @@ class Interp:
             return None
         if k == "for":
             seq = self.ev(s[2], env, src)
+            if isinstance(seq, ChunksMut):
+                def body(item):
+                    inner = dict(env)
+                    inner["__declared__"] = set(pattern_names(s[1]))
+                    inner["__assigned__"] = set()
+                    self.bind(s[1], item, inner, src)
+                    self.ev(s[3], inner, src)
+                    self.write_back(env, inner)
+                seq.run(body)
+                return None
             if is_mut_iter(s[2]) and isinstance(seq, list):
                 seq = refs_of(seq)
             for item in self.iterate(seq, src, s[4]):
@@ -1451,6 +1518,8 @@ class Interp:
             b = len(base) if idx.end is None else idx.end
             if not (0 <= a <= b <= len(base)):
                 raise self.err(src, line, f"slice {a}..{b} of {len(base)}")
+            if idx.start is None and idx.end is None and isinstance(base, list):
+                return base                        # `v[..]` is the whole slice itself (concurrent.rs:82 takes a second &mut to it)
             return list(base[a:b])
         if isinstance(idx, Fe):
             raise self.err(src, line, "field element as index")
@@ -1568,6 +1637,10 @@ class Interp:
             if len(args[0]) * 8 != INT_BITS[segs[0]] or not all(isinstance(x, int) and 0 <= x < 256 for x in args[0]):
                 raise self.err(src, line, f"{segs[0]}::from_le_bytes of {len(args[0])} items")
             return TInt(sum(int(x) << (8 * i) for i, x in enumerate(args[0])), INT_BITS[segs[0]])
+        if name == "current_num_threads" and not args:
+            return self.num_threads
+        if name == "scope" and len(segs) >= 2 and segs[-2] in ("maybe_rayon", "rayon") and len(args) == 1:
+            return self.call_closure(args[0], [RayonScope()])          # the spawned closures run at once, in order
         if name == "from_fn" and "array" in segs:
             # std::array::from_fn: the length is the array type's, which only inference knows; every use in the reference is [_; NUM_TABLES]
             n_ = self.const_value("NUM_TABLES", src)
@@ -1631,6 +1704,8 @@ class Interp:
                 raise self.err(src, line, "constraint argument is not a field element")
             recv.emits.append((X.KINDS[name], v.v if isinstance(v, Fe) else (v.a, v.b), os.path.relpath(src.path, self.ref.root), line))
             return None
+        if name in ("iter_mut", "par_iter_mut") and isinstance(recv, list) and not n[3]:
+            return refs_of(recv)                    # an iterator of `&mut` items: adaptors (skip, zip, enumerate ..) pass the references on
         args = [self.ev(a, env, src) for a in n[3]]
         if name == "zip" and n[3] and is_mut_iter(n[3][0]) and isinstance(args[0], list):
             args[0] = refs_of(args[0])
@@ -1654,6 +1729,20 @@ class Interp:
         return self.method(recv, name, args, src, line)
 
     def method(self, r, name, args, src, line):
+        if isinstance(r, RayonScope):
+            if name == "spawn":
+                self.call_closure(args[0], [r])
+                return None
+            raise self.err(src, line, f"rayon scope .{name}")
+        if isinstance(r, ChunksMut):
+            if name == "enumerate":
+                return ChunksMut(r.base, r.n, True, r.left)
+            if name == "for_each":
+                r.run(lambda item: self.call_closure(args[0], [item]))
+                return None
+            if name == "len":
+                return (len(r.base) + r.n - 1) // r.n
+            raise self.err(src, line, f"chunks_mut().{name}")
         if isinstance(r, Cursor):
             if name == "write_all":
                 return r.write_all(args[0])
@@ -1666,7 +1755,7 @@ class Interp:
                 return v
         # ---- adaptors that do nothing here
         if name in ("iter", "into_iter", "iter_mut", "copied", "cloned", "collect", "collect_vec", "to_vec", "try_into", "unwrap", "expect", "by_ref",
-                    "as_ref", "as_mut", "borrow", "into", "to_owned", "as_slice_of_cells", "peekable", "into_par_iter", "par_iter", "unwrap_or_default"):
+                    "as_ref", "as_mut", "borrow", "borrow_mut", "as_mut_slice", "into", "to_owned", "as_slice_of_cells", "peekable", "into_par_iter", "par_iter", "par_iter_mut", "unwrap_or_default"):
             if name in ("unwrap", "expect") and r is None:
                 raise self.err(src, line, "unwrap of None")
             if name == "to_vec" or name == "collect" or name == "collect_vec":
@@ -1766,8 +1855,12 @@ class Interp:
                 return ((r >> (args[0] % 64)) & ((1 << 64) - 1), args[0] >= 64)
             if name == "count_ones":
                 return bin(r).count("1")
+            if name == "count_zeros":               # of a usize / u64 unless the value carries its type
+                return (r.bits if isinstance(r, TInt) else 64) - bin(r).count("1")
             if name == "trailing_zeros":
                 return (r & -r).bit_length() - 1
+            if name == "next_power_of_two":
+                return 1 if r <= 1 else 1 << (r - 1).bit_length()
             if name == "is_power_of_two":
                 return r > 0 and r & (r - 1) == 0
         if r is None or (not isinstance(r, (list, tuple, Rng, Struct, Enum, Fe, Fe2, int, RepeatForever))):
@@ -1805,6 +1898,8 @@ class Interp:
                 return [(i, x) for i, x in enumerate(items)]
             if name == "zip":
                 o = args[0]
+                if isinstance(o, ChunksMut) and o.left is None and not o.enumerate_:
+                    return ChunksMut(o.base, o.n, False, items)
                 if isinstance(o, RepeatForever):
                     return [(x, clone(o.v)) for x in items]
                 if isinstance(o, Powers):
@@ -1897,8 +1992,26 @@ class Interp:
                 return out
             if name in ("first", "last"):
                 return (items[0] if name == "first" else items[-1]) if items else None
-            if name == "chunks":
+            if name in ("chunks", "chunks_exact", "par_chunks", "par_chunks_exact"):
                 return [items[i:i + args[0]] for i in range(0, len(items), args[0])]
+            if name in ("chunks_mut", "chunks_exact_mut", "par_chunks_mut", "par_chunks_exact_mut") and isinstance(r, list):
+                return ChunksMut(r, args[0])
+            if name == "swap" and isinstance(r, list):
+                r[args[0]], r[args[1]] = r[args[1]], r[args[0]]
+                return None
+            if name == "set_len" and isinstance(r, list):          # after Vec::with_capacity: uninitialised slots
+                if len(r) > args[0]:
+                    del r[args[0]:]
+                r.extend([None] * (args[0] - len(r)))
+                return None
+            if name == "resize" and isinstance(r, list):
+                if len(r) > args[0]:
+                    del r[args[0]:]
+                r.extend([clone(args[1]) for _ in range(args[0] - len(r))])
+                return None
+            if name == "insert" and isinstance(r, list):
+                r.insert(args[0], args[1])
+                return None
             if name == "windows":
                 return [items[i:i + args[0]] for i in range(0, len(items) - args[0] + 1)]
             if isinstance(r, list) and name in ("clear", "pop", "drain", "extend_from_slice", "shrink_to_fit", "copy_from_slice", "truncate", "reserve"):
@@ -2327,6 +2440,72 @@ def primitives(reference):
     return out
 
 
+NTT_FIXTURE = os.path.join(ROOT, "tests", "golden", "ref_ntt_vectors.json")
+NTT_OPS = ("evaluate_poly", "interpolate_poly", "evaluate_poly_with_offset", "interpolate_poly_with_offset")
+
+
+def ntt_interp(reference):
+    """the reference's transforms (plonky2/field/src/cfft/{mod,serial,concurrent}.rs) as the real build runs them: feature "parallel" on, so
+    mod.rs dispatches sizes >= MIN_CONCURRENT_SIZE = 1024 to concurrent.rs (the four-step split_radix_fft) and smaller ones to serial.rs"""
+    it = plonky2_interp(reference)
+    cf = os.path.join(reference, "plonky2", "field", "src", "cfft")
+    it.cfft = os.path.join(cf, "mod.rs")
+    it.extra_files += [it.cfft, os.path.join(cf, "serial.rs"), os.path.join(cf, "concurrent.rs"), os.path.join(reference, "plonky2", "util", "src", "lib.rs")]
+    it.features = {"parallel"}
+    gf = open(os.path.join(reference, "plonky2", "field", "src", "goldilocks_field.rs")).read()
+    for name in ("TWO_ADICITY", "POWER_OF_TWO_GENERATOR", "MULTIPLICATIVE_GROUP_GENERATOR"):
+        it.field_consts[name] = int(re.search(r"const %s: \w+ = (?:Self\()?(\d+)\)?;" % name, gf).group(1))
+    return it
+
+
+def ntt_input(log_n, op):
+    return stream_for(4000 + log_n, NTT_OPS.index(op), 1 << log_n)
+
+
+def ntt_run(it, op, log_n, threads=8):
+    """one transform of the reference on ntt_input(log_n, op) -> output words.  `with_offset`: domain offset = F::coset_shift(), blowup 8 (what
+    PolynomialBatch::lde_values asks for, fri/oracle.rs:120)"""
+    n = 1 << log_n
+    it.num_threads = threads
+    data = [Fe(x) for x in ntt_input(log_n, op)]
+    shift = it.call(("call", ("path", ["F", "coset_shift"], 0), [], 0), {}, X.Src.get(it.cfft))
+    if op in ("evaluate_poly", "evaluate_poly_with_offset"):
+        tw = it.call_free(it.cfft, "get_twiddles", [n])
+    else:
+        tw = it.call_free(it.cfft, "get_inv_twiddles", [n])
+    if op == "evaluate_poly_with_offset":
+        out = it.call_free(it.cfft, op, [data, tw, shift, 8])
+    elif op == "interpolate_poly_with_offset":
+        it.call_free(it.cfft, op, [data, tw, shift])
+        out = data
+    else:
+        it.call_free(it.cfft, op, [data, tw])
+        out = data
+    return [x.v for x in out]
+
+
+def ntt_record(words):
+    import hashlib
+    import struct
+    return {"sha256": hashlib.sha256(struct.pack("<%dQ" % len(words), *words)).hexdigest(), "len": len(words), "head": words[:4], "tail": words[-2:]}
+
+
+def ntt_vectors(reference, sizes=tuple(range(1, 12))):
+    """outputs of the reference's four transforms, sizes 2^1 .. 2^11 (serial.rs below 2^10; concurrent.rs at 2^10 -- square split -- and 2^11 -- the
+    2:1 split), as digests"""
+    it = ntt_interp(reference)
+    out = {"generated_by": "tools/rust_air_eval.py --ntt", "input": "ntt_input(log_n, op) = stream_for(4000 + log_n, index of op, 2^log_n)",
+           "source": "plonky2/field/src/cfft/mod.rs :22 :65 :128 :180 -> serial.rs / concurrent.rs (feature parallel: n >= 1024)", "vectors": []}
+    for log_n in sizes:
+        for op in NTT_OPS:
+            out["vectors"].append({"op": op, "log_n": log_n, "path": "concurrent.rs" if log_n >= 10 else "serial.rs", **ntt_record(ntt_run(it, op, log_n))})
+    # the split into rayon batches must not show: the same outputs with another thread count
+    for op in NTT_OPS:
+        assert ntt_record(ntt_run(it, op, 10, threads=3)) == {k: v for k, v in [x for x in out["vectors"] if x["op"] == op and x["log_n"] == 10][0].items()
+                                                                if k in ("sha256", "len", "head", "tail")}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reference", default="/root/reference")
@@ -2334,8 +2513,22 @@ def main():
     ap.add_argument("--out", default=FIXTURE)
     ap.add_argument("--check", action="store_true")
     ap.add_argument("--primitives", action="store_true", help="the hashing / transcript / FRI-parameter vectors instead of the AIR vectors")
+    ap.add_argument("--ntt", action="store_true", help="the transform vectors (cfft) instead of the AIR vectors")
     a = ap.parse_args()
     sys.setrecursionlimit(20000)
+    if a.ntt:
+        out = NTT_FIXTURE if a.out == FIXTURE else a.out
+        data = ntt_vectors(a.reference)
+        text = json.dumps(data, indent=0) + "\n"
+        print("%d transforms" % len(data["vectors"]))
+        if a.check:
+            if open(out).read() != text:
+                raise SystemExit(out + " is stale")
+            print("fixture is up to date")
+            return
+        open(out, "w").write(text)
+        print("wrote", out, "(%d bytes)" % len(text))
+        return
     if a.primitives:
         out = PRIMITIVES_FIXTURE if a.out == FIXTURE else a.out
         data = primitives(a.reference)
