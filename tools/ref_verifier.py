@@ -289,6 +289,8 @@ def verifier_interp(reference, fast_hash=True, hasher="poseidon"):
         it.field_consts[name] = int(m.group(1))
     if re.search(r"const W: Self = Self\((\d+)\);", open(os.path.join(reference, "plonky2", "field", "src", "goldilocks_extensions.rs")).read()).group(1) != str(Fe2.W):
         raise SystemExit("the quadratic extension's W is not 7")
+    # Hasher::zero_hash (plonk/config.rs:72-78): HASH_SIZE zero bytes through Hash::from_bytes
+    it.assoc_hooks[("Hasher", "zero_hash")] = (lambda args: hash_out(bytes(32), 0)) if hasher == "poseidon" else (lambda args: bytes_hash(bytes(32)))
     poseidon = it.permutation_hook
     if fast_hash:
         fp = FastPoseidon(circ, diag, rc)
@@ -366,6 +368,8 @@ class RefVerifier:
         ch = self.it.call_assoc("AllProof", "get_challenges", [proof, self.ola_stark(), self.config], os.path.join(self.stark_dir, "get_challenges.rs"))
 
         def plain(v):
+            if isinstance(v, R.Opt):
+                return plain(v.v)
             if isinstance(v, Fe):
                 return v.v
             if isinstance(v, Fe2):
@@ -398,3 +402,104 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+class RefProver(RefVerifier):
+    """The reference's PROVER for one table, run from its source: `prove_single_table` (circuits/src/stark/prover.rs:330-567) with everything
+    under it -- `compute_permutation_z_polys`, `PolynomialBatch::from_values / from_coeffs` (ifft, the x8 coset LDE of cfft, transpose,
+    bit-reversal, `MerkleTree::new_v2`), `compute_quotient_polys`, `StarkOpeningSet::new`, `PolynomialBatch::prove_openings`, `fri_proof`
+    (commit phase, proof of work, query rounds) -- and `cross_table_lookup_data` for the table's lookup Z columns.  Only tables small enough for
+    an interpreter (up to a few hundred rows); the transcript state before the table comes from the reference's own
+    `AllProof::get_challenger_states` over the whole proof.  Where the reference leaves a choice, the driver takes the one this repository's
+    provers take: packing width 1 (`<F as Packable>::Packing` is a SIMD width, not a value) and the SMALLEST proof-of-work witness
+    (`find_any` over 0..p may return any)."""
+
+    def __init__(self, reference="/root/reference", hasher="poseidon"):
+        super().__init__(reference, True, hasher)
+        it, ref = self.it, reference
+        cf = os.path.join(ref, "plonky2", "field", "src")
+        pl = os.path.join(ref, "plonky2", "plonky2", "src")
+        it.extra_files += [os.path.join(cf, "cfft", "mod.rs"), os.path.join(cf, "cfft", "serial.rs"), os.path.join(cf, "cfft", "concurrent.rs"),
+                           os.path.join(cf, "polynomial", "division.rs"), os.path.join(cf, "zero_poly_coset.rs"), os.path.join(cf, "types.rs"),
+                           os.path.join(pl, "fri", "oracle.rs"), os.path.join(pl, "fri", "prover.rs"), os.path.join(pl, "hash", "merkle_tree", "concurrent.rs")]
+        it.features = {"parallel"}
+        it.packing_width = 1
+        oracle_rs = os.path.join(pl, "fri", "oracle.rs")
+
+        def get_lde_values_packed(args):
+            # fri/oracle.rs:138-161 for P::WIDTH = 1: the one row get_lde_values returns, each element its own 'pack'
+            return list(it.call_assoc("PolynomialBatch", "get_lde_values", [args[0], args[1], args[2]], oracle_rs))
+        it.assoc_hooks[("PolynomialBatch", "get_lde_values_packed")] = get_lde_values_packed
+        zpc = os.path.join(cf, "zero_poly_coset.rs")
+        # zero_poly_coset.rs:45-53 for P::WIDTH = 1
+        it.assoc_hooks[("ZeroPolyOnCoset", "eval_inverse_packed")] = lambda args: it.call_assoc("ZeroPolyOnCoset", "eval_inverse", [args[0], args[1]], zpc)
+        it.generics["F"] = ["Field"]                # the Field trait's provided functions (plonky2_field types.rs): two_adic_subgroup, cyclic_subgroup_*
+
+    def base_field(self):
+        """the prover's generic code is instantiated with FE = F, D2 = 1 (prover.rs:669, cross_table_lookup.rs:236): `FE::from_basefield` is the
+        identity there, while `F::Extension::from_basefield` stays what it says"""
+        import contextlib
+
+        @contextlib.contextmanager
+        def cm():
+            self.it.extension = False
+            try:
+                yield
+            finally:
+                self.it.extension = True
+        return cm()
+
+    def challenger_at(self, state):
+        return Struct({"__name__": "Challenger", "sponge_state": [Fe(x.v) for x in state], "input_buffer": [], "output_buffer": [], "_phantom": None})
+
+    def prove_table(self, raw, traces, k, max_rows_for_lookups=4096):
+        """the bytes `Buffer::write_proof` gives for the reference's prove_single_table of table k, given the whole proof (for the transcript
+        state before the table) and the twelve traces"""
+        it = self.it
+        proof = decode_all_proof(raw, self.hasher)
+        ola = self.ola_stark()
+        # prove_with_traces sets the two compress challenges before anything else (prover.rs:84-100)
+        ola["bitwise_stark"]["compress_challenge"] = proof["compress_challenges"][2]
+        ola["program_stark"]["compress_challenge"] = proof["compress_challenges"][10]
+        states = it.call_assoc("AllProof", "get_challenger_states", [proof, ola, self.config], os.path.join(self.stark_dir, "get_challenges.rs"))
+        # lookup Z columns: cross_table_lookup_data over the traces; tables too long to interpret are cut to 8 rows (their own Z columns are
+        # then meaningless and not used: a table's Z depends on its own rows and the challenges only)
+        values = []
+        for t in traces:
+            n = t.shape[1] if t.shape[1] <= max_rows_for_lookups else 8
+            values.append([Struct({"__name__": "PolynomialValues", "values": [Fe(int(x)) for x in col[:n]]}) for col in t])
+        ch = self.it.call_assoc("Challenger", "new", [], os.path.join(it.plonky2, "iop", "challenger.rs"))
+        for sp in proof["stark_proofs"]:
+            it.call_assoc("Challenger", "observe_cap", [ch, sp["trace_cap"]], os.path.join(it.plonky2, "iop", "challenger.rs"))
+        with self.base_field():
+            ctl = it.call_free(os.path.join(self.stark_dir, "cross_table_lookup.rs"), "cross_table_lookup_data", [self.config, values, ola["cross_table_lookups"], ch])
+        if [x.v for x in it.call_assoc("Challenger", "compact", [ch], os.path.join(it.plonky2, "iop", "challenger.rs"))] != [x.v for x in states["states"][0]]:
+            raise SystemExit("the transcript before the first table differs between prover side and verifier side")
+        stark = ola[STARK_FIELDS[k]]
+        twiddles = {}
+        commitment = it.call_assoc("PolynomialBatch", "from_values", [clone_values(values[k]), self.config["fri_config"]["rate_bits"], False,
+                                                                      self.config["fri_config"]["cap_height"], None, twiddles],
+                                   os.path.join(it.plonky2, "fri", "oracle.rs"))
+        challenger = self.challenger_at(states["states"][k])
+        with self.base_field():
+            r = it.call_free(os.path.join(self.stark_dir, "prover.rs"), "prove_single_table",
+                             [stark, self.config, values[k], commitment, ctl[k], challenger, None, twiddles])
+        if isinstance(r, Enum):
+            raise R.RustError("prove_single_table returned Err " + str(r.payload))
+        buf = Struct({"__name__": "Buffer", 0: R.Cursor()})
+        it.call_assoc("Buffer", "write_proof", [buf, r], os.path.join(self.stark_dir, "serialization.rs"))
+        after = it.call_assoc("Challenger", "compact", [challenger], os.path.join(it.plonky2, "iop", "challenger.rs"))
+        return bytes(buf[0].data), [x.v for x in after] == [x.v for x in states["states"][k + 1]]
+
+
+def clone_values(vs):
+    return [Struct({"__name__": "PolynomialValues", "values": list(v["values"])}) for v in vs]
+
+
+def table_span(raw, k):
+    """byte range of table k's StarkProof inside an AllProof"""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "integration", "pin"))
+    import compare_with_dump as CD
+    spans = [(n, a, b) for n, a, b in CD.parse_all_proof(raw) if n.startswith("table %d:" % k)]
+    return spans[0][1] - 4, spans[-1][2]          # the cap's u32 count precedes its span

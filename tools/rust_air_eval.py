@@ -174,6 +174,39 @@ class Cursor:
         return None                             # Ok(())
 
 
+class Opt:
+    """`Some(v)` where it must be told from v itself: `cond.then(|| vec)` followed by `.map(|v| ..)` would otherwise map the vector's items.
+    (A literal `Some(x)` stays x; `None` is None.)"""
+
+    def __init__(self, v):
+        self.v = v
+
+
+class PtrCast:
+    def __init__(self, base, group):
+        self.base, self.group = base, group
+
+
+class GroupView:
+    """`slice::from_raw_parts(xs.as_ptr() as *const [T; 2], n)`: xs seen as n arrays of 2 -- the same memory, so later writes to xs show"""
+
+    def __init__(self, base, group, n):
+        self.base, self.group, self.n = base, group, n
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, i):
+        if not 0 <= i < self.n:
+            raise IndexError(i)
+        return self.base[self.group * i:self.group * (i + 1)]
+
+
+class MapEntry:
+    def __init__(self, d, k):
+        self.d, self.k = d, k
+
+
 class RayonScope:
     """the `s` of `rayon::scope(|s| ..)`: `s.spawn(f)` runs f now"""
 
@@ -224,8 +257,9 @@ def is_mut_iter(node):
 
 
 class Params(list):
-    """a function's parameter patterns; `.types[i]` = the tokens of parameter i's type (None for self)"""
+    """a function's parameter patterns; `.types[i]` = the tokens of parameter i's type (None for self); `.ret` = head of the return type"""
     types = ()
+    ret = None
 
 
 class Return(Exception):
@@ -317,6 +351,8 @@ class Parser:
                 continue
             if t == "<":
                 depth += 1
+            elif t == "<<":                     # `Vec<<F as Extendable<D>>::Extension>`
+                depth += 2
             elif t == ">":
                 depth -= 1
             elif t == ">>":
@@ -396,14 +432,30 @@ class Parser:
     def block(self):
         self.expect("{")
         stmts, tail = [], None
+        pending = None
         while self.peek() != "}":
             if self.peek() == "#":           # attribute
                 self.next()
-                self.i = self.src.match(self.i) + 1
+                close_ = self.src.match(self.i)
+                toks = [t for t, _ in self.src.toks[self.i + 1:close_]]
+                self.i = close_ + 1
+                # #[cfg(feature = "x")] / #[cfg(not(feature = "x"))] / #[cfg(test)]: the statement exists only in such a build
+                if toks[:1] == ["cfg"]:
+                    inner = toks[2:-1]
+                    neg = inner[:1] == ["not"]
+                    if neg:
+                        inner = inner[2:-1]
+                    if len(inner) == 3 and inner[0] == "feature" and inner[1] == "=":
+                        pending = (inner[2].strip('"'), neg)
+                    elif inner == ["test"]:
+                        pending = ("test", neg)
                 continue
             if self.eat(";"):
                 continue
             s, is_expr, needs_semi = self.statement()
+            if pending is not None:
+                s = ("cfg", pending[0], pending[1], s)
+                pending = None
             if is_expr and self.peek() == "}":
                 tail = s
                 break
@@ -500,7 +552,15 @@ class Parser:
             if self.peek() == "*" and self.peek(1) in ("mut", "const"):      # `as *mut [F]`: a pointer to the same memory
                 self.next()
                 self.next()
+                group = 1
+                if self.peek() == "[":              # `*const [H::Hash; 2]`: the memory seen as arrays of 2
+                    close_ = self.src.match(self.i)
+                    inner = [t for t, _ in self.src.toks[self.i + 1:close_]]
+                    if ";" in inner and len(inner) - inner.index(";") == 2 and inner[-1].isdigit():
+                        group = int(inner[-1])
                 self.skip_type((")", ",", ";", "}", "]"))
+                if group != 1:
+                    e = ("ptrcast", e, group)
                 continue
             ty = self.next()                  # the type's head
             while self.peek() == "::":
@@ -685,6 +745,14 @@ class Parser:
                     items.append(self.expr())
                     self.eat(",")
                 return ("macro", name, items)
+            if name in ("timed!", "batch_iter_mut!"):      # macro_rules of the reference (util/timing.rs:180, plonky2_util lib.rs:284): arguments are expressions
+                ln = self.line()
+                self.next()
+                items = []
+                while not self.eat(close):
+                    items.append(self.expr())
+                    self.eat(",")
+                return ("macro", name, items, ln)
             if name == "cfg!":                # cfg!(feature = "parallel"): asked of the driver's feature set
                 toks = [t for t, _ in self.src.toks[self.i + 1:end]]
                 self.i = end + 1
@@ -769,6 +837,7 @@ class Interp:
         self.near_cache = {}
         self.field_consts = {}              # TWO_ADICITY, POWER_OF_TWO_GENERATOR, MULTIPLICATIVE_GROUP_GENERATOR of goldilocks_field.rs (set by a driver)
         self.extension = False              # True while the verifier runs: FE = F::Extension is the quadratic extension (D = 2), not F itself
+        self.packing_width = 0              # P::WIDTH where the reference's code is generic over a packing (a driver sets 1)
         self.features = set()               # cargo features `cfg!(feature = "..")` sees: the reference builds with "parallel" (a driver sets it)
         self.num_threads = 8                # what maybe_rayon::current_num_threads() answers (results must not depend on it)
         self.assoc_hooks = {}               # (type, fn) -> python function of the argument list: the reference's calls into crates outside its tree
@@ -787,6 +856,7 @@ class Interp:
                 raise RustError(f"{path}: fn {name} not found")
             (plo, phi), (blo, bhi) = self.impl_index(path).get(("", name), fns[name])       # a free function before a method of the same name
             params = self.parse_params(src, plo, phi)
+            params.ret = self.ret_head(src, phi, blo)
             body = Parser(src, blo, bhi + 1).block()
             self.fn_cache[key] = (params, body, src)
         return self.fn_cache[key]
@@ -876,6 +946,40 @@ class Interp:
         self.impl_cache[key] = out
         return out
 
+    def default_struct(self, name, src):
+        """`#[derive(Default)]` of a struct with named fields: Vec -> [], Option -> None, integers -> 0, bool -> false, F -> 0 (found in the
+        file at hand, then anywhere in the tree); a struct that is not found stays an empty record"""
+        st = Struct({"__name__": name})
+        for f in [src.path] + self.ref.files + self.extra_files:
+            T = X.Src.get(f).toks
+            for i in range(len(T) - 2):
+                if T[i][0] == "struct" and T[i + 1][0] == name:
+                    j = i + 2
+                    while T[j][0] not in ("{", ";", "("):
+                        j += 1
+                    if T[j][0] != "{":
+                        return st
+                    end = X.Src.get(f).match(j)
+                    k = j + 1
+                    while k < end:
+                        while T[k][0] == "#":
+                            k = X.Src.get(f).match(k + 1) + 1
+                        if T[k][0] == "pub":
+                            k += 1
+                            if T[k][0] == "(":
+                                k = X.Src.get(f).match(k) + 1
+                        field = T[k][0]
+                        ty0 = T[k + 2][0]
+                        st[field] = [] if ty0 == "Vec" else 0 if ty0 in INT_TYPES else False if ty0 == "bool" else Fe(0) if ty0 in ("F", "P") else None
+                        depth = 0
+                        k += 2
+                        while k < end and not (T[k][0] == "," and depth == 0):
+                            depth += {"<": 1, ">": -1, ">>": -2, "(": 1, ")": -1, "[": 1, "]": -1}.get(T[k][0], 0)
+                            k += 1
+                        k += 1
+                    return st
+        return st
+
     def call_free(self, path, name, args):
         """a free function of one file (`call_fn` takes the first `fn` of that name, which may be a method)"""
         v = self.call_assoc("", name, args, path)
@@ -901,8 +1005,27 @@ class Interp:
         if key not in self.fn_cache:
             src = X.Src.get(path)
             (plo, phi), (blo, bhi) = ranges
-            self.fn_cache[key] = (self.parse_params(src, plo, phi), Parser(src, blo, bhi + 1).block(), src)
+            params = self.parse_params(src, plo, phi)
+            params.ret = self.ret_head(src, phi, blo)
+            self.fn_cache[key] = (params, Parser(src, blo, bhi + 1).block(), src)
         return self.fn_cache[key]
+
+    @staticmethod
+    def ret_head(src, phi, blo):
+        """the head of a function's declared return type (`-> PolynomialValues<F>` gives "PolynomialValues"), or None"""
+        toks = [t for t, _ in src.toks[phi + 1:blo]]
+        if toks[:1] != ["->"]:
+            return None
+        toks = [t for t in toks[1:] if t not in ("&", "mut") and not t.startswith("'")]
+        return toks[0] if toks else None
+
+    @staticmethod
+    def coerce_return(v, params):
+        """`res.into()` as the tail of a function declared to return PolynomialValues<F> / PolynomialCoeffs<F>: the From<Vec<F>> impl"""
+        ret = getattr(params, "ret", None)
+        if isinstance(v, list) and ret in ("PolynomialValues", "PolynomialCoeffs"):
+            return Struct({"__name__": ret, ("values" if ret == "PolynomialValues" else "coeffs"): v})
+        return v
 
     @staticmethod
     def parse_params(src, plo, phi):
@@ -950,7 +1073,7 @@ class Interp:
 
     def call_assoc(self, ty, name, args, here, self_val=None, has_self=False):
         if (ty, name) in self.assoc_hooks:
-            return self.assoc_hooks[(ty, name)](args)
+            return self.assoc_hooks[(ty, name)](([self_val] + list(args)) if has_self else args)
         found = self.find_assoc(ty, name, here)
         if found is None:
             return NOT_FOUND
@@ -977,9 +1100,12 @@ class Interp:
         if self.depth > 200:
             raise RustError(f"{path}: call depth")
         try:
-            return self.ev(body, env, src)
+            v = self.ev(body, env, src)
+            if isinstance(v, list) and body[0] == "block" and body[2] is not None and body[2][0] == "field" and body[2][1] == ("path", ["self"], body[2][1][2]):
+                v = list(v)          # `fn compact(&mut self) -> [F; W] { ..; self.sponge_state }`: an array leaves a borrowed struct by copy
+            return self.coerce_return(v, params)
         except Return as r:
-            return r.v
+            return self.coerce_return(r.v, params)
         finally:
             self.depth -= 1
             for i, cenv, cname in wb:
@@ -1141,7 +1267,7 @@ class Interp:
             for p, x in zip(pat[1], v):
                 self.bind(p, x, env, src)
         elif k == "pcall":
-            self.bind(pat[2][0], v, env, src)            # Some(x)
+            self.bind(pat[2][0], v.v if isinstance(v, Opt) else v, env, src)            # Some(x)
         elif k == "pstruct":
             for name, sub in pat[2]:
                 if name not in v:
@@ -1173,7 +1299,7 @@ class Interp:
             if pat[1][-1] == "Some":
                 if v is None:
                     return False
-                return self.matches(pat[2][0], v, env, src)
+                return self.matches(pat[2][0], v.v if isinstance(v, Opt) else v, env, src)
             if isinstance(v, Enum) and v.variant == pat[1][-1] and v.payload is not None and len(v.payload) == len(pat[2]):
                 return all(self.matches(p_, x, env, src) for p_, x in zip(pat[2], v.payload))
             return False
@@ -1204,9 +1330,14 @@ class Interp:
                 args = list(args[0])
             else:
                 raise RustError(f"{c.src.path}: closure of {len(c.params)} parameters called with {len(args)}")
+        env["__declared__"] = set(n_ for p in c.params for n_ in pattern_names(p))
+        env["__assigned__"] = set()
         for p, a in zip(c.params, args):
             self.bind(p, a, env, c.src)
-        return self.ev(c.body, env, c.src)
+        try:
+            return self.ev(c.body, env, c.src)
+        finally:
+            self.write_back(c.env, env)          # a closure that assigns a captured variable (`pair_index >>= 1` inside `.map(|i| ..)`)
 
     def call_fn(self, path, name, args, self_val=None):
         params, body, src = self.fn_ast(path, name)
@@ -1226,9 +1357,9 @@ class Interp:
         if self.depth > 200:
             raise RustError(f"{path}: call depth")
         try:
-            return self.ev(body, env, src)
+            return self.coerce_return(self.ev(body, env, src), params)
         except Return as r:
-            return r.v
+            return self.coerce_return(r.v, params)
         finally:
             self.depth -= 1
             for i, cenv, cname in wb:
@@ -1244,7 +1375,13 @@ class Interp:
         raise self.err(src, line, f"cannot iterate {type(v).__name__}")
 
     # ---- arithmetic
+    OP_TRAIT = {"+": "add", "-": "sub", "*": "mul", "/": "div"}
+
     def binop(self, op, a, b, src, line):
+        if isinstance(a, Struct) and "__name__" in a and op in self.OP_TRAIT:        # `&acc + &p`: impl Add for &PolynomialCoeffs<F>
+            r = self.call_assoc(a["__name__"], self.OP_TRAIT[op], [a, b], src.path)
+            if r is not NOT_FOUND:
+                return r
         if isinstance(a, (ZeroSum, OneProduct)) and isinstance(b, (Fe, Fe2)):
             a = Fe(int(a))
         if isinstance(b, (ZeroSum, OneProduct)) and isinstance(a, (Fe, Fe2)):
@@ -1347,6 +1484,9 @@ class Interp:
             return Rng(a, b)
         if k in ("mutref", "deref"):
             return self.ev(n[1], env, src)
+        if k == "ptrcast":
+            v = self.ev(n[1], env, src)
+            return PtrCast(v, n[2]) if isinstance(v, list) else v
         if k == "try":                           # `expr?`: an Err leaves the function (Ok(x) and Some(x) are x here)
             v = self.ev(n[1], env, src)
             if isinstance(v, Enum) and v.variant == "Err":
@@ -1390,6 +1530,21 @@ class Interp:
                 return [tuple(t) for t in zip(*cols)]
             if n[1] == "cfg!":
                 return n[3] in self.features
+            if n[1] == "timed!":                     # push / pop on the timing tree around the last argument: its value
+                return self.ev(n[2][-1], env, src)
+            if n[1] == "batch_iter_mut!":
+                # plonky2_util lib.rs:284-319 with feature "parallel": batches of len / threads.next_power_of_two() items, or one call c(e, 0) when
+                # that is below the minimum
+                vals = [self.ev(x, env, src) for x in n[2]]
+                e, c = vals[0], vals[-1]
+                min_batch = vals[1] if len(vals) == 3 else 1
+                threads = self.num_threads
+                batch = len(e) // (1 if threads <= 1 else 1 << (threads - 1).bit_length()) if "parallel" in self.features else 0
+                if batch < min_batch or batch < 1:
+                    self.call_closure(c, [e, 0])
+                else:
+                    ChunksMut(e, batch, True).run(lambda item: self.call_closure(c, [item[1], item[0] * batch]))
+                return None
             if n[1] == "ensure!":
                 if not self.truthy(self.ev(n[2][0], env, src)):
                     raise Return(Enum("Result", "Err", [f"{os.path.basename(src.path)}:{n[3]}"]))
@@ -1403,6 +1558,10 @@ class Interp:
             return self.assign(n, env, src)
         if k == "value":
             return n[1]
+        if k == "cfg":
+            if (n[1] in self.features) != n[2]:
+                return self.stmt(n[3], env, src) if n[3][0] in ("let", "for", "while", "return") else self.ev(n[3], env, src)
+            return None
         if k == "unit":
             return None
         if k == "str":
@@ -1483,6 +1642,13 @@ class Interp:
 
     def assign(self, n, env, src):
         op, lhs, rhs, line = n[1], n[2], self.ev(n[3], env, src), n[4]
+        if op != "=" and op[:-1] in self.OP_TRAIT:
+            target = lhs[1] if lhs[0] in ("deref", "paren") else lhs
+            cur = self.ev(target, env, src) if target[0] in ("path", "field", "mcall", "index") else None
+            if isinstance(cur, Struct) and "__name__" in cur:              # `final_poly += quotient`: impl AddAssign for PolynomialCoeffs<F>
+                r = self.call_assoc(cur["__name__"], self.OP_TRAIT[op[:-1]] + "_assign", [cur, rhs], src.path)
+                if r is not NOT_FOUND:
+                    return None
         if lhs[0] == "deref" and lhs[1][0] == "path" and len(lhs[1][1]) == 1 and isinstance(env.get(lhs[1][1][0]), ElemRef):
             r = env[lhs[1][1][0]]
             r.set(rhs if op == "=" else self.binop(op[:-1], r.get(), rhs, src, line))
@@ -1513,6 +1679,8 @@ class Interp:
         raise self.err(src, line, "assignment target")
 
     def index(self, base, idx, src, line):
+        if isinstance(base, GroupView):
+            return base[idx]
         if isinstance(idx, Rng):
             a = idx.start or 0
             b = len(base) if idx.end is None else idx.end
@@ -1547,9 +1715,11 @@ class Interp:
             if name in ("true", "false"):
                 return name == "true"
         if len(segs) >= 2 and name in FIELD_CONSTS and segs[-2] in ("P", "F", "FE", "Scalar", "GoldilocksField", "Self", "Extension"):
-            return Fe(FIELD_CONSTS[name])
+            return Fe2(FIELD_CONSTS[name], 0) if segs[-2] == "Extension" else Fe(FIELD_CONSTS[name])
         if len(segs) >= 2 and name in self.field_consts and segs[-2] in ("F", "Self", "GoldilocksField"):
             return Fe(self.field_consts[name]) if name != "TWO_ADICITY" else self.field_consts[name]
+        if len(segs) == 2 and segs[0] == "P" and name == "WIDTH" and self.packing_width:
+            return self.packing_width
         if len(segs) == 2 and segs[0] in INT_TYPES and name == "BITS":
             return {"u8": 8, "u16": 16, "u32": 32, "u64": 64, "u128": 128, "usize": 64, "i32": 32, "i64": 64, "isize": 64}[segs[0]]
         if len(segs) == 2 and segs[0] in INT_TYPES and name in ("MAX", "MIN"):
@@ -1592,8 +1762,8 @@ class Interp:
         name = segs[-1]
         if len(segs) == 1 and name in env and isinstance(env[name], Closure):
             return self.call_closure(env[name], args)
-        if name == "from_basefield" and self.extension and isinstance(args[0], (Fe, Fe2)):
-            return Fe2.of(args[0])
+        if name == "from_basefield" and isinstance(args[0], (Fe, Fe2)) and (self.extension or (len(segs) >= 2 and segs[-2] == "Extension")):
+            return Fe2.of(args[0])          # `F::Extension::from_basefield` always; `FE::from_basefield` where FE is the extension (the verifier)
         if name in FIELD_CTORS:
             v = args[0]
             return v if isinstance(v, Fe) else Fe(v)
@@ -1637,6 +1807,16 @@ class Interp:
             if len(args[0]) * 8 != INT_BITS[segs[0]] or not all(isinstance(x, int) and 0 <= x < 256 for x in args[0]):
                 raise self.err(src, line, f"{segs[0]}::from_le_bytes of {len(args[0])} items")
             return TInt(sum(int(x) << (8 * i) for i, x in enumerate(args[0])), INT_BITS[segs[0]])
+        if name == "from_raw_parts" and len(args) == 2 and isinstance(args[0], PtrCast):
+            if args[0].group * args[1] > len(args[0].base):
+                raise self.err(src, line, "from_raw_parts beyond the allocation")
+            return GroupView(args[0].base, args[0].group, args[1])
+        if name == "new" and len(segs) >= 2 and segs[-2] in ("BTreeMap", "HashMap"):
+            return {}
+        if name == "from_slice" and len(segs) == 2 and segs[0] == "P" and self.packing_width == 1 and isinstance(args[0], list) and len(args[0]) == 1:
+            return args[0][0]                       # P::from_slice(&xs[i..i + 1]) for a packing of width 1
+        if name in ("max", "min") and len(args) == 2 and all(isinstance(x, int) for x in args) and (len(segs) == 1 or segs[-2] == "cmp"):
+            return max(args) if name == "max" else min(args)
         if name == "current_num_threads" and not args:
             return self.num_threads
         if name == "scope" and len(segs) >= 2 and segs[-2] in ("maybe_rayon", "rayon") and len(args) == 1:
@@ -1654,7 +1834,7 @@ class Interp:
         if name == "from" and len(segs) >= 2 and segs[-2] in INT_TYPES | {"F", "P", "FE"}:
             return args[0]
         if name == "default" and len(segs) >= 2:
-            return Struct({"__name__": segs[-2]})
+            return self.default_struct(segs[-2], src)
         if len(segs) >= 2 and segs[-2] in self.generics:
             for ty in self.generics[segs[-2]]:
                 r = self.call_assoc(ty, name, args, src.path)
@@ -1685,6 +1865,11 @@ class Interp:
                         break
         if target is None and len(segs) >= 2 and re.match(r"^[A-Z]", segs[-2]) and re.match(r"^[A-Z]", name):
             return Enum(segs[-2], name, list(args))         # FriReductionStrategy::ConstantArityBits(4, 5)
+        if target is None and len(segs) == 1 and re.match(r"^[A-Z][a-z]", name):
+            st = Struct({"__name__": env.get("__impl__", name) if name == "Self" else name})       # a tuple struct: MerkleCap(cap)
+            for i_, a in enumerate(args):
+                st[i_] = a
+            return st
         if target is None:
             raise self.err(src, line, f"function `{'::'.join(segs)}` not found")
         params, _, _ = self.fn_ast(target, name)
@@ -1729,6 +1914,41 @@ class Interp:
         return self.method(recv, name, args, src, line)
 
     def method(self, r, name, args, src, line):
+        if isinstance(r, Opt) or (r is None and name in ("map", "as_ref", "as_mut", "unwrap_or", "and_then", "cloned", "copied")):
+            some = isinstance(r, Opt)
+            if name in ("as_ref", "as_mut", "cloned", "copied"):
+                return r
+            if name == "clone":
+                return Opt(clone(r.v))
+            if name == "map":
+                return Opt(self.call_closure(args[0], [r.v])) if some else None
+            if name == "and_then":
+                return self.call_closure(args[0], [r.v]) if some else None
+            if name in ("unwrap", "expect"):
+                return r.v
+            if name == "unwrap_or":
+                return r.v if some else args[0]
+            if name == "unwrap_or_default":
+                return r.v
+            if name in ("is_some", "is_none"):
+                return some == (name == "is_some")
+            if name in ("iter", "into_iter"):
+                return [r.v]
+            raise self.err(src, line, f"Option::{name}")
+        if isinstance(r, GroupView):
+            if name in ("par_iter", "iter"):
+                return [r[i] for i in range(len(r))]
+            if name == "len":
+                return len(r)
+            raise self.err(src, line, f"raw-parts view .{name}")
+        if isinstance(r, MapEntry):
+            if name == "or_insert_with":
+                if r.k not in r.d:
+                    r.d[r.k] = self.call_closure(args[0], [])
+                return r.d[r.k]
+            raise self.err(src, line, f"map entry .{name}")
+        if isinstance(r, dict) and not isinstance(r, Struct) and name == "entry":
+            return MapEntry(r, args[0])
         if isinstance(r, RayonScope):
             if name == "spawn":
                 self.call_closure(args[0], [r])
@@ -1755,11 +1975,13 @@ class Interp:
                 return v
         # ---- adaptors that do nothing here
         if name in ("iter", "into_iter", "iter_mut", "copied", "cloned", "collect", "collect_vec", "to_vec", "try_into", "unwrap", "expect", "by_ref",
-                    "as_ref", "as_mut", "borrow", "borrow_mut", "as_mut_slice", "into", "to_owned", "as_slice_of_cells", "peekable", "into_par_iter", "par_iter", "par_iter_mut", "unwrap_or_default"):
+                    "as_ref", "as_mut", "borrow", "borrow_mut", "as_mut_slice", "as_ptr", "as_mut_ptr", "into", "to_owned", "as_slice_of_cells", "peekable", "into_par_iter", "par_iter", "par_iter_mut", "unwrap_or_default"):
             if name in ("unwrap", "expect") and r is None:
                 raise self.err(src, line, "unwrap of None")
             if name == "to_vec" or name == "collect" or name == "collect_vec":
                 return list(self.iterate(r, src, line)) if isinstance(r, (list, tuple, Rng)) else r
+            if isinstance(r, Rng) and (r.end - r.start) > 1 << 24:
+                return r                            # 0..=p-1: only ever searched (`find_any`), never collected
             if isinstance(r, Rng) and name in ("iter", "into_iter"):
                 return r.items()
             if isinstance(r, list) and name in ("iter", "into_iter"):
@@ -1827,9 +2049,9 @@ class Interp:
                 return [r]
         if isinstance(r, bool):
             if name == "then":
-                return self.call_closure(args[0], []) if r else None
+                return Opt(self.call_closure(args[0], [])) if r else None
             if name == "then_some":
-                return args[0] if r else None
+                return Opt(args[0]) if r else None
         if isinstance(r, int) and not isinstance(r, bool):
             if name == "pow":
                 return r ** args[0]
@@ -1870,6 +2092,12 @@ class Interp:
             return (r is not None) == (name == "is_some")
         if isinstance(r, tuple) and name == "to_basefield_array":
             return list(r)
+        if isinstance(r, Rng) and name in ("find_any", "find_first", "find"):
+            # rayon's find_any may return any match; the first one is the choice this repository's provers make (the minimal witness)
+            for i_ in range(r.start, r.end):
+                if self.truthy(self.call_closure(args[0], [i_])):
+                    return Opt(TInt(i_, 64))
+            return None
         if isinstance(r, Rng) and name in ("contains",):
             return r.start <= args[0] < r.end
         if isinstance(r, Powers):
@@ -1924,7 +2152,7 @@ class Interp:
                 return None
             if name == "filter":
                 return [x for x in items if self.truthy(self.call_closure(args[0], [x]))]
-            if name == "flat_map":
+            if name in ("flat_map", "flat_map_iter"):
                 out = []
                 for x in items:
                     out += self.iterate(self.call_closure(args[0], [x]), src, line)
@@ -1939,6 +2167,10 @@ class Interp:
             if name == "any":
                 return any(self.truthy(self.call_closure(args[0], [x])) for x in items)
             if name == "sum":
+                if items and isinstance(items[0], Struct) and "__name__" in items[0]:
+                    r_ = self.call_assoc(items[0]["__name__"], "sum", [items], src.path)       # impl Sum for PolynomialCoeffs<F>
+                    if r_ is not NOT_FOUND:
+                        return r_
                 if not items:
                     return ZeroSum(0)
                 acc = items[0]
@@ -1996,6 +2228,9 @@ class Interp:
                 return [items[i:i + args[0]] for i in range(0, len(items), args[0])]
             if name in ("chunks_mut", "chunks_exact_mut", "par_chunks_mut", "par_chunks_exact_mut") and isinstance(r, list):
                 return ChunksMut(r, args[0])
+            if name == "reverse" and isinstance(r, list):
+                r.reverse()
+                return None
             if name == "swap" and isinstance(r, list):
                 r[args[0]], r[args[1]] = r[args[1]], r[args[0]]
                 return None
@@ -2014,7 +2249,7 @@ class Interp:
                 return None
             if name == "windows":
                 return [items[i:i + args[0]] for i in range(0, len(items) - args[0] + 1)]
-            if isinstance(r, list) and name in ("clear", "pop", "drain", "extend_from_slice", "shrink_to_fit", "copy_from_slice", "truncate", "reserve"):
+            if isinstance(r, list) and name in ("clear", "pop", "drain", "extend_from_slice", "shrink_to_fit", "copy_from_slice", "truncate", "reserve", "reserve_exact"):
                 if name == "clear":
                     del r[:]
                     return None
@@ -2091,6 +2326,8 @@ class OneProduct(int):
 
 
 def clone(v):
+    if isinstance(v, Opt):
+        return Opt(clone(v.v))
     if isinstance(v, list):
         return [clone(x) for x in v]
     if isinstance(v, Struct):
