@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Writes tests/golden/ref_verified/: a proof of the ORACLE prover and what the REFERENCE's verifier, run from its source, said of it.
 
-    python -m tests.make_ref_verdict [poseidon] [blake3]      (this container only: needs /root/reference; about 12 minutes each)
+    python -m tests.make_ref_verdict [poseidon] [blake3] [--prover-only]     (this container only: needs /root/reference; about 20 minutes each)
 
 The instance is `miniexec.wide_program()` with its program-hash proof, against the reference's own AIR set (ola_stark(): range-check
 table of 2^16 rows, bitwise table of 2^18): 32-bit operands through AND / OR / XOR / GTE / RC kept in memory between uses, the
@@ -11,7 +11,10 @@ configuration of the reference's own end-to-end tests (stark/ola_stark.rs:684); 
   * re-encodes the decoded proof with the interpreted `Buffer::write_all_proof` (serialization.rs:377): the same bytes;
   * runs the interpreted `verify_proof` (verifier.rs:35): Ok(());
   * runs it again on the proof with ONE BIT flipped in each of a list of spans, recording where the reference's verifier stops;
-  * records every challenge `AllProof::get_challenges` derives.
+  * records every challenge `AllProof::get_challenges` derives;
+  * runs the interpreted PROVER, `prove_single_table` (prover.rs:330), on nine of the twelve tables -- from the table's trace, the lookup Z columns of
+    the interpreted `cross_table_lookup_data` and the transcript state of `get_challenger_states` -- and compares its `write_proof` bytes
+    with the table's bytes in the oracle's proof: equal, proof-of-work witness included.
 wide_program[_blake3].proof is the oracle's proof, wide_program[_blake3].json the record.  tests/test_ref_verifier.py replays part of this where the
 reference is present, checks the oracle's own verifier against the record everywhere, and (-m gpu) holds the GPU prover's bytes
 for the same instance to wide_program.proof."""
@@ -68,7 +71,38 @@ def main():
             one(oracle, V, CD, blob, traces, params, compress, hasher)
 
 
+# cpu (94 columns x 128 rows, 251 constraints), memory (32 rows), cmp (16 rows), poseidon_chunk, storage access (256 rows), tape, sccall, program
+# (128 rows, permutation arguments), prog_chunk: every table but the two with fixed tables of 2^16 / 2^18 rows and the 1024 x 134 Poseidon table
+PROVE_TABLES = [0, 1, 3, 6, 7, 8, 9, 10, 11]
+
+
+def prover_section(V, raw, traces, hasher, have=()):
+    """the reference's prove_single_table, interpreted (tools/ref_verifier.py RefProver), on the small tables: its StarkProof bytes against the
+    proof's, and the transcript state it leaves against the verifier side's"""
+    rp = V.RefProver("/root/reference", hasher=hasher)
+    out = [r for r in have if r["table"] in PROVE_TABLES]
+    for k in PROVE_TABLES:
+        if any(r["table"] == k for r in out):
+            continue
+        t = time.time()
+        got, state_ok = rp.prove_table(raw, traces, k)
+        a, b = V.table_span(raw, k)
+        out.append({"table": k, "rows": int(traces[k].shape[1]), "columns": int(traces[k].shape[0]), "bytes": b - a, "equal": got == raw[a:b],
+                    "transcript_after_equal": bool(state_ok), "sha256": hashlib.sha256(got).hexdigest()})
+        print("%s: prove_single_table of table %d (%d x %d): %d bytes, equal %s, transcript after equal %s (%.0f s)" % (
+            hasher, k, traces[k].shape[0], traces[k].shape[1], b - a, got == raw[a:b], state_ok, time.time() - t), flush=True)
+    assert all(x["equal"] and x["transcript_after_equal"] for x in out)
+    return sorted(out, key=lambda r: r["table"])
+
+
 def one(oracle, V, CD, blob, traces, params, compress, hasher):
+    stem = "wide_program" if hasher == "poseidon" else "wide_program_" + hasher
+    if "--prover-only" in sys.argv:
+        raw = open(os.path.join(OUT, stem + ".proof"), "rb").read()
+        record = json.load(open(os.path.join(OUT, stem + ".json")))
+        record["prove_single_table"] = prover_section(V, raw, traces, hasher, record.get("prove_single_table", ()))
+        open(os.path.join(OUT, stem + ".json"), "w").write(json.dumps(record, indent=1) + "\n")
+        return
     t = time.time()
     raw = oracle.prove_with_traces(blob, traces, params, compress)
     print("%s: oracle proof: %d bytes, %.0f s" % (hasher, len(raw), time.time() - t), flush=True)
@@ -100,8 +134,8 @@ def one(oracle, V, CD, blob, traces, params, compress, hasher):
         o_rc, o_why = oracle.verify_all_proof(blob, bad, [int(cc[2]), int(cc[10])])
         print("%-55s reference: %-24s oracle: %s (%.0f s)" % (name, "Ok(())" if ok else "Err " + where, "accept" if o_rc == 0 else "reject", time.time() - t), flush=True)
         record["tampered"].append({"span": name, "byte": off, "bit": 0, "reference": "Ok(())" if ok else "Err " + where, "oracle_accepts": o_rc == 0})
+    record["prove_single_table"] = prover_section(V, raw, traces, hasher)
     os.makedirs(OUT, exist_ok=True)
-    stem = "wide_program" if hasher == "poseidon" else "wide_program_" + hasher
     open(os.path.join(OUT, stem + ".proof"), "wb").write(raw)
     open(os.path.join(OUT, stem + ".json"), "w").write(json.dumps(record, indent=1) + "\n")
     print("wrote", OUT, stem)

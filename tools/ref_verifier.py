@@ -434,6 +434,20 @@ class RefProver(RefVerifier):
         zpc = os.path.join(cf, "zero_poly_coset.rs")
         # zero_poly_coset.rs:45-53 for P::WIDTH = 1
         it.assoc_hooks[("ZeroPolyOnCoset", "eval_inverse_packed")] = lambda args: it.call_assoc("ZeroPolyOnCoset", "eval_inverse", [args[0], args[1]], zpc)
+        # plonky2_field batch_util.rs:29-65: the SIMD-packed elementwise product / sum of two slices, in place -- for a packing of width 1
+        def batch_multiply_inplace(args):
+            out, a = args
+            if len(out) != len(a):
+                raise R.RustError("both arrays must have the same length")
+            out[:] = [it.binop("*", x, y, None, 0) for x, y in zip(out, a)]
+
+        def batch_add_inplace(args):
+            out, a = args
+            if len(out) != len(a):
+                raise R.RustError("both arrays must have the same length")
+            out[:] = [it.binop("+", x, y, None, 0) for x, y in zip(out, a)]
+        it.fn_hooks["batch_multiply_inplace"] = batch_multiply_inplace
+        it.fn_hooks["batch_add_inplace"] = batch_add_inplace
         it.generics["F"] = ["Field"]                # the Field trait's provided functions (plonky2_field types.rs): two_adic_subgroup, cyclic_subgroup_*
 
     def base_field(self):
@@ -453,7 +467,7 @@ class RefProver(RefVerifier):
     def challenger_at(self, state):
         return Struct({"__name__": "Challenger", "sponge_state": [Fe(x.v) for x in state], "input_buffer": [], "output_buffer": [], "_phantom": None})
 
-    def prove_table(self, raw, traces, k, max_rows_for_lookups=4096):
+    def prove_table(self, raw, traces, k, max_rows_for_lookups=4096, full_pow_search=True):
         """the bytes `Buffer::write_proof` gives for the reference's prove_single_table of table k, given the whole proof (for the transcript
         state before the table) and the twelve traces"""
         it = self.it
@@ -482,9 +496,15 @@ class RefProver(RefVerifier):
                                                                       self.config["fri_config"]["cap_height"], None, twiddles],
                                    os.path.join(it.plonky2, "fri", "oracle.rs"))
         challenger = self.challenger_at(states["states"][k])
-        with self.base_field():
-            r = it.call_free(os.path.join(self.stark_dir, "prover.rs"), "prove_single_table",
-                             [stark, self.config, values[k], commitment, ctl[k], challenger, None, twiddles])
+        # the proof-of-work search (fri/prover.rs:126-148) from 0 costs a minute or two interpreted; `full_pow_search=False` checks the proof's
+        # witness and 64 smaller candidates instead
+        it.find_any_hint = None if full_pow_search else proof["stark_proofs"][k]["opening_proof"]["pow_witness"].v
+        try:
+            with self.base_field():
+                r = it.call_free(os.path.join(self.stark_dir, "prover.rs"), "prove_single_table",
+                                 [stark, self.config, values[k], commitment, ctl[k], challenger, None, twiddles])
+        finally:
+            it.find_any_hint = None
         if isinstance(r, Enum):
             raise R.RustError("prove_single_table returned Err " + str(r.payload))
         buf = Struct({"__name__": "Buffer", 0: R.Cursor()})

@@ -837,9 +837,11 @@ class Interp:
         self.near_cache = {}
         self.field_consts = {}              # TWO_ADICITY, POWER_OF_TWO_GENERATOR, MULTIPLICATIVE_GROUP_GENERATOR of goldilocks_field.rs (set by a driver)
         self.extension = False              # True while the verifier runs: FE = F::Extension is the quadratic extension (D = 2), not F itself
+        self.find_any_hint = None           # see the Rng `find_any` method
         self.packing_width = 0              # P::WIDTH where the reference's code is generic over a packing (a driver sets 1)
         self.features = set()               # cargo features `cfg!(feature = "..")` sees: the reference builds with "parallel" (a driver sets it)
         self.num_threads = 8                # what maybe_rayon::current_num_threads() answers (results must not depend on it)
+        self.fn_hooks = {}                  # free function name -> python function of the argument list
         self.assoc_hooks = {}               # (type, fn) -> python function of the argument list: the reference's calls into crates outside its tree
         self.extra_files = []               # files outside the AIR tree whose impl blocks a driver needs (plonky2's fri/, iop/challenger.rs)
         self.generics = {}                  # generic parameter -> the types tried for `H::f(..)`: {"H": ["PoseidonHash", "Hasher"]} (set by a driver)
@@ -1760,6 +1762,8 @@ class Interp:
             raise self.err(src, line, "call of a non-function")
         segs = callee[1]
         name = segs[-1]
+        if name in self.fn_hooks and (len(segs) == 1 or not re.match(r"^[A-Z]", segs[-2])):
+            return self.fn_hooks[name](args)
         if len(segs) == 1 and name in env and isinstance(env[name], Closure):
             return self.call_closure(env[name], args)
         if name == "from_basefield" and isinstance(args[0], (Fe, Fe2)) and (self.extension or (len(segs) >= 2 and segs[-2] == "Extension")):
@@ -1889,6 +1893,12 @@ class Interp:
                 raise self.err(src, line, "constraint argument is not a field element")
             recv.emits.append((X.KINDS[name], v.v if isinstance(v, Fe) else (v.a, v.b), os.path.relpath(src.path, self.ref.root), line))
             return None
+        if name in ("iter_mut", "par_iter_mut") and not n[3] and recv_node[0] == "index":
+            base, idx = self.ev(recv_node[1], env, src), self.ev(recv_node[2], env, src)
+            if isinstance(idx, Rng) and isinstance(base, list):       # `nodes[n..].par_iter_mut()`: references into nodes itself
+                a = idx.start or 0
+                b = len(base) if idx.end is None else idx.end
+                return [ElemRef(base, i) for i in range(a, b)]
         if name in ("iter_mut", "par_iter_mut") and isinstance(recv, list) and not n[3]:
             return refs_of(recv)                    # an iterator of `&mut` items: adaptors (skip, zip, enumerate ..) pass the references on
         args = [self.ev(a, env, src) for a in n[3]]
@@ -2094,6 +2104,17 @@ class Interp:
             return list(r)
         if isinstance(r, Rng) and name in ("find_any", "find_first", "find"):
             # rayon's find_any may return any match; the first one is the choice this repository's provers make (the minimal witness)
+            if self.find_any_hint is not None:
+                # a quick re-run: the hinted value must satisfy the closure and a spread of smaller ones must not (the full search from 0
+                # was done when the record was made)
+                w = self.find_any_hint
+                if not (r.start <= w < r.end) or not self.truthy(self.call_closure(args[0], [w])):
+                    raise self.err(src, line, "the hinted witness does not satisfy the search")
+                for j in range(1, 65):
+                    c = r.start + (w - r.start) * j // 65
+                    if c < w and self.truthy(self.call_closure(args[0], [c])):
+                        raise self.err(src, line, "a smaller witness than the hinted one exists")
+                return Opt(TInt(w, 64))
             for i_ in range(r.start, r.end):
                 if self.truthy(self.call_closure(args[0], [i_])):
                     return Opt(TInt(i_, 64))
@@ -2124,6 +2145,11 @@ class Interp:
                 return items[::-1]
             if name == "enumerate":
                 return [(i, x) for i, x in enumerate(items)]
+            if name == "zip_eq":                    # itertools: zip that panics on different lengths
+                other = self.iterate(args[0], src, line)
+                if len(other) != len(items):
+                    raise self.err(src, line, f"zip_eq of {len(items)} and {len(other)} items")
+                return [tuple(t) for t in zip(items, other)]
             if name == "zip":
                 o = args[0]
                 if isinstance(o, ChunksMut) and o.left is None and not o.enumerate_:
