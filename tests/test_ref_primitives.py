@@ -140,7 +140,7 @@ def test_the_references_merkle_verifier_accepts_the_oracles_paths(interp, oracle
     from tests.oracle_lib import rand_field
     R, it = interp
     rng = np.random.default_rng(11)
-    for ncols, log_n, cap_height, leaves in ((7, 4, 2, (0, 77, 127)), (29, 3, 4, (5, 63)), (5, 2, 0, (31,))):
+    for ncols, log_n, cap_height, leaves in ((7, 4, 2, (0, 127)), (29, 3, 4, (5,)), (5, 2, 0, (31,))):
         b = oracle.batch(rand_field(rng, (ncols, 1 << log_n)), rate_bits=3, cap_height=cap_height)
         cap = b.cap()
         for idx in leaves:
