@@ -203,6 +203,40 @@ def test_the_references_prover_today(record, raw, config):
         assert H.sha256(got).hexdigest() == by[k]["sha256"]
 
 
+@reference
+def test_a_changed_reference_prover_is_noticed(tmp_path):
+    """teeth of the byte comparison: a copy of the reference with one line of its prover changed no longer writes the proof's bytes for the
+    cmp table -- (a) the multiplication of the final polynomial by X dropped (fri/oracle.rs:218), (b) the order of the opening batches the
+    transcript observes swapped (stark/proof.rs), (c) the quotient read one LDE step off (stark/prover.rs: `next_step`)"""
+    import shutil
+    import ref_verifier as V
+    import rust_air_eval as R
+    from tests.make_ref_verdict import instance
+    raw = open(os.path.join(DIR, "wide_program.proof"), "rb").read()
+    traces, _, _ = instance()
+    a, b = V.table_span(raw, 3)
+    edits = [("plonky2/plonky2/src/fri/oracle.rs", "final_poly.coeffs.insert(0, F::Extension::ZERO);", ""),
+             ("circuits/src/stark/proof.rs", ".chain(&self.permutation_ctl_zs)\n                .chain(&self.quotient_polys)",
+              ".chain(&self.quotient_polys)\n                .chain(&self.permutation_ctl_zs)"),
+             ("circuits/src/stark/prover.rs", "let next_step = 1 << quotient_degree_bits;", "let next_step = 2 << quotient_degree_bits;")]
+    for n, (rel, old, new) in enumerate(edits):
+        ref = tmp_path / ("ref%d" % n)
+        for sub in ("circuits/src", "core/src", "plonky2/field/src", "plonky2/plonky2/src", "plonky2/util/src"):
+            shutil.copytree(os.path.join("/root/reference", sub), ref / sub)
+        path = ref / rel
+        text = path.read_text()
+        assert text.count(old) >= 1, rel
+        path.write_text(text.replace(old, new, 1))
+        R.X.Src.cache.clear()
+        try:
+            got, state_ok = V.RefProver(str(ref)).prove_table(raw, traces, 3, full_pow_search=False)
+            noticed = got != raw[a:b] or not state_ok
+        except (R.RustError, ZeroDivisionError, IndexError, AssertionError):
+            noticed = True                     # the changed prover panics, fails its own checks, or the proof's witness no longer fits its transcript
+        assert noticed, rel
+    R.X.Src.cache.clear()
+
+
 @pytest.mark.gpu
 def test_gpu_prover_returns_the_bytes_the_reference_verifier_accepted(record, raw, config):
     from olavm_amd.air import ola_tables as T
