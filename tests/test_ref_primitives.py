@@ -115,6 +115,39 @@ def test_fri_reduction_plans_equal_the_interpreted_reference(vectors, oracle):
     assert vectors["fri_params"][22]["reduction_arity_bits"] == [4, 4, 4, 4, 4]
 
 
+def test_lookup_columns_equal_the_interpreted_permuted_cols(vectors, oracle):
+    """`permuted_cols` (stark/lookup.rs:68-132) interpreted on 54 input / table pairs -- range-check-like lookups, few distinct inputs, inputs
+    all at the top / bottom of the table, tables with repeats and inputs absent from them, inputs above / below every table value, blocks, full
+    width elements: the oracle's restatement (which the device generator is held to, tests/test_gpu_lookup.py) gives the same two columns"""
+    assert len(vectors["permuted_cols"]) == 54
+    for v in vectors["permuted_cols"]:
+        pi, pt = oracle.permuted_cols(u64(v["inputs"]), u64(v["table"]))
+        assert [int(x) for x in pi] == v["permuted_inputs"] and [int(x) for x in pt] == v["permuted_table"], v["case"]
+
+
+@pytest.mark.gpu
+def test_device_lookup_columns_equal_the_interpreted_permuted_cols(vectors):
+    from olavm_amd.backend import Backend
+    be = Backend()
+    for v in vectors["permuted_cols"]:
+        pi, pt = be.permuted_cols(u64(v["inputs"]), u64(v["table"]))
+        assert [int(x) for x in pi] == v["permuted_inputs"] and [int(x) for x in pt] == v["permuted_table"], v["case"]
+    be.close()
+
+
+@pytest.mark.gpu
+def test_device_hashes_equal_the_interpreted_reference(vectors):
+    """the permutation, the row hash and the Merkle compression on the device against the outputs of the reference's own code"""
+    from olavm_amd.backend import Backend
+    be = Backend()
+    st = np.array([v["input"] for v in vectors["poseidon"]], dtype=np.uint64)
+    assert be.poseidon(st).tolist() == [v["output"] for v in vectors["poseidon"]]
+    for v in vectors["hash_no_pad"]:
+        if len(v["input"]) >= 1:                                  # ola_hash_rows is hash_no_pad of each row
+            assert [int(x) for x in be.hash_rows(u64(v["input"]).reshape(1, -1))[0]] == v["digest"], len(v["input"])
+    be.close()
+
+
 reference = pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="the reference tree is not on this machine")
 
 

@@ -2014,6 +2014,8 @@ class Interp:
                 return [r]
             if name in ("to_canonical_u64", "to_noncanonical_u64"):
                 return TInt(r.v, 64)
+            if name == "to_canonical":
+                return r
             if name in ("exp_u64", "exp_power_of_2"):
                 return Fe(pow(r.v, args[0] if name == "exp_u64" else 1 << args[0], P))
             if name == "inverse":
@@ -2091,6 +2093,8 @@ class Interp:
                 return (r.bits if isinstance(r, TInt) else 64) - bin(r).count("1")
             if name == "trailing_zeros":
                 return (r & -r).bit_length() - 1
+            if name in ("cmp", "partial_cmp") and isinstance(args[0], int):
+                return Enum("Ordering", "Less" if r < args[0] else "Greater" if r > args[0] else "Equal")
             if name == "next_power_of_two":
                 return 1 if r <= 1 else 1 << (r - 1).bit_length()
             if name == "is_power_of_two":
@@ -2145,6 +2149,11 @@ class Interp:
                 return items[::-1]
             if name == "enumerate":
                 return [(i, x) for i, x in enumerate(items)]
+            if name in ("sorted_unstable_by_key", "sorted_by_key", "sorted_by_cached_key"):
+                def key_(x):
+                    k_ = self.call_closure(args[0], [x])
+                    return k_.v if isinstance(k_, Fe) else k_
+                return sorted(items, key=key_)
             if name == "zip_eq":                    # itertools: zip that panics on different lengths
                 other = self.iterate(args[0], src, line)
                 if len(other) != len(items):
@@ -2685,6 +2694,25 @@ def primitives(reference):
         out["challenger"].append({"ops": ops, "outputs": outputs, "state": [x.v for x in c["sponge_state"]]})
     out["sources"]["challenger"] = "plonky2/plonky2/src/iop/challenger.rs: Challenger::{new, observe_elements, observe_cap, get_n_challenges, compact}"
 
+    # ---- the lookup argument's column generator (circuits/src/stark/lookup.rs:68-132 permuted_cols)
+    lookup = os.path.join(reference, "circuits", "src", "stark", "lookup.rs")
+    out["permuted_cols"] = []
+    for n in (1, 2, 3, 8, 37, 64):
+        r = stream_for(1300 + n, 0, 4 * n)
+        fixed = list(range(n))
+        cases = [("lookup", [x % n for x in r[:n]], fixed),
+                 ("few-distinct", [x % max(1, n // 8) for x in r[:n]], fixed),
+                 ("all-max", [n - 1] * n, fixed), ("all-min", [0] * n, fixed),
+                 ("dup-table", [x % (2 * n + 3) for x in r[:n]], sorted(3 * (x % max(2, n // 2)) for x in r[n:2 * n])),
+                 ("inputs-above", [5 * n + x % (n + 1) for x in r[:n]], fixed), ("inputs-below", [x % 3 for x in r[:n]], [x + 10 for x in fixed]),
+                 ("blocks", [4 * (i // 4) for i in range(n)], fixed),
+                 ("wide", [r[2 * n + (x % n)] for x in r[:n]], r[2 * n:3 * n][::-1])]
+        for name, inputs, table in cases:
+            got = it.call_free(lookup, "permuted_cols", [[Fe(x) for x in inputs], [Fe(x) for x in table]])
+            out["permuted_cols"].append({"case": "%s n=%d" % (name, n), "inputs": inputs, "table": table,
+                                         "permuted_inputs": [x.v for x in got[0]], "permuted_table": [x.v for x in got[1]]})
+    out["sources"]["permuted_cols"] = "circuits/src/stark/lookup.rs: permuted_cols"
+
     # ---- the proving configuration and the FRI reduction plan (circuits/src/stark/config.rs:18 standard_fast_config, :32 fri_params;
     #      plonky2 fri/mod.rs:36 FriConfig::fri_params; fri/reduction_strategies.rs:30 reduction_arity_bits)
     cfgf = os.path.join(reference, "circuits", "src", "stark", "config.rs")
@@ -2796,8 +2824,9 @@ def main():
         out = PRIMITIVES_FIXTURE if a.out == FIXTURE else a.out
         data = primitives(a.reference)
         text = json.dumps(data, separators=(",", ":")) + "\n"
-        print("%d permutations, %d sponge hashes, %d compressions, %d transcripts, %d FRI plans" % (
-            len(data["poseidon"]), len(data["hash_no_pad"]), len(data["two_to_one"]), len(data["challenger"]), len(data["fri_params"])))
+        print("%d permutations, %d sponge hashes, %d compressions, %d transcripts, %d lookup cases, %d FRI plans" % (
+            len(data["poseidon"]), len(data["hash_no_pad"]), len(data["two_to_one"]), len(data["challenger"]), len(data["permuted_cols"]),
+            len(data["fri_params"])))
         if a.check:
             if open(out).read() != text:
                 raise SystemExit(out + " is stale")
