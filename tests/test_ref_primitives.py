@@ -125,6 +125,31 @@ def test_lookup_columns_equal_the_interpreted_permuted_cols(vectors, oracle):
         assert [int(x) for x in pi] == v["permuted_inputs"] and [int(x) for x in pt] == v["permuted_table"], v["case"]
 
 
+def test_poseidon_table_rows_equal_the_interpreted_generator(vectors):
+    """the reference's row generator for the Poseidon table (fast partial rounds, poseidon_trace.rs:79; generate_poseidon_trace with its
+    padding rows) interpreted for five permutations with each lookup filter: the executor's rows (olavm_amd/air/miniexec.py, which the native
+    trace generator is held to word for word) are the same 134 words, and the padding rows are the row of the zero input"""
+    from olavm_amd.air import miniexec as M
+    t = vectors["poseidon_table"]
+    assert (t["columns"], t["rows"]) == (134, 8) and len(t["live"]) == 5
+    for row, live in zip(t["trace_rows"], t["live"]):
+        assert row == M.poseidon_row(live["input"], tuple(live["filters"]))
+    for row in t["trace_rows"][5:]:
+        assert row == M.poseidon_row([0] * 12)
+
+
+@pytest.mark.gpu
+def test_device_poseidon_table_equals_the_interpreted_generator(vectors):
+    from olavm_amd.backend import Backend
+    t = vectors["poseidon_table"]
+    be = Backend()
+    inputs = np.array([v["input"] for v in t["live"]] + [[0] * 12] * 3, dtype=np.uint64).T.copy()
+    filters = np.array([v["filters"] for v in t["live"]] + [[0] * 4] * 3, dtype=np.uint64).T.copy()
+    got = be.generate_poseidon_trace(inputs, filters)
+    assert got.shape == (134, 8) and got.T.tolist() == t["trace_rows"]
+    be.close()
+
+
 @pytest.mark.gpu
 def test_device_lookup_columns_equal_the_interpreted_permuted_cols(vectors):
     from olavm_amd.backend import Backend

@@ -1604,6 +1604,9 @@ class Interp:
         k = s[0]
         if k == "let":
             v = self.ev(s[2], env, src) if s[2] is not None else None
+            if s[2] is not None and s[2][0] in ("path", "field") and s[1][0] == "pid" and isinstance(v, list) and len(v) <= 4096 \
+                    and all(x is None or isinstance(x, (Fe, Fe2, int, bool)) for x in v):
+                v = list(v)          # `let mut state = input;`: an array is copied, a Vec is moved (the source is dead afterwards): a copy is right for both
             names = pattern_names(s[1])
             env.setdefault("__declared__", set()).update(names)
             self.bind(s[1], v, env, src)
@@ -1985,7 +1988,7 @@ class Interp:
                 return v
         # ---- adaptors that do nothing here
         if name in ("iter", "into_iter", "iter_mut", "copied", "cloned", "collect", "collect_vec", "to_vec", "try_into", "unwrap", "expect", "by_ref",
-                    "as_ref", "as_mut", "borrow", "borrow_mut", "as_mut_slice", "as_ptr", "as_mut_ptr", "into", "to_owned", "as_slice_of_cells", "peekable", "into_par_iter", "par_iter", "par_iter_mut", "unwrap_or_default"):
+                    "as_ref", "as_mut", "borrow", "borrow_mut", "as_mut_slice", "as_ptr", "as_mut_ptr", "into", "to_owned", "as_slice_of_cells", "peekable", "into_par_iter", "par_iter", "par_iter_mut", "unwrap_or_else", "unwrap_or_default"):
             if name in ("unwrap", "expect") and r is None:
                 raise self.err(src, line, "unwrap of None")
             if name == "to_vec" or name == "collect" or name == "collect_vec":
@@ -2712,6 +2715,23 @@ def primitives(reference):
             out["permuted_cols"].append({"case": "%s n=%d" % (name, n), "inputs": inputs, "table": table,
                                          "permuted_inputs": [x.v for x in got[0]], "permuted_table": [x.v for x in got[1]]})
     out["sources"]["permuted_cols"] = "circuits/src/stark/lookup.rs: permuted_cols"
+
+    # ---- rows of the Poseidon table (core/src/crypto/poseidon_trace.rs:79 calculate_poseidon_and_generate_intermediate_trace -- the fast
+    #      partial rounds of core/src/util/poseidon_utils.rs -- then circuits/src/generation/poseidon.rs:5 generate_poseidon_trace with its padding)
+    ptrace = os.path.join(reference, "core", "src", "crypto", "poseidon_trace.rs")
+    gen = os.path.join(reference, "circuits", "src", "generation", "poseidon.rs")
+    flags = ("filter_looked_normal", "filter_looked_treekey", "filter_looked_storage", "filter_looked_storage_branch")
+    cells, meta = [], []
+    for k, filt in enumerate([(0, 0, 0, 0), (1, 0, 0, 0), (0, 1, 0, 0), (0, 0, 1, 0), (0, 0, 0, 1)]):
+        inp = [0] * 12 if k == 0 else [P - 1] * 12 if k == 1 else stream_for(1500 + k, 0, 12)
+        cell = it.call_free(ptrace, "calculate_poseidon_and_generate_intermediate_trace", [[Fe(x) for x in inp]])
+        for name, f in zip(flags, filt):
+            cell[name] = bool(f)
+        cells.append(cell)
+        meta.append({"input": inp, "filters": list(filt)})
+    cols = it.call_free(gen, "generate_poseidon_trace", [cells])          # 5 rows -> padded to 8
+    out["poseidon_table"] = {"columns": len(cols), "rows": len(cols[0]), "live": meta, "trace_rows": [[c[i].v for c in cols] for i in range(len(cols[0]))]}
+    out["sources"]["poseidon_table"] = "core/src/crypto/poseidon_trace.rs: calculate_poseidon_and_generate_intermediate_trace; circuits/src/generation/poseidon.rs: generate_poseidon_trace"
 
     # ---- the proving configuration and the FRI reduction plan (circuits/src/stark/config.rs:18 standard_fast_config, :32 fri_params;
     #      plonky2 fri/mod.rs:36 FriConfig::fri_params; fri/reduction_strategies.rs:30 reduction_arity_bits)
