@@ -12,7 +12,7 @@ configuration of the reference's own end-to-end tests (stark/ola_stark.rs:684); 
   * runs the interpreted `verify_proof` (verifier.rs:35): Ok(());
   * runs it again on the proof with ONE BIT flipped in each of a list of spans, recording where the reference's verifier stops;
   * records every challenge `AllProof::get_challenges` derives;
-  * runs the interpreted PROVER, `prove_single_table` (prover.rs:330), on nine of the twelve tables -- from the table's trace, the lookup Z columns of
+  * runs the interpreted PROVER, `prove_single_table` (prover.rs:330), on ten of the twelve tables -- from the table's trace, the lookup Z columns of
     the interpreted `cross_table_lookup_data` and the transcript state of `get_challenger_states` -- and compares its `write_proof` bytes
     with the table's bytes in the oracle's proof: equal, proof-of-work witness included.
 wide_program[_blake3].proof is the oracle's proof, wide_program[_blake3].json the record.  tests/test_ref_verifier.py replays part of this where the
@@ -71,9 +71,10 @@ def main():
             one(oracle, V, CD, blob, traces, params, compress, hasher)
 
 
-# cpu (94 columns x 128 rows, 251 constraints), memory (32 rows), cmp (16 rows), poseidon_chunk, storage access (256 rows), tape, sccall, program
-# (128 rows, permutation arguments), prog_chunk: every table but the two with fixed tables of 2^16 / 2^18 rows and the 1024 x 134 Poseidon table
-PROVE_TABLES = [0, 1, 3, 6, 7, 8, 9, 10, 11]
+# cpu (94 columns x 128 rows, 251 constraints), memory (32 rows), cmp (16 rows), poseidon (134 columns x 1024 rows: 37 minutes), poseidon_chunk,
+# storage access (256 rows), tape, sccall, program (128 rows, permutation arguments), prog_chunk: every table but the two with fixed tables of
+# 2^16 / 2^18 rows
+PROVE_TABLES = [0, 1, 3, 5, 6, 7, 8, 9, 10, 11]
 
 
 def prover_section(V, raw, traces, hasher, have=()):
