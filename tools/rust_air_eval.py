@@ -1962,6 +1962,19 @@ class Interp:
             raise self.err(src, line, f"map entry .{name}")
         if isinstance(r, dict) and not isinstance(r, Struct) and name == "entry":
             return MapEntry(r, args[0])
+        if isinstance(r, dict) and not isinstance(r, Struct) and name in ("insert", "get", "contains_key", "len", "is_empty", "remove"):
+            key_ = (args[0].v if isinstance(args[0], Fe) else args[0]) if args else None
+            if name == "insert":
+                old_ = r.get(key_)
+                r[key_] = args[1]
+                return old_
+            if name == "get":
+                return r.get(key_)
+            if name == "contains_key":
+                return key_ in r
+            if name == "remove":
+                return r.pop(key_, None)
+            return len(r) if name == "len" else not r
         if isinstance(r, RayonScope):
             if name == "spawn":
                 self.call_closure(args[0], [r])
@@ -2817,6 +2830,48 @@ def ntt_vectors(reference, sizes=tuple(range(1, 12))):
     return out
 
 
+TRACEGEN_FIXTURE = os.path.join(ROOT, "tests", "golden", "ref_tracegen_vectors.json")
+CMP_ROWS = [(5, 3), (3, 5), (7, 7), (0xFFFFFFFF, 0), (0x12345678, 0x9ABCDEF0)]
+RC_ROWS = [(123456789, 1, 0, 0, 0), (65535, 0, 1, 0, 0), (4294967295, 0, 0, 1, 0), (65536, 0, 0, 0, 1), (0, 1, 0, 0, 0), (70000, 0, 0, 0, 1), (70000, 1, 0, 0, 0)]
+
+
+def trace_digest(cols):
+    import hashlib
+    import struct
+    h = hashlib.sha256()
+    for c in cols:
+        h.update(struct.pack("<%dQ" % len(c), *[x.v for x in c]))
+    return {"columns": len(cols), "rows": len(cols[0]), "sha256": h.hexdigest()}
+
+
+def tracegen_vectors(reference, heavy=True):
+    """What the reference's trace generators (circuits/src/generation/*.rs) return -- column-major, as u64 words, digested: the comparison
+    table with live rows, the range-check table (2^16 rows: the fixed column, the looked-up values' limbs and both `permuted_cols` pairs) with
+    one row for each looking table, and the padding-only output of the generators that take no rows here (an execution that never touches
+    the table)"""
+    it = plonky2_interp(reference)
+    g = os.path.join(reference, "circuits", "src", "generation")
+    out = {"generated_by": "tools/rust_air_eval.py --tracegen", "sources": "circuits/src/generation/{builtin,cpu,memory,poseidon,tape,sccall}.rs"}
+    cells = []
+    for a, b in CMP_ROWS:
+        d = abs(a - b)
+        cells.append(Struct({"__name__": "CmpRow", "op0": Fe(a), "op1": Fe(b), "gte": Fe(int(a >= b)), "abs_diff": Fe(d),
+                             "abs_diff_inv": Fe(pow(d, P - 2, P) if d else 0), "filter_looking_rc": Fe(1)}))
+    cmp_ = it.call_free(os.path.join(g, "builtin.rs"), "generate_cmp_trace", [cells])
+    out["cmp"] = {"rows_in": [list(r) for r in CMP_ROWS], **trace_digest(cmp_), "trace": [[x.v for x in c] for c in cmp_]}
+    for name, file, fn in (("cpu", "cpu.rs", "generate_cpu_trace"), ("memory", "memory.rs", "generate_memory_trace"), ("tape", "tape.rs", "generate_tape_trace"),
+                           ("sccall", "sccall.rs", "generate_sccall_trace"), ("poseidon", "poseidon.rs", "generate_poseidon_trace")):
+        cols = it.call_free(os.path.join(g, file), fn, [[]])
+        out[name + "_no_rows"] = {**trace_digest(cols), "trace": [[x.v for x in c] for c in cols]}
+    if heavy:
+        cells = [Struct({"__name__": "RangeCheckRow", "val": Fe(v), "limb_lo": Fe(v % 65536), "limb_hi": Fe(v // 65536), "filter_looked_for_cpu": Fe(a),
+                         "filter_looked_for_mem_sort": Fe(b), "filter_looked_for_mem_region": Fe(c), "filter_looked_for_comparison": Fe(d),
+                         "filter_looked_for_storage": Fe(0)}) for v, a, b, c, d in RC_ROWS]
+        rc = it.call_free(os.path.join(g, "builtin.rs"), "generate_rc_trace", [cells])
+        out["rangecheck"] = {"rows_in": [list(r) for r in RC_ROWS], **trace_digest(rc), "head": [[x.v for x in c[:8]] for c in rc]}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reference", default="/root/reference")
@@ -2825,8 +2880,21 @@ def main():
     ap.add_argument("--check", action="store_true")
     ap.add_argument("--primitives", action="store_true", help="the hashing / transcript / FRI-parameter vectors instead of the AIR vectors")
     ap.add_argument("--ntt", action="store_true", help="the transform vectors (cfft) instead of the AIR vectors")
+    ap.add_argument("--tracegen", action="store_true", help="the trace generators' outputs (generation/*.rs) instead of the AIR vectors")
     a = ap.parse_args()
     sys.setrecursionlimit(20000)
+    if a.tracegen:
+        out = TRACEGEN_FIXTURE if a.out == FIXTURE else a.out
+        data = tracegen_vectors(a.reference)
+        text = json.dumps(data, separators=(",", ":")) + "\n"
+        if a.check:
+            if open(out).read() != text:
+                raise SystemExit(out + " is stale")
+            print("fixture is up to date")
+            return
+        open(out, "w").write(text)
+        print("wrote", out, "(%d bytes)" % len(text))
+        return
     if a.ntt:
         out = NTT_FIXTURE if a.out == FIXTURE else a.out
         data = ntt_vectors(a.reference)
