@@ -66,6 +66,29 @@ def test_tables_without_rows_equal_the_interpreted_generators(vectors):
     assert got[T.COL_MEM_S_PROPHET, 0] == 1 and got[T.COL_MEM_ADDR, 0] == 0 and ref[T.COL_MEM_REGION_PROPHET, 0] == 1
 
 
+def test_bitwise_table_equals_the_interpreted_generator():
+    """`generate_bitwise_trace` (builtin.rs:35-205), interpreted (40 minutes: tools/rust_air_eval.py --tracegen-bitwise): the 2^18-row
+    table -- fixed AND / OR / XOR table, three operations' rows, the compress challenge out of the generator's own transcript over the twelve
+    limb columns (393 216 sponge permutations), sixteen `permuted_cols` pairs -- for operands below 2^24.
+
+    Above that the two part ways, on purpose: the reference writes the fourth limb of op0 / op1 / res to `OP0_LIMBS.end` (builtin.rs:66, :71,
+    :76) -- the exclusive end of a `Range`, one column too far, overwritten by the next write -- so its limb-3 columns are zero whatever the
+    operand and its trace for an operand >= 2^24 violates its own AIR (bitwise_stark.rs: op = sum of limbs).  This repository's generators
+    write the limb; with 32-bit operands the traces differ in exactly the three limb-3 columns and what is derived from them (their permuted
+    columns, and through the transcript the compress challenge and every compress column): found by running the reference's generator."""
+    path = os.path.join(HERE, "golden", "ref_tracegen_bitwise.json")
+    if not os.path.exists(path):
+        pytest.skip("the 40-minute vector has not been generated")
+    from olavm_amd.air import miniexec as M
+    v = json.load(open(path))
+    ops = [(name, int(x), int(y)) for name, x, y in v["ops"]]
+    assert all(x < 1 << 24 and y < 1 << 24 for _, x, y in ops)
+    t, beta = TG.bitwise_trace(None, 8, ops, looked_by_cpu=True, transcript=M._transcript)
+    assert beta == v["beta"]
+    assert t[:, :len(ops)].T.tolist() == v["rows_head"]
+    assert digest(t) == {k: v[k] for k in ("columns", "rows", "sha256")}
+
+
 @pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="the reference tree is not on this machine")
 def test_small_vectors_are_what_the_interpreter_computes_today(vectors):
     sys.path.insert(0, os.path.join(ROOT, "tools"))

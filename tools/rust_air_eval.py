@@ -2872,6 +2872,66 @@ def tracegen_vectors(reference, heavy=True):
     return out
 
 
+BITWISE_FIXTURE = os.path.join(ROOT, "tests", "golden", "ref_tracegen_bitwise.json")
+BITWISE_OPS = [("AND", 0xADBEEF, 0x345678), ("OR", 0xFFFFFF, 0x800001), ("XOR", 0x00FFFF, 0xA5A5A5)]
+
+
+def tracegen_bitwise(reference, ops=BITWISE_OPS):
+    """`generate_bitwise_trace` (generation/builtin.rs:35-205) interpreted: the 2^18-row table (fixed AND / OR / XOR table, the operations'
+    rows, the compress challenge drawn from a transcript over the twelve limb columns, sixteen `permuted_cols` pairs) -- about 40 minutes.
+    Operands below 2^24: the reference writes the fourth limb of op0 / op1 / res to `OP0_LIMBS.end` etc., i.e. one column too far, where the
+    next write overwrites it (builtin.rs:66, 71, 76), so its limb-3 columns stay zero whatever the operand."""
+    it = plonky2_interp(reference)
+    pos = FastPoseidonHook(it)
+    it.permutation_hook = pos
+    fn = {"AND": lambda x, y: x & y, "OR": lambda x, y: x | y, "XOR": lambda x, y: x ^ y}
+    src = X.Src.get(os.path.join(reference, "circuits", "src", "generation", "builtin.rs"))
+    cells = []
+    for name, x, y in ops:
+        z = fn[name](x, y)
+        d = {"__name__": "BitwiseCombinedRow", "opcode": it.method(Enum("OlaOpcode", name), "binary_bit_mask", [], src, 0), "op0": Fe(x), "op1": Fe(y),
+             "res": Fe(z)}
+        for i in range(4):
+            d["op0_%d" % i], d["op1_%d" % i], d["res_%d" % i] = Fe((x >> (8 * i)) & 255), Fe((y >> (8 * i)) & 255), Fe((z >> (8 * i)) & 255)
+        cells.append(Struct(d))
+    tr, beta = it.call_free(src.path, "generate_bitwise_trace", [cells])
+    return {"generated_by": "tools/rust_air_eval.py --tracegen-bitwise", "ops": [list(o) for o in ops], "beta": beta.v, **trace_digest(tr),
+            "rows_head": [[c[i].v for c in tr] for i in range(len(ops))]}
+
+
+class FastPoseidonHook:
+    """the permutation for the 393 216 sponge calls of the bitwise generator's transcript: built from the reference's constant tables and checked
+    against the interpreted poseidon_naive before use (as tools/ref_verifier.py does)"""
+
+    def __init__(self, it):
+        src = X.Src.get(os.path.join(it.plonky2, "hash", "poseidon.rs"))
+        gsrc = X.Src.get(os.path.join(it.plonky2, "hash", "poseidon_goldilocks.rs"))
+        circ = [int(x) for x in it.const_value("MDS_MATRIX_CIRC", gsrc)]
+        diag = [int(x) for x in it.const_value("MDS_MATRIX_DIAG", gsrc)]
+        self.rc = [int(x) for x in it.const_value("ALL_ROUND_CONSTANTS", src)]
+        self.rows = [[circ[(j - r) % 12] + (diag[r] if j == r else 0) for j in range(12)] for r in range(12)]
+        naive = it.permutation_hook
+        for k in range(4):
+            v = [Fe(x) for x in stream_for(8800 + k, 3, 12)]
+            if [x.v for x in naive(list(v))] != [x.v for x in self(v)]:
+                raise SystemExit("direct Poseidon permutation disagrees with the interpreted poseidon_naive")
+
+    def __call__(self, state, segs=None):
+        s = [x.v for x in state]
+        r = 0
+        for full, rounds in ((True, 4), (False, 22), (True, 4)):
+            for _ in range(rounds):
+                k = 12 * r
+                if full:
+                    s = [pow(s[i] + self.rc[k + i], 7, P) for i in range(12)]
+                else:
+                    s = [s[i] + self.rc[k + i] for i in range(12)]
+                    s[0] = pow(s[0], 7, P)
+                s = [sum(m[j] * s[j] for j in range(12)) % P for m in self.rows]
+                r += 1
+        return [Fe(x) for x in s]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reference", default="/root/reference")
@@ -2881,8 +2941,14 @@ def main():
     ap.add_argument("--primitives", action="store_true", help="the hashing / transcript / FRI-parameter vectors instead of the AIR vectors")
     ap.add_argument("--ntt", action="store_true", help="the transform vectors (cfft) instead of the AIR vectors")
     ap.add_argument("--tracegen", action="store_true", help="the trace generators' outputs (generation/*.rs) instead of the AIR vectors")
+    ap.add_argument("--tracegen-bitwise", action="store_true", help="the bitwise table's generator (2^18 rows: about 40 minutes)")
     a = ap.parse_args()
     sys.setrecursionlimit(20000)
+    if a.tracegen_bitwise:
+        data = tracegen_bitwise(a.reference)
+        open(BITWISE_FIXTURE, "w").write(json.dumps(data, separators=(",", ":")) + "\n")
+        print("wrote", BITWISE_FIXTURE)
+        return
     if a.tracegen:
         out = TRACEGEN_FIXTURE if a.out == FIXTURE else a.out
         data = tracegen_vectors(a.reference)
