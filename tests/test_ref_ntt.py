@@ -5,7 +5,8 @@ tools/rust_air_eval.py --ntt interprets plonky2/field/src/cfft/mod.rs with the b
 `evaluate_poly_with_offset` (:65, domain offset `F::coset_shift()`, blowup 8: the commitment's LDE), `interpolate_poly` (:128) and
 `interpolate_poly_with_offset` (:180), which dispatch to serial.rs (`fft_in_place`, `permute`) below 2^10 elements and to
 concurrent.rs (`split_radix_fft`: transpose, inner FFTs, transpose, twiddles, outer FFTs; the batched `permute`, `clone_and_shift`) from
-2^10 on -- sizes 2^1 .. 2^11, i.e. both shapes of the four-step split (square at 2^10, 2:1 at 2^11).  tests/golden/ref_ntt_vectors.json holds
+2^10 on -- sizes 2^1 .. 2^16, i.e. both shapes of the four-step split (square at even, 2:1 at odd exponents) and, from 2^14 on, the sizes
+the GPU transforms on its T-form pass kernels (the kernels of the headline figure).  tests/golden/ref_ntt_vectors.json holds
 a digest of each output.  Here the oracle's transforms (CPU) and the GPU's (`ola_ntt_batch`, -m gpu) are held to them; the larger sizes
 are compared GPU against oracle elsewhere (tests/test_gpu_parity.py, tests/test_gpu_fullsize.py)."""
 import json
@@ -37,9 +38,9 @@ def same(v, words):
 
 
 def test_fixture_covers_both_code_paths_and_all_four_transforms(vectors):
-    assert len(vectors) == 44
+    assert len(vectors) == 64
     assert {(v["op"], v["log_n"]) for v in vectors} == {(op, n) for op in ("evaluate_poly", "interpolate_poly", "evaluate_poly_with_offset",
-                                                                             "interpolate_poly_with_offset") for n in range(1, 12)}
+                                                                             "interpolate_poly_with_offset") for n in range(1, 17)}
     assert {v["path"] for v in vectors if v["log_n"] >= 10} == {"concurrent.rs"} and {v["path"] for v in vectors if v["log_n"] < 10} == {"serial.rs"}
     assert all(v["len"] == (8 if v["op"] == "evaluate_poly_with_offset" else 1) << v["log_n"] for v in vectors)
 

@@ -2814,9 +2814,9 @@ def ntt_record(words):
     return {"sha256": hashlib.sha256(struct.pack("<%dQ" % len(words), *words)).hexdigest(), "len": len(words), "head": words[:4], "tail": words[-2:]}
 
 
-def ntt_vectors(reference, sizes=tuple(range(1, 12))):
-    """outputs of the reference's four transforms, sizes 2^1 .. 2^11 (serial.rs below 2^10; concurrent.rs at 2^10 -- square split -- and 2^11 -- the
-    2:1 split), as digests"""
+def ntt_vectors(reference, sizes=tuple(range(1, 17))):
+    """outputs of the reference's four transforms, sizes 2^1 .. 2^16 (serial.rs below 2^10; concurrent.rs from 2^10 on: square splits at even,
+    2:1 splits at odd exponents), as digests.  2^14 and up are the sizes the GPU runs on its T-form pass kernels.  About 40 minutes."""
     it = ntt_interp(reference)
     out = {"generated_by": "tools/rust_air_eval.py --ntt", "input": "ntt_input(log_n, op) = stream_for(4000 + log_n, index of op, 2^log_n)",
            "source": "plonky2/field/src/cfft/mod.rs :22 :65 :128 :180 -> serial.rs / concurrent.rs (feature parallel: n >= 1024)", "vectors": []}
