@@ -39,8 +39,10 @@ extern "C" {
  * ola_gpu_abi_version() lets it check at start-up that library and header agree (also on sizeof(OlaChallenger)).
  * 5: ola_prove_with_traces_cols (one pointer per column: the reference's [Vec<PolynomialValues<F>>; NUM_TABLES] as it is),
  * ola_gpu_scope_times (the `timed!` scopes with device times, for the caller's TimingTree), ola_gpu_upload_stats; no struct of
- * revision 4 changed. */
-#define OLA_GPU_ABI_VERSION 5
+ * revision 4 changed.
+ * 6: ola_gpu_warmup / ola_gpu_warmup_wait (start-up work ahead of the first context, where the reference calls init_gpu()),
+ * ola_gpu_ntt_pass_times (the transform passes one by one, for the dominant kernel's roofline); no struct changed. */
+#define OLA_GPU_ABI_VERSION 6
 #define OLA_OK 0
 #define OLA_E_INVALID_ARG (-1)
 #define OLA_E_NO_DEVICE (-2)
@@ -105,6 +107,20 @@ int32_t ola_gpu_collective(OlaCtx* ctx, uint32_t* carrier, uint32_t* ranks, char
  * single-device one: a 1-rank communicator).  *ms_per_gather: slowest rank's mean; *mismatches: wrong bytes over all ranks (0). */
 int32_t ola_gpu_all_gather_check(OlaCtx* ctx, uint32_t carrier, size_t bytes_per_rank, uint32_t reps, double* ms_per_gather, uint64_t* mismatches);
 int32_t ola_gpu_free(OlaCtx* ctx);
+/* Start-up ahead of the first context: replaces the reference's early hook -- OlaStark::default() calls
+ * plonky2::field::cfft::ntt::init_gpu() (circuits/src/stark/ola_stark.rs:47, plonky2/field/src/cfft/ntt/mod.rs:53-99) before
+ * prove() generates the traces (client/src/main.rs:191-200).  Returns at once; a helper thread starts the HIP runtime, opens
+ * `device` (-1: the current one), loads the library's code objects (the main one and one per generated quotient kernel) and, with
+ * OLA_WARMUP_PINNED_RING, pins the 128 MB staging ring of the trace upload for the first context created on that device.  None of
+ * this depends on the StarkConfig or the hasher, which the caller does not know yet at that point.  ola_gpu_init /
+ * ola_gpu_init_multi wait for a warm-up that is under way and then find the runtime up (a few milliseconds instead of 0.9 s: the
+ * split is printed under OLA_TIMING=1).  Calling it again is a no-op; a failure inside the thread (no device) is reported by the
+ * ola_gpu_init that follows, as it would have been without the warm-up. */
+#define OLA_WARMUP_PINNED_RING 1u
+int32_t ola_gpu_warmup(int32_t device, uint32_t flags);
+/* Waits for the warm-up thread; *ms_out (may be NULL) = how long it ran.  OLA_E_INVALID_ARG when ola_gpu_warmup was never called,
+ * OLA_E_HIP when the thread failed (message in ola_gpu_last_error). */
+int32_t ola_gpu_warmup_wait(double* ms_out);
 const char* ola_gpu_last_error(void);
 int32_t ola_gpu_sync(OlaCtx* ctx);
 /* Scratch and commitment buffers are recycled through a per-context cache (tens of GB after a 2^22-row proof); this returns
@@ -180,6 +196,19 @@ int32_t ola_gpu_scope_times(OlaCtx* ctx, int32_t enable, OlaScopeTime* out, uint
  * out[5] copier threads, out[6] bytes that crossed the link (columns whose words are all below 2^32 travel as 32-bit words and are
  * widened on the device: OLA_UPLOAD_PACK=0 switches that off), out[7] reserved.  On a multi-device context: rank 0's share. */
 int32_t ola_gpu_upload_stats(OlaCtx* ctx, double out[8]);
+/* The transform passes one by one (the roofline of the DOMINANT kernel needs that kernel's own launch duration, not
+ * the mean over a transform's passes).  enable: 1 / 0 switches on / off, for the transforms that follow, two event records around
+ * every launch of ntt2t_pass_kernel on the context's stream (log_n >= 14; no synchronisation inside a transform), -1 leaves it.
+ * The call drains the stream and returns what was recorded since the last call, summed per kernel instantiation
+ * (template arguments as rocprofv3 prints them: <R, MODE, INV, CB, LM>), and forgets it.  out may be NULL; *n_out = entries. */
+typedef struct OlaPassTime {
+    char kernel[48];
+    uint32_t launches;
+    uint32_t reserved;
+    double total_ms;
+    double elements;            /* field elements the launches transformed (each read once and written once) */
+} OlaPassTime;
+int32_t ola_gpu_ntt_pass_times(OlaCtx* ctx, int32_t enable, OlaPassTime* out, uint32_t cap, uint32_t* n_out);
 /* Self-test of the device field arithmetic: the kernels' modular reduction is written with explicit carry chains in inline
  * assembly (olavm_amd/csrc/gl.cuh); this compares it with the plain C++ reduction on a table of edge values and on `pairs`
  * pseudo-random operand pairs and returns the number of disagreements (0 expected; about 10^9 pairs per 50 ms).  It also runs

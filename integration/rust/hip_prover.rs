@@ -41,6 +41,34 @@ fn airset() -> &'static [u64] {
 struct SendPtr(*mut OlaCtx);
 unsafe impl Send for SendPtr {}
 
+/// Start-up where the reference has it: `OlaStark::default()` calls `plonky2::field::cfft::ntt::init_gpu()`
+/// (circuits/src/stark/ola_stark.rs:47, plonky2/field/src/cfft/ntt/mod.rs:53-99) before `prove()` generates the traces
+/// (client/src/main.rs:191-200); the patch adds this call on the next line.  Returns at once: a helper thread inside the library
+/// starts the HIP runtime, opens the device, loads the code objects and pins the upload ring while the host generates traces;
+/// the first `with_ctx` waits for it and then creates its context in milliseconds.  The hasher and the `StarkConfig` are not
+/// known here (`OlaStark` is generic over `F, D` only) and are not needed.  Errors are left to the `ola_gpu_init` that follows.
+pub fn init_early() {
+    static ONCE: std::sync::Once = std::sync::Once::new();
+    ONCE.call_once(|| {
+        if check_abi().is_ok() {
+            let _ = unsafe { ola_gpu_warmup(-1, OLA_WARMUP_PINNED_RING) };
+        }
+    });
+}
+
+/// What a context was created with: a later call with another `StarkConfig` gets a new context, not the stale one.
+#[derive(Clone, Copy, PartialEq, Eq, Debug)]
+struct CtxKey {
+    rate_bits: u32,
+    cap_height: u32,
+    proof_of_work_bits: u32,
+    arity_bits: u32,
+    final_poly_bits: u32,
+    num_query_rounds: u32,
+    num_challenges: u32,
+    gpus: u32,
+}
+
 /// One context per hash configuration for the life of the process, and ONE proof at a time on the GPU: a context is
 /// thread-compatible, not re-entrant (the reference's own GPU state is process-wide behind a mutex as well:
 /// cfft/ntt/mod.rs:14-17,48-50).  The slot is filled under its lock, so two threads that arrive together create one context,
@@ -48,32 +76,49 @@ unsafe impl Send for SendPtr {}
 /// that many devices and the partition and its exchanges happen inside the library (`OLA_COLLECTIVE` = peer | rccl selects who
 /// moves the bytes).  The guard is held for the whole proof.
 fn with_ctx<R>(hasher: u32, config: &StarkConfig, body: impl FnOnce(*mut OlaCtx) -> Result<R>) -> Result<R> {
-    static CTX: [OnceLock<Mutex<Option<SendPtr>>>; 2] = [OnceLock::new(), OnceLock::new()];
+    static CTX: [OnceLock<Mutex<Option<(SendPtr, CtxKey)>>>; 2] = [OnceLock::new(), OnceLock::new()];
     let mut slot = CTX[hasher as usize].get_or_init(|| Mutex::new(None)).lock().unwrap_or_else(|e| e.into_inner());
+    let fri = &config.fri_config;
+    // the library folds with one arity; StarkConfig::standard_fast_config is ConstantArityBits(4, 5) (config.rs:18-30)
+    let (arity_bits, final_poly_bits) = match fri.reduction_strategy {
+        FriReductionStrategy::ConstantArityBits(a, f) => (a as u32, f as u32),
+        ref other => bail!("the hip backend folds with FriReductionStrategy::ConstantArityBits only, the config asks for {other:?}"),
+    };
+    let key = CtxKey {
+        rate_bits: fri.rate_bits as u32,
+        cap_height: fri.cap_height as u32,
+        proof_of_work_bits: fri.proof_of_work_bits,
+        arity_bits,
+        final_poly_bits,
+        num_query_rounds: fri.num_query_rounds as u32,
+        num_challenges: config.num_challenges as u32,
+        gpus: std::env::var("OLA_GPUS").ok().and_then(|v| v.parse().ok()).unwrap_or(1),
+    };
+    if let Some((old, old_key)) = slot.as_ref() {
+        if *old_key != key {
+            // proving under the first call's FRI parameters would produce a proof the caller's verifier rejects
+            check(unsafe { ola_gpu_free(old.0) })?;
+            *slot = None;
+        }
+    }
     if slot.is_none() {
+        init_early(); // a caller that never built an OlaStark::default(): the same start-up, then waited for below
         check_abi()?;
-        let fri = &config.fri_config;
-        // the library folds with one arity; StarkConfig::standard_fast_config is ConstantArityBits(4, 5) (config.rs:18-30)
-        let (arity_bits, final_poly_bits) = match fri.reduction_strategy {
-            FriReductionStrategy::ConstantArityBits(a, f) => (a as u32, f as u32),
-            ref other => bail!("the hip backend folds with FriReductionStrategy::ConstantArityBits only, the config asks for {other:?}"),
-        };
-        let n: u32 = std::env::var("OLA_GPUS").ok().and_then(|v| v.parse().ok()).unwrap_or(1);
         let mut cfg: OlaGpuConfig = unsafe { std::mem::zeroed() };
         cfg.device = -1;
-        cfg.rate_bits = fri.rate_bits as u32;
-        cfg.cap_height = fri.cap_height as u32;
-        cfg.proof_of_work_bits = fri.proof_of_work_bits;
-        cfg.fri_arity_bits = arity_bits;
-        cfg.fri_final_poly_bits = final_poly_bits;
-        cfg.num_query_rounds = fri.num_query_rounds as u32;
-        cfg.num_challenges = config.num_challenges as u32;
+        cfg.rate_bits = key.rate_bits;
+        cfg.cap_height = key.cap_height;
+        cfg.proof_of_work_bits = key.proof_of_work_bits;
+        cfg.fri_arity_bits = key.arity_bits;
+        cfg.fri_final_poly_bits = key.final_poly_bits;
+        cfg.num_query_rounds = key.num_query_rounds;
+        cfg.num_challenges = key.num_challenges;
         cfg.hasher = hasher;
         let mut c = std::ptr::null_mut();
-        check(unsafe { ola_gpu_init_multi(&cfg, std::ptr::null(), n, &mut c) })?;
-        *slot = Some(SendPtr(c));
+        check(unsafe { ola_gpu_init_multi(&cfg, std::ptr::null(), key.gpus, &mut c) })?;
+        *slot = Some((SendPtr(c), key));
     }
-    body(slot.as_ref().unwrap().0)
+    body(slot.as_ref().unwrap().0 .0)
 }
 
 /// The `timed!` scopes of the proof that has just run, with the GPU's times (`ola_gpu_scope_times`), replayed into the
@@ -149,6 +194,12 @@ where
 
     let words = airset();
     let out = with_ctx(hasher_of::<F, C, D>()?, config, |c| {
+        // the library reads cols[t][0 .. width of table t in the AIR set): a shorter table would be read past its pointer Vec
+        for (t, table) in trace_poly_values.iter().enumerate() {
+            let mut shape = [0u32; 6];
+            check(unsafe { ola_table_shape(c, words.as_ptr(), words.len(), t as u32, shape.as_mut_ptr()) })?;
+            ensure!(table.len() == shape[0] as usize, "table {t} has {} columns, its AIR has {}", table.len(), shape[0]);
+        }
         // scope times cost two event records per scope; ask for them when somebody will read the tree (TimingTree logs at Debug)
         let want_scopes = log::log_enabled!(log::Level::Debug);
         check(unsafe { ola_gpu_scope_times(c, want_scopes as i32, std::ptr::null_mut(), 0, std::ptr::null_mut()) })?;

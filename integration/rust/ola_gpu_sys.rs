@@ -1,4 +1,4 @@
-//! Raw bindings of `libola_gpu.so` (`include/ola_gpu.h`, ABI revision 5) for the reference's `circuits` crate.
+//! Raw bindings of `libola_gpu.so` (`include/ola_gpu.h`, ABI revision 6) for the reference's `circuits` crate.
 //!
 //! Drop into `circuits/src/stark/ola_gpu_sys.rs` (integration/patches/0001-feature-hip.patch adds the `mod` line and the
 //! feature).  Replaces the reference's dead CUDA FFI -- `gpu_init` / `gpu_method` / `gpu_free`,
@@ -11,7 +11,7 @@
 #![allow(non_camel_case_types, dead_code)]
 use std::os::raw::{c_char, c_void};
 
-pub const OLA_GPU_ABI_VERSION: i32 = 5;
+pub const OLA_GPU_ABI_VERSION: i32 = 6;
 pub const OLA_OK: i32 = 0;
 pub const OLA_E_INVALID_ARG: i32 = -1;
 pub const OLA_E_NO_DEVICE: i32 = -2;
@@ -37,6 +37,8 @@ pub const OLA_COLLECTIVE_NONE: u32 = 0;
 pub const OLA_COLLECTIVE_PEER: u32 = 1;
 pub const OLA_COLLECTIVE_RCCL: u32 = 2;
 pub const OLA_PHASE_COUNT: u32 = 7;
+/// ola_gpu_warmup: also pin the trace upload's staging ring
+pub const OLA_WARMUP_PINNED_RING: u32 = 1;
 
 #[repr(C)]
 pub struct OlaCtx {
@@ -87,6 +89,16 @@ pub struct OlaScopeTime {
     pub ms: f64,
     pub sharded_ms: f64,
 }
+/// The launches of one transform-pass kernel instantiation, summed (`ola_gpu_ntt_pass_times`).
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct OlaPassTime {
+    pub kernel: [c_char; 48],
+    pub launches: u32,
+    pub reserved: u32,
+    pub total_ms: f64,
+    pub elements: f64,
+}
 /// `ola_all_gather_fn`: gather `bytes` bytes of device memory from every rank into `recv_dev` (rank order), 0 = done
 pub type OlaAllGatherFn = Option<unsafe extern "C" fn(user: *mut c_void, send_dev: *const c_void, recv_dev: *mut c_void, bytes: usize) -> i32>;
 
@@ -100,6 +112,8 @@ extern "C" {
     pub fn ola_gpu_all_gather_check(ctx: *mut OlaCtx, carrier: u32, bytes_per_rank: usize, reps: u32, ms_per_gather: *mut f64,
         mismatches: *mut u64) -> i32;
     pub fn ola_gpu_free(ctx: *mut OlaCtx) -> i32;
+    pub fn ola_gpu_warmup(device: i32, flags: u32) -> i32;
+    pub fn ola_gpu_warmup_wait(ms_out: *mut f64) -> i32;
     pub fn ola_gpu_last_error() -> *const c_char;
     pub fn ola_gpu_sync(ctx: *mut OlaCtx) -> i32;
     pub fn ola_gpu_trim(ctx: *mut OlaCtx) -> i32;
@@ -108,6 +122,7 @@ extern "C" {
     pub fn ola_gpu_phase_stats(ctx: *mut OlaCtx, out: *mut f64, n_phases: u32) -> i32;
     pub fn ola_gpu_scope_times(ctx: *mut OlaCtx, enable: i32, out: *mut OlaScopeTime, cap: u32, n_out: *mut u32) -> i32;
     pub fn ola_gpu_upload_stats(ctx: *mut OlaCtx, out: *mut f64) -> i32;
+    pub fn ola_gpu_ntt_pass_times(ctx: *mut OlaCtx, enable: i32, out: *mut OlaPassTime, cap: u32, n_out: *mut u32) -> i32;
     pub fn ola_gpu_selftest(ctx: *mut OlaCtx, pairs: u64, mismatches: *mut u64) -> i32;
     pub fn ola_gpu_reserve(ctx: *mut OlaCtx, airset: *const u64, airset_words: usize, log_n: *const u32) -> i32;
     pub fn ola_table_shape(ctx: *mut OlaCtx, airset: *const u64, airset_words: usize, table: u32, out: *mut u32) -> i32;

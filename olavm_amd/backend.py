@@ -32,6 +32,11 @@ class OlaScopeTime(C.Structure):
                 ("is_reference_scope", C.c_uint32), ("start_ms", C.c_double), ("ms", C.c_double), ("sharded_ms", C.c_double)]
 
 
+class OlaPassTime(C.Structure):
+    """include/ola_gpu.h OlaPassTime: the launches of one transform-pass kernel instantiation, summed."""
+    _fields_ = [("kernel", C.c_char * 48), ("launches", C.c_uint32), ("reserved", C.c_uint32), ("total_ms", C.c_double), ("elements", C.c_double)]
+
+
 class OlaChallenger(C.Structure):
     _fields_ = [("sponge_state", C.c_uint64 * 12), ("input_buffer", C.c_uint64 * 8), ("output_buffer", C.c_uint64 * 8),
                 ("input_len", C.c_uint32), ("output_len", C.c_uint32), ("hasher", C.c_uint32), ("reserved", C.c_uint32)]
@@ -69,7 +74,7 @@ def load_library():
     L.ola_gpu_init.argtypes = [C.POINTER(OlaGpuConfig), C.POINTER(C.c_void_p)]
     L.ola_gpu_abi_version.argtypes = [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
     a, b = C.c_size_t(), C.c_size_t()
-    if L.ola_gpu_abi_version(C.byref(a), C.byref(b)) != 5 or a.value != C.sizeof(OlaChallenger) or b.value != C.sizeof(OlaGpuConfig):
+    if L.ola_gpu_abi_version(C.byref(a), C.byref(b)) != 6 or a.value != C.sizeof(OlaChallenger) or b.value != C.sizeof(OlaGpuConfig):
         raise OlaGpuError(-7, "libola_gpu.so and olavm_amd/backend.py disagree on the ABI revision or struct sizes: rebuild the library")
     L.ola_gpu_init_multi.argtypes = [C.POINTER(OlaGpuConfig), C.POINTER(C.c_int32), C.c_uint32, C.POINTER(C.c_void_p)]
     L.ola_gpu_device_count.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
@@ -110,6 +115,9 @@ def load_library():
                                              C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]
     L.ola_gpu_scope_times.argtypes = [C.c_void_p, C.c_int32, C.POINTER(OlaScopeTime), C.c_uint32, C.POINTER(C.c_uint32)]
     L.ola_gpu_upload_stats.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+    L.ola_gpu_warmup.argtypes = [C.c_int32, C.c_uint32]
+    L.ola_gpu_warmup_wait.argtypes = [C.POINTER(C.c_double)]
+    L.ola_gpu_ntt_pass_times.argtypes = [C.c_void_p, C.c_int32, C.POINTER(OlaPassTime), C.c_uint32, C.POINTER(C.c_uint32)]
     L.ola_commit_values_shard.argtypes = [C.c_void_p, C.POINTER(U64P), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                           C.POINTER(C.c_void_p), U64P]
     L.ola_commit_values_shard_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
@@ -146,7 +154,30 @@ EXPORTS = [
     "ola_table_shape", "ola_perm_z", "ola_ctl_z", "ola_quotient", "ola_set_shard_options", "ola_gpu_get_stream",
     "ola_gpu_abi_version", "ola_gpu_init_multi", "ola_gpu_device_count", "ola_gpu_proof_stats", "ola_gpu_phase_stats",
     "ola_gpu_collective", "ola_gpu_all_gather_check", "ola_prove_with_traces_cols", "ola_gpu_scope_times", "ola_gpu_upload_stats",
+    "ola_gpu_warmup", "ola_gpu_warmup_wait", "ola_gpu_ntt_pass_times",
 ]
+
+
+OLA_WARMUP_PINNED_RING = 1
+
+
+def warmup(device=-1, pinned_ring=True):
+    """ola_gpu_warmup: start the HIP runtime, open the device and load the code objects on a helper thread; returns at once
+    (the reference's early hook: OlaStark::default() -> init_gpu(), circuits/src/stark/ola_stark.rs:47)."""
+    L = load_library()
+    rc = L.ola_gpu_warmup(int(device), OLA_WARMUP_PINNED_RING if pinned_ring else 0)
+    if rc != 0:
+        raise OlaGpuError(rc, (L.ola_gpu_last_error() or b"").decode())
+
+
+def warmup_wait():
+    """ola_gpu_warmup_wait -> milliseconds the warm-up thread ran."""
+    L = load_library()
+    ms = C.c_double()
+    rc = L.ola_gpu_warmup_wait(C.byref(ms))
+    if rc != 0:
+        raise OlaGpuError(rc, (L.ola_gpu_last_error() or b"").decode())
+    return ms.value
 
 
 ALL_GATHER_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)
@@ -316,6 +347,15 @@ class Backend:
         self._chk(self.lib.ola_gpu_scope_times(self.ctx, -1, out, n.value, C.byref(n)))
         return [{"name": o.name.decode(), "depth": o.depth, "ref_depth": o.ref_depth, "table": o.table, "reference": bool(o.is_reference_scope),
                  "start_ms": o.start_ms, "ms": o.ms, "sharded_ms": o.sharded_ms} for o in out]
+
+    def ntt_pass_times(self, enable=None):
+        """ola_gpu_ntt_pass_times: switch the per-launch events of the transform passes (True / False / None = leave); -> what was
+        recorded since the last call as {kernel: {"launches", "total_ms", "avg_ms", "elements"}}."""
+        n = C.c_uint32()
+        out = (OlaPassTime * 64)()
+        self._chk(self.lib.ola_gpu_ntt_pass_times(self.ctx, -1 if enable is None else int(bool(enable)), out, 64, C.byref(n)))
+        return {o.kernel.decode(): {"launches": o.launches, "total_ms": o.total_ms, "avg_ms": o.total_ms / max(o.launches, 1), "elements": o.elements}
+                for o in out[:n.value]}
 
     def upload_stats(self):
         """ola_gpu_upload_stats of the last whole proof."""

@@ -223,6 +223,12 @@ struct NttTables {
     std::map<std::pair<int, u64>, TwoLevel> shift;   // (log_n, shift) -> s^k tables (single coset, arbitrary shift)
     std::map<std::tuple<int, int, int, u64>, const u64*> coset_steps;  // (log_n, rate_bits, e, shift) -> per-coset s^(2^e) (ntt2.hip)
     // (log_n, rate_bits, lo/R/inverse, shift) -> per-coset pre-scale tables of a coset transform's first pass (ntt2.hip)
+    // ola_gpu_ntt_pass_times: every T-form pass launch bracketed by two events on the context's stream, summed per kernel
+    // instantiation when read (the per-launch duration of the dominant kernel for bench.py's roofline; off by default)
+    struct PassRec { int R, mode, lm; bool inv; size_t elems; hipEvent_t a, b; };
+    bool pass_timing = false;
+    std::vector<PassRec> pass_recs;
+    ~NttTables() { for (PassRec& r : pass_recs) { if (r.a) (void)hipEventDestroy(r.a); if (r.b) (void)hipEventDestroy(r.b); } }
 };
 
 static u64* upload(DeviceCtx* ctx, const std::vector<u64>& v) {

@@ -325,6 +325,17 @@ static void ntt2t_dispatch(int R, int mode, bool inv, int lm, const Ntt2Params& 
     if (inv) ntt2t_dispatch_inv<true>(R, mode, lm, p, cols, cosets, s);
     else ntt2t_dispatch_inv<false>(R, mode, lm, p, cols, cosets, s);
 }
+// the same launch between two events (NttTables::pass_timing)
+static void ntt2t_dispatch_timed(NttTables& t, int R, int mode, bool inv, int lm, const Ntt2Params& p, size_t cols, size_t cosets, hipStream_t s) {
+    if (!t.pass_timing || t.pass_recs.size() >= 4096) { ntt2t_dispatch(R, mode, inv, lm, p, cols, cosets, s); return; }
+    NttTables::PassRec r{R, mode, lm, inv, ((size_t)1 << p.log_n) * cols * cosets, nullptr, nullptr};
+    HIP_CHECK(hipEventCreate(&r.a));
+    HIP_CHECK(hipEventCreate(&r.b));
+    HIP_CHECK(hipEventRecord(r.a, s));
+    ntt2t_dispatch(R, mode, inv, lm, p, cols, cosets, s);
+    HIP_CHECK(hipEventRecord(r.b, s));
+    t.pass_recs.push_back(r);
+}
 
 // round twiddles of a strided pass, [q1][m]: w_{2^R}^(m*q1), q1 < 16, m < 2^(R-4)
 static const u64* get_round_table(NttTables& t, int R, int inverse) {
@@ -424,11 +435,11 @@ static void ntt2_run_group(NttTables& t, const u64* in, size_t in_col_stride, u6
             if (!last) {
                 p.out = work; p.out_col_stride = work_col_stride; p.out_coset_stride = work_coset_stride;
                 if (lo - 4 < 8 - R) throw OlaError(-7, "ntt2: pass split leaves a strided pass with lo + R < 12");
-                ntt2t_dispatch(R, N2_STRIDED, inverse, lm, p, cols, cosets, stream);
+                ntt2t_dispatch_timed(t, R, N2_STRIDED, inverse, lm, p, cols, cosets, stream);
                 cur_in = work; cur_in_stride = work_col_stride; cur_in_coset = work_coset_stride;
             } else {
                 p.out = out; p.out_col_stride = out_col_stride; p.out_coset_stride = out_coset_stride;
-                ntt2t_dispatch(R, natural_out ? N2_NATURAL_LAST : N2_BITREV_LAST, inverse, 2, p, cols, cosets, stream);
+                ntt2t_dispatch_timed(t, R, natural_out ? N2_NATURAL_LAST : N2_BITREV_LAST, inverse, 2, p, cols, cosets, stream);
             }
         }
         return;

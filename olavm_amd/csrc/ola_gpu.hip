@@ -5,7 +5,9 @@
 
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cstring>
+#include <mutex>
 #include <memory>
 #include <thread>
 #include <string>
@@ -144,13 +146,26 @@ static std::unique_ptr<OlaCtx> create_device_ctx(const OlaGpuConfig& cfg, int de
     c->cfg.device = device;
     c->cfg.stream = stream;
     c->dev.hasher = (int)cfg.hasher;
+    { const char* t = getenv("OLA_TIMING"); c->dev.timing = t && *t && *t != '0'; c->dev.acct.on = c->dev.timing; }   // OLA_TIMING also prints the partition accounting
+    // where ola_gpu_init's time goes (OLA_TIMING): the first HIP call of a process opens the runtime and the device, the first
+    // touch of a symbol loads this library's code object for the device; everything of ours is lazy (tables, pinned ring, pool)
+    auto t0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!c->dev.timing) return;
+        const auto t1 = std::chrono::steady_clock::now();
+        fprintf(stderr, "[ola-timing] init: %-52s %9.3f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        t0 = t1;
+    };
     if (device >= 0) HIP_CHECK(hipSetDevice(device));
     HIP_CHECK(hipGetDevice(&c->dev.device));
+    lap("hipSetDevice / hipGetDevice");
     if (stream) { c->dev.stream = (hipStream_t)stream; c->dev.owns_stream = false; }
     else { HIP_CHECK(hipStreamCreateWithFlags(&c->dev.stream, hipStreamNonBlocking)); c->dev.owns_stream = true; }
-    { const char* t = getenv("OLA_TIMING"); c->dev.timing = t && *t && *t != '0'; c->dev.acct.on = c->dev.timing; }   // OLA_TIMING also prints the partition accounting
+    lap("stream (first real device work: opens the device)");
     poseidon_init(&c->dev);
+    lap("Poseidon constants (loads the code object)");
     c->tables = ntt_tables_create(&c->dev);
+    lap("transform table registry (tables are built on use)");
     return c;
 }
 
@@ -213,16 +228,122 @@ static void prove_with_traces_multi(OlaCtx* ctx, const u64* airset, size_t airse
     bytes = std::move(res[0].bytes);
 }
 
+// ola_gpu_warmup: the process-wide start-up work done AHEAD of the first context, on a helper thread, where the reference brings
+// its own GPU state up -- OlaStark::default() calls plonky2::field::cfft::ntt::init_gpu() (circuits/src/stark/ola_stark.rs:47,
+// plonky2/field/src/cfft/ntt/mod.rs:53-99) before prove() generates the traces (client/src/main.rs:191-200).  What costs time in
+// ola_gpu_init is not ours to shrink (HIP runtime start-up, opening the device, loading the code objects: OLA_TIMING prints the
+// split), but none of it depends on the configuration, so it can run while the host generates traces.  The state is never
+// destroyed (the thread may still be running at exit).
+struct WarmState {
+    std::mutex mu;
+    std::condition_variable cv;
+    bool started = false, done = false;
+    int device = -1;
+    double ms = 0;
+    std::string error;
+    void* ring = nullptr;          // a pinned staging ring for the first context created on `device` (upload.h adopts it)
+    size_t ring_bytes = 0;
+    static WarmState& get() { static WarmState* w = new WarmState(); return *w; }
+};
+static void warmup_body(WarmState& w, int device, uint32_t flags) {
+    const auto t0 = std::chrono::steady_clock::now();
+    const bool timing = [] { const char* t = getenv("OLA_TIMING"); return t && *t && *t != '0'; }();
+    auto t_lap = t0;
+    auto lap = [&](const char* what) {
+        if (!timing) return;
+        const auto t1 = std::chrono::steady_clock::now();
+        fprintf(stderr, "[ola-timing] warm-up thread: %-44s %9.3f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t_lap).count());
+        t_lap = t1;
+    };
+    std::string err;
+    void* ring = nullptr;
+    size_t ring_bytes = 0;
+    int dev = device;
+    try {
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) throw OlaError(OLA_E_NO_DEVICE, "no HIP device visible");
+        lap("HIP runtime start-up (hipGetDeviceCount)");
+        if (device >= ndev) throw OlaError(OLA_E_INVALID_ARG, "device index out of range");
+        if (device >= 0) HIP_CHECK(hipSetDevice(device));
+        HIP_CHECK(hipGetDevice(&dev));
+        HIP_CHECK(hipFree(nullptr));                          // opens the device
+        lap("device open (hipFree(0))");
+        poseidon_upload_constants();                          // first symbol of the main code object: loads it
+        lap("main code object (constants upload)");
+        for (const AirKernelEntry* e : AIR_KERNELS) {         // the generated quotient kernels are one code object each
+            hipFuncAttributes fa;
+            if (hipFuncGetAttributes(&fa, (const void*)e->kernel) != hipSuccess) (void)hipGetLastError();
+        }
+        lap("quotient-kernel code objects");
+        if (flags & OLA_WARMUP_PINNED_RING) {
+            const size_t want = (size_t)128 << 20;            // upload.h's default ring: 8 slots of 16 MB
+            if (hipHostMalloc(&ring, want, hipHostMallocDefault) == hipSuccess) ring_bytes = want;
+            else { (void)hipGetLastError(); ring = nullptr; }
+            lap("pinned staging ring (128 MB)");
+        }
+        HIP_CHECK(hipDeviceSynchronize());
+    } catch (const std::exception& e) { err = e.what(); (void)hipGetLastError(); }
+    std::lock_guard<std::mutex> lk(w.mu);
+    w.device = dev; w.error = err; w.ring = ring; w.ring_bytes = ring_bytes;
+    w.ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    w.done = true;
+    w.cv.notify_all();
+}
+// every context creation waits for a warm-up that is under way (the runtime would serialise the two anyway)
+static void warmup_join() {
+    WarmState& w = WarmState::get();
+    std::unique_lock<std::mutex> lk(w.mu);
+    if (w.started) w.cv.wait(lk, [&] { return w.done; });
+}
+namespace ola {
+// upload.h: the ring a warm-up pinned for this device, once
+void* take_warm_ring(int device, size_t want, size_t* got) {
+    WarmState& w = WarmState::get();
+    std::lock_guard<std::mutex> lk(w.mu);
+    if (!w.done || !w.ring || w.device != device || w.ring_bytes < want) return nullptr;
+    void* r = w.ring;
+    *got = w.ring_bytes;
+    w.ring = nullptr; w.ring_bytes = 0;
+    return r;
+}
+}  // namespace ola
+
 extern "C" {
 
 const char* ola_gpu_last_error(void) { return g_last_error.c_str(); }
 
+int32_t ola_gpu_warmup(int32_t device, uint32_t flags) {
+    try {
+        WarmState& w = WarmState::get();
+        std::lock_guard<std::mutex> lk(w.mu);
+        if (w.started) return OLA_OK;
+        w.started = true;
+        std::thread([&w, device, flags] { warmup_body(w, device, flags); }).detach();
+    } catch (const std::exception& e) { g_last_error = e.what(); return OLA_E_INTERNAL; }
+    return OLA_OK;
+}
+
+int32_t ola_gpu_warmup_wait(double* ms_out) {
+    WarmState& w = WarmState::get();
+    std::unique_lock<std::mutex> lk(w.mu);
+    if (!w.started) { g_last_error = "invalid argument: ola_gpu_warmup was not called"; return OLA_E_INVALID_ARG; }
+    w.cv.wait(lk, [&] { return w.done; });
+    if (ms_out) *ms_out = w.ms;
+    if (!w.error.empty()) { g_last_error = "warm-up failed: " + w.error; return OLA_E_HIP; }
+    return OLA_OK;
+}
+
 int32_t ola_gpu_init(const OlaGpuConfig* cfg, OlaCtx** out_ctx) {
     OLA_TRY
     require(out_ctx != nullptr, "out_ctx is NULL");
+    warmup_join();
     int ndev = 0;
+    const auto t_rt = std::chrono::steady_clock::now();
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
         throw OlaError(OLA_E_NO_DEVICE, "no HIP device visible (the backend has no CPU fallback)");
+    { const char* t = getenv("OLA_TIMING");
+      if (t && *t && *t != '0') fprintf(stderr, "[ola-timing] init: %-52s %9.3f ms\n", "hipGetDeviceCount (HIP runtime start-up)",
+                                        std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_rt).count()); }
     const OlaGpuConfig c = resolve_config(cfg);
     require(c.device < ndev, "device index out of range");
     *out_ctx = create_device_ctx(c, c.device, c.stream).release();
@@ -235,6 +356,7 @@ int32_t ola_gpu_init_multi(const OlaGpuConfig* cfg, const int32_t* devices, uint
     OLA_TRY
     require(out_ctx != nullptr, "out_ctx is NULL");
     require(n_devices == 1 || n_devices == 2 || n_devices == 4 || n_devices == 8, "a context spans 1, 2, 4 or 8 devices");
+    warmup_join();
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
         throw OlaError(OLA_E_NO_DEVICE, "no HIP device visible (the backend has no CPU fallback)");
@@ -967,6 +1089,37 @@ int32_t ola_gpu_scope_times(OlaCtx* ctx, int32_t enable, OlaScopeTime* out, uint
             o.start_ms = r.start_ms; o.ms = r.ms; o.sharded_ms = r.sharded_ms;
         }
         require(recs.size() <= cap, "scope buffer too small (*n_out holds the count)");
+    }
+    OLA_CATCH
+}
+
+int32_t ola_gpu_ntt_pass_times(OlaCtx* ctx, int32_t enable, OlaPassTime* out, uint32_t cap, uint32_t* n_out) {
+    OLA_TRY
+    require(ctx != nullptr, "ctx is NULL");
+    OLA_ON_DEVICE(ctx);
+    NttTables& t = *ctx->tables;
+    HIP_CHECK(hipStreamSynchronize(ctx->dev.stream));
+    std::vector<OlaPassTime> agg;
+    for (NttTables::PassRec& r : t.pass_recs) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) { (void)hipGetLastError(); ms = 0; }
+        char name[sizeof(((OlaPassTime*)0)->kernel)];
+        snprintf(name, sizeof(name), "ntt2t_pass_kernel<%d,%d,%s,8,%d>", r.R, r.mode, r.inv ? "true" : "false", r.lm);
+        size_t i = 0;
+        while (i < agg.size() && strcmp(agg[i].kernel, name) != 0) i++;
+        if (i == agg.size()) { OlaPassTime e = {}; memcpy(e.kernel, name, sizeof(name)); agg.push_back(e); }
+        agg[i].launches++;
+        agg[i].total_ms += ms;
+        agg[i].elements += (double)r.elems;
+        (void)hipEventDestroy(r.a);
+        (void)hipEventDestroy(r.b);
+    }
+    t.pass_recs.clear();
+    if (enable >= 0) t.pass_timing = enable != 0;
+    if (n_out) *n_out = (uint32_t)agg.size();
+    if (out) {
+        require(cap >= agg.size(), "cap is smaller than the number of pass kernels (*n_out)");
+        for (size_t i = 0; i < agg.size(); i++) out[i] = agg[i];
     }
     OLA_CATCH
 }

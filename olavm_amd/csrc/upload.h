@@ -44,6 +44,8 @@ namespace ola {
 typedef unsigned long long u64;   // as in gl.cuh
 
 // where one table's columns are: `cols[c]` (each its own allocation) or `base + c n` (one block)
+void* take_warm_ring(int device, size_t want, size_t* got);   // ola_gpu.hip
+
 struct TraceSource {
     const u64* base = nullptr;
     const u64* const* cols = nullptr;
@@ -199,6 +201,8 @@ class TraceUploader {
         const size_t want = piece_bytes_ * slots_;
         if (ctx_->staging && ctx_->staging_bytes >= want) return;
         if (ctx_->staging) { (void)hipHostFree(ctx_->staging); ctx_->staging = nullptr; ctx_->staging_bytes = 0; }
+        size_t got = 0;
+        if (void* warm = take_warm_ring(ctx_->device, want, &got)) { ctx_->staging = warm; ctx_->staging_bytes = got; return; }   // pinned by ola_gpu_warmup
         HIP_CHECK(hipHostMalloc(&ctx_->staging, want, hipHostMallocDefault));
         ctx_->staging_bytes = want;
     }

@@ -110,7 +110,7 @@ def test_extern_block_matches_the_header():
 def test_structs_and_constants_match_the_header():
     h = _strip_c_comments(open(HEADER).read())
     rs = open(SYS_RS).read()
-    for struct in ("OlaGpuConfig", "OlaChallenger", "OlaScopeTime"):
+    for struct in ("OlaGpuConfig", "OlaChallenger", "OlaScopeTime", "OlaPassTime"):
         cbody = re.search(r"typedef struct %s \{(.*?)\} %s;" % (struct, struct), h, flags=re.S).group(1)
         cf = []
         for ty, nm, arr in re.findall(r"([\w\s\*]+?)\s*\b(\w+)\s*(\[\d+\])?\s*;", cbody):
@@ -148,6 +148,19 @@ def test_patch_is_current_and_applies_to_the_reference(tmp_path):
         assert (tmp_path / dst).read_text() == open(os.path.join(ROOT, "integration", "rust", src)).read()
     prover = (tmp_path / "circuits/src/stark/prover.rs").read_text()
     assert prover.count('#[cfg(feature = "hip")]') == 1 and "prove_with_traces_hip::<F, C, D>" in prover
+    # the backend starts up where the reference starts its own GPU state: the line after init_gpu() in OlaStark::default()
+    # (ola_stark.rs:47), i.e. before prove() generates the traces (client/src/main.rs:191-200)
+    ref_lines = open(os.path.join(REF, "circuits/src/stark/ola_stark.rs")).read().split("\n")
+    assert ref_lines[46].strip() == "plonky2::field::cfft::ntt::init_gpu();" and "fn default() -> Self" in ref_lines[45]
+    stark = (tmp_path / "circuits/src/stark/ola_stark.rs").read_text().split("\n")
+    assert stark[46].strip() == "plonky2::field::cfft::ntt::init_gpu();" and stark[47].strip() == '#[cfg(feature = "hip")]'
+    assert stark[48].strip() == "super::hip_prover::init_early();"
+    shim0 = open(os.path.join(ROOT, "integration", "rust", "hip_prover.rs")).read()
+    assert "pub fn init_early()" in shim0 and "ola_gpu_warmup(-1, OLA_WARMUP_PINNED_RING)" in shim0
+    # the cached context is keyed by the configuration it was created with, and column counts are checked against the AIR set
+    assert "*old_key != key" in shim0 and "ola_table_shape(c, words.as_ptr(), words.len(), t as u32" in shim0
+    client = open(os.path.join(REF, "client/src/main.rs")).read().split("\n")
+    assert "OlaStark::<F, D>::default()" in client[192] and "prove::<F, C, D>(" in client[194]
     # the caller's TimingTree goes in (no `let _ = timing;` any more), and the one method the shim needs exists after the patch
     hip_branch = prover[prover.index('#[cfg(feature = "hip")]'):prover.index("let rate_bits = config.fri_config.rate_bits;")]
     assert "timing," in hip_branch and "let _ = timing" not in hip_branch

@@ -19,9 +19,29 @@ for step in "$@"; do
                  done 2>&1 | grep -v amdgpu | tee $O/ab.txt; cp ab_tmp/libola_cur.so olavm_amd/lib/libola_gpu.so ;;
     multi)       timeout 900 python -m pytest tests/test_gpu_multi.py -x -q 2>&1 | tail -15 | tee $O/pytest.log ;;
     dist)        timeout 1200 python -m pytest tests/test_gpu_distributed.py tests/test_gpu_multi.py -x -q 2>&1 | tail -15 | tee $O/pytest.log ;;
+    start)       # round 6: ola_gpu_init taken apart (OLA_TIMING prints the split), the early hook's tests, the per-pass timing entry point
+                 timeout 600 python -m pytest tests/test_gpu_start.py -x -q 2>&1 | tail -8 | tee $O/pytest.log
+                 for i in 1 2; do OLA_TIMING=1 timeout 300 python -c "
+import time, sys
+sys.path.insert(0, '.')
+import torch
+from olavm_amd import backend as B
+t0 = time.perf_counter(); B.load_library(); t1 = time.perf_counter()
+be = B.Backend(device=0); t2 = time.perf_counter()
+print('dlopen %.1f ms, ola_gpu_init %.1f ms' % ((t1 - t0) * 1e3, (t2 - t1) * 1e3))
+" 2>&1 | grep -v amdgpu; done | tee $O/init_split.txt
+                 OLA_TIMING=1 timeout 300 python -c "
+import time, sys
+sys.path.insert(0, '.')
+import torch
+from olavm_amd import backend as B
+B.load_library(); t0 = time.perf_counter(); B.warmup(0); t1 = time.perf_counter(); ms = B.warmup_wait(); t2 = time.perf_counter()
+be = B.Backend(device=0); t3 = time.perf_counter()
+print('ola_gpu_warmup call %.2f ms, thread %.1f ms, ola_gpu_init after it %.1f ms' % ((t1 - t0) * 1e3, ms, (t3 - t2) * 1e3))
+" 2>&1 | grep -v amdgpu | tee -a $O/init_split.txt ;;
     suite)       timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 | tee $O/pytest.log ;;
     smoke)       timeout 600 python -c 'import __graft_entry__ as g; g.smoke()' 2>&1 | tail -5 | tee $O/smoke.log ;;
-    bench)       timeout 900 python bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err; tail -c 1500 $O/bench.json ;;
+    bench)       timeout 900 python bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err; tail -c 2500 $O/bench.json; cp bench_details.json $O/ 2>/dev/null ;;
     bench2)      timeout 900 python bench.py --gpus 2 --steps 10 --warmup 2 > $O/bench.json 2> $O/bench.err; tail -c 1500 $O/bench.json; tail -3 $O/bench.err ;;
     pool)        OLA_TIMING=0 timeout 600 python -m pytest tests/test_gpu_pool.py tests/test_gpu_host_api.py -x -q 2>&1 | tail -8 | tee $O/pytest.log
                  timeout 600 python - <<'PY' 2>&1 | grep -v amdgpu | tee $O/handover.txt

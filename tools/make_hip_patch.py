@@ -6,8 +6,9 @@ crate; the executor / client path is untouched).
     python tools/make_hip_patch.py [--reference /root/reference] [--check]      # --check: compare with the committed patch
 
 The patch adds circuits/build.rs, circuits/src/stark/{ola_gpu_sys,hip_prover}.rs (verbatim copies of integration/rust/*) and edits
-four files: circuits/Cargo.toml (feature + build script), circuits/src/stark/mod.rs (two `mod` lines),
-circuits/src/stark/prover.rs (the `#[cfg(feature = "hip")]` branch at the top of prove_with_traces, prover.rs:79-105) and
+five files: circuits/Cargo.toml (feature + build script), circuits/src/stark/mod.rs (two `mod` lines),
+circuits/src/stark/prover.rs (the `#[cfg(feature = "hip")]` branch at the top of prove_with_traces, prover.rs:79-105),
+circuits/src/stark/ola_stark.rs (the early start-up next to the reference's own init_gpu(), ola_stark.rs:47) and
 plonky2/plonky2/src/util/timing.rs (`TimingTree::record`: the GPU's scope times enter the caller's tree through it).
 """
 import argparse
@@ -20,7 +21,8 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PATCH = os.path.join(ROOT, "integration", "patches", "0001-feature-hip.patch")
-EDITED = ["circuits/Cargo.toml", "circuits/src/stark/mod.rs", "circuits/src/stark/prover.rs", "plonky2/plonky2/src/util/timing.rs"]
+EDITED = ["circuits/Cargo.toml", "circuits/src/stark/mod.rs", "circuits/src/stark/prover.rs", "circuits/src/stark/ola_stark.rs",
+          "plonky2/plonky2/src/util/timing.rs"]
 ADDED = {"circuits/build.rs": "build.rs", "circuits/src/stark/ola_gpu_sys.rs": "ola_gpu_sys.rs", "circuits/src/stark/hip_prover.rs": "hip_prover.rs"}
 
 
@@ -50,6 +52,12 @@ def edit(path, text):
                "    let rate_bits = config.fri_config.rate_bits;\n    let cap_height = config.fri_config.cap_height;\n\n"
                "    let mut twiddle_map = BTreeMap::new();\n")
         return replace_once(text, old, new, "head of prove_with_traces")
+    if path == "circuits/src/stark/ola_stark.rs":
+        # ola_stark.rs:47: where the reference brings ITS GPU state up (init_gpu, cfft/ntt/mod.rs:53-99), before prove() generates
+        # the traces (client/src/main.rs:191-200) -- the backend's start-up goes to the same place and overlaps the trace generation
+        return replace_once(text, "        plonky2::field::cfft::ntt::init_gpu();\n",
+                            "        plonky2::field::cfft::ntt::init_gpu();\n"
+                            '        #[cfg(feature = "hip")]\n        super::hip_prover::init_early();\n', "init_gpu() call in OlaStark::default()")
     if path == "plonky2/plonky2/src/util/timing.rs":
         # TimingTree's fields are private and push / pop read the host's clock: a scope that ran on the GPU and is already over
         # needs one method that appends a closed node with given times
