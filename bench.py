@@ -265,7 +265,7 @@ heights = [%(log_n)d, %(log_n)d, 18, 1, 16, 10, 10, 10, 10, 10, 10, 10]
 t0 = time.perf_counter()                                  # `ola prove` has read its input: OlaStark::default() is next (client/src/main.rs:193)
 B.load_library()
 if %(early)d:
-    B.warmup(%(device)d)                                  # the patched ola_stark.rs:47 -> hip_prover::init_early(); returns at once
+    B.warmup(%(device)d, airset=blob)                     # the patched ola_stark.rs:47 -> hip_prover::init_early(); returns at once
 t_tr = time.perf_counter()
 traces, params, compress = tracegen.empty_program_instance(log_n=10, range_bits=16, limb_bits=8, log_n_cpu=%(log_n)d, log_n_mem=%(log_n)d)
 assert [int(t.shape[1]).bit_length() - 1 for t in traces] == heights, [int(t.shape[1]).bit_length() - 1 for t in traces]
@@ -274,12 +274,15 @@ be = B.Backend(device=%(device)d, hasher=%(hasher)r)      # hip_prover.rs with_c
 t2 = time.perf_counter()
 p1 = be.prove_with_traces(blob, traces, params, compress)
 t3 = time.perf_counter()
+up1 = be.upload_stats()
 p2 = be.prove_with_traces(blob, traces, params, compress)
 t4 = time.perf_counter()
+up2 = be.upload_stats()
 warm_ms = B.warmup_wait() if %(early)d else None
 print(json.dumps({"early_hook": bool(%(early)d), "start_to_first_proof_seconds": round(t3 - t0, 4), "trace_generation_seconds": round(t1 - t_tr, 3),
                   "init_seconds_seen_by_the_prover": round(t2 - t1, 4), "first_proof_seconds": round(t3 - t2, 4), "second_proof_seconds": round(t4 - t3, 4),
-                  "warmup_thread_ms": warm_ms, "identical": p1 == p2}))
+                  "warmup_thread_ms": warm_ms, "upload_wait_ms": [round(up1["waited_ms"], 1), round(up2["waited_ms"], 1)],
+                  "upload_ms": [round(up1["total_ms"], 1), round(up2["total_ms"], 1)], "identical": p1 == p2}))
 """
 
 
@@ -290,6 +293,10 @@ def cold_process_prove(log_n, device, early, hasher="poseidon"):
     the boundary without the hook: the HIP runtime, the device and the code objects come up inside the first prove_with_traces.
     `excess_over_warm` = (start -> first proof done, minus the host's trace generation) / a warm proof."""
     import subprocess
+    # VRAM that a process has just freed is handed to the next one dirty and is scrubbed inside its hipMalloc (30 ms per GB) until
+    # the driver has cleaned it in the background -- a few seconds (profiles/r06_cold_start.txt: children run back to back show
+    # first proofs of 0.3 - 0.8 s at random, with a 4 s gap 0.237 - 0.243 s).  The gap keeps one child's dirt out of the next one's clock.
+    time.sleep(float(os.environ.get("OLA_COLD_GAP_S", "4")))
     try:
         out = subprocess.run([sys.executable, "-c", COLD_CHILD % {"root": ROOT, "log_n": log_n, "device": device, "early": 1 if early else 0, "hasher": hasher}],
                              capture_output=True, text=True, timeout=900)

@@ -109,15 +109,19 @@ int32_t ola_gpu_all_gather_check(OlaCtx* ctx, uint32_t carrier, size_t bytes_per
 int32_t ola_gpu_free(OlaCtx* ctx);
 /* Start-up ahead of the first context: replaces the reference's early hook -- OlaStark::default() calls
  * plonky2::field::cfft::ntt::init_gpu() (circuits/src/stark/ola_stark.rs:47, plonky2/field/src/cfft/ntt/mod.rs:53-99) before
- * prove() generates the traces (client/src/main.rs:191-200).  Returns at once; a helper thread starts the HIP runtime, opens
+ * prove() generates the traces (client/src/main.rs:193-195).  Returns at once; a helper thread starts the HIP runtime, opens
  * `device` (-1: the current one), loads the library's code objects (the main one and one per generated quotient kernel) and, with
- * OLA_WARMUP_PINNED_RING, pins the 128 MB staging ring of the trace upload for the first context created on that device.  None of
- * this depends on the StarkConfig or the hasher, which the caller does not know yet at that point.  ola_gpu_init /
- * ola_gpu_init_multi wait for a warm-up that is under way and then find the runtime up (a few milliseconds instead of 0.9 s: the
- * split is printed under OLA_TIMING=1).  Calling it again is a no-op; a failure inside the thread (no device) is reported by the
- * ola_gpu_init that follows, as it would have been without the warm-up. */
+ * OLA_WARMUP_PINNED_RING, pins the 128 MB staging ring of the trace upload.  With an AIR set (may be NULL; copied) it also creates
+ * a context with the default configuration and PRIMES it: one throw-away proof per hash configuration of an all-zero instance with
+ * small tables (divisibility check off, bytes discarded), so that every kernel of the proof path has been launched once, the
+ * transform tables exist and the upload path has carried data -- what otherwise makes the first proof of a process 1.2 - 1.4 x a
+ * warm one.  None of this depends on the StarkConfig or the hasher, which the caller does not know yet at that point:
+ * ola_gpu_init / ola_gpu_init_multi wait for a warm-up that is under way and, when cfg->stream is NULL and the device is the
+ * warmed one, take the primed context over (configuration and hasher are set then); otherwise they find at least the runtime up
+ * (5 ms instead of 160 ms: the split is printed under OLA_TIMING=1).  Calling it again is a no-op; a failure inside the thread
+ * (no device) is reported by the ola_gpu_init that follows, as it would have been without the warm-up. */
 #define OLA_WARMUP_PINNED_RING 1u
-int32_t ola_gpu_warmup(int32_t device, uint32_t flags);
+int32_t ola_gpu_warmup(int32_t device, uint32_t flags, const uint64_t* airset, size_t airset_words);
 /* Waits for the warm-up thread; *ms_out (may be NULL) = how long it ran.  OLA_E_INVALID_ARG when ola_gpu_warmup was never called,
  * OLA_E_HIP when the thread failed (message in ola_gpu_last_error). */
 int32_t ola_gpu_warmup_wait(double* ms_out);

@@ -44,14 +44,16 @@ unsafe impl Send for SendPtr {}
 /// Start-up where the reference has it: `OlaStark::default()` calls `plonky2::field::cfft::ntt::init_gpu()`
 /// (circuits/src/stark/ola_stark.rs:47, plonky2/field/src/cfft/ntt/mod.rs:53-99) before `prove()` generates the traces
 /// (client/src/main.rs:191-200); the patch adds this call on the next line.  Returns at once: a helper thread inside the library
-/// starts the HIP runtime, opens the device, loads the code objects and pins the upload ring while the host generates traces;
-/// the first `with_ctx` waits for it and then creates its context in milliseconds.  The hasher and the `StarkConfig` are not
+/// starts the HIP runtime, opens the device, loads the code objects, pins the upload ring and primes a context with a throw-away
+/// proof of a small all-zero instance while the host generates traces; the first `with_ctx` waits for it and takes that context
+/// over.  The hasher and the `StarkConfig` are not
 /// known here (`OlaStark` is generic over `F, D` only) and are not needed.  Errors are left to the `ola_gpu_init` that follows.
 pub fn init_early() {
     static ONCE: std::sync::Once = std::sync::Once::new();
     ONCE.call_once(|| {
         if check_abi().is_ok() {
-            let _ = unsafe { ola_gpu_warmup(-1, OLA_WARMUP_PINNED_RING) };
+            let words = airset();
+            let _ = unsafe { ola_gpu_warmup(-1, OLA_WARMUP_PINNED_RING, words.as_ptr(), words.len()) };
         }
     });
 }

@@ -112,7 +112,7 @@ extern "C" {
     pub fn ola_gpu_all_gather_check(ctx: *mut OlaCtx, carrier: u32, bytes_per_rank: usize, reps: u32, ms_per_gather: *mut f64,
         mismatches: *mut u64) -> i32;
     pub fn ola_gpu_free(ctx: *mut OlaCtx) -> i32;
-    pub fn ola_gpu_warmup(device: i32, flags: u32) -> i32;
+    pub fn ola_gpu_warmup(device: i32, flags: u32, airset: *const u64, airset_words: usize) -> i32;
     pub fn ola_gpu_warmup_wait(ms_out: *mut f64) -> i32;
     pub fn ola_gpu_last_error() -> *const c_char;
     pub fn ola_gpu_sync(ctx: *mut OlaCtx) -> i32;

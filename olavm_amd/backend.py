@@ -115,7 +115,7 @@ def load_library():
                                              C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]
     L.ola_gpu_scope_times.argtypes = [C.c_void_p, C.c_int32, C.POINTER(OlaScopeTime), C.c_uint32, C.POINTER(C.c_uint32)]
     L.ola_gpu_upload_stats.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
-    L.ola_gpu_warmup.argtypes = [C.c_int32, C.c_uint32]
+    L.ola_gpu_warmup.argtypes = [C.c_int32, C.c_uint32, U64P, C.c_size_t]
     L.ola_gpu_warmup_wait.argtypes = [C.POINTER(C.c_double)]
     L.ola_gpu_ntt_pass_times.argtypes = [C.c_void_p, C.c_int32, C.POINTER(OlaPassTime), C.c_uint32, C.POINTER(C.c_uint32)]
     L.ola_commit_values_shard.argtypes = [C.c_void_p, C.POINTER(U64P), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
@@ -161,11 +161,16 @@ EXPORTS = [
 OLA_WARMUP_PINNED_RING = 1
 
 
-def warmup(device=-1, pinned_ring=True):
-    """ola_gpu_warmup: start the HIP runtime, open the device and load the code objects on a helper thread; returns at once
-    (the reference's early hook: OlaStark::default() -> init_gpu(), circuits/src/stark/ola_stark.rs:47)."""
+def warmup(device=-1, pinned_ring=True, airset=None):
+    """ola_gpu_warmup: start the HIP runtime, open the device, load the code objects and -- with an AIR-set blob -- prime a context
+    with a throw-away proof, all on a helper thread; returns at once (the reference's early hook: OlaStark::default() ->
+    init_gpu(), circuits/src/stark/ola_stark.rs:47)."""
     L = load_library()
-    rc = L.ola_gpu_warmup(int(device), OLA_WARMUP_PINNED_RING if pinned_ring else 0)
+    if airset is not None:
+        a = np.ascontiguousarray(airset, dtype=np.uint64)
+        rc = L.ola_gpu_warmup(int(device), OLA_WARMUP_PINNED_RING if pinned_ring else 0, _p(a), a.size)
+    else:
+        rc = L.ola_gpu_warmup(int(device), OLA_WARMUP_PINNED_RING if pinned_ring else 0, None, 0)
     if rc != 0:
         raise OlaGpuError(rc, (L.ola_gpu_last_error() or b"").decode())
 

@@ -174,6 +174,7 @@ struct DeviceCtx {
     bool owns_stream = false;
     int hasher = 0;                            // OLA_HASH_POSEIDON / OLA_HASH_BLAKE3: GenericConfig::Hasher of the Merkle trees and the challenger
     bool timing = false;                       // OLA_TIMING=1: per-phase wall-clock on stderr (synchronises at phase edges)
+    bool priming = false;                      // ola_gpu_warmup's throw-away proof of an all-zero instance: the divisibility check is off
     std::vector<void*> persistent;
     std::multimap<size_t, void*> cache;        // free blocks by size
     std::unordered_map<void*, size_t> live;    // blocks handed out

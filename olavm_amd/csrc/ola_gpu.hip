@@ -39,6 +39,7 @@ struct OlaCtx {
     NttTables* tables = nullptr;
     OlaGpuConfig cfg;
     std::vector<uint8_t> pending_proof;   // an AllProof that did not fit the caller's buffer (ola_take_pending_proof)
+    bool first_proof_done = false;        // the first whole proof reserves its large blocks on a helper thread (prove_all)
     // A context that spans several GPUs (ola_gpu_init_multi): this object is rank 0, `peers` are ranks 1..n-1 (owned), `group`
     // their meeting point (peer_group.h).  Empty / null for a single-device context.
     std::vector<OlaCtx*> peers;
@@ -243,9 +244,44 @@ struct WarmState {
     std::string error;
     void* ring = nullptr;          // a pinned staging ring for the first context created on `device` (upload.h adopts it)
     size_t ring_bytes = 0;
+    OlaCtx* ready = nullptr;       // the context the priming proofs ran on (tables built, pool filled): the first ola_gpu_init on `device` takes it
     static WarmState& get() { static WarmState* w = new WarmState(); return *w; }
 };
-static void warmup_body(WarmState& w, int device, uint32_t flags) {
+// The priming instance: every table all zeros, heights that send the large tables through the three- and two-pass transforms, the
+// small ones through the single-pass kernels and one through the interpreter quotient kernel -- the size classes a real proof
+// uses.  The traces satisfy no AIR; DeviceCtx::priming switches the divisibility check off and the bytes are thrown away.
+static void prime_context(OlaCtx* c, const std::vector<u64>& airset) {
+    const std::vector<size_t> widths = airset_widths(airset.data(), airset.size());
+    const size_t nt = widths.size();
+    static const uint32_t pattern[12] = {12, 12, 18, 3, 16, 10, 10, 10, 10, 10, 10, 10};
+    std::vector<uint32_t> log_n(nt);
+    std::vector<std::vector<u64>> zeros(nt);
+    std::vector<TraceSource> src(nt);
+    for (size_t t = 0; t < nt; t++) {
+        log_n[t] = pattern[t % 12];
+        zeros[t].assign(widths[t] << log_n[t], 0);          // written, not calloc'ed: the upload path reads real pages
+        src[t].base = zeros[t].data();
+    }
+    c->dev.priming = true;
+    const bool acct = c->dev.acct.on, timing = c->dev.timing;
+    c->dev.acct.on = false; c->dev.timing = false;
+    for (uint32_t hasher : {OLA_HASH_POSEIDON, OLA_HASH_BLAKE3}) {
+        c->cfg.hasher = hasher; c->dev.hasher = (int)hasher;
+        std::vector<uint8_t> bytes;
+        try {
+            c->dev.acct.begin_proof();
+            c->dev.scopes_begin();
+            prove_with_traces(&c->dev, *c->tables, c->cfg, airset.data(), airset.size(), src.data(), log_n.data(), nullptr, nullptr, bytes);
+            HIP_CHECK(hipStreamSynchronize(c->dev.stream));
+            c->dev.acct.collect(nullptr);
+        } catch (const std::exception&) { (void)hipGetLastError(); (void)hipStreamSynchronize(c->dev.stream); }
+    }
+    c->dev.priming = false;
+    c->dev.acct.on = acct; c->dev.timing = timing;
+    c->cfg.hasher = OLA_HASH_POSEIDON; c->dev.hasher = 0;
+}
+
+static void warmup_body(WarmState& w, int device, uint32_t flags, std::vector<u64> airset) {
     const auto t0 = std::chrono::steady_clock::now();
     const bool timing = [] { const char* t = getenv("OLA_TIMING"); return t && *t && *t != '0'; }();
     auto t_lap = t0;
@@ -258,6 +294,7 @@ static void warmup_body(WarmState& w, int device, uint32_t flags) {
     std::string err;
     void* ring = nullptr;
     size_t ring_bytes = 0;
+    OlaCtx* ready = nullptr;
     int dev = device;
     try {
         int ndev = 0;
@@ -281,9 +318,20 @@ static void warmup_body(WarmState& w, int device, uint32_t flags) {
             else { (void)hipGetLastError(); ring = nullptr; }
             lap("pinned staging ring (128 MB)");
         }
+        if (!airset.empty()) {
+            // a context with the default configuration, primed by one throw-away proof per hash configuration: every kernel of the
+            // proof path has been launched once, the transform tables exist, the pool holds the small blocks.  ola_gpu_init takes it
+            // over (cfg and hasher are plain fields); the ring goes with it
+            std::unique_ptr<OlaCtx> c = create_device_ctx(resolve_config(nullptr), dev, nullptr);
+            if (ring) { c->dev.staging = ring; c->dev.staging_bytes = ring_bytes; ring = nullptr; ring_bytes = 0; }
+            prime_context(c.get(), airset);
+            ready = c.release();
+            lap("priming proofs (all-zero instance, both hash configurations)");
+        }
         HIP_CHECK(hipDeviceSynchronize());
     } catch (const std::exception& e) { err = e.what(); (void)hipGetLastError(); }
     std::lock_guard<std::mutex> lk(w.mu);
+    w.ready = ready;
     w.device = dev; w.error = err; w.ring = ring; w.ring_bytes = ring_bytes;
     w.ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     w.done = true;
@@ -294,6 +342,22 @@ static void warmup_join() {
     WarmState& w = WarmState::get();
     std::unique_lock<std::mutex> lk(w.mu);
     if (w.started) w.cv.wait(lk, [&] { return w.done; });
+}
+// the primed context, if the warm-up made one for this device and the caller does not bring a stream of its own
+static OlaCtx* take_warm_ctx(const OlaGpuConfig& c, int device) {
+    if (c.stream != nullptr) return nullptr;
+    WarmState& w = WarmState::get();
+    std::lock_guard<std::mutex> lk(w.mu);
+    if (!w.done || !w.ready) return nullptr;
+    int cur = -1;
+    if (device < 0 && hipGetDevice(&cur) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if ((device >= 0 ? device : cur) != w.device) return nullptr;
+    OlaCtx* r = w.ready;
+    w.ready = nullptr;
+    r->cfg = c;
+    r->cfg.device = w.device;
+    r->dev.hasher = (int)c.hasher;
+    return r;
 }
 namespace ola {
 // upload.h: the ring a warm-up pinned for this device, once
@@ -312,13 +376,15 @@ extern "C" {
 
 const char* ola_gpu_last_error(void) { return g_last_error.c_str(); }
 
-int32_t ola_gpu_warmup(int32_t device, uint32_t flags) {
+int32_t ola_gpu_warmup(int32_t device, uint32_t flags, const uint64_t* airset, size_t airset_words) {
     try {
         WarmState& w = WarmState::get();
         std::lock_guard<std::mutex> lk(w.mu);
         if (w.started) return OLA_OK;
+        std::vector<u64> set;
+        if (airset && airset_words) set.assign((const u64*)airset, (const u64*)airset + airset_words);   // the caller's copy need not outlive the call
         w.started = true;
-        std::thread([&w, device, flags] { warmup_body(w, device, flags); }).detach();
+        std::thread([&w, device, flags, set] { warmup_body(w, device, flags, set); }).detach();
     } catch (const std::exception& e) { g_last_error = e.what(); return OLA_E_INTERNAL; }
     return OLA_OK;
 }
@@ -346,7 +412,8 @@ int32_t ola_gpu_init(const OlaGpuConfig* cfg, OlaCtx** out_ctx) {
                                         std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_rt).count()); }
     const OlaGpuConfig c = resolve_config(cfg);
     require(c.device < ndev, "device index out of range");
-    *out_ctx = create_device_ctx(c, c.device, c.stream).release();
+    OlaCtx* warm = take_warm_ctx(c, c.device);
+    *out_ctx = warm ? warm : create_device_ctx(c, c.device, c.stream).release();
     (*out_ctx)->dev.join_pool_registry();
     g_live_contexts.fetch_add(1);
     OLA_CATCH
@@ -371,7 +438,9 @@ int32_t ola_gpu_init_multi(const OlaGpuConfig* cfg, const int32_t* devices, uint
     int prev = -1;
     if (hipGetDevice(&prev) != hipSuccess) { prev = -1; (void)hipGetLastError(); }
     struct Restore { int d; ~Restore() { if (d >= 0) (void)hipSetDevice(d); } } restore{prev};
-    std::unique_ptr<OlaCtx> root = create_device_ctx(c, dv[0], c.stream);
+    OlaCtx* warm = take_warm_ctx(c, dv[0]);
+    std::unique_ptr<OlaCtx> root = warm ? std::unique_ptr<OlaCtx>(warm) : create_device_ctx(c, dv[0], c.stream);
+    if (warm) HIP_CHECK(hipSetDevice(dv[0]));
     if (n_devices > 1) {
         for (uint32_t r = 1; r < n_devices; r++) root->peers.push_back(create_device_ctx(c, dv[r], nullptr).release());
         // xGMI peer access between every pair of distinct devices (the all-gather pulls from the peers' memory)
@@ -828,6 +897,18 @@ static void prove_all(OlaCtx* ctx, const uint64_t* airset, size_t airset_words, 
     std::vector<uint8_t> bytes;
     if (ctx->peers.empty()) {
         const auto t0 = std::chrono::steady_clock::now();
+        // The first whole proof of a context finds an empty pool: a helper thread starts allocating every large block the proof
+        // will ask for (reserve_for_proof, ola_gpu_reserve's list: the ones needed first come first) while this thread uploads
+        // and commits -- hipMalloc of tens of GB, and the driver's scrubbing of previously used VRAM inside it, then overlap the
+        // first commitments instead of stalling each later phase when it asks for a size the pool has not seen (the memory
+        // table's quotient commitment: 104 ms cold against 41 ms warm).  OLA_AUTO_RESERVE=0 switches it off.
+        if (!ctx->first_proof_done) {
+            ctx->first_proof_done = true;
+            static const bool auto_reserve = [] { const char* e = getenv("OLA_AUTO_RESERVE"); return !(e && *e == '0'); }();
+            size_t cached;
+            { std::lock_guard<std::mutex> lk(ctx->dev.mu); cached = ctx->dev.cached_bytes + ctx->dev.pending.size(); }
+            if (auto_reserve && cached < ((size_t)1 << 30)) reserve_for_proof(&ctx->dev, ctx->cfg, (const u64*)airset, airset_words, log_n);
+        }
         ctx->dev.acct.begin_proof();
         ctx->dev.scopes_begin();
         prove_with_traces(&ctx->dev, *ctx->tables, ctx->cfg, (const u64*)airset, airset_words, src.data(), log_n,

@@ -19,9 +19,11 @@ import torch
 from olavm_amd import backend as B
 from tests import oracle_lib
 B.load_library()
+from olavm_amd.air import ola_tables as T
+blob = T.ola_stark().blob() if %(early)d == 2 else None
 t0 = time.perf_counter()
 if %(early)d:
-    B.warmup(0)
+    B.warmup(0, airset=blob)
     t_call = time.perf_counter() - t0
     time.sleep(2.0)                      # the host "generates traces"
     t1 = time.perf_counter()
@@ -49,11 +51,47 @@ def _child(early):
 
 
 def test_warmup_returns_at_once_and_takes_the_start_up_off_the_first_context():
-    early, lazy = _child(1), _child(0)
-    assert early["cap_ok"] and lazy["cap_ok"]                      # a context created after a warm-up computes the same commitment
-    assert early["call_s"] < 0.05, early                           # ola_gpu_warmup does not block
-    assert early["warm_ms"] > 50                                   # the thread did the start-up ...
+    early, primed, lazy = _child(1), _child(2), _child(0)
+    assert early["cap_ok"] and lazy["cap_ok"] and primed["cap_ok"]  # a context created after a warm-up (or taken over from it) computes the same commitment
+    assert early["call_s"] < 0.05 and primed["call_s"] < 0.05, (early, primed)   # ola_gpu_warmup does not block (the AIR set is copied)
+    assert early["warm_ms"] > 50 and primed["warm_ms"] > early["warm_ms"]          # the thread did the start-up (and the priming proofs)
     assert early["init_s"] < 0.25 * lazy["init_s"] + 0.05, (early, lazy)   # ... and ola_gpu_init no longer pays for it
+    assert primed["init_s"] < 0.25 * lazy["init_s"] + 0.05, (primed, lazy)
+
+
+def test_a_primed_context_proves_the_same_bytes_under_both_hashers():
+    """The context ola_gpu_init takes over from the warm-up ran two throw-away proofs of an all-zero instance with the
+    divisibility check off: afterwards it must be indistinguishable -- same AllProof bytes as the oracle prover under the
+    hasher it is given, and a trace that violates its constraints is refused again (OLA_E_QUOTIENT_DEGREE)."""
+    code = r"""
+import sys
+sys.path.insert(0, %r)
+import numpy as np, torch
+from olavm_amd import backend as B
+from olavm_amd.air import miniexec as M, ola_tables as T
+from tests import oracle_lib
+o = oracle_lib.load()
+blob = T.ola_stark(range_bits=4, limb_bits=2).blob()
+B.warmup(0, airset=blob)
+ms = B.warmup_wait()
+traces, params, compress = M.instance(M.fibonacci(12))
+for hasher in ("blake3", "poseidon"):
+    be = B.Backend(device=0, hasher=hasher)      # the first one takes the primed context over, the second is created afresh
+    got = be.prove_with_traces(blob, traces, params, compress)
+    with o.hasher(hasher):
+        assert got == o.prove_with_traces(blob, traces, params, compress), hasher
+    bad = [np.array(t, copy=True) for t in traces]
+    bad[0][3, 1] ^= 1
+    try:
+        be.prove_with_traces(blob, bad, params, compress)
+        raise SystemExit("a broken trace was accepted")
+    except B.OlaGpuError as e:
+        assert e.code == -4, e
+    be.close()
+print("ok %%.1f" %% ms)
+""" % ROOT
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "ok" in out.stdout, (out.stdout[-500:], out.stderr[-1500:])
 
 
 def test_warmup_wait_without_warmup_is_an_error():

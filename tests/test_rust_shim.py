@@ -156,7 +156,7 @@ def test_patch_is_current_and_applies_to_the_reference(tmp_path):
     assert stark[46].strip() == "plonky2::field::cfft::ntt::init_gpu();" and stark[47].strip() == '#[cfg(feature = "hip")]'
     assert stark[48].strip() == "super::hip_prover::init_early();"
     shim0 = open(os.path.join(ROOT, "integration", "rust", "hip_prover.rs")).read()
-    assert "pub fn init_early()" in shim0 and "ola_gpu_warmup(-1, OLA_WARMUP_PINNED_RING)" in shim0
+    assert "pub fn init_early()" in shim0 and "ola_gpu_warmup(-1, OLA_WARMUP_PINNED_RING, words.as_ptr(), words.len())" in shim0
     # the cached context is keyed by the configuration it was created with, and column counts are checked against the AIR set
     assert "*old_key != key" in shim0 and "ola_table_shape(c, words.as_ptr(), words.len(), t as u32" in shim0
     client = open(os.path.join(REF, "client/src/main.rs")).read().split("\n")

@@ -35,7 +35,9 @@ import time, sys
 sys.path.insert(0, '.')
 import torch
 from olavm_amd import backend as B
-B.load_library(); t0 = time.perf_counter(); B.warmup(0); t1 = time.perf_counter(); ms = B.warmup_wait(); t2 = time.perf_counter()
+from olavm_amd.air import ola_tables as T
+blob = T.ola_stark().blob()
+B.load_library(); t0 = time.perf_counter(); B.warmup(0, airset=blob); t1 = time.perf_counter(); ms = B.warmup_wait(); t2 = time.perf_counter()
 be = B.Backend(device=0); t3 = time.perf_counter()
 print('ola_gpu_warmup call %.2f ms, thread %.1f ms, ola_gpu_init after it %.1f ms' % ((t1 - t0) * 1e3, ms, (t3 - t2) * 1e3))
 " 2>&1 | grep -v amdgpu | tee -a $O/init_split.txt ;;
