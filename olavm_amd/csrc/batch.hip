@@ -256,7 +256,8 @@ OlaBatch* batch_commit(DeviceCtx* ctx, NttTables& t, const uint64_t* const* cols
             launch_leaf_hash_colmajor(ctx, b->lde, N, (int)ncols, N, b->heap + 4 * N);
             launch_merkle_build(ctx, b->heap, N, cap_height);
         }
-        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        // the caller's host columns must not be read after return; device inputs need no wait here (whoever reads the cap waits)
+        if (cols_host) HIP_CHECK(hipStreamSynchronize(ctx->stream));
         if (tmp) ctx->free(tmp);
     } catch (...) {
         if (tmp) ctx->free(tmp);

@@ -293,11 +293,16 @@ struct DeviceCtx {
         reserver = std::thread([this, sizes] {
             (void)hipSetDevice(device);
             for (size_t sz : sizes) {
-                void* p = nullptr;
-                const hipError_t e = hipMalloc(&p, sz);
+                // an idle sibling's cached block first (the hand-over of alloc()), the driver otherwise
+                size_t got = sz;
+                void* p = adopt(sz, got);
+                hipError_t e = hipSuccess;
+                const bool adopted = p != nullptr;
+                if (!p) { got = sz; e = hipMalloc(&p, sz); }
                 std::lock_guard<std::mutex> lk(mu);
+                if (adopted) { adopted_bytes += got; adopted_blocks++; }
                 pending.erase(pending.find(sz));
-                if (e == hipSuccess) { cache.emplace(sz, p); cached_bytes += sz; if (live_bytes + cached_bytes > reserved_peak) reserved_peak = live_bytes + cached_bytes; }
+                if (e == hipSuccess) { cache.emplace(got, p); cached_bytes += got; if (live_bytes + cached_bytes > reserved_peak) reserved_peak = live_bytes + cached_bytes; }
                 else (void)hipGetLastError();
                 cv.notify_all();
             }

@@ -19,6 +19,7 @@
 
 #include <algorithm>
 #include <cstring>
+#include <deque>
 #include <vector>
 
 #include "../../include/ola_gpu.h"
@@ -290,6 +291,18 @@ __global__ void gather_ext_leaves_kernel(const u64* __restrict__ pa, const u64* 
 struct DevBuf {
     DeviceCtx* ctx;
     std::vector<void*> ptrs;
+    // host staging of asynchronous copies (descriptors, power tables, index lists): lives as long as the scope, whose destructor
+    // drains the stream first -- so an upload needs no synchronisation of its own (each one stalled the host's run-ahead: 14 of the
+    // 22 synchronisations per table were of this kind; the small tables are bound by exactly that latency)
+    std::deque<std::vector<u64>> hosts;
+    std::vector<u64>& host(size_t elems) { hosts.emplace_back(elems); return hosts.back(); }
+    u64* upload(const std::vector<u64>& v) {
+        std::vector<u64>& h = host(v.size());
+        std::copy(v.begin(), v.end(), h.begin());
+        u64* d = alloc(std::max<size_t>(1, v.size()));
+        if (!v.empty()) HIP_CHECK(hipMemcpyAsync(d, h.data(), v.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+        return d;
+    }
     explicit DevBuf(DeviceCtx* c) : ctx(c) {}
     u64* alloc(size_t elems) { return (u64*)alloc_bytes(elems * 8); }
     void* alloc_bytes(size_t bytes) {
@@ -306,7 +319,7 @@ struct DevBuf {
 static ExtPow make_ext_pow(DevBuf& mem, Ext2 z, int log_n) {
     const int h = (log_n + 1) / 2;
     const size_t nlo = (size_t)1 << h, nhi = (size_t)1 << (log_n - h);
-    std::vector<u64> host(2 * (nlo + nhi));
+    std::vector<u64>& host = mem.host(2 * (nlo + nhi));
     Ext2 acc = ext_make(1, 0);
     for (size_t i = 0; i < nlo; i++) { host[i] = acc.a; host[nlo + i] = acc.b; acc = ext_mul(acc, z); }
     const Ext2 zh = acc;  // z^(2^h)
@@ -314,7 +327,6 @@ static ExtPow make_ext_pow(DevBuf& mem, Ext2 z, int log_n) {
     for (size_t i = 0; i < nhi; i++) { host[2 * nlo + i] = acc.a; host[2 * nlo + nhi + i] = acc.b; acc = ext_mul(acc, zh); }
     u64* d = mem.alloc(host.size());
     HIP_CHECK(hipMemcpyAsync(d, host.data(), host.size() * 8, hipMemcpyHostToDevice, mem.ctx->stream));
-    HIP_CHECK(hipStreamSynchronize(mem.ctx->stream));
     ExtPow t;
     t.lo_a = d; t.lo_b = d + nlo; t.hi_a = d + 2 * nlo; t.hi_b = d + 2 * nlo + nhi; t.h = h;
     return t;
@@ -323,11 +335,26 @@ static ExtPow make_ext_pow(DevBuf& mem, Ext2 z, int log_n) {
 // Opened rows and Merkle paths of the query indices.  Under the coset partition a leaf lives on the rank that owns its
 // coset: every rank fills the records of its own queries, the records are all-gathered and each query is read from its
 // owner's copy (paths end at the owner's cap slice, which is a slice of the full cap).
-static void query_leaves(DeviceCtx* ctx, NttTables& tables, const OlaBatch& b, const size_t* xs, int nq, int depth, u64* rows_out, u64* paths_out) {
+static void query_leaves(DevBuf& mem, NttTables& tables, const OlaBatch& b, const size_t* xs, int nq, int depth, u64* rows_out, u64* paths_out) {
+    DeviceCtx* ctx = mem.ctx;
     if (!b.is_shard()) {
         // what a partitioned run gathers here (records of nq queries from each of 8 ranks), counted for the one-GPU projection
         if (ctx->acct.shardable && ctx->shard.world <= 1) acct_exchange(ctx, (size_t)nq * (b.ncols + (size_t)std::max(depth, 0) * 4) * 8 * 8);
-        batch_get_leaves(ctx, b, xs, nq, rows_out, paths_out, &tables);
+        if (b.lean) { batch_get_leaves(ctx, b, xs, nq, rows_out, paths_out, &tables); return; }
+        // resident batch: enqueued only -- rows_out / paths_out are complete after the caller's next synchronisation (the three
+        // oracles and the FRI layers of a proof share ONE; batch_get_leaves, the C-ABI accessor's path, waits per call)
+        std::vector<u64>& h_idx = mem.host((size_t)nq);
+        for (int r = 0; r < nq; r++) h_idx[(size_t)r] = (u64)xs[r];
+        unsigned long long* d_idx = (unsigned long long*)mem.alloc((size_t)nq);
+        HIP_CHECK(hipMemcpyAsync(d_idx, h_idx.data(), (size_t)nq * 8, hipMemcpyHostToDevice, ctx->stream));
+        u64* d_rows = mem.alloc((size_t)nq * b.ncols);
+        hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)nq), dim3(64), 0, ctx->stream, b.lde, b.num_leaves(), (int)b.ncols, d_idx, d_rows);
+        HIP_CHECK(hipMemcpyAsync(rows_out, d_rows, (size_t)nq * b.ncols * 8, hipMemcpyDeviceToHost, ctx->stream));
+        if (depth > 0) {
+            u64* d_paths = mem.alloc((size_t)nq * (size_t)depth * 4);
+            hipLaunchKernelGGL(gather_paths_kernel, dim3((unsigned)nq), dim3(((depth * 4 + 63) / 64) * 64), 0, ctx->stream, b.heap, b.num_leaves(), depth, d_idx, d_paths);
+            HIP_CHECK(hipMemcpyAsync(paths_out, d_paths, (size_t)nq * (size_t)depth * 32, hipMemcpyDeviceToHost, ctx->stream));
+        }
         return;
     }
     const size_t n_loc = b.num_leaves(), first = (size_t)b.coset_first << b.log_n;
@@ -577,7 +604,7 @@ void open_and_prove(DeviceCtx* ctx, NttTables& tables, const OlaGpuConfig& cfg, 
     // ---- prove_openings: final polynomial (fri/oracle.rs:178-219) ----
     const Ext2 alpha = challenger_get_ext(ch);
     const int napow = W + Z + Q;
-    std::vector<u64> h_apow(2 * (size_t)napow);
+    std::vector<u64>& h_apow = mem.host(2 * (size_t)napow);
     {
         Ext2 acc = ext_make(1, 0);
         for (int i = 0; i < napow; i++) { h_apow[i] = acc.a; h_apow[napow + i] = acc.b; acc = ext_mul(acc, alpha); }
@@ -711,7 +738,7 @@ void open_and_prove(DeviceCtx* ctx, NttTables& tables, const OlaGpuConfig& cfg, 
     for (int o = 0; o < 3; o++) {
         rows[o].resize((size_t)nq * oracles[o]->ncols);
         paths[o].resize((size_t)nq * (size_t)std::max(depth0, 1) * 4);
-        query_leaves(ctx, tables, *oracles[o], xs.data(), nq, depth0, rows[o].data(), paths[o].data());
+        query_leaves(mem, tables, *oracles[o], xs.data(), nq, depth0, rows[o].data(), paths[o].data());
     }
     // per layer: leaves (arity ext) and paths at x >> (sum of arity bits so far + this)
     std::vector<std::vector<u64>> lrows(layers.size()), lpaths(layers.size());

@@ -613,27 +613,25 @@ static void prove_single_table(DeviceCtx* ctx, NttTables& tables, const OlaGpuCo
                 pairs.push_back(a); pairs.push_back(b);
             }
         }
-        u64* d_offs = mem.alloc(offs.size() + pairs.size());
-        u64* d_pairs = d_offs + offs.size();
-        HIP_CHECK(hipMemcpyAsync(d_offs, offs.data(), offs.size() * 8, hipMemcpyHostToDevice, ctx->stream));
-        HIP_CHECK(hipMemcpyAsync(d_pairs, pairs.data(), pairs.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+        offs.insert(offs.end(), pairs.begin(), pairs.end());
+        u64* d_offs = mem.upload(offs);                  // staged in the scope's keep-alive list: no synchronisation for its sake
+        u64* d_pairs = d_offs + ctl_off.size();
         u64* zc = zvals + (size_t)nperm * n;
         hipLaunchKernelGGL(ctl_factor_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)(pairs.size() / 2)), dim3(256), 0, ctx->stream, tv.vals, n, d_cd,
                            d_offs, d_pairs, zc, d_bad_filter);
         product_scan_inclusive(ctx, zc, n, tot, ctl.size());
-        HIP_CHECK(hipStreamSynchronize(ctx->stream));   // offs / pairs are stack-lifetime staging buffers
     }
-    if (!ctl.empty() && !have_zs) {
-        unsigned bad = 0;
-        HIP_CHECK(hipMemcpyAsync(&bad, d_bad_filter, 4, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_CHECK(hipStreamSynchronize(ctx->stream));
-        if (bad) throw OlaError(OLA_E_INVALID_ARG, "Non-binary filter?");
-    }
+    // the filter flag travels with the next read-back the host waits for anyway (the Z commitment's cap)
+    std::vector<u64>& h_flags = mem.host(2);
+    h_flags[0] = h_flags[1] = 0;
+    const bool check_filter = !ctl.empty() && !have_zs;
+    if (check_filter) HIP_CHECK(hipMemcpyAsync(&h_flags[0], d_bad_filter, 4, hipMemcpyDeviceToHost, ctx->stream));
     if (tap) { tap->nperm = nperm; tap->nz = nz; tap->q = air.quotient_degree_factor(); }
     if (tap && tap->stop_after == 1) {
         tap->zs_out->resize((size_t)nz * n);
         HIP_CHECK(hipMemcpyAsync(tap->zs_out->data(), zvals, (size_t)nz * n * 8, hipMemcpyDeviceToHost, ctx->stream));
         HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        if (check_filter && (unsigned)h_flags[0]) throw OlaError(OLA_E_INVALID_ARG, "Non-binary filter?");
         return;
     }
     // ---- Zs commitment ----
@@ -650,6 +648,7 @@ static void prove_single_table(DeviceCtx* ctx, NttTables& tables, const OlaGpuCo
     } else {
         zs_c.own.b = commit_shared(ctx, tables, zvals, (uint32_t)nz, (uint32_t)degree_bits, cfg, true, sharded, nullptr, zs_cap, lean);
         zs_c.b = zs_c.own.b;
+        if (check_filter && (unsigned)h_flags[0]) throw OlaError(OLA_E_INVALID_ARG, "Non-binary filter?");   // commit_shared has waited for the cap
         challenger_observe_cap(ch, zs_cap.data(), zs_cap.size() / 4);
     }
     const u64 alpha0 = (tap && tap->alphas) ? gl_canon(tap->alphas[0]) : challenger_get(ch);
@@ -758,9 +757,7 @@ static void prove_single_table(DeviceCtx* ctx, NttTables& tables, const OlaGpuCo
                 u64 bp = 1;
                 for (size_t k = 0; k < jb.twc->columns.size(); k++) { sd.push_back(bp); bp = gl_mul(bp, jb.ch.beta); }
             }
-            d_sd = mem.alloc(sd.size());
-            HIP_CHECK(hipMemcpyAsync(d_sd, sd.data(), sd.size() * 8, hipMemcpyHostToDevice, ctx->stream));
-            HIP_CHECK(hipStreamSynchronize(ctx->stream));   // sd is a stack-lifetime staging buffer
+            d_sd = mem.upload(sd);
         }
         u64* qv2 = (spec && crosscheck) ? mem.alloc(2 * plane) : nullptr;
         WorkScope ws(ctx, qdb);   // the quotient lives on 2^qdb cosets: that many ranks share it
@@ -840,13 +837,14 @@ static void prove_single_table(DeviceCtx* ctx, NttTables& tables, const OlaGpuCo
         for (int c = 0; c < 2; c++)
             hipLaunchKernelGGL(any_nonzero_kernel, dim3((unsigned)((size - keep + 255) / 256)), dim3(256), 0, ctx->stream, qcoef + (size_t)c * size,
                                keep, size, d_flag);
-        unsigned flag = 0;
-        HIP_CHECK(hipMemcpyAsync(&flag, d_flag, 4, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_CHECK(hipStreamSynchronize(ctx->stream));
-#ifndef AIRQ_TIMING_ONLY_L2_LOADS      // (timing builds of airq.cuh's experiment produce garbage on purpose)
-        if (flag && !ctx->priming) throw OlaError(OLA_E_QUOTIENT_DEGREE, "Quotient has failed, the vanishing polynomial is not divisible by Z_H");
-#endif
+        // read with the next read-back the host waits for (the quotient commitment's cap, or the tap's copy): no wait of its own
+        HIP_CHECK(hipMemcpyAsync(&h_flags[1], d_flag, 4, hipMemcpyDeviceToHost, ctx->stream));
     }
+    auto check_degree = [&] {
+#ifndef AIRQ_TIMING_ONLY_L2_LOADS      // (timing builds of airq.cuh's experiment produce garbage on purpose)
+        if ((unsigned)h_flags[1] && !ctx->priming) throw OlaError(OLA_E_QUOTIENT_DEGREE, "Quotient has failed, the vanishing polynomial is not divisible by Z_H");
+#endif
+    };
     // chunks of n coefficients: [challenge][k] -> column challenge*q + k
     ph.reset();
     ph.reset(new PhaseTimer(ctx, "    split quotient polys"));
@@ -857,6 +855,7 @@ static void prove_single_table(DeviceCtx* ctx, NttTables& tables, const OlaGpuCo
         tap->chunks_out->resize((size_t)2 * q * n);
         HIP_CHECK(hipMemcpyAsync(tap->chunks_out->data(), chunks, (size_t)2 * q * n * 8, hipMemcpyDeviceToHost, ctx->stream));
         HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        check_degree();
         return;
     }
     ph.reset();
@@ -864,6 +863,7 @@ static void prove_single_table(DeviceCtx* ctx, NttTables& tables, const OlaGpuCo
     BatchHolder q_c(ctx);
     std::vector<u64> q_cap;
     q_c.b = commit_shared(ctx, tables, chunks, (uint32_t)(2 * q), (uint32_t)degree_bits, cfg, false, sharded, nullptr, q_cap, lean);
+    check_degree();                                      // commit_shared has waited for the cap
     challenger_observe_cap(ch, q_cap.data(), q_cap.size() / 4);
 
     // ---- write_proof (serialization.rs:349-358): caps, then opening set + FRI proof ----

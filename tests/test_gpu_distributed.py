@@ -93,8 +93,12 @@ def _prove_worker(rank, world, port, q, log_n=12, real=False, hasher="poseidon")
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,log_n,hasher", [(2, 12, "poseidon"), (4, 12, "poseidon"), (8, 12, "poseidon"), (2, 15, "poseidon"),
-                                                 (2, 12, "blake3"), (4, 12, "blake3")])
+# (round 6: the 8-rank and the 4-rank Poseidon cases left the default run -- 100 s of process start-up on the one shared GPU; 8 ranks
+# stay covered by test_coset_partitioned_proof_of_a_real_execution[8] and by the 8-rank multi-device context tests, 4 ranks by the
+# Blake3 case.  OLA_FULL_SUITE=1 brings them back.)
+_FULL = os.environ.get("OLA_FULL_SUITE") == "1"
+@pytest.mark.parametrize("world,log_n,hasher", [(2, 12, "poseidon"), (2, 15, "poseidon"), (2, 12, "blake3"), (4, 12, "blake3")]
+                         + ([(4, 12, "poseidon"), (8, 12, "poseidon")] if _FULL else []))
 def test_coset_partitioned_proof_equals_the_single_gpu_proof(world, log_n, hasher, oracle):
     """SURVEY 8e end to end: `world` ranks (sharing the one test GPU, gloo for the exchanges) each prove with their share
     of the cosets; every rank's AllProof bytes equal the single-GPU proof, which the oracle verifier accepts."""
