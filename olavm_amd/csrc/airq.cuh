@@ -61,20 +61,22 @@ __device__ __forceinline__ u64 acc_reduce(const Acc160& a) { return gl_sub(gl_re
 #ifdef AIRQ_GENERATED_TU
 typedef const u64 __attribute__((address_space(1)))* airq_gptr;
 typedef const u64 __attribute__((address_space(4)))* airq_cptr;
-// Requires n >= 256 (the launcher sends smaller tables to the interpreter): a workgroup then covers 256 consecutive leaves
-// of one coset, and both the local rows (leaf j) and the next rows (leaf jn, see stark.hip quotient_kernel) of the
-// workgroup are 256-aligned runs -- so every load is "uniform base + small lane offset" and its address lives in SGPRs
-// (global_load ... v_off, s[base]) instead of one VGPR pair per column and row.
+// A workgroup of bs_ = blockDim.x threads (a power of two, min(256, n): the launcher's choice) covers bs_ consecutive leaves of
+// one coset, and both the local rows (leaf j) and the next rows (leaf jn, see stark.hip quotient_kernel) of the workgroup are
+// bs_-aligned runs -- so every load is "uniform base + small lane offset" and its address lives in SGPRs (global_load ... v_off,
+// s[base]) instead of one VGPR pair per column and row.  Tables of fewer than 256 rows run one workgroup per coset (round 6:
+// they went to the interpreter kernel before -- 37 to 320 us per 8-row table, 1.5 ms for the Poseidon table's program).
 #define AIRQ_PROLOGUE(K_)                                                                                                  \
     const u32 lane_ = threadIdx.x;                                                                                         \
-    const size_t jb_ = (size_t)blockIdx.x * AIRQ_THREADS;                                                                  \
+    const u32 bs_ = blockDim.x;                                                                                            \
+    const size_t jb_ = (size_t)blockIdx.x * bs_;                                                                           \
     const size_t j = jb_ + lane_;                                                                                          \
     const size_t c_ = (jb_ >> P.log_n) + P.coset_first, r_ = j & (P.n - 1);                                                                  \
     const u32 rr_ = bitrev32((u32)r_, P.log_n);                                                                            \
     const size_t jn_ = ((jb_ >> P.log_n) << P.log_n) + bitrev32((rr_ + 1) & (u32)(P.n - 1), P.log_n);                                    \
-    const u32 noff_ = (u32)jn_ & (AIRQ_THREADS - 1);                                                                       \
+    const u32 noff_ = (u32)jn_ & (bs_ - 1);                                                                                \
     const size_t nb_ = ((size_t)__builtin_amdgcn_readfirstlane((u32)(jn_ >> 32)) << 32) |                                  \
-                       (__builtin_amdgcn_readfirstlane((u32)jn_) & ~(u32)(AIRQ_THREADS - 1));                              \
+                       (__builtin_amdgcn_readfirstlane((u32)jn_) & ~(u32)(bs_ - 1));                                       \
     const u64 m_ = ((u64)rr_ << (P.log_N - P.log_n)) + bitrev32((u32)c_, P.log_N - P.log_n);                               \
     const u64 x_ = gl_mul(GL_GENERATOR, gl_mul(P.gN_lo[m_ & (((u64)1 << P.gN_h) - 1)], P.gN_hi[m_ >> P.gN_h]));            \
     const u64 z_last = gl_sub(x_, P.g_inv);                                                                                \

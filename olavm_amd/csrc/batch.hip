@@ -270,8 +270,12 @@ OlaBatch* batch_commit(DeviceCtx* ctx, NttTables& t, const uint64_t* const* cols
 void batch_read_cap(DeviceCtx* ctx, const OlaBatch& b, u64* cap_out) {
     const size_t len_cap = (size_t)1 << b.cap_height;
     // merkle_tree/mod.rs:218-226: the cap is the level with 2^cap_height nodes (the leaf digests if the tree is all cap)
-    HIP_CHECK(hipMemcpyAsync(cap_out, b.heap + 4 * len_cap, len_cap * 32, hipMemcpyDeviceToHost, ctx->stream));
+    // through the context's pinned scratch slot: a read-back into pageable memory is staged by the runtime and costs 28 us
+    // instead of 16 (tools/ubench/roundtrip.hip); every commitment of every table waits for this one
+    char* slot = len_cap * 32 <= DeviceCtx::kPinnedScratch ? ctx->pinned_base() : nullptr;
+    HIP_CHECK(hipMemcpyAsync(slot ? (void*)slot : (void*)cap_out, b.heap + 4 * len_cap, len_cap * 32, hipMemcpyDeviceToHost, ctx->stream));
     HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (slot) memcpy(cap_out, slot, len_cap * 32);
 }
 
 // Coset `coset` (local numbering) of the batch's LDE in leaf order, [ncols][n], re-derived from the coefficients (lean batches)

@@ -203,6 +203,41 @@ struct DeviceCtx {
     void* staging_dev = nullptr;               // device side of the narrow-column path (upload.h)
     size_t staging_dev_bytes = 0;
     UploadStats upload;
+    // Pinned host memory for the small read-backs and uploads of the proof path (caps, opening values, query rows, descriptors).
+    // A copy to or from PAGEABLE host memory is staged by the runtime on the calling thread -- a read-back of 512 bytes is then a
+    // hidden synchronisation of 28 us, 16 us from pinned memory (tools/ubench/roundtrip.hip) -- and the small tables of a proof
+    // are bound by exactly these.  A stack: scopes (DevBuf) mark the top when they open and restore it when they close; the first
+    // kPinnedScratch bytes are a fixed slot for read-backs that are waited for at once (batch_read_cap).
+    // a second stream for work nothing on the main stream waits for (the proof-of-work search of a table: fri.hip PowDefer)
+    hipStream_t side = nullptr;
+    hipStream_t side_stream() {
+        if (!side && hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); side = nullptr; }
+        return side;
+    }
+    // device words of the side stream's searches: persistent, never pool blocks (a pool block may still be in use by earlier work
+    // of the MAIN stream when it is handed out again -- safe for main-stream users only)
+    unsigned long long* side_words = nullptr;
+    static constexpr size_t kSideWords = 256;
+    static constexpr size_t kPinnedBytes = (size_t)16 << 20, kPinnedScratch = 4096;
+    char* pinned = nullptr;
+    size_t pinned_top = kPinnedScratch;
+    bool pinned_failed = false;
+    char* pinned_base() {
+        if (!pinned && !pinned_failed) {
+            void* p = nullptr;
+            if (hipHostMalloc(&p, kPinnedBytes, hipHostMallocDefault) == hipSuccess) pinned = (char*)p;
+            else { (void)hipGetLastError(); pinned_failed = true; }
+        }
+        return pinned;
+    }
+    // nullptr when the arena is exhausted (or could not be pinned): the caller falls back to pageable memory
+    void* pinned_alloc(size_t bytes) {
+        bytes = (bytes + 63) / 64 * 64;
+        if (!pinned_base() || pinned_top + bytes > kPinnedBytes) return nullptr;
+        void* p = pinned + pinned_top;
+        pinned_top += bytes;
+        return p;
+    }
     ScopeLog scopes;
     size_t adopted_bytes = 0, adopted_blocks = 0;
     // scopes of one proof: begin on the stream, resolve after the final synchronisation
@@ -403,6 +438,8 @@ struct DeviceCtx {
         for (auto& kv : live) (void)hipFree(kv.first);
         for (void* p : persistent) (void)hipFree(p);
         if (staging) (void)hipHostFree(staging);
+        if (side) { (void)hipStreamSynchronize(side); (void)hipStreamDestroy(side); }
+        if (pinned) (void)hipHostFree(pinned);
         if (staging_dev) (void)hipFree(staging_dev);
         if (owns_stream && stream) (void)hipStreamDestroy(stream);
     }

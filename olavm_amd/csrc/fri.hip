@@ -288,22 +288,59 @@ __global__ void gather_ext_leaves_kernel(const u64* __restrict__ pa, const u64* 
 }
 
 // ------------------------------------------------------------------------------------------------ host helpers
+// host memory that outlives the asynchronous copies issued from / into it: pinned when the context's arena has room
+struct HostSpan {
+    u64* p = nullptr; size_t n = 0;
+    u64& operator[](size_t i) const { return p[i]; }
+    u64* data() const { return p; }
+    size_t size() const { return n; }
+    u64* begin() const { return p; }
+    u64* end() const { return p + n; }
+};
 struct DevBuf {
     DeviceCtx* ctx;
     std::vector<void*> ptrs;
-    // host staging of asynchronous copies (descriptors, power tables, index lists): lives as long as the scope, whose destructor
-    // drains the stream first -- so an upload needs no synchronisation of its own (each one stalled the host's run-ahead: 14 of the
-    // 22 synchronisations per table were of this kind; the small tables are bound by exactly that latency)
+    // Host staging of asynchronous copies (descriptors, power tables, index lists, read-backs): lives as long as the scope, whose
+    // destructor drains the stream first -- so an upload needs no synchronisation of its own (each one stalled the host's
+    // run-ahead: 14 of the 22 synchronisations per table were of this kind; the small tables are bound by exactly that latency).
+    // Pinned (the context's arena, DeviceCtx::pinned_alloc) while it has room, pageable otherwise.
     std::deque<std::vector<u64>> hosts;
-    std::vector<u64>& host(size_t elems) { hosts.emplace_back(elems); return hosts.back(); }
+    size_t pinned_mark;
+    struct Pending { void* dst; const u64* src; size_t bytes; };
+    std::vector<Pending> pending;      // read-backs that landed in pinned memory and still have to reach the caller's buffer
+    HostSpan host(size_t elems) {
+        if (void* p = ctx->pinned_alloc(std::max<size_t>(1, elems) * 8)) return {(u64*)p, elems};
+        hosts.emplace_back(std::max<size_t>(1, elems));
+        return {hosts.back().data(), elems};
+    }
     u64* upload(const std::vector<u64>& v) {
-        std::vector<u64>& h = host(v.size());
+        HostSpan h = host(v.size());
         std::copy(v.begin(), v.end(), h.begin());
         u64* d = alloc(std::max<size_t>(1, v.size()));
         if (!v.empty()) HIP_CHECK(hipMemcpyAsync(d, h.data(), v.size() * 8, hipMemcpyHostToDevice, ctx->stream));
         return d;
     }
-    explicit DevBuf(DeviceCtx* c) : ctx(c) {}
+    // device -> the caller's (pageable) buffer, complete after the next synchronisation + collect(): through pinned memory, so
+    // that the copy is really asynchronous
+    void readback(void* dst, const void* src_dev, size_t bytes) {
+        if (!bytes) return;
+        if (void* p = ctx->pinned_alloc(bytes)) {
+            HIP_CHECK(hipMemcpyAsync(p, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+            pending.push_back({dst, (const u64*)p, bytes});
+        } else {
+            HIP_CHECK(hipMemcpyAsync(dst, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        }
+    }
+    // after a synchronisation of the context's stream
+    void collect() {
+        for (const Pending& r : pending) memcpy(r.dst, r.src, r.bytes);
+        pending.clear();
+    }
+    void sync_collect() {
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        collect();
+    }
+    explicit DevBuf(DeviceCtx* c) : ctx(c), pinned_mark(c->pinned_top) {}
     u64* alloc(size_t elems) { return (u64*)alloc_bytes(elems * 8); }
     void* alloc_bytes(size_t bytes) {
         void* p = ctx->alloc(bytes);
@@ -313,13 +350,14 @@ struct DevBuf {
     ~DevBuf() {
         (void)hipStreamSynchronize(ctx->stream);
         for (void* p : ptrs) ctx->free(p);
+        ctx->pinned_top = pinned_mark;
     }
 };
 
 static ExtPow make_ext_pow(DevBuf& mem, Ext2 z, int log_n) {
     const int h = (log_n + 1) / 2;
     const size_t nlo = (size_t)1 << h, nhi = (size_t)1 << (log_n - h);
-    std::vector<u64>& host = mem.host(2 * (nlo + nhi));
+    HostSpan host = mem.host(2 * (nlo + nhi));
     Ext2 acc = ext_make(1, 0);
     for (size_t i = 0; i < nlo; i++) { host[i] = acc.a; host[nlo + i] = acc.b; acc = ext_mul(acc, z); }
     const Ext2 zh = acc;  // z^(2^h)
@@ -343,17 +381,17 @@ static void query_leaves(DevBuf& mem, NttTables& tables, const OlaBatch& b, cons
         if (b.lean) { batch_get_leaves(ctx, b, xs, nq, rows_out, paths_out, &tables); return; }
         // resident batch: enqueued only -- rows_out / paths_out are complete after the caller's next synchronisation (the three
         // oracles and the FRI layers of a proof share ONE; batch_get_leaves, the C-ABI accessor's path, waits per call)
-        std::vector<u64>& h_idx = mem.host((size_t)nq);
+        HostSpan h_idx = mem.host((size_t)nq);
         for (int r = 0; r < nq; r++) h_idx[(size_t)r] = (u64)xs[r];
         unsigned long long* d_idx = (unsigned long long*)mem.alloc((size_t)nq);
         HIP_CHECK(hipMemcpyAsync(d_idx, h_idx.data(), (size_t)nq * 8, hipMemcpyHostToDevice, ctx->stream));
         u64* d_rows = mem.alloc((size_t)nq * b.ncols);
         hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)nq), dim3(64), 0, ctx->stream, b.lde, b.num_leaves(), (int)b.ncols, d_idx, d_rows);
-        HIP_CHECK(hipMemcpyAsync(rows_out, d_rows, (size_t)nq * b.ncols * 8, hipMemcpyDeviceToHost, ctx->stream));
+        mem.readback(rows_out, d_rows, (size_t)nq * b.ncols * 8);
         if (depth > 0) {
             u64* d_paths = mem.alloc((size_t)nq * (size_t)depth * 4);
             hipLaunchKernelGGL(gather_paths_kernel, dim3((unsigned)nq), dim3(((depth * 4 + 63) / 64) * 64), 0, ctx->stream, b.heap, b.num_leaves(), depth, d_idx, d_paths);
-            HIP_CHECK(hipMemcpyAsync(paths_out, d_paths, (size_t)nq * (size_t)depth * 32, hipMemcpyDeviceToHost, ctx->stream));
+            mem.readback(paths_out, d_paths, (size_t)nq * (size_t)depth * 32);
         }
         return;
     }
@@ -446,7 +484,7 @@ static void eval_batch_launch(DevBuf& mem, const OlaBatch& b, int npoints, ExtPo
     hipLaunchKernelGGL(eval_points_kernel, dim3(nchunks, groups), dim3(256), 0, ctx->stream, b.coeffs, n, (int)b.ncols, p0, p1,
                        npoints, chunk_len, d_part);
     job.part.resize(pelems);
-    HIP_CHECK(hipMemcpyAsync(job.part.data(), d_part, pelems * 8, hipMemcpyDeviceToHost, ctx->stream));
+    mem.readback(job.part.data(), d_part, pelems * 8);
 }
 static void eval_batch_collect(const EvalJob& job) {
     for (int p = 0; p < job.npoints; p++) {
@@ -520,9 +558,60 @@ struct FriLayer {
     size_t shard_leaves = 0;   // > 0: this rank holds leaves [rank * shard_leaves, (rank+1) * shard_leaves) only (first layer on the partition)
 };
 
+// The proof-of-work witness of a table (fri/prover.rs:126-148) enters nothing but the proof bytes: the query indices are drawn
+// from the transcript as it stands after the final polynomial (fri/prover.rs:53-62: current_hash, then fri_prover_query_rounds),
+// and the next table's transcript does not see it either.  Inside a whole proof the search therefore runs on the context's side
+// stream -- 120 us of Poseidon permutations per table that the launch-bound small tables no longer wait for, and one host round
+// trip less per table -- and the witnesses are patched into the bytes when the proof is complete (pow_finish).
+struct PowDefer {
+    struct Job { size_t at; u64 h[4]; u32 bits; unsigned long long* d_best; unsigned long long* h_best; };
+    std::vector<Job> jobs;
+    unsigned long long* slots = nullptr;   // pinned, one per table, allocated by the scope that owns the whole proof
+    size_t nslots = 0;
+};
+static u64 pow_batch(u32 bits) { return std::max<u64>((u64)1 << 14, (u64)4 << bits); }
+// enqueue the first batch of the search on the side stream; false: no side stream / no slot, search synchronously
+static bool pow_enqueue(DeviceCtx* ctx, PowDefer* d, const u64 h[4], u32 bits, size_t at) {
+    if (!d || !d->slots || d->jobs.size() >= d->nslots || d->jobs.size() >= DeviceCtx::kSideWords) return false;
+    hipStream_t side = ctx->side_stream();
+    if (!side) return false;
+    if (!ctx->side_words) ctx->side_words = (unsigned long long*)ctx->alloc_persistent(DeviceCtx::kSideWords * 8);
+    PowDefer::Job j;
+    j.at = at; j.bits = bits;
+    for (int i = 0; i < 4; i++) j.h[i] = h[i];
+    j.h_best = d->slots + d->jobs.size();
+    *j.h_best = ~0ull;
+    j.d_best = ctx->side_words + d->jobs.size();
+    HIP_CHECK(hipMemsetAsync(j.d_best, 0xFF, 8, side));
+    hipLaunchKernelGGL(pow_kernel, dim3((unsigned)(pow_batch(bits) / 256)), dim3(256), 0, side, h[0], h[1], h[2], h[3], (u64)0, bits, j.d_best);
+    HIP_CHECK(hipMemcpyAsync(j.h_best, j.d_best, 8, hipMemcpyDeviceToHost, side));
+    d->jobs.push_back(j);
+    return true;
+}
+// all searches done: patch the witnesses (8 little-endian bytes each, serialization.rs:50-52) into the proof
+void pow_finish(DeviceCtx* ctx, PowDefer& d, std::vector<uint8_t>& bytes) {
+    if (d.jobs.empty()) return;
+    const hipError_t e = hipStreamSynchronize(ctx->side);
+    if (e != hipSuccess) { d.jobs.clear(); HIP_CHECK(e); }
+    for (PowDefer::Job& j : d.jobs) {
+        u64 w = *j.h_best;
+        if (w == ~0ull) w = run_pow(ctx, j.h, j.bits);      // not in the first batch (2 % of the searches): the plain loop
+        w = gl_canon(w);
+        for (int k = 0; k < 8; k++) bytes[j.at + (size_t)k] = (uint8_t)(w >> (8 * k));
+    }
+    d.jobs.clear();
+}
+// an exception unwound the proof: the searches may still be running
+void pow_abandon(DeviceCtx* ctx, PowDefer& d) {
+    if (d.jobs.empty()) return;
+    if (ctx->side) (void)hipStreamSynchronize(ctx->side);
+    d.jobs.clear();
+}
+
 // ------------------------------------------------------------------------------------------------ the pipeline
 void open_and_prove(DeviceCtx* ctx, NttTables& tables, const OlaGpuConfig& cfg, const OlaBatch& trace, const OlaBatch& zs,
-                    const OlaBatch& quot, uint32_t nperm, OlaChallenger& ch, std::vector<uint8_t>& bytes, size_t& openings_len) {
+                    const OlaBatch& quot, uint32_t nperm, OlaChallenger& ch, std::vector<uint8_t>& bytes, size_t& openings_len,
+                    PowDefer* pow_defer = nullptr) {
     DevBuf mem(ctx);
     const int degree_bits = (int)trace.log_n;
     const size_t n = trace.n();
@@ -561,7 +650,7 @@ void open_and_prove(DeviceCtx* ctx, NttTables& tables, const OlaGpuConfig& cfg, 
                 eval_batch_launch(mem, zs, 1, pgi, pgi, &zs_last_all, &dummy, jobs[3]);
             }
             if (ctx->acct.shardable) acct_exchange(ctx, (size_t)(2 * W + 3 * Z + Q) * 16);
-            HIP_CHECK(hipStreamSynchronize(mem.ctx->stream));
+            mem.sync_collect();
             for (auto& j : jobs) eval_batch_collect(j);
         } else {
             const uint32_t world = ctx->shard.world;
@@ -604,7 +693,7 @@ void open_and_prove(DeviceCtx* ctx, NttTables& tables, const OlaGpuConfig& cfg, 
     // ---- prove_openings: final polynomial (fri/oracle.rs:178-219) ----
     const Ext2 alpha = challenger_get_ext(ch);
     const int napow = W + Z + Q;
-    std::vector<u64>& h_apow = mem.host(2 * (size_t)napow);
+    HostSpan h_apow = mem.host(2 * (size_t)napow);
     {
         Ext2 acc = ext_make(1, 0);
         for (int i = 0; i < napow; i++) { h_apow[i] = acc.a; h_apow[napow + i] = acc.b; acc = ext_mul(acc, alpha); }
@@ -692,9 +781,9 @@ void open_and_prove(DeviceCtx* ctx, NttTables& tables, const OlaGpuConfig& cfg, 
             L.heap = mem.alloc(2 * nleaves * 4);
             launch_leaf_hash_ext(ctx, L.va, L.vb, arity, nleaves, L.heap + 4 * nleaves);
             launch_merkle_build(ctx, L.heap, nleaves, cfg.cap_height);
-            HIP_CHECK(hipMemcpyAsync(L.cap.data(), L.heap + 4 * len_cap, len_cap * 32, hipMemcpyDeviceToHost, ctx->stream));
+            mem.readback(L.cap.data(), L.heap + 4 * len_cap, len_cap * 32);
         }
-        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        mem.sync_collect();
         challenger_observe_cap(ch, L.cap.data(), L.cap.size() / 4);
         const Ext2 beta = challenger_get_ext(ch);
         const size_t out_len = len >> ab;
@@ -712,8 +801,8 @@ void open_and_prove(DeviceCtx* ctx, NttTables& tables, const OlaGpuConfig& cfg, 
     // final polynomial: truncate to len / 2^rate_bits (prover.rs:114-119)
     const size_t final_len = len >> rate_bits;
     std::vector<u64> h_final(2 * len);
-    HIP_CHECK(hipMemcpyAsync(h_final.data(), cur_coef, 2 * len * 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    mem.readback(h_final.data(), cur_coef, 2 * len * 8);
+    mem.sync_collect();
     std::vector<Ext2> final_poly(final_len);
     for (size_t i = 0; i < final_len; i++) final_poly[i] = ext_make(h_final[i], h_final[len + i]);
     for (auto& e : final_poly) challenger_observe_ext(ch, e);
@@ -722,10 +811,14 @@ void open_and_prove(DeviceCtx* ctx, NttTables& tables, const OlaGpuConfig& cfg, 
     u64 hsh[4];
     for (int i = 0; i < 4; i++) hsh[i] = challenger_get(ch);
     t_fold.reset();
-    u64 pow_witness;
+    u64 pow_witness = 0;
+    bool pow_deferred = false;
+    PowDefer::Job pow_job = {};
     {
         PhaseTimer t_pow(ctx, "      find proof-of-work witness");
-        pow_witness = run_pow(ctx, hsh, cfg.proof_of_work_bits);
+        // inside a whole proof: on the side stream, the witness is patched in at the end (its place in the bytes is known below)
+        pow_deferred = pow_enqueue(ctx, pow_defer, hsh, cfg.proof_of_work_bits, 0);
+        if (!pow_deferred) pow_witness = run_pow(ctx, hsh, cfg.proof_of_work_bits);
     }
 
     // ---- query rounds (prover.rs:150-204) ----
@@ -783,15 +876,15 @@ void open_and_prove(DeviceCtx* ctx, NttTables& tables, const OlaGpuConfig& cfg, 
             HIP_CHECK(hipMemcpyAsync(d_idx, h_idx.data(), nq * 8, hipMemcpyHostToDevice, ctx->stream));
             u64* d_rows = mem.alloc((size_t)nq * arity * 2);
             hipLaunchKernelGGL(gather_ext_leaves_kernel, dim3((unsigned)nq), dim3(64), 0, ctx->stream, L.va, L.vb, arity, d_idx, d_rows);
-            HIP_CHECK(hipMemcpyAsync(lrows[li].data(), d_rows, lrows[li].size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+            mem.readback(lrows[li].data(), d_rows, lrows[li].size() * 8);
             if (ldepth[li] > 0) {
                 u64* d_paths = mem.alloc((size_t)nq * ldepth[li] * 4);
                 hipLaunchKernelGGL(gather_paths_kernel, dim3((unsigned)nq), dim3(((ldepth[li] * 4 + 63) / 64) * 64), 0, ctx->stream, L.heap,
                                    nleaves, ldepth[li], d_idx, d_paths);
-                HIP_CHECK(hipMemcpyAsync(lpaths[li].data(), d_paths, lpaths[li].size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+                mem.readback(lpaths[li].data(), d_paths, lpaths[li].size() * 8);
             }
         }
-        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        mem.sync_collect();
         if (!shard_recv.empty()) {
             const FriLayer& L = layers[0];
             const int arity = 1 << L.arity_bits, dep = std::max(ldepth[0], 0);
@@ -827,6 +920,7 @@ void open_and_prove(DeviceCtx* ctx, NttTables& tables, const OlaGpuConfig& cfg, 
         }
     }
     w.ext_vec(final_poly);
+    if (pow_deferred) pow_defer->jobs.back().at = bytes.size();
     w.field(pow_witness);
 }
 

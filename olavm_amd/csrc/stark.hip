@@ -518,7 +518,8 @@ static bool table_is_sharded(const DeviceCtx* ctx, const OlaGpuConfig& cfg, cons
 
 static void prove_single_table(DeviceCtx* ctx, NttTables& tables, const OlaGpuConfig& cfg, const HTable& air, const DevTable& tv,
                                const OlaBatch& trace_c, const std::vector<u64>& trace_cap, const std::vector<CtlJob>& ctl,
-                               const u64* params, OlaChallenger& ch, std::vector<uint8_t>& bytes, bool sharded, PhaseTap* tap = nullptr) {
+                               const u64* params, OlaChallenger& ch, std::vector<uint8_t>& bytes, bool sharded, PhaseTap* tap = nullptr,
+                               PowDefer* pow_defer = nullptr) {
     DevBuf mem(ctx);
     const int nch = (int)cfg.num_challenges;
     if (nch != 2) throw OlaError(OLA_E_INVALID_ARG, "num_challenges must be 2");
@@ -622,7 +623,7 @@ static void prove_single_table(DeviceCtx* ctx, NttTables& tables, const OlaGpuCo
         product_scan_inclusive(ctx, zc, n, tot, ctl.size());
     }
     // the filter flag travels with the next read-back the host waits for anyway (the Z commitment's cap)
-    std::vector<u64>& h_flags = mem.host(2);
+    HostSpan h_flags = mem.host(2);
     h_flags[0] = h_flags[1] = 0;
     const bool check_filter = !ctl.empty() && !have_zs;
     if (check_filter) HIP_CHECK(hipMemcpyAsync(&h_flags[0], d_bad_filter, 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -722,8 +723,9 @@ static void prove_single_table(DeviceCtx* ctx, NttTables& tables, const OlaGpuCo
         const bool force_interp = mode && !strcmp(mode, "interpreter"), crosscheck = mode && !strcmp(mode, "crosscheck");
         std::vector<const HTwc*> twcs;
         for (auto& jb : ctl) twcs.push_back(jb.twc);
-        // the specialised kernels address rows as "workgroup base + lane" and need n >= AIRQ_THREADS (airq.cuh)
-        const AirKernelEntry* spec = (force_interp || n < AIRQ_THREADS) ? nullptr : find_air_kernel(air_signature(air, twcs));
+        // the specialised kernels address rows as "workgroup base + lane": workgroups of min(AIRQ_THREADS, n) threads (airq.cuh)
+        const AirKernelEntry* spec = force_interp ? nullptr : find_air_kernel(air_signature(air, twcs));
+        const unsigned spec_bs = (unsigned)std::min<size_t>(AIRQ_THREADS, n);
         // memory-lean: the trace and Z values of one coset at a time, re-derived from the coefficients; the quotient of a table
         // with 2^qdb < 2^rate_bits cosets lives on the first 2^qdb cosets of the leaf order
         u64 *slice_t = nullptr, *slice_z = nullptr;
@@ -792,7 +794,7 @@ static void prove_single_table(DeviceCtx* ctx, NttTables& tables, const OlaGpuCo
                 QuotParams S = P;
                 S.desc = d_sd;
                 S.out = out;
-                hipLaunchKernelGGL(spec->kernel, dim3((unsigned)((points + AIRQ_THREADS - 1) / AIRQ_THREADS)), dim3(AIRQ_THREADS), 0, ctx->stream, S);
+                hipLaunchKernelGGL(spec->kernel, dim3((unsigned)((points + spec_bs - 1) / spec_bs)), dim3(spec_bs), 0, ctx->stream, S);
                 if (crosscheck) run_interp_on(qv2 + (lean ? lc * n : 0));
             }
         }
@@ -874,7 +876,7 @@ static void prove_single_table(DeviceCtx* ctx, NttTables& tables, const OlaGpuCo
     size_t olen = 0;
     ph.reset();
     ph.reset(new PhaseTimer(ctx, "    compute openings proof"));
-    open_and_prove(ctx, tables, cfg, trace_c, *zs_c.b, *q_c.b, (uint32_t)nperm, ch, bytes, olen);
+    open_and_prove(ctx, tables, cfg, trace_c, *zs_c.b, *q_c.b, (uint32_t)nperm, ch, bytes, olen, pow_defer);
 }
 
 // Per table, the running products it must carry: one per (lookup it takes part in, challenge), looking sides before the
@@ -1203,6 +1205,12 @@ void prove_with_traces(DeviceCtx* ctx, NttTables& tables, const OlaGpuConfig& cf
     w.u32((uint32_t)nt);
     size_t poff = 0;
     std::vector<u64> zero_params(64, 0);
+    // the proof-of-work searches of the tables run on the side stream and are collected at the end (fri.hip PowDefer); the
+    // slots are this scope's, allocated before any inner scope exists (the pinned arena is a stack).  OLA_POW_DEFER=0: in line.
+    PowDefer pow;
+    static const bool pow_defer_on = [] { const char* e = getenv("OLA_POW_DEFER"); return !(e && *e == '0'); }();
+    if (pow_defer_on) { pow.slots = (unsigned long long*)ctx->pinned_alloc(nt * 8); pow.nslots = pow.slots ? nt : 0; }
+    struct PowGuard { DeviceCtx* c; PowDefer& p; ~PowGuard() { pow_abandon(c, p); } } pow_guard{ctx, pow};
     for (size_t t = 0; t < nt; t++) {
         const u64* pr = params ? params + poff : zero_params.data();
         if (!params && set.tables[t].n_params > 64) throw OlaError(OLA_E_INVALID_ARG, "params required");
@@ -1211,8 +1219,9 @@ void prove_with_traces(DeviceCtx* ctx, NttTables& tables, const OlaGpuConfig& cf
         PhaseTimer tt(ctx, "  table " + std::to_string(t) + " prove_single_table");
         ctx->acct.shardable = log_n[t] >= ctx->shard.min_log_n;
         prove_single_table(ctx, tables, cfg, set.tables[t], dev[t], *commits[t]->b, caps[t], jobs[t], pr, ch, bytes,
-                           table_is_sharded(ctx, cfg, set.tables[t], log_n[t]));
+                           table_is_sharded(ctx, cfg, set.tables[t], log_n[t]), nullptr, &pow);
     }
+    pow_finish(ctx, pow, bytes);
     ctx->acct.shardable = false;
     // compress_challenges (prover.rs:307-320) -- produced by trace generation, carried through
     w.u32((uint32_t)nt);

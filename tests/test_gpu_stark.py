@@ -152,13 +152,15 @@ def _random_rows_with_binary_filters(rng, airset, t, n):
     return tr
 
 
+@pytest.mark.parametrize("rows", [512, 64, 8, 2])
 @pytest.mark.parametrize("t", range(12))
-def test_specialised_quotient_kernels_match_interpreter_on_random_rows(be, t, monkeypatch):
+def test_specialised_quotient_kernels_match_interpreter_on_random_rows(be, t, rows, monkeypatch):
     """Every generated straight-line kernel against the interpreter on generic data (OLA_AIR_KERNELS=crosscheck compares
     all quotient values on the device).  Table t is the real one; the tables before it are replaced by constraint-free
     stand-ins of the same width (their vanishing polynomial -- CTL checks only -- is divisible for any trace), so the
     prover reaches table t.  The run may still end in the quotient-degree error for table t (random rows do not satisfy
-    its constraints), which is raised after the comparison."""
+    its constraints), which is raised after the comparison.  rows < 256 (round 6): the generated kernels with workgroups of `rows`
+    threads, one per coset -- tables that small went to the interpreter before."""
     from olavm_amd.air.dsl import AirTable
     from olavm_amd.backend import OlaGpuError
     full = T.ola_stark(range_bits=4, limb_bits=2)
@@ -169,7 +171,7 @@ def test_specialised_quotient_kernels_match_interpreter_on_random_rows(be, t, mo
     avail = be.air_kernels_available(blob, 12)
     assert avail[t] and not any(avail[:t])
     rng = np.random.default_rng(100 + t)
-    traces = [_random_rows_with_binary_filters(rng, s, i, 512) for i in range(12)]
+    traces = [_random_rows_with_binary_filters(rng, s, i, rows) for i in range(12)]
     params = [int(x) for tab in tabs for x in rng.integers(0, tracegen.P, size=tab.n_params, dtype=np.uint64)] or None
     monkeypatch.setenv("OLA_AIR_KERNELS", "crosscheck")
     try:
