@@ -385,7 +385,7 @@ int32_t ola_prove_with_traces(OlaCtx* ctx, const uint64_t* airset, size_t airset
  * cols[t][c]: pointer to the 2^log_n[t] values of column c of table t, wherever the caller's allocator put it; the Rust shim
  * passes `c.values.as_ptr() as *const u64` and copies nothing (precedent for per-column pointers: cfft/ntt/mod.rs:123-147).
  * ola_prove_with_traces is the special case cols[t][c] = traces[t] + c 2^log_n[t].  Everything else as above; host columns are
- * staged through the context's pinned ring by a few copier threads (OLA_UPLOAD_THREADS, default 6; olavm_amd/csrc/upload.h),
+ * staged through the context's pinned ring by a few copier threads (OLA_UPLOAD_THREADS, default min(4, host threads per rank - 1); olavm_amd/csrc/upload.h),
  * a table whose FIRST column is device memory is taken as resident on this GPU column by column. */
 int32_t ola_prove_with_traces_cols(OlaCtx* ctx, const uint64_t* airset, size_t airset_words, const uint64_t* const* const* cols,
                                    const uint32_t* log_n, const uint64_t* params, const uint64_t* compress_challenges,

@@ -207,6 +207,27 @@ def plan_lds(segcells, capacity):
     return hits, puts, loads
 
 
+def check_plan(plan, seen):
+    """The slot plan was made from a COUNTING print; the final print must cut the program into the same segments and touch the
+    same cells in each (a CL(slot) read of a differently segmented program would return another cell's value, and only the GPU
+    byte comparisons would notice).  Also replays the slots: a cell served from a slot was parked there by an earlier segment and
+    nothing has been parked over it since; a segment never parks into a slot it still reads."""
+    hits, puts, segs = plan
+    assert len(seen) == len(segs) == len(hits) == len(puts), (len(seen), len(segs), len(hits), len(puts))
+    for i, (a, b) in enumerate(zip(seen, segs)):
+        assert a == b, ("segment %d reads other cells than the plan assumed" % i, sorted(a ^ b))
+    slot = {}
+    for i, (hit, put) in enumerate(zip(hits, puts)):
+        for c, sl in hit.items():
+            assert slot.get(sl) == c, ("segment %d: slot %d holds %r, not %r" % (i, sl, slot.get(sl), c))
+            assert c in segs[i]
+        assert not set(hit.values()) & set(put.values()), ("segment %d parks into a slot it reads" % i)
+        assert len(set(put.values())) == len(put)
+        for c, sl in put.items():
+            assert c in segs[i] and c not in hit
+            slot[sl] = c
+
+
 def table_kernel(airset, t, name, num_challenges=2):
     """-> (source text of the kernel, K).  Printed several times: a counting print per candidate evaluation order finds the cells
     the lookup section keeps in registers and the cells every segment touches; plan_lds decides from that which cells sit in the
@@ -225,7 +246,7 @@ def table_kernel(airset, t, name, num_challenges=2):
             _table_kernel(airset, t, name, num_challenges, uses=uses, ctl_regs=regs, order=order, ctl_order=ctl_order)
             hits, puts, loads = plan_lds(uses["segs"], LDS_SLOTS)
             if best is None or loads < best[0]:
-                best = (loads, order, regs, (hits, puts), ctl_order)
+                best = (loads, order, regs, (hits, puts, [set(x) for x in uses["segs"]]), ctl_order)
         if len(tab.emits) < 3:
             break
     loads, order, regs, plan, ctl_order = best
@@ -259,6 +280,7 @@ def _table_kernel(airset, t, name, num_challenges=2, uses=None, ctl_regs=(), pla
     state = {"seg": 0, "ops": 0, "local": {}, "cells": {}}      # seg: running index over ALL segments (program, permutation, lookups)
     if uses is not None:
         uses["segs"].append(set())
+    seen = [set()]        # the cells this print touches per segment (checked against the plan's segments at the end)
 
     def cell(row, c):
         """Expression of trace cell (row 'L' / 'N', column c) at this place of the kernel."""
@@ -271,8 +293,9 @@ def _table_kernel(airset, t, name, num_challenges=2, uses=None, ctl_regs=(), pla
             uses["segs"][state["seg"]].add(k)
             if section["name"] == "ctl":
                 uses["ctl"][k] = uses["ctl"].get(k, 0) + 1
+        seen[state["seg"]].add(k)
         if plan is not None:
-            hits, puts = plan
+            hits, puts = plan[0], plan[1]
             if k in hits[state["seg"]]:
                 return "CL(%d)" % hits[state["seg"]][k]
             if k in puts[state["seg"]]:
@@ -289,6 +312,7 @@ def _table_kernel(airset, t, name, num_challenges=2, uses=None, ctl_regs=(), pla
         state["ops"] = 0
         state["local"] = {}
         state["cells"] = {}
+        seen.append(set())
         if uses is not None:
             uses["segs"].append(set())
 
@@ -440,6 +464,8 @@ def _table_kernel(airset, t, name, num_challenges=2, uses=None, ctl_regs=(), pla
         next_segment()
     e.idx = first_idx + 2 * len(jobs)
     assert e.idx == K, (e.idx, K)
+    if plan is not None:
+        check_plan(plan, seen)
     e.add("AIRQ_EPILOGUE")
     head = "// table %d (%s): %d columns, %d constraints, %d permutation Zs, %d CTL Zs, K = %d\n" % (
         t, tab.name, tab.ncols, len(tab.emits), nperm, len(jobs), K)

@@ -85,6 +85,9 @@ static void challenger_observe_ext(OlaChallenger& ch, Ext2 e) {
 struct ExtPow {
     const u64* lo_a; const u64* lo_b; const u64* hi_a; const u64* hi_b;
     int h;
+    // hi[kh] cut into 22-bit limbs for eval_points_wide_kernel: per kh twelve words [a: w0 w1 w2 | a 2^32: w0 w1 w2 | b: ... | b 2^32: ...]
+    // (null when the table was built without them)
+    const u32* hi_limbs;
 };
 __device__ __forceinline__ Ext2 ext_pow_lookup(const ExtPow& t, size_t k) {
     const size_t il = k & (((size_t)1 << t.h) - 1), ih = k >> t.h;
@@ -143,6 +146,129 @@ __global__ __launch_bounds__(256) void eval_points_kernel(const u64* __restrict_
                     o[1] = red[256];
                 }
             }
+        }
+    }
+}
+
+// The same evaluations for n >= 2^15 (round 6).  eval_points_kernel spends 124 VALU instructions per coefficient (two points):
+// four modular multiplications with their reductions, four modular additions, and a share of the two extension multiplications
+// that assemble z^k from the table -- 11 GB of coefficients of a 2^22-row proof at 1.0 - 1.2 TB/s, issue-bound
+// (profiles/r05_proof_pmc_blake3.txt: 2.72 G wave-instructions, traffic 1.0 x algorithmic).  Here
+//   f(z) = sum_kl lo[kl] * ( sum_kh hi[kh] f[kh 2^h + kl] ),      z^k = lo[k mod 2^h] hi[k >> h]:
+// a thread owns one kl and C columns and walks kh, so that
+//   * the multiplier hi[kh] is the same for the whole workgroup: it arrives through the scalar cache in SGPRs, cut by the host
+//     into three 22-bit limbs of w and of w 2^32 mod p (f w = f_lo w + f_hi (w 2^32));
+//   * a product f_half x limb is below 2^54, so the three limb positions are plain 64-bit sums of up to 1024 products: six
+//     v_mad_u64_u32 per coefficient, point and component, no carry, no reduction, no dependency between them;
+//   * the three sums are folded once per thread (one 128-bit reduction), multiplied by lo[kl] and added up over the workgroup.
+// 24 instructions per coefficient for two points instead of 124; the kernel then waits for HBM.
+// partial[pt][chunk][col] as for eval_points_kernel, chunk = blockIdx.x.
+#define EVALW_MAX_KH 512      // 2 products per step and sum: 1024 x 2^54 <= 2^64
+__device__ __forceinline__ u64 evalw_fold(const u64 (&c)[3]) {
+    // c0 + c1 2^22 + c2 2^44 as a 128-bit number (< 2^109), then one reduction
+    const unsigned __int128 v = (unsigned __int128)c[0] + ((unsigned __int128)c[1] << 22) + ((unsigned __int128)c[2] << 44);
+    return gl_reduce128((u64)v, (u64)(v >> 64));
+}
+// a load at (uniform base) + (the lane's 32-bit byte offset): the base stays in an SGPR pair (the empty statement hides the
+// offset's value, which keeps the optimiser from folding it into per-column VGPR pointers outside the loop: eight registers
+// that cost the kernel its fourth wave)
+__device__ __forceinline__ u64 evalw_load(const char* base, u32 off) {
+    asm("" : "+v"(off));
+    return *reinterpret_cast<const u64*>(base + off);
+}
+// a w + c = one v_mad_u64_u32 with w from an SGPR.  The empty statement pins the order of the additions: without it the optimiser
+// adds the two products of a limb position first and the running sum last -- a third instruction per pair.
+__device__ __forceinline__ u64 evalw_mad(u32 a, u32 w, u64 c) {
+    u64 d = c + (u64)a * w;
+    asm("" : "+v"(d));
+    return d;
+}
+__device__ __forceinline__ u64 wave_sum_gl(u64 v) {
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) {
+        const u32 lo = (u32)__shfl_xor((int)(u32)v, s, 64), hi = (u32)__shfl_xor((int)(u32)(v >> 32), s, 64);
+        v = gl_add(v, ((u64)hi << 32) | lo);
+    }
+    return v;
+}
+template <int C, int NP>
+__global__ __launch_bounds__(256) void eval_points_wide_kernel(const u64* __restrict__ coeffs, size_t n, int ncols, ExtPow p0, ExtPow p1,
+                                                               unsigned nlo_blocks, unsigned kh_per_block, u64* __restrict__ partial) {
+    __shared__ u64 red[4][C * NP * 2];
+    const int h = p0.h;
+    const unsigned lb = blockIdx.x % nlo_blocks, split = blockIdx.x / nlo_blocks;
+    const size_t kl = (size_t)lb * 256 + threadIdx.x;
+    const int c0 = blockIdx.y * C;
+    const unsigned kh0 = split * kh_per_block, kh1 = kh0 + kh_per_block;
+    u64 acc[C][NP][2][3];
+#pragma unroll
+    for (int c = 0; c < C; c++)
+#pragma unroll
+        for (int p = 0; p < NP; p++)
+#pragma unroll
+            for (int e = 0; e < 2; e++)
+#pragma unroll
+                for (int i = 0; i < 3; i++) acc[c][p][e][i] = 0;
+    // addresses: a uniform base per column and step (SGPRs) plus the thread's byte offset (one VGPR); the coefficients of step
+    // kh + 1 are asked for before step kh is multiplied
+    const u32 koff = (u32)(kl * 8);
+    const char* cbase[C];
+#pragma unroll
+    for (int c = 0; c < C; c++) cbase[c] = reinterpret_cast<const char*>(coeffs + (size_t)min(c0 + c, ncols - 1) * n);     // surplus columns redo the last one
+    const u32* __restrict__ L0 = p0.hi_limbs;
+    const u32* __restrict__ L1 = p1.hi_limbs;
+    auto load = [&](u64 (&f)[C], unsigned kh) {
+#pragma unroll
+        for (int c = 0; c < C; c++) f[c] = evalw_load(cbase[c] + (((size_t)kh << h) << 3), koff);
+    };
+    auto step = [&](const u64 (&f)[C], unsigned kh) {
+        u32 w[NP][12];
+#pragma unroll
+        for (int i = 0; i < 12; i++) {
+            w[0][i] = L0[(size_t)kh * 12 + i];
+            if (NP > 1) w[NP - 1][i] = L1[(size_t)kh * 12 + i];
+        }
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+            const u32 f0 = (u32)f[c], f1 = (u32)(f[c] >> 32);
+#pragma unroll
+            for (int p = 0; p < NP; p++)
+#pragma unroll
+                for (int e = 0; e < 2; e++)
+#pragma unroll
+                    for (int i = 0; i < 3; i++) {       // two multiply-adds INTO the sum (written as one expression the optimiser adds the products first: a third instruction)
+                        acc[c][p][e][i] = evalw_mad(f0, w[p][6 * e + i], acc[c][p][e][i]);
+                        acc[c][p][e][i] = evalw_mad(f1, w[p][6 * e + 3 + i], acc[c][p][e][i]);
+                    }
+        }
+    };
+    // two steps per turn (kh_per_block is even), each multiplying one buffer while the other one's loads are in flight
+    u64 fa[C], fb[C];
+    load(fa, kh0);
+    for (unsigned kh = kh0; kh < kh1; kh += 2) {
+        load(fb, kh + 1);
+        step(fa, kh);
+        load(fa, kh + 2 < kh1 ? kh + 2 : kh);
+        step(fb, kh + 1);
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int p = 0; p < NP; p++) {
+        const ExtPow& tp = p == 0 ? p0 : p1;
+        const Ext2 wl = ext_make(tp.lo_a[kl], tp.lo_b[kl]);
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+            const Ext2 v = ext_mul(ext_make(evalw_fold(acc[c][p][0]), evalw_fold(acc[c][p][1])), wl);
+            const u64 sa = wave_sum_gl(v.a), sb = wave_sum_gl(v.b);
+            if (lane == 0) { red[wave][(c * NP + p) * 2] = sa; red[wave][(c * NP + p) * 2 + 1] = sb; }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < C * NP * 2) {
+        const int idx = threadIdx.x, e = idx & 1, p = (idx >> 1) % NP, c = (idx >> 1) / NP;
+        if (c0 + c < ncols) {
+            const u64 sum = gl_add(gl_add(red[0][idx], red[1][idx]), gl_add(red[2][idx], red[3][idx]));
+            partial[(((size_t)p * gridDim.x + blockIdx.x) * ncols + (c0 + c)) * 2 + e] = sum;
         }
     }
 }
@@ -278,6 +404,41 @@ __global__ __launch_bounds__(256) void fold_kernel(const u64* __restrict__ ca, c
     ob[j] = s.b;
 }
 
+// The same fold for arity 16 with loads on consecutive addresses (round 6): thread j of fold_kernel reads sixteen words 128 bytes
+// apart from thread j + 1's -- 16.4 GB fetched per 2^22-row proof for 1.1 GB of coefficients (profiles/r05_proof_pmc_blake3.txt).
+// Here a thread loads TWO neighbouring coefficients of both planes with 16-byte loads, eight neighbouring lanes hold one output's
+// sixteen, and three exchanges join them: s = c_even + beta c_odd, then pairs by beta^2, beta^4, beta^8.  `nz_out` outputs are
+// computed (the caller zero-fills the rest: the first layer's planes are zero beyond the n coefficients, 7/8 of their length).
+__device__ __forceinline__ Ext2 ext_shfl_xor(Ext2 v, int m) {
+    Ext2 r;
+    r.a = ((u64)(u32)__shfl_xor((int)(u32)(v.a >> 32), m, 64) << 32) | (u32)__shfl_xor((int)(u32)v.a, m, 64);
+    r.b = ((u64)(u32)__shfl_xor((int)(u32)(v.b >> 32), m, 64) << 32) | (u32)__shfl_xor((int)(u32)v.b, m, 64);
+    return r;
+}
+__global__ __launch_bounds__(256) void fold16_kernel(const u64* __restrict__ ca, const u64* __restrict__ cb, size_t nz_out, Ext2 b1, Ext2 b2, Ext2 b4,
+                                                     Ext2 b8, u64* __restrict__ oa, u64* __restrict__ ob) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;      // pair index: coefficients 2t, 2t + 1
+    const size_t last = nz_out * 8 - 1;
+    const size_t tt = t < last ? t : last;                               // surplus lanes redo the last pair: the wave stays whole
+    const ulonglong2 va = *reinterpret_cast<const ulonglong2*>(ca + 2 * tt);
+    const ulonglong2 vb = *reinterpret_cast<const ulonglong2*>(cb + 2 * tt);
+    Ext2 s = ext_add(ext_make(va.x, vb.x), ext_mul(ext_make(va.y, vb.y), b1));
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        const int m = 1 << r;
+        const Ext2 pw = r == 0 ? b2 : (r == 1 ? b4 : b8);
+        const Ext2 o = ext_shfl_xor(s, m);
+        const bool up = (lane & m) != 0;
+        const Ext2 lo = up ? o : s, hi = up ? s : o;
+        s = ext_add(lo, ext_mul(hi, pw));
+    }
+    if ((t & 7) == 0 && t <= last) {
+        oa[t >> 3] = s.a;
+        ob[t >> 3] = s.b;
+    }
+}
+
 // out[q][2k], out[q][2k+1] = (a, b)[idx[q]*arity + k]
 __global__ void gather_ext_leaves_kernel(const u64* __restrict__ pa, const u64* __restrict__ pb, int arity,
                                          const unsigned long long* __restrict__ idx, u64* __restrict__ out) {
@@ -354,20 +515,38 @@ struct DevBuf {
     }
 };
 
-static ExtPow make_ext_pow(DevBuf& mem, Ext2 z, int log_n) {
+// two-level power tables of `count` extension points, one host buffer, one upload (a table's opening phase needs six: zeta,
+// g zeta, g^-1 and their inverses -- six copies of a few hundred bytes each before round 6).  The first `nlimb` of them also get
+// the limb form of their hi table (eval_points_wide_kernel).
+static void make_ext_pows(DevBuf& mem, const Ext2* z, int count, int log_n, ExtPow* out, int nlimb = 0) {
     const int h = (log_n + 1) / 2;
-    const size_t nlo = (size_t)1 << h, nhi = (size_t)1 << (log_n - h);
-    HostSpan host = mem.host(2 * (nlo + nhi));
-    Ext2 acc = ext_make(1, 0);
-    for (size_t i = 0; i < nlo; i++) { host[i] = acc.a; host[nlo + i] = acc.b; acc = ext_mul(acc, z); }
-    const Ext2 zh = acc;  // z^(2^h)
-    acc = ext_make(1, 0);
-    for (size_t i = 0; i < nhi; i++) { host[2 * nlo + i] = acc.a; host[2 * nlo + nhi + i] = acc.b; acc = ext_mul(acc, zh); }
-    u64* d = mem.alloc(host.size());
-    HIP_CHECK(hipMemcpyAsync(d, host.data(), host.size() * 8, hipMemcpyHostToDevice, mem.ctx->stream));
-    ExtPow t;
-    t.lo_a = d; t.lo_b = d + nlo; t.hi_a = d + 2 * nlo; t.hi_b = d + 2 * nlo + nhi; t.h = h;
-    return t;
+    const size_t nlo = (size_t)1 << h, nhi = (size_t)1 << (log_n - h), per = 2 * (nlo + nhi), lper = 6 * nhi;   // 12 u32 per kh
+    const size_t total = per * (size_t)count + lper * (size_t)nlimb;
+    HostSpan host = mem.host(total);
+    u64* d = mem.alloc(total);
+    for (int i = 0; i < count; i++) {
+        u64* hp = host.data() + per * (size_t)i;
+        Ext2 acc = ext_make(1, 0);
+        for (size_t k = 0; k < nlo; k++) { hp[k] = acc.a; hp[nlo + k] = acc.b; acc = ext_mul(acc, z[i]); }
+        const Ext2 zh = acc;  // z^(2^h)
+        acc = ext_make(1, 0);
+        for (size_t k = 0; k < nhi; k++) { hp[2 * nlo + k] = acc.a; hp[2 * nlo + nhi + k] = acc.b; acc = ext_mul(acc, zh); }
+        u64* dp = d + per * (size_t)i;
+        out[i].lo_a = dp; out[i].lo_b = dp + nlo; out[i].hi_a = dp + 2 * nlo; out[i].hi_b = dp + 2 * nlo + nhi; out[i].h = h;
+        out[i].hi_limbs = nullptr;
+        if (i < nlimb) {
+            u32* lp = reinterpret_cast<u32*>(host.data() + per * (size_t)count + lper * (size_t)i);
+            for (size_t k = 0; k < nhi; k++)
+                for (int e = 0; e < 2; e++) {
+                    const u64 w = gl_canon(hp[2 * nlo + (e ? nhi : 0) + k]), ws = gl_mul(w, (u64)1 << 32);
+                    u32* q = lp + 12 * k + 6 * e;
+                    q[0] = (u32)(w & 0x3FFFFF); q[1] = (u32)((w >> 22) & 0x3FFFFF); q[2] = (u32)(w >> 44);
+                    q[3] = (u32)(ws & 0x3FFFFF); q[4] = (u32)((ws >> 22) & 0x3FFFFF); q[5] = (u32)(ws >> 44);
+                }
+            out[i].hi_limbs = reinterpret_cast<const u32*>(d + per * (size_t)count + lper * (size_t)i);
+        }
+    }
+    HIP_CHECK(hipMemcpyAsync(d, host.data(), total * 8, hipMemcpyHostToDevice, mem.ctx->stream));
 }
 
 // Opened rows and Merkle paths of the query indices.  Under the coset partition a leaf lives on the rank that owns its
@@ -444,45 +623,88 @@ struct EvalJob {
     uint32_t cpr = 0;           // columns per rank
     size_t send_off = 0;        // this job's slot in a rank's record: [npoints][cpr][2] words
 };
-// partial[pt][chunk][col][2] -> out[pt][cpr][2] (columns beyond ncols_loc stay zero)
-__global__ __launch_bounds__(256) void eval_reduce_kernel(const u64* __restrict__ partial, unsigned nchunks, int ncols_loc, int npoints,
-                                                          int cpr, u64* __restrict__ out) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= npoints * cpr) return;
-    const int p = t / cpr, c = t % cpr;
+// partial[pt][chunk][col][2] -> out[pt][cpr][2] (columns beyond ncols_loc stay zero); one wave per (point, column)
+__global__ __launch_bounds__(64) void eval_reduce_kernel(const u64* __restrict__ partial, unsigned nchunks, int ncols_loc, int npoints,
+                                                         int cpr, u64* __restrict__ out) {
+    const int p = blockIdx.x / cpr, c = blockIdx.x % cpr;
+    (void)npoints;
     u64 a = 0, b = 0;
     if (c < ncols_loc)
-        for (unsigned ch = 0; ch < nchunks; ch++) {
+        for (unsigned ch = threadIdx.x; ch < nchunks; ch += 64) {
             const u64* v = partial + (((size_t)p * nchunks + ch) * ncols_loc + c) * 2;
             a = gl_add(a, v[0]);
             b = gl_add(b, v[1]);
         }
-    out[((size_t)p * cpr + c) * 2] = a;
-    out[((size_t)p * cpr + c) * 2 + 1] = b;
+    a = wave_sum_gl(a);
+    b = wave_sum_gl(b);
+    if (threadIdx.x == 0) {
+        out[((size_t)p * cpr + c) * 2] = a;
+        out[((size_t)p * cpr + c) * 2 + 1] = b;
+    }
+}
+// one batch of columns at one or two points -> chunk partials; returns the number of chunks
+#define EVALW_C 4
+static unsigned eval_points_plan(size_t n, int log_n, uint32_t ncols, const ExtPow& p0, const ExtPow& p1, size_t* chunk_len, unsigned* khpb) {
+    static const bool wide_off = getenv("OLA_EVAL_WIDE") && !strcmp(getenv("OLA_EVAL_WIDE"), "0");
+    *khpb = 0;
+    if (!wide_off && log_n >= 15 && p0.hi_limbs && p1.hi_limbs && ncols) {
+        const int h = p0.h;
+        const size_t nlo_blocks = ((size_t)1 << h) / 256, nhi = (size_t)1 << (log_n - h), groups = (ncols + EVALW_C - 1) / EVALW_C;
+        // enough workgroups to fill the chip several times over, as many steps per workgroup as that leaves (the fold, the
+        // multiplication by lo[kl] and the sum over the workgroup cost about twenty steps)
+        size_t per = EVALW_MAX_KH;
+        while (per > 32 && nlo_blocks * groups * (nhi / per) < 2048) per >>= 1;
+        per = std::min(per, nhi);
+        *khpb = (unsigned)per;
+        return (unsigned)(nlo_blocks * (nhi / per));
+    }
+    *chunk_len = std::max<size_t>(4096, (n + 255) / 256);
+    return (unsigned)((n + *chunk_len - 1) / *chunk_len);
+}
+static void eval_points_launch(DeviceCtx* ctx, const u64* coeffs, size_t n, uint32_t ncols, const ExtPow& p0, const ExtPow& p1, int npoints,
+                               unsigned nchunks, size_t chunk_len, unsigned khpb, u64* d_part) {
+    if (khpb) {
+        const dim3 grid(nchunks, (ncols + EVALW_C - 1) / EVALW_C);
+        const unsigned nlo_blocks = (unsigned)(((size_t)1 << p0.h) / 256);
+        if (npoints > 1)
+            hipLaunchKernelGGL((eval_points_wide_kernel<EVALW_C, 2>), grid, dim3(256), 0, ctx->stream, coeffs, n, (int)ncols, p0, p1, nlo_blocks, khpb, d_part);
+        else
+            hipLaunchKernelGGL((eval_points_wide_kernel<EVALW_C, 1>), grid, dim3(256), 0, ctx->stream, coeffs, n, (int)ncols, p0, p0, nlo_blocks, khpb, d_part);
+        return;
+    }
+    hipLaunchKernelGGL(eval_points_kernel, dim3(nchunks, (ncols + EVAL_CG - 1) / EVAL_CG), dim3(256), 0, ctx->stream, coeffs, n, (int)ncols, p0, p1,
+                       npoints, chunk_len, d_part);
 }
 static void eval_batch_launch(DevBuf& mem, const OlaBatch& b, int npoints, ExtPow p0, ExtPow p1, std::vector<Ext2>* out0,
                               std::vector<Ext2>* out1, EvalJob& job, u64* d_send = nullptr) {
     DeviceCtx* ctx = mem.ctx;
     const size_t n = b.n();
-    const size_t chunk_len = std::max<size_t>(4096, (n + 255) / 256);
-    const unsigned nchunks = (unsigned)((n + chunk_len - 1) / chunk_len);
+    size_t chunk_len = 0;
+    unsigned khpb = 0;
+    const uint32_t cols_here = d_send ? std::min(b.ncols, std::min(b.ncols, ctx->shard.rank * job.cpr) + job.cpr) - std::min(b.ncols, ctx->shard.rank * job.cpr) : b.ncols;
+    const unsigned nchunks = eval_points_plan(n, (int)b.log_n, cols_here, p0, p1, &chunk_len, &khpb);
     job.nchunks = nchunks; job.ncols = b.ncols; job.npoints = npoints; job.out0 = out0; job.out1 = out1;
     if (d_send) {           // this rank's columns only
         const uint32_t cpr = job.cpr, c0 = std::min(b.ncols, ctx->shard.rank * cpr), c1 = std::min(b.ncols, c0 + cpr);
         const uint32_t mine = c1 - c0;
         u64* d_part = mem.alloc(std::max<size_t>(1, (size_t)npoints * nchunks * mine * 2));
-        if (mine)
-            hipLaunchKernelGGL(eval_points_kernel, dim3(nchunks, (mine + EVAL_CG - 1) / EVAL_CG), dim3(256), 0, ctx->stream, b.coeffs + (size_t)c0 * n, n,
-                               (int)mine, p0, p1, npoints, chunk_len, d_part);
-        hipLaunchKernelGGL(eval_reduce_kernel, dim3((unsigned)((npoints * cpr + 255) / 256)), dim3(256), 0, ctx->stream, d_part, nchunks, (int)mine,
-                           npoints, (int)cpr, d_send + job.send_off);
+        if (mine) eval_points_launch(ctx, b.coeffs + (size_t)c0 * n, n, mine, p0, p1, npoints, nchunks, chunk_len, khpb, d_part);
+        hipLaunchKernelGGL(eval_reduce_kernel, dim3((unsigned)(npoints * cpr)), dim3(64), 0, ctx->stream, d_part, nchunks, (int)mine, npoints, (int)cpr,
+                           d_send + job.send_off);
         return;
     }
-    const unsigned groups = (b.ncols + EVAL_CG - 1) / EVAL_CG;
     const size_t pelems = (size_t)npoints * nchunks * b.ncols * 2;
     u64* d_part = mem.alloc(pelems);
-    hipLaunchKernelGGL(eval_points_kernel, dim3(nchunks, groups), dim3(256), 0, ctx->stream, b.coeffs, n, (int)b.ncols, p0, p1,
-                       npoints, chunk_len, d_part);
+    eval_points_launch(ctx, b.coeffs, n, b.ncols, p0, p1, npoints, nchunks, chunk_len, khpb, d_part);
+    if (nchunks > 16 && b.ncols) {      // many chunks: add them up on the device, the host reads one record per column
+        u64* d_sum = mem.alloc((size_t)npoints * b.ncols * 2);
+        hipLaunchKernelGGL(eval_reduce_kernel, dim3((unsigned)(npoints * b.ncols)), dim3(64), 0, ctx->stream, d_part, nchunks, (int)b.ncols, npoints,
+                           (int)b.ncols, d_sum);
+        job.nchunks = 1;
+        job.part.resize((size_t)npoints * b.ncols * 2);
+        mem.readback(job.part.data(), d_sum, job.part.size() * 8);
+        return;
+    }
     job.part.resize(pelems);
     mem.readback(job.part.data(), d_part, pelems * 8);
 }
@@ -632,8 +854,15 @@ void open_and_prove(DeviceCtx* ctx, NttTables& tables, const OlaGpuConfig& cfg, 
     const u64 g = gl_root_of_unity(degree_bits);
     const Ext2 zeta_next = ext_scalar_mul(zeta, g);
     const Ext2 g_inv = ext_make(gl_inv(g), 0);
-    ExtPow pz = make_ext_pow(mem, zeta, degree_bits), pzn = make_ext_pow(mem, zeta_next, degree_bits),
-           pgi = make_ext_pow(mem, g_inv, degree_bits);
+    const Ext2 zpts[3] = {zeta, zeta_next, g_inv};
+    ExtPow zpow[3], zinv[3];
+    {
+        const Ext2 six[6] = {zeta, zeta_next, g_inv, ext_inv(zeta), ext_inv(zeta_next), ext_inv(g_inv)};
+        ExtPow tabs[6];
+        make_ext_pows(mem, six, 6, degree_bits, tabs, 3);
+        for (int b = 0; b < 3; b++) { zpow[b] = tabs[b]; zinv[b] = tabs[3 + b]; }
+    }
+    const ExtPow pz = zpow[0], pzn = zpow[1], pgi = zpow[2];
     std::vector<Ext2> local, next, zs_local, zs_next, q_local, zs_last_all, dummy;
     {
         EvalJob jobs[4];
@@ -706,12 +935,9 @@ void open_and_prove(DeviceCtx* ctx, NttTables& tables, const OlaGpuConfig& cfg, 
     const int l0 = W + Z + Q, l1 = W + Z, l2 = Z - (int)nperm;
     (void)l0;
     const bool use2 = l2 > 0;
-    const Ext2 zpts[3] = {zeta, zeta_next, g_inv};
-    const ExtPow zpow[3] = {pz, pzn, pgi};
-    ExtPow zinv[3];
+    (void)zpts;
     u64* tot = mem.alloc((n + SCAN_B - 1) / SCAN_B + 1);
     for (int b = 0; b < 3; b++) {
-        zinv[b] = make_ext_pow(mem, ext_inv(zpts[b]), degree_bits);
         if (b == 2 && !use2) continue;
         hipLaunchKernelGGL(weight_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, S + 2 * b * n, S + (2 * b + 1) * n,
                            n, zpow[b]);
@@ -734,6 +960,7 @@ void open_and_prove(DeviceCtx* ctx, NttTables& tables, const OlaGpuConfig& cfg, 
     u64 shift = GL_GENERATOR;
     size_t len = N;
     u64* cur_coef = coef;  // planes [a | b] each `len`
+    size_t nz = n;         // coefficients that can be non-zero (the planes are zero beyond them)
     // Under the coset partition the FIRST layer -- 15/16 of the commit phase's values and leaves -- is divided like a commitment
     // (fri/prover.rs:72-121): its bit-reversed values are the leaf-order LDE of the n coefficients (the planes
     // are zero beyond n), a rank extends and hashes its cosets only (n/arity leaves per coset), builds their sub-trees and the
@@ -789,9 +1016,24 @@ void open_and_prove(DeviceCtx* ctx, NttTables& tables, const OlaGpuConfig& cfg, 
         const size_t out_len = len >> ab;
         u64* folded = mem.alloc(2 * out_len);
         {
-            PhaseScope ph(ctx, PH_FRI_FOLD, (double)(len + out_len) * 16, (double)len);
-            hipLaunchKernelGGL(fold_kernel, dim3((unsigned)((out_len + 255) / 256)), dim3(256), 0, ctx->stream, cur_coef, cur_coef + len, out_len,
-                               arity, beta, folded, folded + out_len);
+            static const bool fold16_off = getenv("OLA_FOLD16") && !strcmp(getenv("OLA_FOLD16"), "0");
+            if (arity == 16 && !fold16_off && nz % 16 == 0 && nz >= 4096) {
+                const size_t nz_out = nz / 16;
+                PhaseScope ph(ctx, PH_FRI_FOLD, (double)(nz + nz_out) * 16, (double)nz);
+                if (nz_out < out_len) {
+                    HIP_CHECK(hipMemsetAsync(folded + nz_out, 0, (out_len - nz_out) * 8, ctx->stream));
+                    HIP_CHECK(hipMemsetAsync(folded + out_len + nz_out, 0, (out_len - nz_out) * 8, ctx->stream));
+                }
+                const Ext2 b2 = ext_mul(beta, beta), b4 = ext_mul(b2, b2), b8 = ext_mul(b4, b4);
+                hipLaunchKernelGGL(fold16_kernel, dim3((unsigned)((nz_out * 8 + 255) / 256)), dim3(256), 0, ctx->stream, cur_coef, cur_coef + len, nz_out, beta,
+                                   b2, b4, b8, folded, folded + out_len);
+                nz = nz_out;
+            } else {
+                PhaseScope ph(ctx, PH_FRI_FOLD, (double)(len + out_len) * 16, (double)len);
+                hipLaunchKernelGGL(fold_kernel, dim3((unsigned)((out_len + 255) / 256)), dim3(256), 0, ctx->stream, cur_coef, cur_coef + len, out_len,
+                                   arity, beta, folded, folded + out_len);
+                nz = std::min(out_len, (nz + arity - 1) / arity);
+            }
         }
         cur_coef = folded;
         len = out_len;

@@ -310,6 +310,36 @@ __global__ __launch_bounds__(256) void leaf_b3_ext_kernel(const u64* __restrict_
     b3_leaf<MULTI>([&](u32 i) { return gl_canon(((i & 1) ? plane_b : plane_a)[j * arity + (i >> 1)]); }, (u32)(2 * arity), d);
     b3_store_digest(out + j * 4, d);
 }
+// The same leaves for arity 16, through LDS (round 6).  A thread of leaf_b3_ext_kernel reads 16 + 16 words 128 bytes apart from its
+// neighbour's: a wave touches 64 lines per load and the lines are gone from the vector cache before their other words are asked
+// for -- 17.1 GB fetched per 2^22-row proof for 1.2 GB of values (profiles/r05_proof_pmc_blake3.txt).  Here a workgroup copies
+// its 128 leaves x 16 values of both planes with 16-byte loads on consecutive addresses and every thread hashes its leaf out of
+// LDS (rows padded to 17 words: conflict-free for 8-byte reads).
+#define B3X_LEAVES 128
+__global__ __launch_bounds__(B3X_LEAVES) void leaf_b3_ext16_kernel(const u64* __restrict__ plane_a, const u64* __restrict__ plane_b, size_t num_leaves,
+                                                                   u64* __restrict__ out) {
+    __shared__ u64 tile[2][B3X_LEAVES * 17];
+    const size_t j0 = (size_t)blockIdx.x * B3X_LEAVES;
+    const size_t base = j0 * 16;
+    const size_t avail = (num_leaves - j0 < (size_t)B3X_LEAVES ? num_leaves - j0 : (size_t)B3X_LEAVES) * 16;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const size_t e = 2 * ((size_t)threadIdx.x + B3X_LEAVES * i);
+        if (e < avail) {
+            const ulonglong2 va = *reinterpret_cast<const ulonglong2*>(plane_a + base + e);
+            const ulonglong2 vb = *reinterpret_cast<const ulonglong2*>(plane_b + base + e);
+            const size_t at = (e >> 4) * 17 + (e & 15);
+            tile[0][at] = va.x; tile[0][at + 1] = va.y;
+            tile[1][at] = vb.x; tile[1][at + 1] = vb.y;
+        }
+    }
+    __syncthreads();
+    const size_t j = j0 + threadIdx.x;
+    if (j >= num_leaves) return;
+    u32 d[8];
+    b3_leaf<false>([&](u32 i) { return gl_canon(tile[i & 1][threadIdx.x * 17 + (i >> 1)]); }, 32u, d);
+    b3_store_digest(out + j * 4, d);
+}
 __global__ __launch_bounds__(256) void merkle_level_b3_kernel(u64* __restrict__ heap, size_t first, size_t count) {
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= count) return;
@@ -382,6 +412,12 @@ void launch_leaf_hash_ext(DeviceCtx* ctx, const u64* pa, const u64* pb, int arit
         require_leaf_width((size_t)(2 * arity));
         if (num_leaves) {
             const dim3 grid((unsigned)((num_leaves + 255) / 256));
+            static const bool staged = !(getenv("OLA_LEAF_EXT_STAGED") && !strcmp(getenv("OLA_LEAF_EXT_STAGED"), "0"));
+            if (arity == 16 && staged && num_leaves >= 1024 && (((uintptr_t)pa | (uintptr_t)pb) & 15) == 0) {
+                hipLaunchKernelGGL(leaf_b3_ext16_kernel, dim3((unsigned)((num_leaves + B3X_LEAVES - 1) / B3X_LEAVES)), dim3(B3X_LEAVES), 0, ctx->stream, pa, pb,
+                                   num_leaves, out);
+                return;
+            }
             if ((size_t)(2 * arity) > (size_t)B3_CHUNK_WORDS) hipLaunchKernelGGL(leaf_b3_ext_kernel<true>, grid, dim3(256), 0, ctx->stream, pa, pb, arity, num_leaves, out);
             else hipLaunchKernelGGL(leaf_b3_ext_kernel<false>, grid, dim3(256), 0, ctx->stream, pa, pb, arity, num_leaves, out);
         }

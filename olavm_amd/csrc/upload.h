@@ -83,6 +83,9 @@ class TraceUploader {
         cancel_.store(true);
         { std::lock_guard<std::mutex> lk(mu_); cv_.notify_all(); }
         join_all();
+        // error path: copies and widen kernels already queued still write into the destination buffers, which the unwinding caller
+        // is about to hand back to the context's cache -- drain the upload streams before that
+        for (hipStream_t st : streams_) if (st) (void)hipStreamSynchronize(st);
         for (hipEvent_t e : events_) if (e) (void)hipEventDestroy(e);
         if (start_ev_) (void)hipEventDestroy(start_ev_);
         for (hipStream_t st : streams_) if (st) (void)hipStreamDestroy(st);

@@ -217,3 +217,24 @@ def test_generated_kernels_on_the_host_equal_the_air_data(tmp_path, variant):
         lag_first, lag_last, z_last = (int(x) for x in w[2 * ncols + 2 * nz + nd:])
         want = reference_point(airset, t, Tl, Tn, Zl, Zn, D, lag_first, lag_last, z_last)
         assert list(g) == want, "table %d (%s)" % (t, airset.tables[t].name)
+
+
+def test_slot_plan_check_rejects_a_print_that_segments_differently():
+    """the LDS slot plan comes from a counting print; the final print re-records the cells of every segment and
+    check_plan compares (and replays the slots).  Here: the real plan of the CPU table passes, doctored ones do not."""
+    segs = [{("L", 1), ("L", 2)}, {("L", 1), ("N", 3)}, {("L", 2), ("L", 1)}]
+    hits, puts, _ = codegen.plan_lds(segs, 2)
+    plan = (hits, puts, segs)
+    codegen.check_plan(plan, [set(s) for s in segs])
+    with pytest.raises(AssertionError):                 # one segment more
+        codegen.check_plan(plan, [set(s) for s in segs] + [set()])
+    with pytest.raises(AssertionError):                 # same cut, another cell
+        codegen.check_plan(plan, [set(segs[0]), {("L", 1), ("N", 4)}, set(segs[2])])
+    bad_hits = [dict(h) for h in hits]
+    for i, h in enumerate(bad_hits):                    # a cell served from a slot nobody parked it in
+        if h:
+            c = next(iter(h))
+            h[c] = 1 - h[c]
+            break
+    with pytest.raises(AssertionError):
+        codegen.check_plan((bad_hits, puts, segs), [set(s) for s in segs])

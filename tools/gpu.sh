@@ -112,6 +112,27 @@ for _ in range(4):
 print(os.environ["AB_HASHER"], "wall %.1f ms, quotient kernels %.2f ms, opening evaluations %.2f ms, LDE %.2f ms, leaves %.2f ms" % best)
 PY
                  done 2>&1 | grep -v amdgpu | tee $O/quot.txt ;;
+    openings)    # round 6: eval_points_wide_kernel, fold16_kernel, leaf_b3_ext16_kernel against the kernels they replace (environment switches, same box, alternating)
+                 for h in blake3 poseidon; do for v in 0 1 0 1; do AB_HASHER=$h OLA_EVAL_WIDE=$v OLA_FOLD16=$v OLA_LEAF_EXT_STAGED=$v timeout 300 python - <<'PY'
+import os, sys
+sys.path.insert(0, ".")
+from olavm_amd.air import ola_tables as T, tracegen
+from olavm_amd.backend import Backend
+blob = T.ola_stark().blob()
+traces, params, compress = tracegen.empty_program_instance(log_n=10, range_bits=16, limb_bits=8, log_n_cpu=22, log_n_mem=22)
+be = Backend(device=0, hasher=os.environ["AB_HASHER"])
+be.proof_stats(enable=True)
+best = None
+import hashlib
+for _ in range(4):
+    proof = be.prove_with_traces(blob, traces, params, compress)
+    st, ph = be.proof_stats(), be.phase_stats()
+    if best is None or st["wall_ms"] < best[0]:
+        best = (st["wall_ms"], ph["open_eval"][0], ph["fri_fold"][0], ph["leaf_hash"][0], ph["quotient"][0])
+print(os.environ["AB_HASHER"], "new" if os.environ["OLA_EVAL_WIDE"] == "1" else "old", "wall %.1f ms, opening evaluations %.2f ms, folds %.3f ms, leaves %.2f ms, quotient %.2f ms" % best,
+      "proof sha256", hashlib.sha256(bytes(proof)).hexdigest()[:16])
+PY
+                 done; done 2>&1 | grep -v amdgpu | tee $O/ab.txt ;;
     phases)      OLA_TIMING=1 timeout 600 python tools/bench_prove.py 22 2 2> $O/phases.txt | tail -3; OLA_HASHER=blake3 OLA_TIMING=1 timeout 600 python tools/bench_prove.py 22 2 2> $O/phases_blake3.txt | tail -3 ;;
     ntt_group)   # Infinity-Cache blocking of the transforms: working-set target in MB (0 = whole batch per launch)
                  for mb in 0 32 64 96 128 192; do
