@@ -9,7 +9,8 @@ fewer points per second.
 
 The random-linear-combination of constraints is accumulated lazily: sum_i alpha^(K-1-i) * c_i is the value the reference's
 Horner recurrence `acc = acc*alpha + c_i` (constraint_consumer.rs:57-64) produces, so each emitted constraint costs two
-64x64->128 multiply-accumulates into 160-bit sums (one per challenge) and the reductions mod p happen once per point.
+multiply-accumulates into lazy sums (one per challenge; round 6: three 64-bit sums of 22-bit-limb products, airq.cuh Acc3 --
+160-bit sums of 128-bit products before) and the reductions mod p happen once per point.
 Transition constraints share their `z_last` factor the same way.
 
 Run as a script to (re)generate olavm_amd/csrc/gen/air_kernels.inc for the OlaStark table sets the tests and benches use.
@@ -27,9 +28,69 @@ def _lit(v):
     return "0x%Xull" % (int(v) % P)
 
 
+LIMB_LOADS_AHEAD = int(os.environ.get("OLA_AIRQ_LIMB_LOADS_AHEAD", "2"))    # uses of limb slots between a slot's load and its own use
+W_MARK, USE_MARK = "/*W*/", "/*U*/"     # lines that load limb slots / lines that use them (hoist_limb_loads)
+
+
+def hoist_limb_loads(lines):
+    """The limb forms of the multipliers stream through the scalar cache (40 KB per point for the CPU table: no cache holds them),
+    and a scalar load issued where it is used is waited for on the spot.  Every AIRQ_W line is therefore moved up to just behind
+    the PREVIOUS use of limb slots (or segment barrier) -- one use ahead, twelve SGPRs -- as far as C++ scope allows: the
+    declaration must stay in a block that is still open where it is used."""
+    def delta(ln):
+        return ln.count("{") - ln.count("}")
+    out = list(lines)
+    i = 0
+    while i < len(out):
+        if not out[i].rstrip().endswith(W_MARK):
+            i += 1
+            continue
+        # depth before each line, relative to the W line (0); walk upwards
+        depth, lowest, best, uses = 0, 0, i, 0
+        j = i - 1
+        while j >= 0:
+            ln = out[j]
+            if "AIRQ_SEGMENT_BARRIER" in ln or "AIRQ_LIMBS_AT" in ln:
+                break
+            if ln.rstrip().endswith(USE_MARK):
+                uses += 1
+                if uses >= LIMB_LOADS_AHEAD:
+                    break
+            depth -= delta(ln)          # depth before line j
+            if depth <= lowest:
+                lowest = depth
+                best = j                # inserting before line j keeps the declaration in an enclosing, still open block
+            j -= 1
+        if best != i:
+            out.insert(best, out.pop(i))
+        i += 1
+    return out
+
+
+ACC_REFOLD_EVERY = 480   # multiply-accumulates into one lazy sum before it is folded and restarted (airq.cuh Acc3: 512 at most)
+
+
 class _Emitter:
     def __init__(self, K):
         self.lines, self.K, self.idx = [], K, 0
+        self.n_all = self.n_trans = 0
+        self.limb_src = []      # per limb slot (three descriptor words each, in the order the kernel uses them): the u64 word it is the limb form of
+
+    def slot(self, *words):
+        """consecutive limb slots for the given u64 descriptor words -> index of the first"""
+        s0 = len(self.limb_src)
+        self.limb_src.extend(words)
+        return s0
+
+    def _count(self, trans):
+        if trans:
+            self.n_trans += 1
+            if self.n_trans % ACC_REFOLD_EVERY == 0:
+                self.add("AIRQ_REFOLD_TRANS;")
+        else:
+            self.n_all += 1
+            if self.n_all % ACC_REFOLD_EVERY == 0:
+                self.add("AIRQ_REFOLD_ALL;")
 
     def add(self, s):
         self.lines.append("    " + s)
@@ -41,14 +102,17 @@ class _Emitter:
             self.idx += 1
         else:
             i = index
+        sl = self.slot(D_W + i, D_W + self.K + i)     # the two challenges' weights, side by side in the limb area
+        self.add("AIRQ_W(%d); AIRQ_W(%d); %s" % (sl, sl + 1, W_MARK))
         if kind == KIND_ALL:
-            self.add("AIRQ_EMIT_ALL(%d, %s);" % (i, expr))
+            self.add("AIRQ_EMIT_ALL(%d, %d, %d, %s); %s" % (i, sl, sl + 1, expr, USE_MARK))
         elif kind == KIND_TRANSITION:
-            self.add("AIRQ_EMIT_TRANS(%d, %s);" % (i, expr))
+            self.add("AIRQ_EMIT_TRANS(%d, %d, %d, %s); %s" % (i, sl, sl + 1, expr, USE_MARK))
         elif kind == KIND_FIRST:
-            self.add("AIRQ_EMIT_ALL(%d, gl_mul(%s, lag_first));" % (i, expr))
+            self.add("AIRQ_EMIT_ALL(%d, %d, %d, gl_mul(%s, lag_first)); %s" % (i, sl, sl + 1, expr, USE_MARK))
         else:
-            self.add("AIRQ_EMIT_ALL(%d, gl_mul(%s, lag_last));" % (i, expr))
+            self.add("AIRQ_EMIT_ALL(%d, %d, %d, gl_mul(%s, lag_last)); %s" % (i, sl, sl + 1, expr, USE_MARK))
+        self._count(kind == KIND_TRANSITION)
 
 
 def _lincol(col, row, cell=None):
@@ -228,7 +292,7 @@ def check_plan(plan, seen):
             slot[sl] = c
 
 
-def table_kernel(airset, t, name, num_challenges=2):
+def table_kernel(airset, t, name, num_challenges=2, with_limbs=False):
     """-> (source text of the kernel, K).  Printed several times: a counting print per candidate evaluation order finds the cells
     the lookup section keeps in registers and the cells every segment touches; plan_lds decides from that which cells sit in the
     LDS slots when; the order with the fewest loads from global memory is printed for good."""
@@ -250,8 +314,8 @@ def table_kernel(airset, t, name, num_challenges=2):
         if len(tab.emits) < 3:
             break
     loads, order, regs, plan, ctl_order = best
-    src, K = _table_kernel(airset, t, name, num_challenges, ctl_regs=regs, plan=plan, order=order, ctl_order=ctl_order)
-    return src, K
+    src, K, nl = _table_kernel(airset, t, name, num_challenges, ctl_regs=regs, plan=plan, order=order, ctl_order=ctl_order)
+    return (src, K, nl) if with_limbs else (src, K)
 
 
 def _table_kernel(airset, t, name, num_challenges=2, uses=None, ctl_regs=(), plan=None, order=None, ctl_order=False):
@@ -419,6 +483,7 @@ def _table_kernel(airset, t, name, num_challenges=2, uses=None, ctl_regs=(), pla
     for i, twc in enumerate(jobs):
         d_job[i] = off
         off += 1 + len(twc.columns)
+    e.lines.insert(1, "    AIRQ_LIMBS_AT(%d);" % off)      # the limb area follows the u64 words
     section["name"] = "ctl_head"
     if ctl_regs:
         e.add("const u64 " + ", ".join("h%s%d = %s" % (r, c, cell(r, c)) for r, c in ctl_regs) + ";")
@@ -441,18 +506,21 @@ def _table_kernel(airset, t, name, num_challenges=2, uses=None, ctl_regs=(), pla
     for twc, idxs in glist:
         e.add("{")
         e.add("  const u64 el0 = %s, en0 = %s;" % (_lincol(twc.columns[0], "L", cell), _lincol(twc.columns[0], "N", cell)))   # beta^0 term
-        e.add("  Acc160 " + ", ".join("al%d = {el0, 0, 0}, an%d = {en0, 0, 0}" % (i, i) for i in idxs) + ";")
+        e.add("  AIRQ_ACC " + ", ".join("al%d = AIRQ_ACC_INIT(el0), an%d = AIRQ_ACC_INIT(en0)" % (i, i) for i in idxs) + ";")
         for k, col in enumerate(twc.columns):
             if k == 0:
                 continue
             e.add("  { const u64 el = %s, en = %s;" % (_lincol(col, "L", cell), _lincol(col, "N", cell)))
-            for i in idxs:
-                e.add("    acc_mad(al%d, el, D[%d]); acc_mad(an%d, en, D[%d]);" % (i, d_job[i] + 1 + k, i, d_job[i] + 1 + k))
+            sl = e.slot(*[d_job[i] + 1 + k for i in idxs])
+            e.lines.insert(len(e.lines) - 1, "      " + " ".join("AIRQ_W(%d);" % (sl + n_) for n_ in range(len(idxs))) + " " + W_MARK)    # before the block of this column
+            for n_, i in enumerate(idxs):
+                e.add("    AIRQ_MAD(al%d, el, %d, %d); AIRQ_MAD(an%d, en, %d, %d);%s" % (i, d_job[i] + 1 + k, sl + n_, i, d_job[i] + 1 + k, sl + n_,
+                                                                                         " " + USE_MARK if n_ == len(idxs) - 1 else ""))
             e.add("  }")
         if twc.filter_column is not None:
             e.add("  const u64 fl = %s, fn = %s;" % (_lincol(twc.filter_column, "L", cell), _lincol(twc.filter_column, "N", cell)))
         for i in idxs:
-            e.add("  { u64 cl = gl_add(acc_reduce(al%d), D[%d]), cn = gl_add(acc_reduce(an%d), D[%d]);" % (i, d_job[i], i, d_job[i]))
+            e.add("  { u64 cl = gl_add(AIRQ_ACC_REDUCE(al%d), D[%d]), cn = gl_add(AIRQ_ACC_REDUCE(an%d), D[%d]);" % (i, d_job[i], i, d_job[i]))
             if twc.filter_column is not None:   # select(f, x) = f*x + 1 - f
                 e.add("    cl = gl_sub(gl_add(gl_mul(fl, cl), 1), fl); cn = gl_sub(gl_add(gl_mul(fn, cn), 1), fn);")
             e.add("    const u64 zl = ZL(%d), zn = ZN(%d);" % (nperm + i, nperm + i))
@@ -469,8 +537,10 @@ def _table_kernel(airset, t, name, num_challenges=2, uses=None, ctl_regs=(), pla
     e.add("AIRQ_EPILOGUE")
     head = "// table %d (%s): %d columns, %d constraints, %d permutation Zs, %d CTL Zs, K = %d\n" % (
         t, tab.name, tab.ncols, len(tab.emits), nperm, len(jobs), K)
-    src = head + "__global__ __launch_bounds__(AIRQ_THREADS) void %s(QuotParams P) {\n%s\n}\n" % (name, "\n".join(e.lines))
-    return src, K
+    src = head + "__global__ __launch_bounds__(AIRQ_THREADS) void %s(QuotParams P) {\n%s\n}\n" % (name, "\n".join(hoist_limb_loads(e.lines)))
+    src += "// limb slot -> the descriptor word it is the limb form of (the host appends the limb area in this order: the kernel reads it front to back)\n"
+    src += "static const int %s_limb_src[%d] = {%s};\n" % (name, max(1, len(e.limb_src)), ", ".join(str(x) for x in e.limb_src) or "0")
+    return src, K, len(e.limb_src)
 
 
 def generate(airsets):
@@ -483,13 +553,13 @@ def generate(airsets):
             name = "airq_%016x" % sig
             if name + ".hip" in files:
                 continue
-            src, K = table_kernel(s, t, name)
+            src, K, nl = table_kernel(s, t, name, with_limbs=True)
             tab = s.tables[t]
             files[name + ".hip"] = (
                 "// GENERATED by olavm_amd/air/codegen.py -- do not edit; regenerated by __graft_entry__.build().\n"
                 "#define AIRQ_GENERATED_TU 1\n#include \"../airq.cuh\"\nnamespace ola {\n" + src +
-                "extern const AirKernelEntry %s_entry;\nconst AirKernelEntry %s_entry = {0x%016Xull, %s, %d, %d, %d, \"%s\"};\n}  // namespace ola\n"
-                % (name, name, sig, name, K, tab.n_params, tab.num_permutation_batches(), tab.name))
+                "extern const AirKernelEntry %s_entry;\nconst AirKernelEntry %s_entry = {0x%016Xull, %s, %d, %d, %d, \"%s\", %s_limb_src, %d};\n}  // namespace ola\n"
+                % (name, name, sig, name, K, tab.n_params, tab.num_permutation_batches(), tab.name, name, nl))
             entries.append(name)
     reg = "// GENERATED by olavm_amd/air/codegen.py -- do not edit.\n"
     reg += "".join("extern const AirKernelEntry %s_entry;\n" % n for n in entries)

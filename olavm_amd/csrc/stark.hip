@@ -759,6 +759,20 @@ static void prove_single_table(DeviceCtx* ctx, NttTables& tables, const OlaGpuCo
                 u64 bp = 1;
                 for (size_t k = 0; k < jb.twc->columns.size(); k++) { sd.push_back(bp); bp = gl_mul(bp, jb.ch.beta); }
             }
+            // limb forms of the uniform multipliers (airq.cuh Acc3), one slot per use in the kernel's own order
+            auto push_limbs = [&sd](u64 w) {
+                w = gl_canon(w);
+                const u64 v = gl_mul(w, (u64)1 << 32), M = 0x3FFFFF;
+                sd.push_back((w & M) | (((w >> 22) & M) << 32));
+                sd.push_back((w >> 44) | ((v & M) << 32));
+                sd.push_back(((v >> 22) & M) | ((v >> 44) << 32));
+            };
+            const size_t u64_words = sd.size();
+            sd.reserve(u64_words + 3 * (size_t)spec->n_limbs);
+            for (int sl = 0; sl < spec->n_limbs; sl++) {
+                if ((size_t)spec->limb_src[sl] >= u64_words) throw OlaError(OLA_E_INVALID_ARG, "generated kernel and descriptor disagree");
+                push_limbs(sd[(size_t)spec->limb_src[sl]]);
+            }
             d_sd = mem.upload(sd);
         }
         u64* qv2 = (spec && crosscheck) ? mem.alloc(2 * plane) : nullptr;

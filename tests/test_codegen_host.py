@@ -51,8 +51,17 @@ struct QuotParams { const u64 *Tl, *Tn, *Zl, *Zn, *D; u64 lag_first, lag_last, z
 #define CL(s) cache_[s]
 #define AIRQ_SEGMENT_BARRIER
 #define AIRQ_SEGMENT_BARRIER_C
-#define AIRQ_EMIT_ALL(i, v) { const u64 v_ = (v); acc_mad(accA0, v_, D[8 + (i)]); acc_mad(accA1, v_, D[8 + AIRQ_K + (i)]); }
-#define AIRQ_EMIT_TRANS(i, v) { const u64 v_ = (v); acc_mad(accT0, v_, D[8 + (i)]); acc_mad(accT1, v_, D[8 + AIRQ_K + (i)]); }
+// the accumulator interface of airq.cuh, on the u64 forms of the multipliers (the limb forms are the device's: tests/test_gpu_stark.py)
+#define AIRQ_LIMBS_AT(o) constexpr int AIRQ_L0 = (o); (void)AIRQ_L0
+#define AIRQ_ACC Acc160
+#define AIRQ_ACC_INIT(v) {(v), 0, 0}
+#define AIRQ_W(s)
+#define AIRQ_MAD(a, x, wi, s) acc_mad(a, x, D[wi])
+#define AIRQ_ACC_REDUCE(a) acc_reduce(a)
+#define AIRQ_REFOLD_ALL
+#define AIRQ_REFOLD_TRANS
+#define AIRQ_EMIT_ALL(i, s0, s1, v) { const u64 v_ = (v); acc_mad(accA0, v_, D[8 + (i)]); acc_mad(accA1, v_, D[8 + AIRQ_K + (i)]); }
+#define AIRQ_EMIT_TRANS(i, s0, s1, v) { const u64 v_ = (v); acc_mad(accT0, v_, D[8 + (i)]); acc_mad(accT1, v_, D[8 + AIRQ_K + (i)]); }
 #define AIRQ_EPILOGUE { const u64 zh_inv = D[0]; \
     P.out[0] = gl_mul(gl_add(acc_reduce(accA0), gl_mul(z_last, acc_reduce(accT0))), zh_inv); \
     P.out[1] = gl_mul(gl_add(acc_reduce(accA1), gl_mul(z_last, acc_reduce(accT1))), zh_inv); }

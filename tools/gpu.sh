@@ -133,6 +133,27 @@ print(os.environ["AB_HASHER"], "new" if os.environ["OLA_EVAL_WIDE"] == "1" else 
       "proof sha256", hashlib.sha256(bytes(proof)).hexdigest()[:16])
 PY
                  done; done 2>&1 | grep -v amdgpu | tee $O/ab.txt ;;
+    quot_ab)     # round 6: lazy sums of the quotient kernels as 22-bit limb products (Acc3) against the 160-bit sums (ab_tmp/libola_acc160.so, tools/build_variant_gen.sh)
+                 timeout 1200 python -m pytest tests/test_gpu_stark.py tests/test_gpu_blake3.py -x -q 2>&1 | tail -3 | tee $O/pytest.log
+                 cp olavm_amd/lib/libola_gpu.so ab_tmp/libola_cur.so
+                 for v in ${AB_VARIANTS:-acc160 cur acc160 cur}; do cp ab_tmp/libola_$v.so olavm_amd/lib/libola_gpu.so; AB_NAME=$v AB_HASHER=blake3 timeout 300 python - <<'PY'
+import os, sys, hashlib
+sys.path.insert(0, ".")
+from olavm_amd.air import ola_tables as T, tracegen
+from olavm_amd.backend import Backend
+blob = T.ola_stark().blob()
+traces, params, compress = tracegen.empty_program_instance(log_n=10, range_bits=16, limb_bits=8, log_n_cpu=22, log_n_mem=22)
+be = Backend(device=0, hasher=os.environ["AB_HASHER"])
+be.proof_stats(enable=True)
+best = None
+for _ in range(4):
+    proof = be.prove_with_traces(blob, traces, params, compress)
+    st, ph = be.proof_stats(), be.phase_stats()
+    if best is None or st["wall_ms"] < best[0]:
+        best = (st["wall_ms"], ph["quotient"][0])
+print(os.environ["AB_NAME"], "wall %.1f ms, quotient kernels %.2f ms" % best, "proof sha256", hashlib.sha256(bytes(proof)).hexdigest()[:16])
+PY
+                 done 2>&1 | grep -v amdgpu | tee $O/ab.txt; cp ab_tmp/libola_cur.so olavm_amd/lib/libola_gpu.so ;;
     phases)      OLA_TIMING=1 timeout 600 python tools/bench_prove.py 22 2 2> $O/phases.txt | tail -3; OLA_HASHER=blake3 OLA_TIMING=1 timeout 600 python tools/bench_prove.py 22 2 2> $O/phases_blake3.txt | tail -3 ;;
     ntt_group)   # Infinity-Cache blocking of the transforms: working-set target in MB (0 = whole batch per launch)
                  for mb in 0 32 64 96 128 192; do
