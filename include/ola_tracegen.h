@@ -37,6 +37,12 @@ typedef struct OlaTraceSet OlaTraceSet;
  * table (generation/builtin.rs:120-131) and the state roots before and after the run (generation/prog.rs:23-29) -- and the two
  * arguments are ignored; ola_tracegen_betas returns the values used (they are the proof's compress_challenges). */
 #define OLA_TRACEGEN_EXPLICIT_BETAS 2u
+/* flags: reproduce the two places where the reference's generators write rows its own AIR rejects, for comparing whole pipelines with
+ * a build of the reference (integration/pin/) -- not for proving: (a) the fourth limb of a bitwise operand / result is left zero
+ * (generation/builtin.rs:66,71,76 store it at `OP*_LIMBS.end`, the exclusive end of the column range, and the next write replaces it);
+ * (b) the memory table of a run without memory cells is generation/memory.rs:95-153's: every row a prophet-region row, row 0 without
+ * its selector (default: one stack-region row first, so that memory_stark.rs:265-270 hold on the wrap-around). */
+#define OLA_TRACEGEN_REFERENCE_QUIRKS 4u
 
 /* Executes the program (at most max_steps CPU rows) and builds the 12 tables of ola_stark(range_bits, limb_bits) in
  * `enum Table` order.  range_bits / limb_bits are 16 / 8 in the reference; smaller values give structurally identical

@@ -16,7 +16,7 @@ class OlaInstr(C.Structure):
 
 
 EXPORTS = ["ola_tracegen_run", "ola_tracegen_table", "ola_tracegen_cpu_rows", "ola_tracegen_free", "ola_tracegen_last_error", "ola_tracegen_betas"]
-OLA_TRACEGEN_PROVE_PROGRAM_HASH, OLA_TRACEGEN_EXPLICIT_BETAS = 1, 2
+OLA_TRACEGEN_PROVE_PROGRAM_HASH, OLA_TRACEGEN_EXPLICIT_BETAS, OLA_TRACEGEN_REFERENCE_QUIRKS = 1, 2, 4
 
 
 def lib_path():
@@ -51,7 +51,7 @@ def encode(prog):
     return arr
 
 
-def instance(prog, range_bits=4, limb_bits=2, bitwise_beta=None, program_beta=None, prove_program_hash=False, max_steps=1 << 16):
+def instance(prog, range_bits=4, limb_bits=2, bitwise_beta=None, program_beta=None, prove_program_hash=False, max_steps=1 << 16, reference_quirks=False):
     """Same contract as miniexec.instance(prog, ...).  -> (traces, params, compress).  Betas left at None are derived by the
     generator's own Fiat-Shamir transcript, as the reference does; explicit values (both or neither) are for tests."""
     assert (bitwise_beta is None) == (program_beta is None), "give both compress challenges or neither"
@@ -61,7 +61,8 @@ def instance(prog, range_bits=4, limb_bits=2, bitwise_beta=None, program_beta=No
     code = (C.c_uint64 * 4)(*prog.code_addr)
     stor = (C.c_uint64 * 4)(*prog.storage_addr)
     handle = C.c_void_p()
-    flags = (OLA_TRACEGEN_PROVE_PROGRAM_HASH if prove_program_hash else 0) | (OLA_TRACEGEN_EXPLICIT_BETAS if explicit else 0)
+    flags = ((OLA_TRACEGEN_PROVE_PROGRAM_HASH if prove_program_hash else 0) | (OLA_TRACEGEN_EXPLICIT_BETAS if explicit else 0) |
+             (OLA_TRACEGEN_REFERENCE_QUIRKS if reference_quirks else 0))
     rc = L.ola_tracegen_run(ins, len(prog.ins), code, stor, range_bits, limb_bits, bitwise_beta if explicit else 0, program_beta if explicit else 0,
                             max_steps, flags, C.byref(handle))
     if rc != 0:

@@ -479,7 +479,7 @@ def prog_chunk_and_poseidon(prog, words, n_poseidon_min=8, extra_rows=(), result
     return t, pt
 
 
-def memory_trace(cells):
+def memory_trace(cells, reference_quirks=False):
     """Memory table of stack- and heap-region accesses (generation/memory.rs:5-95; cell rules of core's memory trace): rows
     sorted by (address, clk); diff / rw_addr_unchanged / rc_value columns relate each row to its predecessor, rc_value
     (the clock difference on an unchanged address, else the address difference) is range-checked through the
@@ -489,6 +489,8 @@ def memory_trace(cells):
     -> (trace, range-checked sort values, range-checked region values)"""
     cells = sorted(cells)
     n = TG.next_pow2(max(len(cells) + 1, 8))
+    if reference_quirks and not cells:          # generation/memory.rs:95-153 as it is (tracegen.memory_padding_trace)
+        return TG.memory_padding_trace(n, reference_quirks=True), [], []
     t = np.zeros((T.NUM_MEM_COLS, n), dtype=np.uint64)
     rc_vals, cond_vals = [], []
     prev = None
@@ -638,9 +640,11 @@ def derive_program_beta(start_root, end_root):
     return ch.get()
 
 
-def instance(prog, range_bits=4, limb_bits=2, bitwise_beta=None, program_beta=None, prove_program_hash=False, max_steps=1 << 16):
+def instance(prog, range_bits=4, limb_bits=2, bitwise_beta=None, program_beta=None, prove_program_hash=False, max_steps=1 << 16, reference_quirks=False):
     """The 12 traces (enum Table order), params and compress challenges of ola_stark(range_bits, limb_bits) for one run of
-    `prog`.  The compress challenges of the bitwise and program tables are derived as the reference derives them (a
+    `prog`.  reference_quirks: the two places where the reference's generators write something its own AIR rejects are reproduced
+    (bitwise limb 3, memory table of a run without memory cells -- tracegen.bitwise_trace / memory_padding_trace): for comparing whole
+    pipelines with a build of the reference, not for proving.  The compress challenges of the bitwise and program tables are derived as the reference derives them (a
     transcript over the bitwise limb columns, generation/builtin.rs:120-131, and over the start / end state roots,
     generation/prog.rs:23-29); explicit values are for tests only.  With miniature fixed tables, RC / GTE operands must stay below 2^(2*range_bits) and bitwise operands below
     2^(4*limb_bits).  `prove_program_hash`: close the program-hash chain with a result line and a state-tree proof that
@@ -667,10 +671,11 @@ def instance(prog, range_bits=4, limb_bits=2, bitwise_beta=None, program_beta=No
     for a, b in side["cmp"]:
         d = abs(a - b)
         cmp_rows.append((a, b, int(a >= b), d, _inv(d), 1))
-    mem, mem_rc, mem_cond = memory_trace(side["mem"])
+    mem, mem_rc, mem_cond = memory_trace(side["mem"], reference_quirks=reference_quirks)
     rc_rows = ([(v, 1, 0, 0, 0) for v in side["rc"]] + [(r[3], 0, 0, 0, 1) for r in cmp_rows] + [(v, 0, 1, 0, 0) for v in mem_rc]
                + [(v, 0, 0, 1, 0) for v in mem_cond])
-    bitwise = TG.bitwise_trace(bitwise_beta, limb_bits, side["bitwise"], looked_by_cpu=True, transcript=_transcript if bitwise_beta is None else None)
+    bitwise = TG.bitwise_trace(bitwise_beta, limb_bits, side["bitwise"], looked_by_cpu=True, transcript=_transcript if bitwise_beta is None else None,
+                               reference_quirks=reference_quirks)
     if bitwise_beta is None:
         bitwise, bitwise_beta = bitwise
     traces = [

@@ -111,10 +111,27 @@ def cpu_padding_trace(n):
     return t
 
 
-def memory_padding_trace(n):
+def memory_padding_trace(n, reference_quirks=False):
+    """Memory table of an execution without memory cells.  reference_quirks: the rows generation/memory.rs:95-153 writes -- EVERY row a
+    prophet-region row starting at address p - (2^32 - 1), row 0 without its S_PROPHET selector and address step (the table then breaks
+    memory_stark.rs:265-270 on the wrap-around from the last row to row 0; for comparing whole pipelines with a build of the reference,
+    integration/pin/).  Default: one stack-region row first, the reference's prophet rows one place later."""
     t = np.zeros((T.NUM_MEM_COLS, n), dtype=np.uint64)
     span = 2**32 - 1
     addr = (0 - span) % P
+    if reference_quirks:
+        i = np.arange(n, dtype=np.uint64)
+        a = (np.uint64(addr) + i) % np.uint64(P)
+        neg = (np.uint64(P) - a) % np.uint64(P)
+        t[T.COL_MEM_ADDR] = a
+        t[T.COL_MEM_IS_WRITE] = 1
+        t[T.COL_MEM_DIFF_ADDR_COND] = neg
+        t[T.COL_MEM_RC_VALUE] = neg
+        t[T.COL_MEM_REGION_PROPHET] = 1
+        t[T.COL_MEM_S_PROPHET, 1:] = 1
+        t[T.COL_MEM_DIFF_ADDR, 1:] = 1
+        t[T.COL_MEM_DIFF_ADDR_INV, 1:] = 1
+        return t
     t[T.COL_MEM_S_PROPHET] = 1
     t[T.COL_MEM_IS_WRITE] = 1                        # row 0: stack region, address 0, written once
     i = np.arange(1, n, dtype=np.uint64)
@@ -132,13 +149,16 @@ def memory_padding_trace(n):
     return t
 
 
-def bitwise_trace(beta, limb_bits=8, ops=(), looked_by_cpu=False, transcript=None):
+def bitwise_trace(beta, limb_bits=8, ops=(), looked_by_cpu=False, transcript=None, reference_quirks=False):
     """generation/builtin.rs:35-205 with `limb_bits`-wide limbs: the fixed AND/OR/XOR table, and one row per operation in
     `ops` = [(name, op0, op1)] (operands of 4 limbs) with its limbs, compressed limbs and the permuted lookup columns.
     The rows carry FILTER = 0 (nothing in the CPU table looks them up, but every bitwise constraint and in-table lookup
     is live on them) unless looked_by_cpu, in which case they are the looked-up side of the CPU's AND / OR / XOR rows.
     `transcript` (a factory of Challenger objects): derive the compress challenge from the twelve limb columns as
-    generation/builtin.rs:120-131 does and return (trace, beta) instead of using `beta`."""
+    generation/builtin.rs:120-131 does and return (trace, beta) instead of using `beta`.
+    reference_quirks: the fourth limb of op0 / op1 / res is NOT stored -- generation/builtin.rs:66,71,76 write it to `OP*_LIMBS.end`, the
+    exclusive end of the column range, where the next group's write replaces it, so the reference's limb-3 columns are zero whatever the
+    operand (docs/EXPERIMENTS.md "a defect of the reference's bitwise trace generator"); everything derived from the limb columns follows."""
     size = 1 << limb_bits
     per = size * size
     n = next_pow2(max(size, 3 * per, len(ops)))
@@ -159,6 +179,8 @@ def bitwise_trace(beta, limb_bits=8, ops=(), looked_by_cpu=False, transcript=Non
         t[T.BW_TAG, r], t[T.BW_OP0, r], t[T.BW_OP1, r], t[T.BW_RES, r] = T.op_mask(name), x, y, z
         t[T.BW_FILTER, r] = int(looked_by_cpu)
         for i, (lx, ly, lz) in enumerate(zip(limbs(x), limbs(y), limbs(z))):
+            if reference_quirks and i == 3:
+                continue
             t[T.BW_OP0_LIMBS.start + i, r], t[T.BW_OP1_LIMBS.start + i, r], t[T.BW_RES_LIMBS.start + i, r] = lx, ly, lz
     if transcript is not None:
         ch = transcript()

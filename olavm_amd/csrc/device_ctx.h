@@ -196,6 +196,7 @@ struct DeviceCtx {
     //     ordered behind it),
     // all checked under the sibling's `mu`: whatever is in its cache then was freed by finished calls whose work has completed.
     std::atomic<int> calls{0};
+    std::atomic<int> pins{0};                  // siblings looking at this context's cache outside the registry lock (adopt / release_idle_siblings)
     bool lends = false;
     // pinned staging ring of the trace upload (upload.h), kept from proof to proof: hipHostMalloc costs milliseconds per 100 MB
     void* staging = nullptr;
@@ -269,10 +270,25 @@ struct DeviceCtx {
     }
     void leave_pool_registry() {
         PoolRegistry& R = PoolRegistry::get();
-        std::lock_guard<std::mutex> lk(R.mu);
-        for (size_t i = 0; i < R.all.size(); i++)
-            if (R.all[i] == this) { R.all.erase(R.all.begin() + (long)i); break; }
+        {
+            std::lock_guard<std::mutex> lk(R.mu);
+            for (size_t i = 0; i < R.all.size(); i++)
+                if (R.all[i] == this) { R.all.erase(R.all.begin() + (long)i); break; }
+        }
+        // a sibling that took this context off the list before it left may still be asking its stream: wait for it (microseconds)
+        while (pins.load() != 0) std::this_thread::yield();
     }
+    // the siblings on this device that lend, pinned so that they stay alive after the registry lock is released: the runtime calls
+    // that follow (hipStreamQuery, hipFree) must not run under the one lock every context of the process needs to come and go
+    std::vector<DeviceCtx*> pin_siblings() {
+        std::vector<DeviceCtx*> v;
+        PoolRegistry& R = PoolRegistry::get();
+        std::lock_guard<std::mutex> rk(R.mu);
+        for (DeviceCtx* o : R.all)
+            if (o != this && o->lends && o->device == device) { o->pins.fetch_add(1); v.push_back(o); }
+        return v;
+    }
+    static void unpin(const std::vector<DeviceCtx*>& v) { for (DeviceCtx* o : v) o->pins.fetch_sub(1); }
     // true when `o` (locked by the caller) may hand blocks of its cache to this context right now
     bool sibling_is_idle(DeviceCtx* o) {
         if (o->calls.load() != 0) return false;
@@ -284,31 +300,29 @@ struct DeviceCtx {
     }
     void* adopt(size_t want, size_t& got) {
         if (!lends) return nullptr;
-        PoolRegistry& R = PoolRegistry::get();
-        std::lock_guard<std::mutex> rk(R.mu);
-        for (DeviceCtx* o : R.all) {
-            if (o == this || !o->lends || o->device != device) continue;
+        const std::vector<DeviceCtx*> sib = pin_siblings();
+        void* p = nullptr;
+        for (DeviceCtx* o : sib) {
             std::unique_lock<std::mutex> lk(o->mu, std::try_to_lock);
             if (!lk.owns_lock()) continue;
             auto it = o->cache.lower_bound(want);
             if (it == o->cache.end() || it->first > want + want / 4) continue;
             if (!sibling_is_idle(o)) continue;
-            void* p = it->second;
+            p = it->second;
             got = it->first;
             o->cached_bytes -= got;
             o->cache.erase(it);
-            return p;
+            break;
         }
-        return nullptr;
+        unpin(sib);
+        return p;
     }
     // out of memory: the cached blocks of idle siblings on this device go back to the driver
     size_t release_idle_siblings() {
         if (!lends) return 0;
         size_t freed = 0;
-        PoolRegistry& R = PoolRegistry::get();
-        std::lock_guard<std::mutex> rk(R.mu);
-        for (DeviceCtx* o : R.all) {
-            if (o == this || !o->lends || o->device != device) continue;
+        const std::vector<DeviceCtx*> sib = pin_siblings();
+        for (DeviceCtx* o : sib) {
             std::unique_lock<std::mutex> lk(o->mu, std::try_to_lock);
             if (!lk.owns_lock() || o->cache.empty() || !sibling_is_idle(o)) continue;
             for (auto& kv : o->cache) (void)hipFree(kv.second);
@@ -316,6 +330,7 @@ struct DeviceCtx {
             o->cache.clear();
             o->cached_bytes = 0;
         }
+        unpin(sib);
         if (freed && timing) fprintf(stderr, "[ola-timing] device allocator: out of memory, released %.1f GB cached by idle contexts on this GPU\n", freed / 1e9);
         return freed;
     }

@@ -647,7 +647,7 @@ uint32_t mem_opcode(MemOp op) {
 }
 
 // generation/memory.rs:5-95: cells sorted by (address, clock); stack and heap regions live, prophet-region padding after them
-void memory_table(std::vector<MemCell> cells, Table& t, std::vector<u64>& rc_vals, std::vector<u64>& cond_vals) {
+void memory_table(std::vector<MemCell> cells, Table& t, std::vector<u64>& rc_vals, std::vector<u64>& cond_vals, bool quirks) {
     std::sort(cells.begin(), cells.end(), [](const MemCell& a, const MemCell& b) {
         if (a.addr != b.addr) return a.addr < b.addr;
         if (a.clk != b.clk) return a.clk < b.clk;
@@ -688,6 +688,15 @@ void memory_table(std::vector<MemCell> cells, Table& t, std::vector<u64>& rc_val
         have_prev = true; prev_addr = c.addr; prev_clk = c.clk; prev_heap = heap;
     }
     u64 a = subm(0, span);
+    if (quirks && cells.empty()) {       // OLA_TRACEGEN_REFERENCE_QUIRKS: generation/memory.rs:95-153 as it is
+        for (size_t i = 0; i < n; i++) {
+            t.at(COL_MEM_ADDR, i) = a; t.at(COL_MEM_IS_WRITE, i) = t.at(COL_MEM_REGION_PROPHET, i) = 1;
+            t.at(COL_MEM_DIFF_ADDR_COND, i) = t.at(COL_MEM_RC_VALUE, i) = subm(0, a);
+            if (i) t.at(COL_MEM_S_PROPHET, i) = t.at(COL_MEM_DIFF_ADDR, i) = t.at(COL_MEM_DIFF_ADDR_INV, i) = 1;
+            a = addm(a, 1);
+        }
+        return;
+    }
     const u64 last_addr = have_prev ? prev_addr : 0;
     const size_t start = cells.empty() ? 1 : cells.size();
     if (cells.empty()) { t.at(COL_MEM_S_PROPHET, 0) = 1; t.at(COL_MEM_IS_WRITE, 0) = 1; }
@@ -826,7 +835,7 @@ void rc_table(const std::vector<RcRow>& rows, uint32_t range_bits, Table& t) {
 // generation/builtin.rs:35-205 with limb_bits-wide limbs
 // `derive`: the compress challenge is drawn from a transcript that has observed the twelve limb columns (OP0, OP1, RES limbs
 // over the whole padded height), as generation/builtin.rs:120-131 does; otherwise the caller's `beta` is used (tests only)
-u64 bitwise_table(u64 beta, bool derive, uint32_t limb_bits, const std::vector<BwOp>& ops, Table& t) {
+u64 bitwise_table(u64 beta, bool derive, uint32_t limb_bits, const std::vector<BwOp>& ops, Table& t, bool quirks) {
     const size_t size = (size_t)1 << limb_bits, per = size * size;
     const size_t n = next_pow2(std::max(std::max(size, 3 * per), ops.size()));
     t.init(COL_NUM_BITWISE, n);
@@ -850,7 +859,7 @@ u64 bitwise_table(u64 beta, bool derive, uint32_t limb_bits, const std::vector<B
         const u64 tag = 1ULL << ops[r].op;
         t.at(BW_TAG, r) = tag; t.at(BW_OP0, r) = x; t.at(BW_OP1, r) = y; t.at(BW_RES, r) = z;
         t.at(BW_FILTER, r) = 1;                                                     // looked up by the CPU's AND / OR / XOR rows
-        for (int i = 0; i < 4; i++) {
+        for (int i = 0; i < (quirks ? 3 : 4); i++) {      // OLA_TRACEGEN_REFERENCE_QUIRKS: the fourth limb is lost (generation/builtin.rs:66,71,76)
             const u64 lx = (x >> (limb_bits * i)) & (size - 1), ly = (y >> (limb_bits * i)) & (size - 1), lz = (z >> (limb_bits * i)) & (size - 1);
             t.at(BW_OP0_LIMBS_START + i, r) = lx; t.at(BW_OP1_LIMBS_START + i, r) = ly; t.at(BW_RES_LIMBS_START + i, r) = lz;
         }
@@ -913,6 +922,7 @@ int32_t ola_tracegen_run(const OlaInstr* program, size_t n_instr, const uint64_t
         std::unique_ptr<OlaTraceSet> set(new OlaTraceSet());
         const bool prove_program_hash = flags & OLA_TRACEGEN_PROVE_PROGRAM_HASH;
         const bool explicit_betas = flags & OLA_TRACEGEN_EXPLICIT_BETAS;
+        const bool quirks = flags & OLA_TRACEGEN_REFERENCE_QUIRKS;
         Run R;
         StorageTree tree;
         const Hash4 code_key{code_addr[0], code_addr[1], code_addr[2], code_addr[3]};
@@ -951,14 +961,14 @@ int32_t ola_tracegen_run(const OlaInstr* program, size_t n_instr, const uint64_t
         prog_chunk_and_poseidon(code_addr, words, builtin_rows, prove_program_hash, T[PROG_CHUNK], T[POSEIDON]);
         std::vector<u64> abs_diffs, mem_rc, mem_cond;
         cmp_table(R.cmp, T[CMP], abs_diffs);
-        memory_table(R.mem, T[MEMORY], mem_rc, mem_cond);
+        memory_table(R.mem, T[MEMORY], mem_rc, mem_cond, quirks);
         std::vector<RcRow> rc;
         for (u64 v : R.rc) rc.push_back({v, {1, 0, 0, 0}});
         for (u64 v : abs_diffs) rc.push_back({v, {0, 0, 0, 1}});
         for (u64 v : mem_rc) rc.push_back({v, {0, 1, 0, 0}});
         for (u64 v : mem_cond) rc.push_back({v, {0, 0, 1, 0}});
         rc_table(rc, range_bits, T[RANGECHECK]);
-        set->bitwise_beta = bitwise_table(bitwise_beta, !explicit_betas, limb_bits, R.bitwise, T[BITWISE]);
+        set->bitwise_beta = bitwise_table(bitwise_beta, !explicit_betas, limb_bits, R.bitwise, T[BITWISE], quirks);
         storage_table(R.storage, prog_reads, T[STORAGE_ACCESS]);
         tape_table(R.tape, T[TAPE]);
         flag_padding(T[SCCALL], NUM_COL_SCCALL, 8, COL_SCCALL_IS_PADDING);

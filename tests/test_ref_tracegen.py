@@ -89,6 +89,50 @@ def test_bitwise_table_equals_the_interpreted_generator():
     assert digest(t) == {k: v[k] for k in ("columns", "rows", "sha256")}
 
 
+def test_reference_quirks_switch_reproduces_the_generators_as_they_are(vectors, oracle):
+    """The opt-in `reference_quirks` mode ("missing" 7): the memory table of a run without memory cells IS the interpreted
+    generator's output, word for word; the bitwise table leaves the fourth limbs zero as generation/builtin.rs:66,71,76 do -- identical to
+    the interpreted 2^18-row table for 24-bit operands (both modes are), and for 32-bit operands different from the default mode in exactly
+    the columns docs/EXPERIMENTS.md lists, with a trace that the table's own AIR rejects (the default mode's passes).  Python and native
+    generators agree in this mode too."""
+    v = vectors["memory_no_rows"]
+    assert TG.memory_padding_trace(v["rows"], reference_quirks=True).tolist() == v["trace"]
+    from olavm_amd.air import fastexec, miniexec as M
+    path = os.path.join(HERE, "golden", "ref_tracegen_bitwise.json")
+    if os.path.exists(path):
+        b = json.load(open(path))
+        ops = [(name, int(x), int(y)) for name, x, y in b["ops"]]
+        t, beta = TG.bitwise_trace(None, 8, ops, looked_by_cpu=True, transcript=M._transcript, reference_quirks=True)
+        assert beta == b["beta"] and digest(t) == {k: b[k] for k in ("columns", "rows", "sha256")}
+    ops = [("AND", 0xDEADBEEF, 0x0F0F0F0F), ("XOR", 0x80000001, 0x7FFFFFFF), ("OR", 5, 9)]
+    plain = TG.bitwise_trace(12345, 8, ops, looked_by_cpu=True)
+    quirk = TG.bitwise_trace(12345, 8, ops, looked_by_cpu=True, reference_quirks=True)
+    limb3 = [T.BW_OP0_LIMBS.start + 3, T.BW_OP1_LIMBS.start + 3, T.BW_RES_LIMBS.start + 3]
+    assert all(not quirk[c].any() for c in limb3) and all(plain[c].any() for c in limb3)
+    differing = {c for c in range(T.COL_NUM_BITWISE) if not np.array_equal(plain[c], quirk[c])}
+    derived = {T.BW_OP0_LIMBS_PERMUTED.start + 3, T.BW_OP1_LIMBS_PERMUTED.start + 3, T.BW_RES_LIMBS_PERMUTED.start + 3,
+               T.BW_FIX_RANGE_CHECK_U8_PERMUTED.start + 3, T.BW_FIX_RANGE_CHECK_U8_PERMUTED.start + 7, T.BW_FIX_RANGE_CHECK_U8_PERMUTED.start + 11,
+               T.BW_COMPRESS_LIMBS.start + 3, T.BW_COMPRESS_PERMUTED.start + 3, T.BW_FIX_COMPRESS_PERMUTED.start + 3}
+    assert set(limb3) <= differing <= set(limb3) | derived, sorted(differing)
+    s = T.ola_stark()
+    bw = [t.name for t in s.tables].index("bitwise")
+    params = [12345]
+    assert oracle.check_constraints(s.blob(), bw, plain, params) == -1
+    assert oracle.check_constraints(s.blob(), bw, quirk, params) >= 0          # op = sum of limbs fails on the first live row
+    # whole instances, Python against native, both quirks at once (a run without memory cells and with 32-bit bitwise operands)
+    p = M.Program()
+    p.add("MOV", dst=1, op1=("imm", 0xDEADBEEF)).add("MOV", dst=2, op1=("imm", 0x0F0F0F0F)).add("AND", dst=3, op0=1, op1=2).add("END")
+    want, wp, _ = M.instance(p, range_bits=16, limb_bits=8, reference_quirks=True)
+    got, gp, _ = fastexec.instance(p, range_bits=16, limb_bits=8, reference_quirks=True)
+    assert wp == gp
+    for i, (a, c) in enumerate(zip(want, got)):
+        assert np.array_equal(a, c), i
+    ref2 = np.array(v["trace"], dtype=np.uint64)
+    assert np.array_equal(want[1][:, :2], ref2)                               # the reference's two rows head this repository's eight
+    default, _, _ = M.instance(p, range_bits=16, limb_bits=8)
+    assert not np.array_equal(default[1], want[1]) and not np.array_equal(default[2], want[2])
+
+
 @pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="the reference tree is not on this machine")
 def test_small_vectors_are_what_the_interpreter_computes_today(vectors):
     sys.path.insert(0, os.path.join(ROOT, "tools"))
