@@ -174,13 +174,13 @@ def phase_block(be, hasher="poseidon"):
     ms, pts, byts = ph["quotient"]
     if ms > 0:      # quotient row streaming is HBM-class -- bytes = the LDE cells a point reads (local and next row of the trace and Z batches) + 16 written
         out["quotient"] = {"ms": round(ms, 2), "points_per_s_G": round(pts / (ms * 1e-3) / 1e9, 3), "bytes": int(byts),
-                           "GBps": round(byts / (ms * 1e-3) / 1e9, 1), "frac": round(byts / (ms * 1e-3) / (HBM_PEAK_GBPS * 1e9), 4), "bound": "hbm (contract); measured: re-loads of trace cells on top of 48 k VALU instructions per point -- "
-                                    "the CPU table's kernel issues 611 cell loads per point for 346 distinct cells (758 in round 4: profiles/r05_quotient_belady_order.txt, "
-                                    "per-kernel HBM bytes in profiles/r05_proof_pmc_blake3.txt), and runs in 44 ms when its loads hit L2 (profiles/r04_quotient_cell_cache.txt)"}
+                           "GBps": round(byts / (ms * 1e-3) / 1e9, 1), "frac": round(byts / (ms * 1e-3) / (HBM_PEAK_GBPS * 1e9), 4), "bound": "hbm (contract); measured: re-loads of trace cells on top of 36 k VALU instructions per point (48 k before "
+                                    "round 6's limb-product sums: profiles/r06_quotient_limb_sums.txt) -- the CPU table's kernel issues 611 cell loads per point for 346 distinct cells "
+                                    "(profiles/r05_quotient_belady_order.txt; per-kernel HBM bytes in profiles/r06_proof_pmc_blake3.txt)"}
     ms, prods, byts = ph["open_eval"]
     if ms > 0:      # every coefficient of every committed polynomial read once per point pair
         out["open_eval"] = {"ms": round(ms, 2), "coefficient_point_products_per_s_G": round(prods / (ms * 1e-3) / 1e9, 2), "bytes": int(byts),
-                            "GBps": round(byts / (ms * 1e-3) / 1e9, 1), "frac": round(byts / (ms * 1e-3) / (HBM_PEAK_GBPS * 1e9), 4), "bound": "hbm (contract); extension multiply-add chains (measured)"}
+                            "GBps": round(byts / (ms * 1e-3) / 1e9, 1), "frac": round(byts / (ms * 1e-3) / (HBM_PEAK_GBPS * 1e9), 4), "bound": "hbm; round 6: 25 VALU per coefficient (22-bit limb products, multiplier in SGPRs; 124 before), profiles/r06_openings_ab.txt"}
     return out
 
 
@@ -840,9 +840,16 @@ def compact_line(res):
     st = res.get("start")
     if isinstance(st, dict):
         out["start"] = {k: v for k, v in st.items() if isinstance(v, (int, float, bool))}
-    for k in ("open_eval_frac", "fri_fold_frac", "small_tables_ms"):
-        if res.get(k) is not None:
-            out[k] = res[k]
+    # the HBM-class kernels of the openings (Blake3-configuration 2^22-row proof: bytes every coefficient once / device time of the
+    # phase) and the launch-bound tables of the README-shape proof
+    for name, path in (("open_eval_frac", ("prove", "blake3_config", "kernels", "open_eval", "frac")),
+                       ("fri_fold_frac", ("prove", "blake3_config", "kernels", "fri_fold", "frac_of_hbm_peak")),
+                       ("fri_fold_ms", ("prove", "blake3_config", "kernels", "fri_fold", "ms")),
+                       ("quotient_ms", ("prove", "blake3_config", "kernels", "quotient", "ms")),
+                       ("small_tables_ms", ("readme_fibo_loop_blake3", "partition", "replicated_breakdown_ms", "tables_below_the_partition_threshold"))):
+        v = res.get(name) if res.get(name) is not None else _num(res, *path)
+        if v is not None:
+            out[name] = v
     out["details"] = os.path.basename(DETAILS_FILE)
     return out
 
