@@ -345,6 +345,33 @@ __global__ __launch_bounds__(256) void merkle_level_b3_kernel(u64* __restrict__ 
     if (t >= count) return;
     b3_node(heap + 8 * (first + t), heap + 4 * (first + t));
 }
+// `nlev` (<= 8) consecutive levels in one launch (round 6): a workgroup computes 256 nodes of the level of `first` nodes from their
+// children in the heap, then the 128, 64, ... nodes above them out of LDS -- every level is still written to the heap (sibling paths
+// read it), but only the bottom one is read back.  Measured on the 2^22-row Blake3 proof (profiles/r06_merkle_levels_per_launch.txt,
+// 314 level launches and 20.6 GB per proof before): eight levels per launch are SLOWER (6.3 -> 8.4 ms: the upper levels run on 128, 64,
+// ... 1 lanes of a workgroup that keeps its slot for eight compressions in a row), two or three are a little faster (5.8 ms), four 6.0;
+// the default is two (OLA_MERKLE_FUSED_LEVELS, 0 = one launch per level).
+__global__ __launch_bounds__(256) void merkle_levels_b3_kernel(u64* __restrict__ heap, size_t first, int nlev) {
+    __shared__ u64 sh[2][256 * 4];
+    const int t = threadIdx.x;
+    u64 d[4];
+    {
+        const size_t node = first + (size_t)blockIdx.x * 256 + t;
+        b3_node(heap + 8 * node, d);
+#pragma unroll
+        for (int k = 0; k < 4; k++) { heap[4 * node + k] = d[k]; sh[0][4 * t + k] = d[k]; }
+    }
+    for (int l = 1; l < nlev; l++) {
+        __syncthreads();
+        const int count = 256 >> l;
+        if (t < count) {
+            const size_t node = (first >> l) + (size_t)blockIdx.x * count + t;
+            b3_node(&sh[(l - 1) & 1][8 * t], d);
+#pragma unroll
+            for (int k = 0; k < 4; k++) { heap[4 * node + k] = d[k]; sh[l & 1][4 * t + k] = d[k]; }
+        }
+    }
+}
 // levels of `first` nodes and fewer (first <= blockDim.x) down to the level of `last` nodes in one workgroup
 __global__ __launch_bounds__(256) void merkle_top_b3_kernel(u64* __restrict__ heap, size_t first, size_t last) {
     for (size_t level = first; level >= last && level >= 1; level >>= 1) {
@@ -438,6 +465,15 @@ void launch_merkle_build(DeviceCtx* ctx, u64* heap, size_t num_leaves, uint32_t 
     PhaseScope ph(ctx, PH_MERKLE_LEVELS, num_leaves > last ? (double)(num_leaves - last) : 0.0, num_leaves > last ? (double)(num_leaves - last) * 96 : 0.0);
     size_t level = num_leaves / 2;
     if (is_b3(ctx)) {
+        static const int fused = getenv("OLA_MERKLE_FUSED_LEVELS") ? atoi(getenv("OLA_MERKLE_FUSED_LEVELS")) : 2;
+        if (fused > 1 && last <= top && (level & (level - 1)) == 0) {
+            while (level > top) {          // level is a power of two >= 512: up to `fused` levels per launch, the last of them still above `top`
+                int nlev = 0;
+                while (nlev < fused && nlev < 8 && (level >> nlev) > top) nlev++;
+                hipLaunchKernelGGL(merkle_levels_b3_kernel, dim3((unsigned)(level / 256)), dim3(256), 0, ctx->stream, heap, level, nlev);
+                level >>= nlev;
+            }
+        }
         for (; level >= last && level > top; level /= 2)
             hipLaunchKernelGGL(merkle_level_b3_kernel, dim3((unsigned)((level + 255) / 256)), dim3(256), 0, ctx->stream, heap, level, level);
         if (level >= last && level >= 1) hipLaunchKernelGGL(merkle_top_b3_kernel, dim3(1), dim3(256), 0, ctx->stream, heap, level, last);

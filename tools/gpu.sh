@@ -154,6 +154,26 @@ for _ in range(4):
 print(os.environ["AB_NAME"], "wall %.1f ms, quotient kernels %.2f ms" % best, "proof sha256", hashlib.sha256(bytes(proof)).hexdigest()[:16])
 PY
                  done 2>&1 | grep -v amdgpu | tee $O/ab.txt; cp ab_tmp/libola_cur.so olavm_amd/lib/libola_gpu.so ;;
+    merkle_ab)   # round 6: eight Blake3 Merkle levels per launch (merkle_levels_b3_kernel) against one launch per level (OLA_MERKLE_FUSED_LEVELS=0)
+                 [ "${AB_SKIP_TESTS:-0}" = 1 ] || timeout 1200 python -m pytest tests/test_gpu_blake3.py tests/test_gpu_fullsize.py -x -q -k "blake3 or b3 or commitment" 2>&1 | tail -3 | tee $O/pytest.log
+                 for v in ${AB_LEVELS:-0 2 3 4 0 2 3 4}; do AB_HASHER=blake3 OLA_MERKLE_FUSED_LEVELS=$v timeout 300 python - <<'PY'
+import os, sys, hashlib
+sys.path.insert(0, ".")
+from olavm_amd.air import ola_tables as T, tracegen
+from olavm_amd.backend import Backend
+blob = T.ola_stark().blob()
+traces, params, compress = tracegen.empty_program_instance(log_n=10, range_bits=16, limb_bits=8, log_n_cpu=22, log_n_mem=22)
+be = Backend(device=0, hasher=os.environ["AB_HASHER"])
+be.proof_stats(enable=True)
+best = None
+for _ in range(4):
+    proof = be.prove_with_traces(blob, traces, params, compress)
+    st, ph = be.proof_stats(), be.phase_stats()
+    if best is None or st["wall_ms"] < best[0]:
+        best = (st["wall_ms"], ph["merkle_levels"][0], ph["leaf_hash"][0])
+print("levels per launch:", os.environ["OLA_MERKLE_FUSED_LEVELS"], "wall %.1f ms, Merkle levels %.2f ms, leaves %.2f ms" % best, "proof sha256", hashlib.sha256(bytes(proof)).hexdigest()[:16])
+PY
+                 done 2>&1 | grep -v amdgpu | tee $O/ab.txt ;;
     phases)      OLA_TIMING=1 timeout 600 python tools/bench_prove.py 22 2 2> $O/phases.txt | tail -3; OLA_HASHER=blake3 OLA_TIMING=1 timeout 600 python tools/bench_prove.py 22 2 2> $O/phases_blake3.txt | tail -3 ;;
     ntt_group)   # Infinity-Cache blocking of the transforms: working-set target in MB (0 = whole batch per launch)
                  for mb in 0 32 64 96 128 192; do
