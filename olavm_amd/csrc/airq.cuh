@@ -75,7 +75,11 @@ __device__ __forceinline__ void acc3_mad(Acc3& a, u64 x, u64 w01, u64 w23, u64 w
     const u32 x0 = (u32)x, x1 = (u32)(x >> 32);
     a.c0 = acc3_step(x0, (u32)w01, a.c0);
     a.c1 = acc3_step(x0, (u32)(w01 >> 32), a.c1);
+#ifdef OLA_SELFTEST_FAULT_ACC3     // fault injection for ola_gpu_selftest (tools/gpu.sh selftest_fault): one limb off by one for 1 operand in 4096
+    a.c2 = acc3_step(x0, (u32)w23 ^ ((x0 & 0xFFFu) == 0 ? 1u : 0u), a.c2);
+#else
     a.c2 = acc3_step(x0, (u32)w23, a.c2);
+#endif
     a.c0 = acc3_step(x1, (u32)(w23 >> 32), a.c0);
     a.c1 = acc3_step(x1, (u32)w45, a.c1);
     a.c2 = acc3_step(x1, (u32)(w45 >> 32), a.c2);

@@ -3,7 +3,9 @@
 // arithmetic on limb vectors that sit on the bounds, and the carry-flag forms of the 128 -> 64 bit reduction (gl.cuh, inline
 // assembly with hand-placed wait states) against the plain C++ forms of the same header, on every pair of a table of edge values
 // and on `pairs` pseudo-random operand pairs biased towards words whose halves are all ones or all zeros -- where the carries
-// live.  A product check an integrator can run once at start-up on a new driver / compiler; the GPU test-suite runs it too.
+// live; and (round 6) the lazy sums of 22-bit limb products of the quotient and opening-evaluation kernels against canonical
+// multiply-and-add, up to the 512 products a sum may hold.  A product check an integrator can run once at start-up on a new driver /
+// compiler; the GPU test-suite runs it too.
 #include <hip/hip_runtime.h>
 
 #include <vector>
@@ -11,6 +13,7 @@
 #include "device_ctx.h"
 #include "gl.cuh"
 #include "ntt2t.cuh"
+#include "airq.cuh"
 
 namespace ola {
 
@@ -112,6 +115,46 @@ __global__ __launch_bounds__(256) void tform_selftest_kernel(u64 per_thread, uns
     if (local) atomicAdd(bad, local);
 }
 
+// ---- the lazy sums of 22-bit limb products (round 6: airq.cuh Acc3 = the arithmetic of eval_points_wide_kernel, fri.hip) against
+// canonical multiply-and-add: sums of 1 .. 512 products (512 = the most a sum may hold), operands biased towards all-ones words and
+// p - 1, whose limbs are the largest -- the sample with 512 maximal products sits exactly on the headroom the design claims.
+__device__ __forceinline__ unsigned st_limb_sum_check(u64 h) {
+    const int count = (h & 7) == 0 ? 512 : 1 + (int)((h >> 8) % 512);
+    const int shape = (int)((h >> 3) & 3);
+    Acc3 a = {0, 0, 0};
+    u64 want = 0;
+    u64 s = st_mix(h);
+    for (int i = 0; i < count; i++) {
+        u64 x = st_mix(s), w = st_mix(s + 1);
+        s = w;
+        if (shape == 1) { x = ~0ull; w = GL_P - 1; }                       // every product maximal
+        else if (shape == 2) { x |= 0xFFFFFFFF00000000ull; w |= 0xFFFFFFFFull; }
+        const u64 wc = gl_canon(w), v = gl_mul(wc, 1ull << 32), M = 0x3FFFFF;   // the host's push_limbs (stark.hip) / make_ext_pows (fri.hip)
+        acc3_mad(a, x, (wc & M) | (((wc >> 22) & M) << 32), (wc >> 44) | ((v & M) << 32), ((v >> 22) & M) | ((v >> 44) << 32));
+        want = gl_add(want, gl_mul(x, wc));
+    }
+    unsigned bad = acc3_reduce(a) != want;
+    const Acc3 again = acc3_init(acc3_reduce(a));                              // AIRQ_REFOLD_*: fold and restart
+    bad += acc3_reduce(again) != want;
+    if ((h & 0xFF) == 0) {
+        // the corner itself: 512 multiply-accumulates of an all-ones word with six all-ones limbs (no multiplier has them; the sums
+        // then hold 1024 x (2^32 - 1)(2^22 - 1) < 2^64 each)
+        const u64 M = 0x3FFFFF, all = M | (M << 32);
+        Acc3 c = {0, 0, 0};
+        for (int i = 0; i < 512; i++) acc3_mad(c, ~0ull, all, all, all);
+        const u64 L = gl_add(gl_add(M, gl_mul(M, 1ull << 22)), gl_mul(M, 1ull << 44));     // the value the limbs stand for
+        const u64 one = gl_mul(gl_add(0xFFFFFFFFull, 0xFFFFFFFFull), L);                     // x_lo L + x_hi L
+        bad += acc3_reduce(c) != gl_mul(one, 512);
+    }
+    return bad;
+}
+__global__ __launch_bounds__(256) void limb_sum_selftest_kernel(u64 per_thread, unsigned long long* __restrict__ bad) {
+    const u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long local = 0;
+    for (u64 i = 0; i < per_thread; i++) local += st_limb_sum_check(st_mix(gid * 0xD1342543DE82EF95ull + i * 0x9E3779B97F4A7C15ull + 0x5EED));
+    if (local) atomicAdd(bad, local);
+}
+
 u64 field_selftest(DeviceCtx* ctx, u64 pairs) {
     std::vector<u64> e = {0, 1, 2, 0xFFFFFFFFull, 0x100000000ull, 0x100000001ull, 0xFFFFFFFEull, GL_P - 1, GL_P, GL_P + 1, GL_P - 2, ~0ull, ~0ull - 1,
                           0xFFFFFFFF00000000ull, 0xFFFFFFFEFFFFFFFFull, 0x8000000000000000ull, 0x7FFFFFFFFFFFFFFFull, 0xFFFFFFFF00000002ull,
@@ -127,6 +170,8 @@ u64 field_selftest(DeviceCtx* ctx, u64 pairs) {
     hipLaunchKernelGGL(field_selftest_kernel, dim3(blocks), dim3(256), 0, ctx->stream, d_e, (int)e.size(), (pairs + blocks * 256 - 1) / (blocks * 256), d_bad);
     // the T-form primitives on a sixteenth as many samples (each sample checks 22 identities)
     hipLaunchKernelGGL(tform_selftest_kernel, dim3(blocks), dim3(256), 0, ctx->stream, (pairs / 16 + blocks * 256 - 1) / (blocks * 256), d_bad);
+    // the limb-product sums: one sum of up to 512 products per 4096 pairs asked for (at least one per thread of a small grid)
+    hipLaunchKernelGGL(limb_sum_selftest_kernel, dim3(256), dim3(256), 0, ctx->stream, std::max<u64>(1, pairs / 4096 / (256 * 256)), d_bad);
     HIP_CHECK(hipMemcpyAsync(&bad, d_bad, 8, hipMemcpyDeviceToHost, ctx->stream));
     HIP_CHECK(hipStreamSynchronize(ctx->stream));
     return bad;

@@ -174,6 +174,13 @@ for _ in range(4):
 print("levels per launch:", os.environ["OLA_MERKLE_FUSED_LEVELS"], "wall %.1f ms, Merkle levels %.2f ms, leaves %.2f ms" % best, "proof sha256", hashlib.sha256(bytes(proof)).hexdigest()[:16])
 PY
                  done 2>&1 | grep -v amdgpu | tee $O/ab.txt ;;
+    selftest_fault) # the device self-test must notice a fault injected into the limb-product sums (ab_tmp/libola_fault.so: tools/build_variant.sh fault -DOLA_SELFTEST_FAULT_ACC3)
+                 cp olavm_amd/lib/libola_gpu.so ab_tmp/libola_cur.so
+                 for v in cur fault; do cp ab_tmp/libola_$v.so olavm_amd/lib/libola_gpu.so; timeout 300 python -c "
+import sys; sys.path.insert(0, '.')
+from olavm_amd.backend import Backend
+be = Backend(device=0); print('$v library: ola_gpu_selftest(2^31) mismatches =', be.selftest(1 << 31)); be.close()" 2>&1 | grep -v amdgpu; done | tee $O/selftest.txt
+                 cp ab_tmp/libola_cur.so olavm_amd/lib/libola_gpu.so ;;
     phases)      OLA_TIMING=1 timeout 600 python tools/bench_prove.py 22 2 2> $O/phases.txt | tail -3; OLA_HASHER=blake3 OLA_TIMING=1 timeout 600 python tools/bench_prove.py 22 2 2> $O/phases_blake3.txt | tail -3 ;;
     ntt_group)   # Infinity-Cache blocking of the transforms: working-set target in MB (0 = whole batch per launch)
                  for mb in 0 32 64 96 128 192; do
