@@ -42,7 +42,7 @@ extern "C" {
  * revision 4 changed.
  * 6: ola_gpu_warmup / ola_gpu_warmup_wait (start-up work ahead of the first context, where the reference calls init_gpu()),
  * ola_gpu_ntt_pass_times (the transform passes one by one, for the dominant kernel's roofline); no struct changed. */
-#define OLA_GPU_ABI_VERSION 6
+#define OLA_GPU_ABI_VERSION 7
 #define OLA_OK 0
 #define OLA_E_INVALID_ARG (-1)
 #define OLA_E_NO_DEVICE (-2)
@@ -358,6 +358,35 @@ int32_t ola_open_and_prove(OlaCtx* ctx, const OlaBatch* trace, const OlaBatch* z
 /* FRI proof of work (fri/prover.rs:126-148): the MINIMAL witness i such that
  * Poseidon.hash_no_pad([h0..h3, i])[0] has >= bits leading zeros. */
 int32_t ola_pow(OlaCtx* ctx, const uint64_t h[4], uint32_t bits, uint64_t* witness);
+
+/* ---- the same, one step per call (ABI revision 7): for a host that keeps the reference's own loops and its own Challenger and
+ * hands over the device work only.  Each beta depends on the previous layer's cap through the host challenger
+ * (fri/prover.rs:98-101), so the commit phase is layer-stepped.  The bytes the steps return reassemble to ola_open_and_prove's
+ * (tests/test_gpu_fri_steps.py does exactly that with ola_challenger_*).  Single-device contexts; the three batches must outlive
+ * the OlaFri.
+ *   ola_open                   StarkOpeningSet::new (circuits/src/stark/proof.rs:198-233) at the caller's zeta: the opening set in
+ *                              wire format (serialization.rs write_stark_opening_set) -- decode, then
+ *                              challenger.observe_openings(&openings.to_fri_openings()) (fri/challenges.rs:16-23)
+ *   ola_fri_plan               fri_params.reduction_arity_bits (fri/reduction_strategies.rs:40-52) and the final polynomial's length
+ *   ola_fri_commit_begin       PolynomialBatch::prove_openings up to the final polynomial (fri/oracle.rs:178-219), alpha =
+ *                              challenger.get_extension_challenge()
+ *   ola_fri_commit_next_layer  one turn of fri_committed_trees (fri/prover.rs:72-121): folds by the PREVIOUS layer's beta (NULL for the
+ *                              first layer), commits the current polynomial's values on its coset, cap_out = 2^cap_height x 4 words
+ *   ola_fri_commit_finish      folds by the last beta (NULL when the plan has no layer): the final polynomial, (a, b) pairs
+ *                              (prover.rs:114-119); *n_out = its length
+ *   ola_pow (above)            fri_proof_of_work (prover.rs:126-148), minimal witness
+ *   ola_fri_query              fri_prover_query_rounds (prover.rs:150-204) for the caller's indices (challenger output mod the LDE
+ *                              size): the query round proofs in wire format (serialization.rs:305-317: count, per query the three
+ *                              oracles' rows and paths and every layer's leaf and path) */
+typedef struct OlaFri OlaFri;
+int32_t ola_open(OlaCtx* ctx, const OlaBatch* trace, const OlaBatch* zs, const OlaBatch* quotient, uint32_t num_permutation_zs,
+                 const uint64_t zeta[2], uint8_t* out, size_t cap, size_t* out_len, OlaFri** fri_out);
+int32_t ola_fri_plan(const OlaFri* fri, uint32_t* arity_bits, uint32_t cap, uint32_t* n_layers, uint32_t* final_poly_len);
+int32_t ola_fri_commit_begin(OlaFri* fri, const uint64_t alpha[2]);
+int32_t ola_fri_commit_next_layer(OlaFri* fri, const uint64_t* beta, uint64_t* cap_out);
+int32_t ola_fri_commit_finish(OlaFri* fri, const uint64_t* beta, uint64_t* final_poly_out, size_t cap_elems, size_t* n_out);
+int32_t ola_fri_query(OlaFri* fri, const uint64_t* x_index, uint32_t n, uint8_t* out, size_t cap, size_t* out_len);
+int32_t ola_fri_free(OlaFri* fri);
 
 /* ---- the whole multi-table proof: replaces prove_with_traces (circuits/src/stark/prover.rs:79-327) -------------
  * airset: the AIR-set description (tables, constraint programs, permutation pairs, cross-table lookups) as a u64

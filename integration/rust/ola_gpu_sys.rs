@@ -11,7 +11,7 @@
 #![allow(non_camel_case_types, dead_code)]
 use std::os::raw::{c_char, c_void};
 
-pub const OLA_GPU_ABI_VERSION: i32 = 6;
+pub const OLA_GPU_ABI_VERSION: i32 = 7;
 pub const OLA_OK: i32 = 0;
 pub const OLA_E_INVALID_ARG: i32 = -1;
 pub const OLA_E_NO_DEVICE: i32 = -2;
@@ -46,6 +46,11 @@ pub struct OlaCtx {
 }
 #[repr(C)]
 pub struct OlaBatch {
+    _p: [u8; 0],
+}
+/// one table's opening proof between the steps of `ola_open` / `ola_fri_*`
+#[repr(C)]
+pub struct OlaFri {
     _p: [u8; 0],
 }
 /// `StarkConfig::standard_fast_config()` (circuits/src/stark/config.rs:18-30) + device selection + the hash configuration.
@@ -170,6 +175,14 @@ extern "C" {
         num_permutation_zs: u32, challenger: *mut OlaChallenger, out: *mut u8, cap: usize, out_len: *mut usize,
         openings_len: *mut usize) -> i32;
     pub fn ola_pow(ctx: *mut OlaCtx, h: *const u64, bits: u32, witness: *mut u64) -> i32;
+    pub fn ola_open(ctx: *mut OlaCtx, trace: *const OlaBatch, zs: *const OlaBatch, quotient: *const OlaBatch, num_permutation_zs: u32,
+        zeta: *const u64, out: *mut u8, cap: usize, out_len: *mut usize, fri_out: *mut *mut OlaFri) -> i32;
+    pub fn ola_fri_plan(fri: *const OlaFri, arity_bits: *mut u32, cap: u32, n_layers: *mut u32, final_poly_len: *mut u32) -> i32;
+    pub fn ola_fri_commit_begin(fri: *mut OlaFri, alpha: *const u64) -> i32;
+    pub fn ola_fri_commit_next_layer(fri: *mut OlaFri, beta: *const u64, cap_out: *mut u64) -> i32;
+    pub fn ola_fri_commit_finish(fri: *mut OlaFri, beta: *const u64, final_poly_out: *mut u64, cap_elems: usize, n_out: *mut usize) -> i32;
+    pub fn ola_fri_query(fri: *mut OlaFri, x_index: *const u64, n: u32, out: *mut u8, cap: usize, out_len: *mut usize) -> i32;
+    pub fn ola_fri_free(fri: *mut OlaFri) -> i32;
     pub fn ola_prove_with_traces(ctx: *mut OlaCtx, airset: *const u64, airset_words: usize, traces: *const *const u64,
         log_n: *const u32, params: *const u64, compress_challenges: *const u64, out: *mut u8, cap: usize,
         out_len: *mut usize) -> i32;

@@ -74,7 +74,7 @@ def load_library():
     L.ola_gpu_init.argtypes = [C.POINTER(OlaGpuConfig), C.POINTER(C.c_void_p)]
     L.ola_gpu_abi_version.argtypes = [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
     a, b = C.c_size_t(), C.c_size_t()
-    if L.ola_gpu_abi_version(C.byref(a), C.byref(b)) != 6 or a.value != C.sizeof(OlaChallenger) or b.value != C.sizeof(OlaGpuConfig):
+    if L.ola_gpu_abi_version(C.byref(a), C.byref(b)) != 7 or a.value != C.sizeof(OlaChallenger) or b.value != C.sizeof(OlaGpuConfig):
         raise OlaGpuError(-7, "libola_gpu.so and olavm_amd/backend.py disagree on the ABI revision or struct sizes: rebuild the library")
     L.ola_gpu_init_multi.argtypes = [C.POINTER(OlaGpuConfig), C.POINTER(C.c_int32), C.c_uint32, C.POINTER(C.c_void_p)]
     L.ola_gpu_device_count.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
@@ -155,6 +155,7 @@ EXPORTS = [
     "ola_gpu_abi_version", "ola_gpu_init_multi", "ola_gpu_device_count", "ola_gpu_proof_stats", "ola_gpu_phase_stats",
     "ola_gpu_collective", "ola_gpu_all_gather_check", "ola_prove_with_traces_cols", "ola_gpu_scope_times", "ola_gpu_upload_stats",
     "ola_gpu_warmup", "ola_gpu_warmup_wait", "ola_gpu_ntt_pass_times",
+    "ola_open", "ola_fri_plan", "ola_fri_commit_begin", "ola_fri_commit_next_layer", "ola_fri_commit_finish", "ola_fri_query", "ola_fri_free",
 ]
 
 
@@ -233,6 +234,54 @@ class Challenger:
         o = Challenger(self.lib, int(self.c.hasher))
         C.memmove(C.byref(o.c), C.byref(self.c), C.sizeof(OlaChallenger))
         return o
+
+
+class FriSteps:
+    """An OlaFri: the opening proof of one table, one step per call (ola_fri_*; include/ola_gpu.h "one step per call")."""
+
+    def __init__(self, be, handle):
+        self.be, self.h = be, handle
+        n, fl = C.c_uint32(), C.c_uint32()
+        ab = (C.c_uint32 * 64)()
+        be._chk(be.lib.ola_fri_plan(self.h, ab, 64, C.byref(n), C.byref(fl)))
+        self.arity_bits, self.final_poly_len = [int(ab[i]) for i in range(n.value)], fl.value
+
+    def begin(self, alpha):
+        a = np.ascontiguousarray(alpha, dtype=np.uint64)
+        self.be._chk(self.be.lib.ola_fri_commit_begin(self.h, _p(a)))
+
+    def next_layer(self, beta=None):
+        """-> the layer's cap (2^cap_height x 4 words); beta = the PREVIOUS layer's challenge, None for the first layer"""
+        cap = np.empty((1 << self.be.cap_height, 4), dtype=np.uint64)
+        b = None if beta is None else np.ascontiguousarray(beta, dtype=np.uint64)
+        self.be._chk(self.be.lib.ola_fri_commit_next_layer(self.h, None if b is None else _p(b), _p(cap)))
+        return cap
+
+    def finish(self, beta=None):
+        """-> final polynomial as (len, 2) words"""
+        out = np.empty((max(self.final_poly_len, 1), 2), dtype=np.uint64)
+        n = C.c_size_t(0)
+        b = None if beta is None else np.ascontiguousarray(beta, dtype=np.uint64)
+        self.be._chk(self.be.lib.ola_fri_commit_finish(self.h, None if b is None else _p(b), _p(out), out.shape[0], C.byref(n)))
+        return out[:n.value]
+
+    def query(self, x_index):
+        x = np.ascontiguousarray(x_index, dtype=np.uint64)
+        need = C.c_size_t(0)
+        cap = 1 << 18
+        while True:
+            buf = C.create_string_buffer(cap)
+            rc = self.be.lib.ola_fri_query(self.h, _p(x), x.size, buf, cap, C.byref(need))
+            if rc != 0 and need.value > cap:
+                cap = need.value
+                continue
+            self.be._chk(rc)
+            return bytes(buf.raw[:need.value])
+
+    def free(self):
+        if self.h:
+            self.be.lib.ola_fri_free(self.h)
+            self.h = None
 
 
 class Batch:
@@ -660,6 +709,20 @@ class Backend:
         flags = (C.c_uint8 * ntables)()
         self._chk(self.lib.ola_air_kernels_available(_p(blob), blob.size, flags, ntables))
         return [bool(x) for x in flags]
+
+    def open(self, trace, zs, quot, num_permutation_zs, zeta):
+        """ola_open: StarkOpeningSet::new at `zeta` = (a, b) -> (opening-set bytes in wire format, FriSteps for the rest of the opening proof)"""
+        z = np.ascontiguousarray(zeta, dtype=np.uint64)
+        need, h = C.c_size_t(0), C.c_void_p()
+        cap = 1 << 16
+        while True:
+            buf = C.create_string_buffer(cap)
+            rc = self.lib.ola_open(self.ctx, trace.h, zs.h, quot.h, num_permutation_zs, _p(z), buf, cap, C.byref(need), C.byref(h))
+            if rc != 0 and need.value > cap:
+                cap = need.value
+                continue
+            self._chk(rc)
+            return bytes(buf.raw[:need.value]), FriSteps(self, h)
 
     def open_and_prove(self, trace, zs, quot, num_permutation_zs, challenger):
         need, olen = C.c_size_t(0), C.c_size_t(0)

@@ -469,8 +469,10 @@ struct DevBuf {
     size_t pinned_mark;
     struct Pending { void* dst; const u64* src; size_t bytes; };
     std::vector<Pending> pending;      // read-backs that landed in pinned memory and still have to reach the caller's buffer
+    bool use_pinned = true;            // false: a scope that outlives its call (OlaFri) -- the arena is a stack and is left to the calls
     HostSpan host(size_t elems) {
-        if (void* p = ctx->pinned_alloc(std::max<size_t>(1, elems) * 8)) return {(u64*)p, elems};
+        if (use_pinned)
+            if (void* p = ctx->pinned_alloc(std::max<size_t>(1, elems) * 8)) return {(u64*)p, elems};
         hosts.emplace_back(std::max<size_t>(1, elems));
         return {hosts.back().data(), elems};
     }
@@ -485,7 +487,7 @@ struct DevBuf {
     // that the copy is really asynchronous
     void readback(void* dst, const void* src_dev, size_t bytes) {
         if (!bytes) return;
-        if (void* p = ctx->pinned_alloc(bytes)) {
+        if (void* p = use_pinned ? ctx->pinned_alloc(bytes) : nullptr) {
             HIP_CHECK(hipMemcpyAsync(p, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
             pending.push_back({dst, (const u64*)p, bytes});
         } else {
@@ -1164,6 +1166,255 @@ void open_and_prove(DeviceCtx* ctx, NttTables& tables, const OlaGpuConfig& cfg, 
     w.ext_vec(final_poly);
     if (pow_deferred) pow_defer->jobs.back().at = bytes.size();
     w.field(pow_witness);
+}
+
+// ------------------------------------------------------------------------------------------------ the same, one step per call
+// "ola_open; ola_fri_commit_begin / next_layer(beta, cap_out) / finish(final_poly_out) -- layer-stepped because each
+// beta depends on the previous cap through the host challenger (fri/prover.rs:98-101); ola_pow; ola_fri_query".  For a host that
+// keeps the reference's own loops (StarkOpeningSet::new, prove_openings, fri_committed_trees, fri_proof_of_work,
+// fri_prover_query_rounds) and its own Challenger, and hands only the device work over.  Same kernels and helpers as
+// open_and_prove above, whose bytes the steps reassemble to (tests/test_gpu_fri_steps.py); single-device contexts only.
+}  // namespace ola
+struct OlaFri {      // (global, like OlaBatch: the C header names it)
+    ola::DeviceCtx* ctx;
+    ola::NttTables* tables;
+    OlaGpuConfig cfg;
+    const OlaBatch *trace, *zs, *quot;
+    uint32_t nperm;
+    ola::DevBuf mem;                  // everything that lives between the steps
+    int degree_bits, rate_bits, stage = 0;   // 0 opened, 1 polynomial built / layers being committed, 2 finished
+    size_t n, N, len, nz;
+    ola::Ext2 zeta;
+    ola::ExtPow zpow[3], zinv[3];
+    std::vector<int> arities;
+    std::vector<ola::FriLayer> layers;
+    ola::u64* cur_coef = nullptr;
+    ola::u64 shift = ola::GL_GENERATOR;
+    void* owner = nullptr;            // the OlaCtx the batches belong to (the C wrappers make its device current)
+    OlaFri(ola::DeviceCtx* c, ola::NttTables* t, const OlaGpuConfig& g, const OlaBatch* tr, const OlaBatch* z, const OlaBatch* q, uint32_t np)
+        : ctx(c), tables(t), cfg(g), trace(tr), zs(z), quot(q), nperm(np), mem(c) {
+        mem.use_pinned = false;
+        degree_bits = (int)tr->log_n; rate_bits = (int)g.rate_bits;
+        n = tr->n(); N = n << rate_bits; len = N; nz = n;
+        arities = ola::fri_arities(cfg, degree_bits);
+        int tot = 0;
+        for (int a : arities) tot += a;
+        if (tot > degree_bits + rate_bits - (int)cfg.cap_height) throw ola::OlaError(OLA_E_INVALID_ARG, "FRI total reduction arity is too large.");
+    }
+};
+namespace ola {
+
+// StarkOpeningSet::new (circuits/src/stark/proof.rs:198-233) at the caller's zeta: the opening set in wire format
+// (serialization.rs write_stark_opening_set: local, next, permutation_ctl_zs, its next, ctl_zs_last, quotient_polys)
+void fri_steps_open(OlaFri& f, const u64 zeta_in[2], std::vector<uint8_t>& bytes) {
+    DeviceCtx* ctx = f.ctx;
+    const int degree_bits = f.degree_bits;
+    f.zeta = ext_make(gl_canon(zeta_in[0]), gl_canon(zeta_in[1]));
+    if (ext_eq(ext_pow(f.zeta, (u64)1 << degree_bits), ext_make(1, 0))) throw OlaError(OLA_E_ZETA_IN_SUBGROUP, "Opening point is in the subgroup.");
+    const u64 g = gl_root_of_unity(degree_bits);
+    const Ext2 zeta_next = ext_scalar_mul(f.zeta, g), g_inv = ext_make(gl_inv(g), 0);
+    {
+        const Ext2 six[6] = {f.zeta, zeta_next, g_inv, ext_inv(f.zeta), ext_inv(zeta_next), ext_inv(g_inv)};
+        ExtPow tabs[6];
+        make_ext_pows(f.mem, six, 6, degree_bits, tabs, 3);
+        for (int b = 0; b < 3; b++) { f.zpow[b] = tabs[b]; f.zinv[b] = tabs[3 + b]; }
+    }
+    std::vector<Ext2> local, next, zs_local, zs_next, q_local, zs_last_all, dummy;
+    {
+        DevBuf tmp(ctx);
+        EvalJob jobs[4];
+        eval_batch_launch(tmp, *f.trace, 2, f.zpow[0], f.zpow[1], &local, &next, jobs[0]);
+        eval_batch_launch(tmp, *f.zs, 2, f.zpow[0], f.zpow[1], &zs_local, &zs_next, jobs[1]);
+        eval_batch_launch(tmp, *f.quot, 1, f.zpow[0], f.zpow[0], &q_local, &dummy, jobs[2]);
+        eval_batch_launch(tmp, *f.zs, 1, f.zpow[2], f.zpow[2], &zs_last_all, &dummy, jobs[3]);
+        tmp.sync_collect();
+        for (auto& j : jobs) eval_batch_collect(j);
+    }
+    std::vector<u64> ctl_last;
+    for (int i = (int)f.nperm; i < (int)f.zs->ncols; i++) ctl_last.push_back(zs_last_all[i].a);
+    ByteWriter w{bytes, ctx->hasher == (int)OLA_HASH_BLAKE3};
+    w.ext_vec(local); w.ext_vec(next); w.ext_vec(zs_local); w.ext_vec(zs_next);
+    w.field_vec(ctl_last.data(), ctl_last.size());
+    w.ext_vec(q_local);
+}
+
+// prove_openings up to the final polynomial (fri/oracle.rs:178-219) with the caller's alpha
+void fri_steps_begin(OlaFri& f, const u64 alpha_in[2]) {
+    if (f.stage != 0) throw OlaError(OLA_E_INVALID_ARG, "ola_fri_commit_begin: already begun");
+    DeviceCtx* ctx = f.ctx;
+    const OlaBatch &trace = *f.trace, &zs = *f.zs, &quot = *f.quot;
+    const int W = (int)trace.ncols, Z = (int)zs.ncols, Q = (int)quot.ncols;
+    const size_t n = f.n, N = f.N;
+    const Ext2 alpha = ext_make(gl_canon(alpha_in[0]), gl_canon(alpha_in[1]));
+    const int napow = W + Z + Q;
+    u64* coef = f.mem.alloc(2 * N);
+    {
+        DevBuf tmp(ctx);
+        HostSpan h_apow = tmp.host(2 * (size_t)napow);
+        Ext2 acc = ext_make(1, 0);
+        for (int i = 0; i < napow; i++) { h_apow[i] = acc.a; h_apow[napow + i] = acc.b; acc = ext_mul(acc, alpha); }
+        u64* d_apow = tmp.alloc(h_apow.size());
+        HIP_CHECK(hipMemcpyAsync(d_apow, h_apow.data(), h_apow.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+        u64* S = tmp.alloc(6 * n);
+        hipLaunchKernelGGL(compose_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, trace.coeffs, W, zs.coeffs, Z, quot.coeffs, Q,
+                           (int)f.nperm, n, d_apow, napow, S);
+        const int l1 = W + Z, l2 = Z - (int)f.nperm;
+        const bool use2 = l2 > 0;
+        u64* tot = tmp.alloc((n + SCAN_B - 1) / SCAN_B + 1);
+        for (int b = 0; b < 3; b++) {
+            if (b == 2 && !use2) continue;
+            hipLaunchKernelGGL(weight_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, S + 2 * b * n, S + (2 * b + 1) * n, n, f.zpow[b]);
+            scan_plane(tmp, S + 2 * b * n, n, tot);
+            scan_plane(tmp, S + (2 * b + 1) * n, n, tot);
+        }
+        const Ext2 w2 = ext_make(1, 0);
+        const Ext2 w1 = use2 ? ext_pow(alpha, (u64)l2) : ext_make(1, 0);
+        const Ext2 w0 = ext_mul(ext_pow(alpha, (u64)l1), w1);
+        hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, S, n, f.zinv[0], f.zinv[1], f.zinv[2], w0, w1, w2,
+                           use2 ? 1 : 0, coef, coef + N, N);
+    }       // (the scope waits for the stream before its scratch goes back to the pool)
+    f.cur_coef = coef;
+    f.stage = 1;
+}
+
+static void fri_steps_fold(OlaFri& f, const u64 beta_in[2]) {
+    DeviceCtx* ctx = f.ctx;
+    const int ab = f.layers.back().arity_bits, arity = 1 << ab;
+    const Ext2 beta = ext_make(gl_canon(beta_in[0]), gl_canon(beta_in[1]));
+    const size_t len = f.len, out_len = len >> ab;
+    u64* folded = f.mem.alloc(2 * out_len);
+    if (arity == 16 && f.nz % 16 == 0 && f.nz >= 4096) {
+        const size_t nz_out = f.nz / 16;
+        if (nz_out < out_len) {
+            HIP_CHECK(hipMemsetAsync(folded + nz_out, 0, (out_len - nz_out) * 8, ctx->stream));
+            HIP_CHECK(hipMemsetAsync(folded + out_len + nz_out, 0, (out_len - nz_out) * 8, ctx->stream));
+        }
+        const Ext2 b2 = ext_mul(beta, beta), b4 = ext_mul(b2, b2), b8 = ext_mul(b4, b4);
+        hipLaunchKernelGGL(fold16_kernel, dim3((unsigned)((nz_out * 8 + 255) / 256)), dim3(256), 0, ctx->stream, f.cur_coef, f.cur_coef + len, nz_out, beta, b2, b4, b8,
+                           folded, folded + out_len);
+        f.nz = nz_out;
+    } else {
+        hipLaunchKernelGGL(fold_kernel, dim3((unsigned)((out_len + 255) / 256)), dim3(256), 0, ctx->stream, f.cur_coef, f.cur_coef + len, out_len, arity, beta, folded,
+                           folded + out_len);
+        f.nz = std::min(out_len, (f.nz + arity - 1) / arity);
+    }
+    f.cur_coef = folded;
+    f.len = out_len;
+    f.shift = gl_pow(f.shift, (u64)arity);
+}
+
+// one turn of fri_committed_trees (fri/prover.rs:72-121): fold by the previous layer's beta (none before the first layer), then
+// commit the values of the current polynomial on its coset -> the layer's cap
+void fri_steps_next_layer(OlaFri& f, const u64* beta, u64* cap_out) {
+    if (f.stage != 1) throw OlaError(OLA_E_INVALID_ARG, "ola_fri_commit_next_layer: call ola_fri_commit_begin first");
+    if (f.layers.size() >= f.arities.size()) throw OlaError(OLA_E_INVALID_ARG, "ola_fri_commit_next_layer: every layer of the reduction plan is committed");
+    if (f.layers.empty() != (beta == nullptr)) throw OlaError(OLA_E_INVALID_ARG, "ola_fri_commit_next_layer: beta is NULL for the first layer and only there");
+    DeviceCtx* ctx = f.ctx;
+    if (beta) fri_steps_fold(f, beta);
+    const int ab = f.arities[f.layers.size()], arity = 1 << ab;
+    const size_t len = f.len, len_cap = (size_t)1 << f.cfg.cap_height, nleaves = len >> ab;
+    int cur_bits = 0;
+    while (((size_t)1 << cur_bits) < len) cur_bits++;
+    FriLayer L;
+    L.len = len; L.arity_bits = ab;
+    L.cap.resize(len_cap * 4);
+    L.va = f.mem.alloc(2 * len);
+    L.vb = L.va + len;
+    ntt_coset_evaluate(*f.tables, f.cur_coef, L.va, nullptr, cur_bits, 2, f.shift, false);
+    L.heap = f.mem.alloc(2 * nleaves * 4);
+    launch_leaf_hash_ext(ctx, L.va, L.vb, arity, nleaves, L.heap + 4 * nleaves);
+    launch_merkle_build(ctx, L.heap, nleaves, f.cfg.cap_height);
+    HIP_CHECK(hipMemcpyAsync(L.cap.data(), L.heap + 4 * len_cap, len_cap * 32, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    std::copy(L.cap.begin(), L.cap.end(), cap_out);
+    f.layers.push_back(L);
+}
+
+// fold by the last beta and hand out the final polynomial, truncated to len / 2^rate_bits coefficients (prover.rs:114-119)
+size_t fri_steps_finish(OlaFri& f, const u64* beta, u64* final_poly_out, size_t cap_elems) {
+    if (f.stage != 1 || f.layers.size() != f.arities.size()) throw OlaError(OLA_E_INVALID_ARG, "ola_fri_commit_finish: layers of the reduction plan are missing");
+    if (f.layers.empty() != (beta == nullptr)) throw OlaError(OLA_E_INVALID_ARG, "ola_fri_commit_finish: beta is NULL exactly when the plan has no layer");
+    if (beta) fri_steps_fold(f, beta);
+    const size_t final_len = f.len >> f.rate_bits;
+    if (final_len > cap_elems || !final_poly_out) throw OlaError(OLA_E_INVALID_ARG, "ola_fri_commit_finish: output buffer too small");
+    std::vector<u64> h(2 * f.len);
+    HIP_CHECK(hipMemcpyAsync(h.data(), f.cur_coef, 2 * f.len * 8, hipMemcpyDeviceToHost, f.ctx->stream));
+    HIP_CHECK(hipStreamSynchronize(f.ctx->stream));
+    for (size_t i = 0; i < final_len; i++) { final_poly_out[2 * i] = h[i]; final_poly_out[2 * i + 1] = h[f.len + i]; }
+    f.stage = 2;
+    return final_len;
+}
+
+// fri_prover_query_rounds (fri/prover.rs:150-204) for the caller's indices: the query round proofs in wire format
+// (serialization.rs:305-317, the part between the caps and the final polynomial: count, then per query the three oracles' rows
+// and paths and every layer's leaf and path)
+void fri_steps_query(OlaFri& f, const u64* x_index, uint32_t nq_in, std::vector<uint8_t>& bytes) {
+    if (f.stage != 2) throw OlaError(OLA_E_INVALID_ARG, "ola_fri_query: call ola_fri_commit_finish first");
+    DeviceCtx* ctx = f.ctx;
+    const int nq = (int)nq_in;
+    std::vector<size_t> xs(nq);
+    for (int r = 0; r < nq; r++) {
+        if (x_index[r] >= (u64)f.N) throw OlaError(OLA_E_INVALID_ARG, "ola_fri_query: index beyond the LDE");
+        xs[r] = (size_t)x_index[r];
+    }
+    const OlaBatch* oracles[3] = {f.trace, f.zs, f.quot};
+    const int depth0 = f.degree_bits + f.rate_bits - (int)f.cfg.cap_height;
+    std::vector<std::vector<u64>> rows(3), paths(3), lrows(f.layers.size()), lpaths(f.layers.size());
+    std::vector<int> ldepth(f.layers.size());
+    {
+        DevBuf tmp(ctx);
+        for (int o = 0; o < 3; o++) {
+            rows[o].resize((size_t)nq * oracles[o]->ncols);
+            paths[o].resize((size_t)nq * (size_t)std::max(depth0, 1) * 4);
+            query_leaves(tmp, *f.tables, *oracles[o], xs.data(), nq, depth0, rows[o].data(), paths[o].data());
+        }
+        std::vector<size_t> cur = xs;
+        std::vector<std::vector<unsigned long long>> h_idx_all(f.layers.size());
+        for (size_t li = 0; li < f.layers.size(); li++) {
+            FriLayer& L = f.layers[li];
+            const int arity = 1 << L.arity_bits;
+            const size_t nleaves = L.len >> L.arity_bits;
+            int lb = 0;
+            while (((size_t)1 << lb) < nleaves) lb++;
+            ldepth[li] = lb - (int)f.cfg.cap_height;
+            std::vector<unsigned long long>& h_idx = h_idx_all[li];
+            h_idx.resize(nq);
+            for (int r = 0; r < nq; r++) { cur[r] >>= L.arity_bits; h_idx[r] = cur[r]; }
+            lrows[li].resize((size_t)nq * arity * 2);
+            if (ldepth[li] > 0) lpaths[li].resize((size_t)nq * ldepth[li] * 4);
+            unsigned long long* d_idx = (unsigned long long*)tmp.alloc(nq);
+            HIP_CHECK(hipMemcpyAsync(d_idx, h_idx.data(), nq * 8, hipMemcpyHostToDevice, ctx->stream));
+            u64* d_rows = tmp.alloc((size_t)nq * arity * 2);
+            hipLaunchKernelGGL(gather_ext_leaves_kernel, dim3((unsigned)nq), dim3(64), 0, ctx->stream, L.va, L.vb, arity, d_idx, d_rows);
+            tmp.readback(lrows[li].data(), d_rows, lrows[li].size() * 8);
+            if (ldepth[li] > 0) {
+                u64* d_paths = tmp.alloc((size_t)nq * ldepth[li] * 4);
+                hipLaunchKernelGGL(gather_paths_kernel, dim3((unsigned)nq), dim3(((ldepth[li] * 4 + 63) / 64) * 64), 0, ctx->stream, L.heap, nleaves, ldepth[li], d_idx,
+                                   d_paths);
+                tmp.readback(lpaths[li].data(), d_paths, lpaths[li].size() * 8);
+            }
+        }
+        tmp.sync_collect();
+    }
+    ByteWriter w{bytes, ctx->hasher == (int)OLA_HASH_BLAKE3};
+    w.u32((uint32_t)nq);
+    for (int r = 0; r < nq; r++) {
+        w.u32(3);
+        for (int o = 0; o < 3; o++) {
+            w.field_vec(rows[o].data() + (size_t)r * oracles[o]->ncols, oracles[o]->ncols);
+            w.merkle_proof(paths[o].data() + (size_t)r * (size_t)std::max(depth0, 0) * 4, std::max(depth0, 0));
+        }
+        w.u32((uint32_t)f.layers.size());
+        for (size_t li = 0; li < f.layers.size(); li++) {
+            const int arity = 1 << f.layers[li].arity_bits;
+            w.u32((uint32_t)arity);
+            for (int k = 0; k < arity; k++) {
+                w.field(lrows[li][((size_t)r * arity + k) * 2]);
+                w.field(lrows[li][((size_t)r * arity + k) * 2 + 1]);
+            }
+            w.merkle_proof(ldepth[li] > 0 ? lpaths[li].data() + (size_t)r * ldepth[li] * 4 : nullptr, ldepth[li] > 0 ? ldepth[li] : 0);
+        }
+    }
 }
 
 }  // namespace ola

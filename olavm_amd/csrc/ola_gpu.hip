@@ -891,6 +891,81 @@ int32_t ola_open_and_prove(OlaCtx* ctx, const OlaBatch* trace, const OlaBatch* z
     OLA_CATCH
 }
 
+// ---- the same, one step per call (fri.hip "one step per call")
+int32_t ola_open(OlaCtx* ctx, const OlaBatch* trace, const OlaBatch* zs, const OlaBatch* quotient, uint32_t num_permutation_zs, const uint64_t zeta[2],
+                 uint8_t* out, size_t cap, size_t* out_len, OlaFri** fri_out) {
+    OLA_TRY
+    OLA_ON_DEVICE(ctx);
+    require(ctx && trace && zs && quotient && zeta && out_len && fri_out, "null pointer");
+    require(ctx->peers.empty() && ctx->dev.shard.world <= 1, "the step-wise opening entry points run on single-device contexts");
+    require_full(trace); require_full(zs); require_full(quotient);
+    require(trace->log_n == zs->log_n && trace->log_n == quotient->log_n, "degree mismatch between commitments");
+    require(num_permutation_zs <= zs->ncols, "num_permutation_zs");
+    std::unique_ptr<OlaFri> f(new OlaFri(&ctx->dev, &*ctx->tables, ctx->cfg, trace, zs, quotient, num_permutation_zs));
+    f->owner = ctx;
+    std::vector<uint8_t> bytes;
+    fri_steps_open(*f, (const u64*)zeta, bytes);
+    *out_len = bytes.size();
+    if (bytes.size() > cap || !out) throw OlaError(OLA_E_INVALID_ARG, "output buffer too small");
+    memcpy(out, bytes.data(), bytes.size());
+    *fri_out = f.release();
+    OLA_CATCH
+}
+int32_t ola_fri_plan(const OlaFri* fri, uint32_t* arity_bits, uint32_t cap, uint32_t* n_layers, uint32_t* final_poly_len) {
+    OLA_TRY
+    require(fri && n_layers, "null pointer");
+    *n_layers = (uint32_t)fri->arities.size();
+    if (final_poly_len) {
+        int d = fri->degree_bits;
+        for (int a : fri->arities) d -= a;
+        *final_poly_len = 1u << d;
+    }
+    require(!arity_bits || cap >= fri->arities.size(), "arity_bits too small");
+    if (arity_bits) for (size_t i = 0; i < fri->arities.size(); i++) arity_bits[i] = (uint32_t)fri->arities[i];
+    OLA_CATCH
+}
+int32_t ola_fri_commit_begin(OlaFri* fri, const uint64_t alpha[2]) {
+    OLA_TRY
+    require(fri && alpha, "null pointer");
+    OLA_ON_DEVICE((OlaCtx*)fri->owner);
+    fri_steps_begin(*fri, (const u64*)alpha);
+    OLA_CATCH
+}
+int32_t ola_fri_commit_next_layer(OlaFri* fri, const uint64_t* beta, uint64_t* cap_out) {
+    OLA_TRY
+    require(fri && cap_out, "null pointer");
+    OLA_ON_DEVICE((OlaCtx*)fri->owner);
+    fri_steps_next_layer(*fri, (const u64*)beta, (u64*)cap_out);
+    OLA_CATCH
+}
+int32_t ola_fri_commit_finish(OlaFri* fri, const uint64_t* beta, uint64_t* final_poly_out, size_t cap_elems, size_t* n_out) {
+    OLA_TRY
+    require(fri && final_poly_out, "null pointer");
+    OLA_ON_DEVICE((OlaCtx*)fri->owner);
+    const size_t got = fri_steps_finish(*fri, (const u64*)beta, (u64*)final_poly_out, cap_elems);
+    if (n_out) *n_out = got;
+    OLA_CATCH
+}
+int32_t ola_fri_query(OlaFri* fri, const uint64_t* x_index, uint32_t n, uint8_t* out, size_t cap, size_t* out_len) {
+    OLA_TRY
+    require(fri && (x_index || n == 0) && out_len, "null pointer");
+    OLA_ON_DEVICE((OlaCtx*)fri->owner);
+    std::vector<uint8_t> bytes;
+    fri_steps_query(*fri, (const u64*)x_index, n, bytes);
+    *out_len = bytes.size();
+    if (bytes.size() > cap || !out) throw OlaError(OLA_E_INVALID_ARG, "output buffer too small");
+    memcpy(out, bytes.data(), bytes.size());
+    OLA_CATCH
+}
+int32_t ola_fri_free(OlaFri* fri) {
+    OLA_TRY
+    if (fri) {
+        OLA_ON_DEVICE((OlaCtx*)fri->owner);
+        delete fri;
+    }
+    OLA_CATCH
+}
+
 // the body of both whole-proof entry points: `src[t]` says where table t's columns are
 static void prove_all(OlaCtx* ctx, const uint64_t* airset, size_t airset_words, const std::vector<TraceSource>& src, const uint32_t* log_n,
                       const uint64_t* params, const uint64_t* compress_challenges, uint8_t* out, size_t cap, size_t* out_len) {

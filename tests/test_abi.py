@@ -34,7 +34,7 @@ def test_abi_revision_and_struct_sizes(lib):
     hdr = open(os.path.join(ROOT, "include", "ola_gpu.h")).read()
     want = int(re.search(r"#define OLA_GPU_ABI_VERSION (\d+)", hdr).group(1))
     a, b = C.c_size_t(), C.c_size_t()
-    assert lib.ola_gpu_abi_version(C.byref(a), C.byref(b)) == want == 6
+    assert lib.ola_gpu_abi_version(C.byref(a), C.byref(b)) == want == 7
     assert a.value == C.sizeof(OlaChallenger) == 240 and b.value == C.sizeof(OlaGpuConfig)
     assert lib.ola_gpu_abi_version(None, None) == want
     # OlaScopeTime (revision 5): char[64], 4 x 32 bits, 3 doubles -- the layout integration/rust/ola_gpu_sys.rs declares
