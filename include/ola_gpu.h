@@ -365,7 +365,7 @@ int32_t ola_pow(OlaCtx* ctx, const uint64_t h[4], uint32_t bits, uint64_t* witne
  * (tests/test_gpu_fri_steps.py does exactly that with ola_challenger_*).  Single-device contexts; the three batches must outlive
  * the OlaFri.
  *   ola_open                   StarkOpeningSet::new (circuits/src/stark/proof.rs:198-233) at the caller's zeta: the opening set in
- *                              wire format (serialization.rs write_stark_opening_set) -- decode, then
+ *                              wire format (serialization.rs:164-175 write_opening_set; read it back with read_opening_set, :176-193) -- decode, then
  *                              challenger.observe_openings(&openings.to_fri_openings()) (fri/challenges.rs:16-23)
  *   ola_fri_plan               fri_params.reduction_arity_bits (fri/reduction_strategies.rs:40-52) and the final polynomial's length
  *   ola_fri_commit_begin       PolynomialBatch::prove_openings up to the final polynomial (fri/oracle.rs:178-219), alpha =
@@ -376,7 +376,7 @@ int32_t ola_pow(OlaCtx* ctx, const uint64_t h[4], uint32_t bits, uint64_t* witne
  *                              (prover.rs:114-119); *n_out = its length
  *   ola_pow (above)            fri_proof_of_work (prover.rs:126-148), minimal witness
  *   ola_fri_query              fri_prover_query_rounds (prover.rs:150-204) for the caller's indices (challenger output mod the LDE
- *                              size): the query round proofs in wire format (serialization.rs:305-317: count, per query the three
+ *                              size): the query round proofs in wire format (write_fri_query_rounds, serialization.rs:275-292: count, per query the three
  *                              oracles' rows and paths and every layer's leaf and path) */
 typedef struct OlaFri OlaFri;
 int32_t ola_open(OlaCtx* ctx, const OlaBatch* trace, const OlaBatch* zs, const OlaBatch* quotient, uint32_t num_permutation_zs,

@@ -250,6 +250,76 @@ inline F fri_proof_of_work(const Gpu& g, const HashOut& current_hash, uint32_t b
     return w;
 }
 
+// ---- circuits/src/stark/prover.rs:499-553 + fri/oracle.rs:167-241 + fri/prover.rs:20-204: the opening proof of one table ----------
+// One call with the transcript inside the library (the fast path): returns {opening-set bytes, FriProof bytes}, `challenger` advances as
+// the reference's does.
+inline std::pair<std::vector<uint8_t>, std::vector<uint8_t>> open_and_prove(const Gpu& g, const PolynomialBatch& trace, const PolynomialBatch& zs,
+                                                                            const PolynomialBatch& quotient, uint32_t num_permutation_zs,
+                                                                            Challenger& challenger) {
+    std::vector<uint8_t> out((size_t)1 << 20);
+    size_t len = 0, olen = 0;
+    auto call = [&]() {
+        return ola_open_and_prove(g.ctx(), trace.handle(), zs.handle(), quotient.handle(), num_permutation_zs, &challenger.raw(), out.data(), out.size(), &len, &olen);
+    };
+    int32_t rc = call();
+    if (rc == OLA_E_INVALID_ARG && len > out.size()) { out.resize(len); rc = call(); }
+    check(rc);
+    return {std::vector<uint8_t>(out.begin(), out.begin() + (long)olen), std::vector<uint8_t>(out.begin() + (long)olen, out.begin() + (long)len)};
+}
+// The same one step per call, for a caller that keeps the reference's loops and its own Challenger (ABI revision 7).
+class FriSteps {
+public:
+    // StarkOpeningSet::new (proof.rs:198-233): the opening set in wire format (Buffer::read_opening_set reads it)
+    FriSteps(const Gpu& g, const PolynomialBatch& trace, const PolynomialBatch& zs, const PolynomialBatch& quotient, uint32_t num_permutation_zs,
+             const std::array<F, 2>& zeta)
+        : g_(&g) {
+        openings.resize((size_t)1 << 16);
+        size_t len = 0;
+        auto call = [&]() { return ola_open(g.ctx(), trace.handle(), zs.handle(), quotient.handle(), num_permutation_zs, zeta.data(), openings.data(), openings.size(), &len, &h_); };
+        int32_t rc = call();
+        if (rc == OLA_E_INVALID_ARG && len > openings.size()) { openings.resize(len); rc = call(); }
+        check(rc);
+        openings.resize(len);
+        uint32_t n = 0, fl = 0;
+        check(ola_fri_plan(h_, nullptr, 0, &n, &fl));
+        reduction_arity_bits.resize(n);
+        check(ola_fri_plan(h_, reduction_arity_bits.data(), n, &n, &fl));
+        final_poly_len = fl;
+    }
+    FriSteps(const FriSteps&) = delete;
+    ~FriSteps() { if (h_) ola_fri_free(h_); }
+    void begin(const std::array<F, 2>& alpha) { check(ola_fri_commit_begin(h_, alpha.data())); }                       // fri/oracle.rs:178-219
+    MerkleCap next_layer(const std::array<F, 2>* beta) {                                                               // fri/prover.rs:72-121, one turn
+        MerkleCap cap((size_t)1 << g_->config.cap_height);
+        check(ola_fri_commit_next_layer(h_, beta ? beta->data() : nullptr, cap[0].data()));
+        return cap;
+    }
+    std::vector<std::array<F, 2>> finish(const std::array<F, 2>* beta) {                                               // prover.rs:114-119
+        std::vector<std::array<F, 2>> poly(final_poly_len ? final_poly_len : 1);
+        size_t n = 0;
+        check(ola_fri_commit_finish(h_, beta ? beta->data() : nullptr, poly[0].data(), poly.size(), &n));
+        poly.resize(n);
+        return poly;
+    }
+    std::vector<uint8_t> query_rounds(const std::vector<F>& x_index) {                                                 // prover.rs:150-204, wire format
+        std::vector<uint8_t> out((size_t)1 << 20);
+        size_t len = 0;
+        auto call = [&]() { return ola_fri_query(h_, x_index.data(), (uint32_t)x_index.size(), out.data(), out.size(), &len); };
+        int32_t rc = call();
+        if (rc == OLA_E_INVALID_ARG && len > out.size()) { out.resize(len); rc = call(); }
+        check(rc);
+        out.resize(len);
+        return out;
+    }
+    std::vector<uint8_t> openings;                  // write_opening_set's bytes (serialization.rs:164-175)
+    std::vector<uint32_t> reduction_arity_bits;     // fri_params.reduction_arity_bits
+    size_t final_poly_len = 0;
+
+private:
+    const Gpu* g_;
+    OlaFri* h_ = nullptr;
+};
+
 // ---- circuits/src/stark/prover.rs:79-327 --------------------------------------------------------------------------------------------
 // `airset`: the tables and cross-table lookups as data (olavm_amd/air/dsl.py blob); traces[t]: table t column-major,
 // width_t columns of 2^log_n[t] words; params: per-table public parameters in blob order; compress_challenges: one per

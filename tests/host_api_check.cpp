@@ -8,10 +8,12 @@
 //   poseidon test_vectors                plonky2/plonky2/src/hash/poseidon_goldilocks.rs:281-314
 //   no_duplicate_challenges              plonky2/plonky2/src/iop/challenger.rs:317-338
 //   proof_of_work                        plonky2/plonky2/src/fri/prover.rs:126-156 + verifier check fri/verifier.rs:57-66
+//   prove_openings / fri_proof loops     plonky2/plonky2/src/fri/oracle.rs:167-241, fri/prover.rs:20-204 (steps against the fused call)
 //   prove_with_traces                    circuits/src/stark/prover.rs:79 (bytes are compared by the Python driver)
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <fstream>
 #include <iostream>
 #include <random>
@@ -144,6 +146,68 @@ int main(int argc, char** argv) {
         const F wit = fri_proof_of_work(gpu, h, bits);
         const auto out = hash::permute(gpu, {h[0], h[1], h[2], h[3], wit, 0, 0, 0, 0, 0, 0, 0});   // hash_no_pad([h.., witness])
         EXPECT((out[0] >> (64 - bits)) == 0);                                                       // leading_zeros >= bits
+    }
+
+    // ---- the opening proof one step per call with this side's Challenger (the reference's prove_openings / fri_proof loops,
+    //      fri/oracle.rs:167-241, fri/prover.rs:20-204) against the fused call: same bytes, same transcript
+    for (uint32_t log_n : {6u, 13u}) {
+        const size_t n = (size_t)1 << log_n;
+        std::vector<PolynomialValues> tv(5), zv(3);
+        std::vector<PolynomialCoeffs> qc(2);
+        for (auto& c : tv) c = rand_vec(rng, n);
+        for (auto& c : zv) c = rand_vec(rng, n);
+        for (auto& c : qc) c = rand_vec(rng, n);
+        const auto bt = PolynomialBatch::from_values(gpu, tv), bz = PolynomialBatch::from_values(gpu, zv);
+        const auto bq = PolynomialBatch::from_coeffs(gpu, qc);
+        Challenger fused(gpu);
+        for (const auto* b : {&bt, &bz, &bq}) fused.observe_cap(b->merkle_cap());
+        Challenger mine = fused;
+        const auto want = open_and_prove(gpu, bt, bz, bq, 1, fused);
+        auto words = [](const std::vector<uint8_t>& b, size_t& at) {      // read_field_ext_vec / read_field_vec: u32 count, then little-endian words
+            uint32_t k; std::memcpy(&k, b.data() + at, 4); at += 4;
+            return k;
+        };
+        FriSteps st(gpu, bt, bz, bq, 1, mine.get_extension_challenge());
+        EXPECT(st.openings == want.first);
+        {   // observe_openings in to_fri_openings order (proof.rs:235-265): local, zs, quotient, next, zs next, ctl_zs_last as extension elements
+            std::vector<std::vector<F>> vec;
+            size_t at = 0;
+            for (int part = 0; part < 6; part++) {
+                const uint32_t k = words(st.openings, at);
+                const size_t nw = part == 4 ? k : 2 * (size_t)k;
+                std::vector<F> v(nw);
+                std::memcpy(v.data(), st.openings.data() + at, nw * 8);
+                at += nw * 8;
+                vec.push_back(v);
+            }
+            for (int part : {0, 2, 5, 1, 3}) mine.observe_elements(vec[part]);
+            for (F x : vec[4]) { mine.observe_element(x); mine.observe_element(0); }
+        }
+        st.begin(mine.get_extension_challenge());
+        std::vector<MerkleCap> caps;
+        std::array<F, 2> beta{};
+        for (size_t i = 0; i < st.reduction_arity_bits.size(); i++) {
+            caps.push_back(st.next_layer(i ? &beta : nullptr));
+            mine.observe_cap(caps.back());
+            beta = mine.get_extension_challenge();
+        }
+        const auto final_poly = st.finish(caps.empty() ? nullptr : &beta);
+        for (const auto& e : final_poly) { mine.observe_element(e[0]); mine.observe_element(e[1]); }
+        const F witness = fri_proof_of_work(gpu, mine.get_hash(), gpu.config.proof_of_work_bits);
+        std::vector<F> xs(gpu.config.num_query_rounds);
+        for (auto& x : xs) x = mine.get_challenge() % ((F)n << gpu.config.rate_bits);
+        const auto rounds = st.query_rounds(xs);
+        std::vector<uint8_t> got;
+        auto put32 = [&](uint32_t v) { for (int i = 0; i < 4; i++) got.push_back((uint8_t)(v >> (8 * i))); };
+        auto put64 = [&](F v) { for (int i = 0; i < 8; i++) got.push_back((uint8_t)(v >> (8 * i))); };
+        put32((uint32_t)caps.size());
+        for (const auto& cap : caps) { put32((uint32_t)cap.size()); for (const auto& h : cap) for (F x : h) put64(x); }
+        got.insert(got.end(), rounds.begin(), rounds.end());
+        put32((uint32_t)final_poly.size());
+        for (const auto& e : final_poly) { put64(e[0]); put64(e[1]); }
+        put64(witness);
+        EXPECT(got == want.second);
+        EXPECT(mine.get_challenge() == fused.get_challenge());
     }
 
     // ---- permuted_cols: a permutation of both columns, and Halo2's rule on a valid lookup
