@@ -13,13 +13,18 @@
 // table t have arrived".  Tables are sent in the order the caller gives (prove_with_traces: small tables first, then the large
 // ones in descending size, so that what is left to do after the last byte is the smallest large table's Merkle tree).
 //   OLA_UPLOAD=staged (default) | pageable (round 4's path: hipMemcpyAsync from the caller's memory, kept as the A/B control)
-//   OLA_UPLOAD_THREADS (default 4), OLA_UPLOAD_PIECE_MB (16), OLA_UPLOAD_SLOTS (8), OLA_UPLOAD_STREAMS (2), OLA_UPLOAD_PACK (1)
+//   OLA_UPLOAD_THREADS (default 4), OLA_UPLOAD_PIECE_MB (16), OLA_UPLOAD_SLOTS (8), OLA_UPLOAD_STREAMS (2), OLA_UPLOAD_PACK (1), OLA_UPLOAD_SOLO_KB (512), OLA_UPLOAD_PACK8 (1)
 // Narrow columns (OLA_UPLOAD_PACK, default on): most columns of an execution trace hold small values -- selectors, opcodes,
 // addresses, clocks, 32-bit limbs.  While a copier thread fills a slot with a piece of ONE column it checks, block by block,
 // whether every word of the piece is below 2^32; if so only the low halves go into the slot, half the bytes cross the link,
 // and a kernel on the upload stream widens them into the prover's buffer (through a small device-side ring).  The first word
 // of 2^32 or more ends the attempt (a column of field-sized values fails in its first block) and the piece travels as 64-bit
 // words.  The device buffer holds the same canonical words either way.
+// Round 6: (a) a column can only be packed when it has a piece to itself, and columns shorter than a slot used to share one -- a
+// 2^20-row table (8 MB columns, two per slot) sent 8 % fewer bytes instead of 40 %: columns of OLA_UPLOAD_SOLO_KB (512 KB) and
+// more now get their own piece; (b) a column whose words are all below 2^8 (selectors, flags, opcode bits: 82 % of the words of
+// an executed Fibonacci trace) travels as BYTES (OLA_UPLOAD_PACK8, tried first).  README-shape proof: 1.12 -> 0.69 -> 0.3 GB over
+// the link.
 // Tables that are already in device memory are copied device to device without staging.
 // Not built: hipHostRegister of the caller's columns -- pinning 4.29 GB took 212.8 ms on the test box (50 ms per GB, three
 // times the transfer itself; tools/ubench/h2d_rates.hip, profiles/r05_h2d_rates.txt), and page-rounded registrations take in
@@ -63,6 +68,21 @@ __global__ __launch_bounds__(256) void upload_widen_kernel(const uint32_t* __res
     }
 }
 
+// the same for columns whose words are all below 2^8 (selectors, flags, opcode bits: 82 % of the words of an executed Fibonacci trace)
+__global__ __launch_bounds__(256) void upload_widen8_kernel(const uint8_t* __restrict__ in, u64* __restrict__ out, size_t n) {
+    const size_t i0 = ((size_t)blockIdx.x * 256 + threadIdx.x) * 8;
+    if (i0 + 8 <= n) {
+        const uint2 v = *reinterpret_cast<const uint2*>(in + i0);
+        ulonglong2* o = reinterpret_cast<ulonglong2*>(out + i0);
+        o[0] = make_ulonglong2(v.x & 0xFF, (v.x >> 8) & 0xFF);
+        o[1] = make_ulonglong2((v.x >> 16) & 0xFF, v.x >> 24);
+        o[2] = make_ulonglong2(v.y & 0xFF, (v.y >> 8) & 0xFF);
+        o[3] = make_ulonglong2((v.y >> 16) & 0xFF, v.y >> 24);
+    } else {
+        for (size_t i = i0; i < n; i++) out[i] = in[i];
+    }
+}
+
 class TraceUploader {
   public:
     enum Mode { STAGED = 0, PAGEABLE = 1 };
@@ -74,6 +94,8 @@ class TraceUploader {
         slots_ = (size_t)env_int("OLA_UPLOAD_SLOTS", 8, 2, 1024);
         nstreams_ = (size_t)env_int("OLA_UPLOAD_STREAMS", 2, 1, 4);
         pack_ = env_int("OLA_UPLOAD_PACK", 1, 0, 1) != 0;
+        solo_bytes_ = (size_t)env_int("OLA_UPLOAD_SOLO_KB", 512, 0, 1 << 20) << 10;
+        pack8_ = env_int("OLA_UPLOAD_PACK8", 1, 0, 1) != 0;
         const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
         // the ranks of a multi-device context upload side by side: keep the copier threads of all of them within the machine
         const unsigned share = std::max(1u, hw / std::max(1u, ctx->shard.world));
@@ -146,7 +168,7 @@ class TraceUploader {
         s.threads = mode_ == STAGED ? nthreads_ : 1;
         s.link_bytes = mode_ == STAGED ? (double)link_bytes_.load() : (double)bytes_;
         if (ctx_->timing)
-            fprintf(stderr, "[ola-timing] trace upload (%s, %u copier thread(s)): %.2f GB of trace (%.2f GB over the link: narrow columns travel as 32-bit words) in %.3f ms = %.1f GB/s of trace; the proving thread waited %.3f ms for column groups; first group complete after %.3f ms\n",
+            fprintf(stderr, "[ola-timing] trace upload (%s, %u copier thread(s)): %.2f GB of trace (%.2f GB over the link: narrow columns travel as 32-bit words or bytes) in %.3f ms = %.1f GB/s of trace; the proving thread waited %.3f ms for column groups; first group complete after %.3f ms\n",
                     mode_ == STAGED ? "pinned staging ring" : "pageable hipMemcpyAsync", s.threads, bytes_ / 1e9, s.link_bytes / 1e9, total_ms_,
                     total_ms_ > 0 ? bytes_ / 1e6 / total_ms_ : 0.0, waited_ms_, first_ms_);
         if (failed_) throw OlaError(-5, "trace upload failed: " + error_);
@@ -184,7 +206,10 @@ class TraceUploader {
                         pieces_.push_back({(uint32_t)t, c, c + 1, r, std::min(rows_per, j.n - r), r + rows_per >= j.n ? c + 1 : c, false});
             } else {
                 // small columns travel together; device-resident tables go column group by column group
-                const uint32_t per = whole ? j.chunk : (uint32_t)std::max<size_t>(1, piece_bytes_ / col_bytes);
+                // (round 6) a column can only travel narrow when it has a piece to itself: columns of solo_bytes_ and more do, also where
+                // several would fit a slot -- a 2^20-row table (8 MB columns, two per 16 MB slot) sent 8 % fewer bytes instead of 40 %
+                const bool solo = !whole && pack_ && solo_bytes_ && col_bytes >= solo_bytes_ && j.n >= 4096;
+                const uint32_t per = whole ? j.chunk : solo ? 1u : (uint32_t)std::max<size_t>(1, piece_bytes_ / col_bytes);
                 for (uint32_t c = 0; c < j.ncols; c += per) {
                     const uint32_t c1 = std::min(j.ncols, c + per);
                     pieces_.push_back({(uint32_t)t, c, c1, 0, j.n, c1, dev});
@@ -228,6 +253,17 @@ class TraceUploader {
         }
         return true;
     }
+    // low bytes of src[0, n) into dst while every word is below 2^8
+    static bool pack_low_bytes(uint8_t* __restrict__ dst, const u64* __restrict__ src, size_t n) {
+        const size_t block = 4096;
+        for (size_t b = 0; b < n; b += block) {
+            const size_t e = std::min(n, b + block);
+            u64 hi = 0;
+            for (size_t i = b; i < e; i++) { hi |= src[i]; dst[i] = (uint8_t)src[i]; }
+            if (hi >> 8) return false;
+        }
+        return true;
+    }
     void fail(hipError_t e) {
         std::lock_guard<std::mutex> lk(mu_);
         if (!failed_) { failed_ = true; error_ = hipGetErrorString(e); }
@@ -268,7 +304,9 @@ class TraceUploader {
                 if (e == hipSuccess) e = hipEventRecord(events_[i % slots_], st);
             } else {
                 char* slot = (char*)ctx_->staging + (i % slots_) * piece_bytes_;
-                const bool narrow = pack_ && p.c1 - p.c0 == 1 && p.rows >= 4096 && pack_low_halves((uint32_t*)slot, src_of(p, p.c0), p.rows);
+                const bool packable = pack_ && p.c1 - p.c0 == 1 && p.rows >= 4096;
+                const bool bytes = packable && pack8_ && pack_low_bytes((uint8_t*)slot, src_of(p, p.c0), p.rows);
+                const bool narrow = bytes || (packable && pack_low_halves((uint32_t*)slot, src_of(p, p.c0), p.rows));
                 if (!narrow) {
                     for (uint32_t c = p.c0; c < p.c1; c++) {
                         memcpy(slot + (size_t)(c - p.c0) * p.rows * 8, src_of(p, c), p.rows * 8);
@@ -278,12 +316,14 @@ class TraceUploader {
                 std::lock_guard<std::mutex> lk(issue_mu_);
                 if (narrow) {
                     uint32_t* d32 = (uint32_t*)((char*)ctx_->staging_dev + (i % slots_) * (piece_bytes_ / 2));
-                    e = hipMemcpyAsync(d32, slot, p.rows * 4, hipMemcpyHostToDevice, st);
+                    const size_t wire = p.rows * (bytes ? 1 : 4);
+                    e = hipMemcpyAsync(d32, slot, wire, hipMemcpyHostToDevice, st);
                     if (e == hipSuccess) {
-                        hipLaunchKernelGGL(upload_widen_kernel, dim3((unsigned)((p.rows + 1023) / 1024)), dim3(256), 0, st, d32, dst_of(p), p.rows);
+                        if (bytes) hipLaunchKernelGGL(upload_widen8_kernel, dim3((unsigned)((p.rows + 2047) / 2048)), dim3(256), 0, st, (const uint8_t*)d32, dst_of(p), p.rows);
+                        else hipLaunchKernelGGL(upload_widen_kernel, dim3((unsigned)((p.rows + 1023) / 1024)), dim3(256), 0, st, d32, dst_of(p), p.rows);
                         e = hipGetLastError();
                     }
-                    link_bytes_.fetch_add(p.rows * 4);
+                    link_bytes_.fetch_add(wire);
                 } else {
                     e = hipMemcpyAsync(dst_of(p), slot, bytes_of(p), hipMemcpyHostToDevice, st);
                     link_bytes_.fetch_add(bytes_of(p));
@@ -349,6 +389,8 @@ class TraceUploader {
     std::atomic<size_t> next_{0};
     std::atomic<size_t> link_bytes_{0};               // what actually crossed the link
     bool pack_ = true;
+    bool pack8_ = true;                               // columns of byte-sized words travel as bytes (OLA_UPLOAD_PACK8)
+    size_t solo_bytes_ = 512 << 10;                   // columns of this size and more get a piece of their own (0: never)
     size_t completed_ = 0;                            // pieces retired (guarded by mu_)
     std::atomic<bool> cancel_{false};
     Mode mode_ = STAGED, pieces_plan_ = STAGED;       // pieces_plan_: the mode plan() cut the pieces for

@@ -72,7 +72,7 @@ def test_upload_paths_and_ring_geometries_agree(be, oracle, monkeypatch):
 
 
 def test_narrow_columns_travel_as_32_bit_words(be, oracle, monkeypatch):
-    """Columns whose words are all below 2^32 cross the link as 32-bit words and are widened on the device (upload.h); columns with
+    """Columns whose words are all below 2^32 cross the link as 32-bit words (below 2^8: as bytes) and are widened on the device (upload.h); columns with
     field-sized values (hashes, products, inverses) travel whole, also when the first large word comes late in the column.  An executed
     program has all three kinds.  Same proof bytes with the packing on and off."""
     from olavm_amd.air import fastexec
@@ -92,9 +92,28 @@ def test_narrow_columns_travel_as_32_bit_words(be, oracle, monkeypatch):
     # at least the narrow columns of the large tables were halved (a piece is judged by itself: the narrow first half of a 2^18-row
     # column whose large words come later travels narrow, too)
     saved = total - st["link_bytes"]
-    assert sum(int((~(t >= (1 << 32)).any(axis=1)).sum()) * t.shape[1] * 4 for t in big) <= saved < total // 2, st
+    # round 6: columns whose words are all below 2^8 travel as bytes (7 of 8 bytes saved), the other narrow ones as 32-bit words
+    byte_cols = sum(int((~(t >= (1 << 8)).any(axis=1)).sum()) * t.shape[1] for t in big)
+    half_cols = sum(int((~(t >= (1 << 32)).any(axis=1)).sum()) * t.shape[1] for t in big) - byte_cols
+    assert byte_cols > 0 and half_cols > 0
+    assert byte_cols * 7 + half_cols * 4 <= saved < total * 7 // 8, st
     rc, why = oracle.verify_all_proof(blob, want, params)
     assert rc == 0, why
+    monkeypatch.setenv("OLA_UPLOAD_PACK8", "0")             # 32-bit words only: round 5's path
+    assert be.prove_with_traces(blob, traces, params, compress) == want
+    st = be.upload_stats()
+    saved = total - st["link_bytes"]
+    assert (byte_cols + half_cols) * 4 <= saved < total // 2, st
+    monkeypatch.delenv("OLA_UPLOAD_PACK8")
+    # columns shorter than a slot get a piece of their own (OLA_UPLOAD_SOLO_KB): with 16 MB slots the 1 MB columns of this trace used to
+    # share pieces and none of them was packed
+    monkeypatch.setenv("OLA_UPLOAD_PIECE_MB", "16")
+    assert be.prove_with_traces(blob, traces, params, compress) == want
+    assert total - be.upload_stats()["link_bytes"] >= byte_cols * 7 + half_cols * 4
+    monkeypatch.setenv("OLA_UPLOAD_SOLO_KB", "0")
+    assert be.prove_with_traces(blob, traces, params, compress) == want
+    assert be.upload_stats()["link_bytes"] == total
+    monkeypatch.delenv("OLA_UPLOAD_SOLO_KB")
     monkeypatch.setenv("OLA_UPLOAD_PACK", "0")
     assert be.prove_with_traces(blob, traces, params, compress) == want
     st = be.upload_stats()
