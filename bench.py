@@ -161,10 +161,16 @@ def phase_block(be, hasher="poseidon"):
             m["valu"] = {"wave_insts_per_s_G": round(wi / 1e9, 1), "frac_of_2_cycle_issue_peak": round(wi / VALU_PEAK_GUIDE, 3),
                          "insts_per_permutation": POSEIDON_VALU_PER_PERMUTATION}
         out["merkle"] = m
+    top = getattr(be, "phase_top", {})
+
+    def dominant(name):
+        """the phase's scope that moved the most bytes: what one large launch reaches, without the launch-bound small ones"""
+        tms, tb = top.get(name, (0, 0))
+        return {"ms": round(tms, 4), "bytes": int(tb), "GBps": round(tb / (tms * 1e-3) / 1e9, 1), "frac": round(tb / (tms * 1e-3) / (HBM_PEAK_GBPS * 1e9), 4)} if tms > 0 else None
     ms, byts, elems = ph["fri_fold"]
     if ms > 0:
         out["fri_fold"] = {"ms": round(ms, 3), "GBps": round(byts / (ms * 1e-3) / 1e9, 1), "extension_elements": int(elems),
-                           "frac_of_hbm_peak": round(byts / (ms * 1e-3) / (HBM_PEAK_GBPS * 1e9), 4)}
+                           "frac_of_hbm_peak": round(byts / (ms * 1e-3) / (HBM_PEAK_GBPS * 1e9), 4), "dominant_launch": dominant("fri_fold")}
     ms, byts, cc = ph["lde"]
     if ms > 0:
         out["lde"] = {"ms": round(ms, 2), "GBps": round(byts / (ms * 1e-3) / 1e9, 1), "column_cosets": int(cc)}
@@ -180,7 +186,8 @@ def phase_block(be, hasher="poseidon"):
     ms, prods, byts = ph["open_eval"]
     if ms > 0:      # every coefficient of every committed polynomial read once per point pair
         out["open_eval"] = {"ms": round(ms, 2), "coefficient_point_products_per_s_G": round(prods / (ms * 1e-3) / 1e9, 2), "bytes": int(byts),
-                            "GBps": round(byts / (ms * 1e-3) / 1e9, 1), "frac": round(byts / (ms * 1e-3) / (HBM_PEAK_GBPS * 1e9), 4), "bound": "hbm; round 6: 25 VALU per coefficient (22-bit limb products, multiplier in SGPRs; 124 before), profiles/r06_openings_ab.txt"}
+                            "GBps": round(byts / (ms * 1e-3) / 1e9, 1), "frac": round(byts / (ms * 1e-3) / (HBM_PEAK_GBPS * 1e9), 4), "dominant_launch": dominant("open_eval"),
+                            "bound": "hbm; round 6: 25 VALU per coefficient (22-bit limb products, multiplier in SGPRs; 124 before), profiles/r06_openings_ab.txt"}
     return out
 
 
@@ -853,6 +860,8 @@ def compact_line(res):
     for name, path in (("open_eval_frac", ("prove", "blake3_config", "kernels", "open_eval", "frac")),
                        ("fri_fold_frac", ("prove", "blake3_config", "kernels", "fri_fold", "frac_of_hbm_peak")),
                        ("fri_fold_ms", ("prove", "blake3_config", "kernels", "fri_fold", "ms")),
+                       ("fri_fold_dominant_frac", ("prove", "blake3_config", "kernels", "fri_fold", "dominant_launch", "frac")),
+                       ("open_eval_dominant_frac", ("prove", "blake3_config", "kernels", "open_eval", "dominant_launch", "frac")),
                        ("quotient_ms", ("prove", "blake3_config", "kernels", "quotient", "ms")),
                        ("small_tables_ms", ("readme_fibo_loop_blake3", "partition", "replicated_breakdown_ms", "tables_below_the_partition_threshold"))):
         v = res.get(name) if res.get(name) is not None else _num(res, *path)

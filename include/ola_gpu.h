@@ -169,6 +169,9 @@ int32_t ola_gpu_proof_stats(OlaCtx* ctx, int32_t enable, double out[8]);
 #define OLA_PHASE_QUOTIENT 5
 #define OLA_PHASE_OPEN_EVAL 6
 #define OLA_PHASE_COUNT 7
+/* Asked for 2 * OLA_PHASE_COUNT rows, rows OLA_PHASE_COUNT + p hold phase p's DOMINANT scope -- the one launch (or group of launches) that
+ * moved the most bytes: {device ms, its bytes, 0}.  A phase's totals hide it behind the launch-bound small ones (a proof has about thirty
+ * FRI folds, two of them large). */
 int32_t ola_gpu_phase_stats(OlaCtx* ctx, double* out /* 3 * n_phases */, uint32_t n_phases);
 /* The reference's `timed!` scopes of the LAST whole proof with device times, for the caller's TimingTree (prover.rs:84
  * `timing: &mut TimingTree`; plonky2/plonky2/src/util/timing.rs:7-194; scope names prover.rs:111-553, fri/oracle.rs:56-90,221-225,

@@ -362,9 +362,12 @@ class Backend:
     def phase_stats(self):
         """ola_gpu_phase_stats of the last proof (accounting must be on): {phase: (ms, units0, units1)}."""
         n = len(self.PHASES)
-        out = (C.c_double * (3 * n))()
-        self._chk(self.lib.ola_gpu_phase_stats(self.ctx, out, n))
-        return {name: (out[3 * i], out[3 * i + 1], out[3 * i + 2]) for i, name in enumerate(self.PHASES)}
+        out = (C.c_double * (6 * n))()
+        self._chk(self.lib.ola_gpu_phase_stats(self.ctx, out, 2 * n))
+        st = {name: (out[3 * i], out[3 * i + 1], out[3 * i + 2]) for i, name in enumerate(self.PHASES)}
+        # rows n + p: the phase's dominant scope (most bytes): (ms, bytes)
+        self.phase_top = {name: (out[3 * (n + i)], out[3 * (n + i) + 1]) for i, name in enumerate(self.PHASES)}
+        return st
 
     def device_count(self):
         n = C.c_uint32()

@@ -88,9 +88,12 @@ struct ScopeLog {
 enum { PH_LEAF_HASH = 0, PH_MERKLE_LEVELS, PH_FRI_FOLD, PH_LDE, PH_INTT, PH_QUOTIENT, PH_OPEN_EVAL, PH_COUNT };
 struct WorkAcct {
     bool on = false;
-    struct Span { hipEvent_t a, b; int maxlog; int scope; };   // maxlog >= 100: a phase span, phase = maxlog - 100; scope: ScopeLog index or -1
+    struct Span { hipEvent_t a, b; int maxlog; int scope; double bytes = 0; };   // maxlog >= 100: a phase span, phase = maxlog - 100; scope: ScopeLog index or -1
     double phase_ms[PH_COUNT] = {};
     double phase_units[PH_COUNT][2] = {};
+    // the scope of each phase that moved the most bytes (its dominant launch): device time and bytes -- a phase's total hides it behind
+    // the launch-bound small ones (a proof has thirty folds, two of them large)
+    double phase_top_ms[PH_COUNT] = {}, phase_top_bytes[PH_COUNT] = {};
     std::vector<Span> spans;
     std::vector<hipEvent_t> spare;
     double sharded_ms[4] = {0, 0, 0, 0};   // [k]: work that divides by min(G, 2^k), k = 1..3
@@ -124,14 +127,17 @@ struct WorkAcct {
         in_proof = true;
         for (double& m : sharded_ms) m = 0;
         wall_ms = 0; exchange_bytes = 0; exchanges = 0;
-        for (int i = 0; i < PH_COUNT; i++) { phase_ms[i] = 0; phase_units[i][0] = phase_units[i][1] = 0; }
+        for (int i = 0; i < PH_COUNT; i++) { phase_ms[i] = 0; phase_units[i][0] = phase_units[i][1] = 0; phase_top_ms[i] = phase_top_bytes[i] = 0; }
     }
     // after the stream has been synchronised
     void collect(ScopeLog* log = nullptr) {
         for (Span& s : spans) {
             float ms = 0;
             if (s.a && s.b && hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) {
-                if (s.maxlog >= 100) phase_ms[s.maxlog - 100] += ms;
+                if (s.maxlog >= 100) {
+                    phase_ms[s.maxlog - 100] += ms;
+                    if (s.bytes > phase_top_bytes[s.maxlog - 100]) { phase_top_bytes[s.maxlog - 100] = s.bytes; phase_top_ms[s.maxlog - 100] = ms; }
+                }
                 else {
                     sharded_ms[s.maxlog] += ms;
                     if (log) for (int i = s.scope; i >= 0 && i < (int)log->recs.size(); i = log->recs[(size_t)i].parent) log->recs[(size_t)i].sharded_ms += ms;
@@ -484,8 +490,11 @@ struct PhaseScope {
     DeviceCtx* ctx;
     hipEvent_t a = nullptr;
     int phase;
+    double bytes = 0;
     PhaseScope(DeviceCtx* c, int phase_, double units0, double units1 = 0) : ctx(c), phase(phase_) {
         if (!ctx->acct.on) return;
+        static const int bytes_at[PH_COUNT] = {1, 1, 0, 0, 0, 1, 1};       // which of a phase's two unit counters is its bytes (ola_gpu.h)
+        bytes = bytes_at[phase] ? units1 : units0;
         ctx->acct.phase_units[phase][0] += units0;
         ctx->acct.phase_units[phase][1] += units1;
         a = ctx->acct.get();
@@ -495,7 +504,7 @@ struct PhaseScope {
         if (!a) return;
         hipEvent_t b = ctx->acct.get();
         if (b && hipEventRecord(b, ctx->stream) != hipSuccess) { (void)hipGetLastError(); ctx->acct.spare.push_back(b); b = nullptr; }
-        ctx->acct.add_span({a, b, 100 + phase, -1});
+        ctx->acct.add_span({a, b, 100 + phase, -1, bytes});
     }
 };
 // an exchange of the partition: `gathered_bytes` = payload of all ranks together

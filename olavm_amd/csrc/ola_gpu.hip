@@ -1216,6 +1216,10 @@ int32_t ola_gpu_phase_stats(OlaCtx* ctx, double* out, uint32_t n_phases) {
         out[3 * i] = i < PH_COUNT ? a.phase_ms[i] : 0;
         out[3 * i + 1] = i < PH_COUNT ? a.phase_units[i][0] : 0;
         out[3 * i + 2] = i < PH_COUNT ? a.phase_units[i][1] : 0;
+        if (i >= PH_COUNT && i < 2 * PH_COUNT) {          // rows OLA_PHASE_COUNT + p: phase p's dominant scope (the one that moved the most bytes)
+            out[3 * i] = a.phase_top_ms[i - PH_COUNT];
+            out[3 * i + 1] = a.phase_top_bytes[i - PH_COUNT];
+        }
     }
     OLA_CATCH
 }
