@@ -142,12 +142,13 @@ def num_emits(airset, t, num_challenges=2):
     return len(tab.emits) + 2 * tab.num_permutation_batches(num_challenges) + 2 * len(airset.ctl_jobs(t, num_challenges))
 
 
-SEGMENT_OPS = 64     # field operations between two code-motion barriers
+SEGMENT_OPS = int(os.environ.get("OLA_AIRQ_SEGMENT_OPS", "64"))     # field operations between two code-motion barriers
 # Re-loads of trace cells are what the large tables' kernels wait for (the CPU table: 1 247 cell loads in the source for 331
 # distinct cells, none of them answered by a cache -- profiles/r04_proof_pmc_*.txt).  Two places a cell can stay instead:
-CTL_REG_CELLS = 12   # cells most lookups of the table read (clk, the selectors, ...): in registers for the whole lookup section
+CTL_REG_CELLS = int(os.environ.get("OLA_AIRQ_CTL_REG_CELLS", "12"))   # cells most lookups of the table read (clk, the selectors, ...): in registers for the whole lookup section
 CTL_REG_MIN_USES = 6
-LDS_SLOTS = 20       # lane-private LDS slots per thread (20 x 2 KB per workgroup: four workgroups per CU still fit in 160 KB)
+LDS_SLOTS = int(os.environ.get("OLA_AIRQ_LDS_SLOTS", "20"))       # lane-private LDS slots per thread (20 x 2 KB per workgroup: four workgroups per CU still fit in 160 KB)
+MIN_WAVES = int(os.environ.get("OLA_AIRQ_MIN_WAVES", "4"))        # waves per SIMD the kernels are compiled for (__launch_bounds__: 4 -> 128 VGPRs, 3 -> 168)
 ORDER_WINDOWS = (0, 2, 3, 5, 8)   # candidate evaluation orders of the constraint program: 0 = the reference's, W = greedy with a window of W constraints
 
 
@@ -537,7 +538,7 @@ def _table_kernel(airset, t, name, num_challenges=2, uses=None, ctl_regs=(), pla
     e.add("AIRQ_EPILOGUE")
     head = "// table %d (%s): %d columns, %d constraints, %d permutation Zs, %d CTL Zs, K = %d\n" % (
         t, tab.name, tab.ncols, len(tab.emits), nperm, len(jobs), K)
-    src = head + "__global__ __launch_bounds__(AIRQ_THREADS) void %s(QuotParams P) {\n%s\n}\n" % (name, "\n".join(hoist_limb_loads(e.lines)))
+    src = head + "__global__ __launch_bounds__(AIRQ_THREADS, %d) void %s(QuotParams P) {\n%s\n}\n" % (MIN_WAVES, name, "\n".join(hoist_limb_loads(e.lines)))
     src += "// limb slot -> the descriptor word it is the limb form of (the host appends the limb area in this order: the kernel reads it front to back)\n"
     src += "static const int %s_limb_src[%d] = {%s};\n" % (name, max(1, len(e.limb_src)), ", ".join(str(x) for x in e.limb_src) or "0")
     return src, K, len(e.limb_src)

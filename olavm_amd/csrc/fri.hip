@@ -513,7 +513,7 @@ struct DevBuf {
     ~DevBuf() {
         (void)hipStreamSynchronize(ctx->stream);
         for (void* p : ptrs) ctx->free(p);
-        ctx->pinned_top = pinned_mark;
+        if (use_pinned) ctx->pinned_top = pinned_mark;      // (a scope that never took from the arena does not rewind it either)
     }
 };
 

@@ -67,7 +67,7 @@ struct QuotParams { const u64 *Tl, *Tn, *Zl, *Zn, *D; u64 lag_first, lag_last, z
     P.out[1] = gl_mul(gl_add(acc_reduce(accA1), gl_mul(z_last, acc_reduce(accT1))), zh_inv); }
 #define AIRQ_THREADS 256
 #define __global__
-#define __launch_bounds__(x)
+#define __launch_bounds__(...)
 %(kernels)s
 typedef void (*kern_t)(QuotParams);
 static kern_t KERNELS[] = {%(names)s};
